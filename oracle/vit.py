@@ -1,0 +1,133 @@
+"""Oracle: DINOv2 / DINOv1 ViT backbone forward and the last-layer key hook.
+TEST INFRASTRUCTURE ONLY.
+
+The backbone arithmetic is NOT in /root/reference: data/utils/feature_extractor.py:20,25
+instantiates HuggingFace ``transformers.AutoModel`` (requirement.txt:6, unpinned; 5.15.0
+installed here).  ``dinov2_forward`` restates transformers==5.15.0
+models/dinov2/modeling_dinov2.py (embeddings :38-149, eager attention :153-179, self-attention
+:181-235, output :238-253, layer-scale :272-278, MLP :281-297, layer :342-381) on a flat
+state dict with HF parameter names.  ``dinov1_forward`` restates the in-repo
+models/backbones/dino.py:96-261 (fused qkv, no LayerScale, scale_factor+0.1 pos-embed
+interpolation :202-221) with its parameter names.  Both return the tensor the reference's
+hook captures (feature_extractor.py:42,46-47,55-58): the LAST layer's key projection
+*including bias, before the head split*, CLS dropped, reshaped [B,C,h,w].
+"""
+import math
+import torch
+import torch.nn.functional as F
+
+from .resize import torch_bicubic
+
+
+def layer_norm(x, w, b, eps):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def gelu_erf(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def attention(q, k, v, heads):
+    """eager_attention_forward (modeling_dinov2.py:153-179): softmax(QK^T * hd^-0.5) V."""
+    B, N, D = q.shape
+    hd = D // heads
+    q = q.view(B, N, heads, hd).transpose(1, 2)
+    k = k.view(B, N, heads, hd).transpose(1, 2)
+    v = v.view(B, N, heads, hd).transpose(1, 2)
+    s = torch.matmul(q, k.transpose(2, 3)) * (hd ** -0.5)
+    p = torch.softmax(s, dim=-1)
+    return torch.matmul(p, v).transpose(1, 2).reshape(B, N, D)
+
+
+def patch_embed(img, w, b, patch):
+    """conv(patch, stride patch) == per-patch dot product; flatten(2).transpose(1,2)."""
+    return F.conv2d(img, w, b, stride=patch).flatten(2).transpose(1, 2)
+
+
+def dinov2_pos_embed(pos, n_h, n_w):
+    """modeling_dinov2.py:57-95.  pos [1,1+n0,D]."""
+    n0 = pos.shape[1] - 1
+    if n0 == n_h * n_w and n_h == n_w:
+        return pos
+    s = int(n0 ** 0.5)
+    pp = pos[:, 1:].reshape(1, s, s, -1).permute(0, 3, 1, 2).float()
+    pp = torch_bicubic(pp, n_h, n_w).to(pos.dtype)
+    return torch.cat((pos[:, :1], pp.permute(0, 2, 3, 1).reshape(1, n_h * n_w, -1)), 1)
+
+
+def dinov2_forward(img, sd, heads, patch=14, eps=1e-6, n_layers=None, full_last_layer=True):
+    """Returns (last_hidden_state [B,N,D] after the final LayerNorm, key [B,D,h,w])."""
+    B, _, H, W = img.shape
+    pre = "embeddings."
+    x = patch_embed(img, sd[pre + "patch_embeddings.projection.weight"], sd[pre + "patch_embeddings.projection.bias"], patch)
+    x = torch.cat((sd[pre + "cls_token"].expand(B, -1, -1), x), 1)
+    x = x + dinov2_pos_embed(sd[pre + "position_embeddings"], H // patch, W // patch)
+    L = n_layers if n_layers is not None else 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.layer."))
+    key = None
+    for i in range(L):
+        p = f"encoder.layer.{i}."
+        h = layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
+        a = p + "attention.attention."
+        k = h @ sd[a + "key.weight"].t() + sd[a + "key.bias"]
+        if i == L - 1:
+            key = k
+            if not full_last_layer:
+                break
+        q = h @ sd[a + "query.weight"].t() + sd[a + "query.bias"]
+        v = h @ sd[a + "value.weight"].t() + sd[a + "value.bias"]
+        o = attention(q, k, v, heads)
+        o = o @ sd[p + "attention.output.dense.weight"].t() + sd[p + "attention.output.dense.bias"]
+        x = o * sd[p + "layer_scale1.lambda1"] + x
+        h = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
+        h = gelu_erf(h @ sd[p + "mlp.fc1.weight"].t() + sd[p + "mlp.fc1.bias"])
+        h = h @ sd[p + "mlp.fc2.weight"].t() + sd[p + "mlp.fc2.bias"]
+        x = h * sd[p + "layer_scale2.lambda1"] + x
+    last = layer_norm(x, sd["layernorm.weight"], sd["layernorm.bias"], eps) if full_last_layer else None
+    gh, gw = H // patch, W // patch
+    key_map = key[:, 1:, :].reshape(B, gh, gw, -1).permute(0, 3, 1, 2)   # feature_extractor.py:55-58
+    return last, key_map
+
+
+def dinov1_pos_embed(pos, n_h, n_w):
+    """models/backbones/dino.py:202-221 (note: dino.py names them w0,h0 from (w,h)=x.shape[2:])."""
+    n0 = pos.shape[1] - 1
+    if n0 == n_h * n_w and n_h == n_w:
+        return pos
+    s = int(math.sqrt(n0))
+    sf_h = (n_h + 0.1) / math.sqrt(n0)
+    sf_w = (n_w + 0.1) / math.sqrt(n0)
+    pp = pos[:, 1:].reshape(1, s, s, -1).permute(0, 3, 1, 2)
+    oh, ow = int(math.floor(s * sf_h)), int(math.floor(s * sf_w))
+    pp = torch_bicubic(pp, oh, ow, scale_h=sf_h, scale_w=sf_w)
+    return torch.cat((pos[:, :1], pp.permute(0, 2, 3, 1).reshape(1, oh * ow, -1)), 1)
+
+
+def dinov1_forward(img, sd, heads, patch=8, eps=1e-6, full_last_layer=True):
+    """Returns (cls/norm output [B,N,D], key [B,D,h,w]) as ViTFeat(vit_feat='k') (dino.py:294-320)."""
+    B, _, H, W = img.shape
+    x = patch_embed(img, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], patch)
+    x = torch.cat((sd["cls_token"].expand(B, -1, -1), x), 1)
+    x = x + dinov1_pos_embed(sd["pos_embed"], H // patch, W // patch)
+    L = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+    D = x.shape[-1]
+    key = None
+    for i in range(L):
+        p = f"blocks.{i}."
+        h = layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
+        qkv = h @ sd[p + "attn.qkv.weight"].t() + sd[p + "attn.qkv.bias"]
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        if i == L - 1:
+            key = k
+            if not full_last_layer:
+                break
+        o = attention(q, k, v, heads)
+        x = x + (o @ sd[p + "attn.proj.weight"].t() + sd[p + "attn.proj.bias"])
+        h = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
+        h = gelu_erf(h @ sd[p + "mlp.fc1.weight"].t() + sd[p + "mlp.fc1.bias"])
+        x = x + (h @ sd[p + "mlp.fc2.weight"].t() + sd[p + "mlp.fc2.bias"])
+    last = layer_norm(x, sd["norm.weight"], sd["norm.bias"], eps) if full_last_layer else None
+    gh, gw = H // patch, W // patch
+    key_map = key[:, 1:, :].reshape(B, gh, gw, -1).permute(0, 3, 1, 2)
+    return last, key_map

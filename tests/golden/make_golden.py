@@ -1,0 +1,404 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference) on CPU.
+
+Run in the build container only (the reference never travels to the GPU box):
+    python tests/golden/make_golden.py
+The reference has no tests or fixtures of its own, so these captured
+input/output vectors are the parity pins for oracle/ and, through it, for the HIP path.
+Import recipe = SURVEY.md Appendix B: stub the absent third-party modules (torchvision, timm,
+cv2, prettytable, ntplib), skip models/__init__.py, and neutralise the hard-coded
+``.to('cuda')``.  Only data (tensors in, tensors out) is written -- no reference source.
+"""
+import os
+import sys
+import types
+import importlib.util
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+from scipy import ndimage  # noqa: E402
+import transformers  # noqa: E402,F401  (must be imported before torchvision is stubbed)
+from transformers import Dinov2Config, Dinov2Model  # noqa: E402
+
+
+def mod(n, **a):
+    m = types.ModuleType(n)
+    m.__dict__.update(a)
+    sys.modules[n] = m
+    return m
+
+
+mod("models").__path__ = [REF + "/models"]
+
+
+class DropPath(nn.Module):
+    def __init__(self, p=0.0):
+        super().__init__()
+
+    def forward(self, x):
+        return x
+
+
+mod("timm")
+mod("timm.models")
+mod("timm.models.layers", DropPath=DropPath, to_2tuple=lambda x: (x, x), trunc_normal_=nn.init.trunc_normal_)
+mod("timm.models.registry", register_model=lambda f: f)
+
+
+def connectedComponents(img, connectivity=8):
+    lab, n = ndimage.label(img > 0, structure=np.ones((3, 3)))
+    return n + 1, lab.astype(np.int32)
+
+
+def boundingRect(m):
+    ys, xs = np.nonzero(m)
+    return int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)
+
+
+mod("cv2", connectedComponents=connectedComponents, boundingRect=boundingRect)
+
+
+class _T:
+    def __init__(self, *a, **k):
+        pass
+
+
+mod("torchvision").transforms = mod("torchvision.transforms", Compose=_T, Resize=_T, ToTensor=_T, Normalize=_T, ToPILImage=_T)
+mod("prettytable", PrettyTable=object)
+mod("ntplib")
+_to = torch.Tensor.to
+torch.Tensor.to = lambda s, *a, **k: s if (a and a[0] == "cuda") else _to(s, *a, **k)
+
+from engine.config.config import CfgNode  # noqa: E402
+from models.uscod import baseline  # noqa: E402
+from models.discriminator import Discriminator  # noqa: E402
+import engine.runner.loop_UCOD_DPL as L  # noqa: E402
+
+
+def npify(d):
+    return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, **d):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **npify(d))
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def sd_flat(prefix, module):
+    return {prefix + k: v.clone() for k, v in module.state_dict().items()}
+
+
+def model_cfg(dim, fs):
+    return CfgNode(dict(dim=dim, feature_size=fs, ema_weight=0.99, dis_use_features=False))
+
+
+# ----------------------------------------------------------------------------- G1: decoder fwd + grads
+def g1():
+    for tag, (B, C, H, W) in {"c384": (2, 384, 14, 14), "c768": (2, 768, 8, 8)}.items():
+        torch.manual_seed(100 + C)
+        m = baseline(model_cfg(C, H))
+        x = torch.randn(B, C, H, W)
+        r1, r2 = torch.randn(B, 1, H, W), torch.randn(B, 1, H, W)
+        fg, bg, extra = m(x)
+        teacher = m(x, ema=True)
+        loss = (fg * r1).sum() + (bg * r2).sum() + 1000.0 * extra
+        names = [n for n, _ in m.decoder.named_parameters()]
+        grads = torch.autograd.grad(loss, list(m.decoder.parameters()), allow_unused=True)
+        out = dict(x=x, r1=r1, r2=r2, fg=fg, bg=bg, extra=extra, teacher=teacher)
+        out.update(sd_flat("sd.", m))
+        for n, g in zip(names, grads):
+            out["grad." + n] = torch.zeros(()) if g is None else g
+        # fp64 run of the same module: pins the naive orthogonality loss for the Gram rewrite (G10)
+        m64 = baseline(model_cfg(C, H)).double()
+        m64.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+        _, _, extra64 = m64(x.double())
+        out["extra_fp64"] = extra64
+        save("g1_decoder_" + tag, **out)
+
+
+# ----------------------------------------------------------------------------- G2: shipped checkpoints
+def g2():
+    from safetensors.torch import load_file
+    for ver, C in (("dinov2", 768), ("dinov1", 384)):
+        sd = load_file(f"{REF}/weights/UCOD_DPL_{ver}.safetensors")
+        C = sd["decoder.decoupling.weight"].shape[1]
+        m = baseline(model_cfg(C, 10))
+        m.load_state_dict(sd, strict=True)
+        b, c, h, w = torch.meshgrid(torch.arange(1.), torch.arange(float(C)), torch.arange(10.), torch.arange(10.), indexing="ij")
+        x = torch.sin(0.37 * c + 1.3 * h + 0.7 * w) + 0.25 * torch.cos(0.011 * c * (h + 1) - 0.5 * w)
+        fg, bg, extra = m(x)
+        teacher = m(x, ema=True)
+        # weights are NOT stored (they stay in the reference repo); keys/shapes are, for the strict-load test
+        save("g2_shipped_" + ver, fg=fg, bg=bg, extra=extra, teacher=teacher,
+             keys=np.array(sorted(sd.keys())), shapes=np.array([str(tuple(sd[k].shape)) for k in sorted(sd.keys())]))
+
+
+# ----------------------------------------------------------------------------- G3: discriminator
+def g3():
+    torch.manual_seed(3)
+    d = Discriminator(model_cfg(768, 68))
+    for p in d.parameters():
+        p.requires_grad = True
+    before = sd_flat("sd0.", d)
+    mask = (torch.rand(4, 1, 68, 68) > 0.6).float()
+    mask[:, :, 20:40, 10:50] = 1.0
+    r = torch.randn(4, 1)
+    prob = d(mask, None)
+    loss = (prob * r).sum()
+    names = [n for n, _ in d.named_parameters()]
+    grads = torch.autograd.grad(loss, list(d.parameters()))
+    out = dict(mask=mask, r=r, prob=prob)
+    out.update(before)
+    out.update(sd_flat("sd1.", d))
+    for n, g in zip(names, grads):
+        out["grad." + n] = g
+    # second call on a different mask (running stats keep moving)
+    mask2 = torch.zeros(4, 1, 68, 68)
+    mask2[:, :, 5:30, 30:60] = 1.0
+    out["mask2"] = mask2
+    out["prob2"] = d(mask2, None).detach()
+    out.update(sd_flat("sd2.", d))
+    save("g3_discriminator", **out)
+
+
+# ----------------------------------------------------------------------------- fake runner for the loops
+class NullLogger:
+    def log(self, *a, **k):
+        pass
+
+    info = error = log_table = log
+
+
+def make_loop(C, fs, seed, lr0=6e-4, dis_lr0=1e-3):
+    torch.manual_seed(seed)
+    cfg = CfgNode(dict(
+        model_cfg=dict(dim=C, feature_size=fs, ema_weight=0.99, dis_use_features=False),
+        train_cfg=dict(max_epoch=25, start_finetune=-5, lr0=lr0, dis_lr0=dis_lr0, step_lr_size=2, dis_step_lr_size=2,
+                       step_lr_gamma=0.95, dis_step_lr_gamma=0.95, merge_alpha=0.5, dist_train=False, dis_epoch=1),
+    ))
+    model = baseline(cfg.model_cfg)
+    disc = Discriminator(cfg.model_cfg)
+    # the trained EMA teacher differs from the student: perturb it so the test can tell them apart
+    with torch.no_grad():
+        for p in model.decoder_ema.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    opt = torch.optim.AdamW(model.parameters(), lr=cfg.train_cfg.lr0)
+    dis_opt = torch.optim.AdamW(disc.parameters(), lr=cfg.train_cfg.dis_lr0)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=cfg.train_cfg.step_lr_size, gamma=cfg.train_cfg.step_lr_gamma)
+    dis_sched = torch.optim.lr_scheduler.StepLR(dis_opt, step_size=cfg.train_cfg.dis_step_lr_size, gamma=cfg.train_cfg.dis_step_lr_gamma)
+    runner = SimpleNamespace(model=model, discriminator=disc, optimizer=opt, lr_scheduler=sched, dis_optimizer=dis_opt,
+                             dis_lr_scheduler=dis_sched, logger=NullLogger(),
+                             accelerator=SimpleNamespace(backward=lambda loss: loss.backward()))
+    loop = L.TrainLoop.__new__(L.TrainLoop)
+    loop.cfg = cfg
+    loop._runner = runner
+    loop._max_epoch = cfg.train_cfg.max_epoch
+    loop._start_finetune = cfg.train_cfg.start_finetune
+    loop._cur_epoch = 0
+    loop.global_step = 0
+    loop.finetune = False
+    loop.criterion = nn.BCEWithLogitsLoss()
+    loop.dis_loss = nn.BCELoss()
+    loop.merge_alpha = cfg.train_cfg.merge_alpha
+    loop.ema_alpha = cfg.model_cfg.ema_weight
+    loop.progress_manager = SimpleNamespace(start_task=lambda *a: None, update_task=lambda *a: None, reset_task=lambda *a: None)
+    return loop
+
+
+def batch(B, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(B, C, 14, 14, generator=g)
+    pl = (torch.rand(B, 1, 16, 16, generator=g) > 0.7).float()
+    return {"pseudo_label": pl, "label_tensor": torch.zeros(1), "features": feats, "img_path": ["x"]}
+
+
+# ----------------------------------------------------------------------------- G4: APM merge
+def g4():
+    loop = make_loop(384, 28, seed=4)
+    g = torch.Generator().manual_seed(44)
+    pl = torch.rand(4, 1, 28, 28, generator=g)
+    teacher = torch.randn(4, 1, 28, 28, generator=g) * 2
+    student = torch.randn(4, 1, 28, 28, generator=g) * 2
+    out = dict(pl=pl, teacher=teacher, student=student)
+    out.update(sd_flat("disc0.", loop.runner.discriminator))
+    for ep in (0, 10, 19, 20):
+        loop._cur_epoch = ep
+        merged, dl = loop.merge_pseudo_label(pl, teacher, student, None)
+        out[f"merged_ep{ep}"] = merged
+        out[f"dis_loss_ep{ep}"] = dl
+        out.update(sd_flat(f"disc_after_ep{ep}.", loop.runner.discriminator))
+    save("g4_apm_merge", **out)
+
+
+# ----------------------------------------------------------------------------- G5: full training steps
+def g5():
+    loop = make_loop(384, 28, seed=5)
+    out = {}
+    out.update(sd_flat("model0.", loop.runner.model))
+    out.update(sd_flat("disc0.", loop.runner.discriminator))
+    for step in range(3):
+        b = batch(4, 384, 500 + step)
+        out[f"features{step}"] = b["features"]
+        out[f"pl{step}"] = b["pseudo_label"]
+        lr_before = loop.runner.optimizer.param_groups[0]["lr"]
+        loss = loop._process_batch(b)
+        loop.global_step += 1                             # run_epoch's own increment (loop_UCOD_DPL.py:143)
+        out[f"loss{step}"] = loss.detach()
+        out[f"lr_used{step}"] = np.float64(lr_before)
+        for n, p in loop.runner.model.decoder.named_parameters():
+            out[f"grad{step}.{n}"] = p.grad.clone() if p.grad is not None else torch.zeros(())
+        out.update(sd_flat(f"model{step + 1}.", loop.runner.model))
+        out.update(sd_flat(f"disc{step + 1}.", loop.runner.discriminator))
+    save("g5_process_batch", **out)
+
+
+# ----------------------------------------------------------------------------- G6: discriminator phase
+def g6():
+    loop = make_loop(384, 28, seed=6)
+    d = loop.runner.discriminator
+    out = {}
+    out.update(sd_flat("model0.", loop.runner.model))
+    out.update(sd_flat("disc0.", d))
+    b = batch(4, 384, 600)
+    out["features"] = b["features"]
+    out["pl"] = b["pseudo_label"]
+    loop.runner.train_dataloader = [b]
+    losses = []
+    loop.runner.logger = SimpleNamespace(log=lambda s, *a, **k: losses.append(s), info=lambda *a: None)
+    for p in d.parameters():
+        p.requires_grad = True
+    loop.Discriminator_epoch()
+    for n, p in d.named_parameters():
+        out["grad." + n] = p.grad.clone()
+    out["loss_str"] = np.array(losses)
+    out.update(sd_flat("disc1.", d))
+    save("g6_discriminator_step", **out)
+
+
+# ----------------------------------------------------------------------------- G7: Look-Twice integer table
+def g7():
+    rng = np.random.default_rng(7)
+    V = L.ValLoop_Look_Twice
+    masks, boxes_dyn, boxes_const = [], [], []
+    H = W = 64
+
+    def blob(m, cy, cx, ry, rx):
+        yy, xx = np.mgrid[0:H, 0:W]
+        m[((yy - cy) / max(ry, 1)) ** 2 + ((xx - cx) / max(rx, 1)) ** 2 <= 1.0] = 1
+
+    cases = []
+    for i in range(240):
+        m = np.zeros((H, W), np.uint8)
+        kind = i % 6
+        if kind == 0 and i < 12:
+            pass                                         # empty
+        elif kind == 1:
+            blob(m, rng.integers(10, 54), rng.integers(10, 54), rng.integers(12, 30), rng.integers(12, 30))   # one large
+        elif kind == 2:
+            for _ in range(rng.integers(2, 7)):
+                blob(m, rng.integers(0, H), rng.integers(0, W), rng.integers(2, 7), rng.integers(2, 7))       # many small
+        elif kind == 3:
+            blob(m, rng.integers(0, 4), rng.integers(0, W), rng.integers(3, 9), rng.integers(3, 9))           # edge-touching
+            blob(m, rng.integers(H - 4, H), rng.integers(0, W), rng.integers(3, 9), rng.integers(3, 9))
+        elif kind == 4:
+            blob(m, rng.integers(20, 60), rng.integers(5, 60), rng.integers(3, 6), rng.integers(3, 10))       # low & small -> br/fr big
+        else:
+            m[rng.integers(0, H, 40), rng.integers(0, W, 40)] = 1                                             # speckle
+            blob(m, rng.integers(8, 56), rng.integers(8, 56), rng.integers(4, 8), rng.integers(4, 8))
+        cases.append(m)
+    fake = SimpleNamespace(img_size=(H, W), cfg=SimpleNamespace(val_cfg=SimpleNamespace(look_twice_th=0.15, expand_type="dynamic")))
+    fake.expand_bbox = lambda *a, **k: V.expand_bbox(fake, *a, **k)
+    recs = []
+    for m in cases:
+        # logits whose upsample-to-(H,W) is the identity: feed at full resolution
+        logits = torch.from_numpy(m.astype(np.float32) * 8 - 4).view(1, 1, H, W)
+        row = {"mask": m}
+        for et in ("dynamic", "const"):
+            fake.cfg.val_cfg.expand_type = et
+            try:
+                _, bx = V.process_preds(fake, logits, None)
+                row[et] = "none" if bx is None else ";".join(",".join(str(v) for v in b) for b in bx)
+            except ValueError:
+                row[et] = "ValueError"
+            except ZeroDivisionError:
+                row[et] = "ZeroDivisionError"
+        recs.append(row)
+    rb = []
+    for _ in range(64):
+        b = [int(v) for v in rng.integers(0, 400, 4)]
+        ow, oh, nw, nh = (int(v) for v in rng.integers(100, 2000, 4))
+        rb.append(b + [ow, oh, nw, nh] + V.resize_bbox(None, b, ow, oh, nw, nh))
+    save("g7_look_twice_int", masks=np.stack([r["mask"] for r in recs]), dynamic=np.array([r["dynamic"] for r in recs]),
+         const=np.array([r["const"] for r in recs]), resize_bbox=np.array(rb, np.int64))
+
+
+# ----------------------------------------------------------------------------- G8: ViT backbones
+def g8():
+    # DINOv2 (HF): D=128, 2 heads x hd 64, 3 layers; native grid (no pos interpolation) and interpolated grid
+    for tag, (img, pre) in {"native": (70, 70), "interp": (70, 56)}.items():
+        torch.manual_seed(8)
+        cfg = Dinov2Config(hidden_size=128, num_hidden_layers=3, num_attention_heads=2, image_size=pre, patch_size=14,
+                           mlp_ratio=4, layerscale_value=1.0)
+        m = Dinov2Model(cfg).eval()
+        with torch.no_grad():
+            for n, p in m.named_parameters():              # non-trivial LN / layerscale / bias values
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn_like(p))
+                if "position_embeddings" in n or "cls_token" in n:
+                    p.mul_(0.05)
+        keys = {}
+        m.encoder.layer[-1].attention.attention.key.register_forward_hook(lambda mod_, i, o: keys.__setitem__("k", o.detach()))
+        x = torch.randn(2, 3, img, img)
+        with torch.no_grad():
+            out = m(x)
+        k = keys["k"]
+        B, Ntok, C = k.shape
+        g = int((Ntok - 1) ** 0.5)
+        kmap = k[:, 1:, :].reshape(B, g, g, C).permute(0, 3, 1, 2)
+        d = dict(x=x, last_hidden_state=out.last_hidden_state, key=kmap)
+        d.update({"sd." + n: v for n, v in m.state_dict().items()})
+        save("g8_dinov2_" + tag, **d)
+    # DINOv1 (in-repo dino.py)
+    spec = importlib.util.spec_from_file_location("ref_dino", REF + "/models/backbones/dino.py")
+    dino = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dino)
+    from functools import partial
+    for tag, (img, pre) in {"native": (32, 32), "interp": (48, 32)}.items():
+        torch.manual_seed(81)
+        m = dino.VisionTransformer(img_size=[pre], patch_size=8, embed_dim=128, depth=3, num_heads=2, mlp_ratio=4,
+                                   qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6)).eval()
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn_like(p))
+        feat = {}
+        m.blocks[-1].attn.qkv.register_forward_hook(lambda mod_, i, o: feat.__setitem__("qkv", o.detach()))
+        x = torch.randn(2, 3, img, img)
+        with torch.no_grad():
+            tok = m.prepare_tokens(x)
+            for blk in m.blocks:
+                tok = blk(tok)
+            last = m.norm(tok)
+        qkv = feat["qkv"]
+        B, Ntok, _ = qkv.shape
+        k = qkv.reshape(B, Ntok, 3, 2, 64).permute(2, 0, 3, 1, 4)[1].transpose(1, 2).reshape(B, Ntok, 128)
+        g = img // 8
+        kmap = k[:, 1:].transpose(1, 2).reshape(B, 128, g, g)                  # ViTFeat 'k' (dino.py:308-320)
+        d = dict(x=x, last_hidden_state=last, key=kmap)
+        d.update({"sd." + n: v for n, v in m.state_dict().items()})
+        save("g8_dinov1_" + tag, **d)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    for w in which:
+        globals()[w]()
