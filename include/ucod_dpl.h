@@ -1,0 +1,173 @@
+/* ucod_dpl.h -- C ABI of libucod_dpl.so: the MI355X (gfx950) hot path of UCOD-DPL.
+ *
+ * The reference (Heartfirey/UCOD-DPL) is pure Python/PyTorch: it has no FFI of its own.  The
+ * boundary this library replaces is therefore the set of ATen / HuggingFace op call sites on the
+ * path BASELINE.json:north_star names; every entry point below cites the reference lines whose
+ * device arithmetic it takes over (paths relative to the reference repo root).  The Python host
+ * side (ucod_dpl_amd/) binds these with ctypes and re-exposes the reference's module interface
+ * (models/uscod.py::baseline, models/discriminator.py::Discriminator,
+ * data/utils/feature_extractor.py::backbone, engine/runner/loop_UCOD_DPL.py::TrainLoop).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; nothing is allocated inside;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous,
+ *     stream-ordered and re-entrant; workspace sizes come from the *_workspace_bytes helpers;
+ *   - return value: 0 on success, UCOD_EINVAL (-1) for rejected arguments, otherwise a hipError_t;
+ *   - "bf16" buffers are raw uint16 bfloat16; "f32" are IEEE float.
+ *   - tensors are dense row-major; [B,C,H,W] is NCHW exactly as the reference holds them.
+ */
+#ifndef UCOD_DPL_H
+#define UCOD_DPL_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UCOD_ABI_VERSION 1
+int ucod_abi_version(void);
+/* 1 when a gfx950 device is visible to this process (hipGetDeviceProperties().gcnArchName) */
+int ucod_device_is_gfx950(void);
+
+/* ------------------------------------------------------------------ ViT backbone (rows B1-B8) */
+
+/* GEMM epilogues: C[m][n] = sum_k A[m][k]*B[n][k], A:[M,K] B:[N,K] bf16, K contiguous (y = x W^T) */
+enum {
+  UCOD_EPI_BIAS_BF16 = 0,            /* out bf16[M,N] = C + bias[n]            QKV: modeling_dinov2.py:199-212, dino.py:103,110 */
+  UCOD_EPI_BIAS_GELU_BF16 = 1,       /* out bf16[M,N] = gelu_erf(C + bias[n])  MLP fc1: modeling_dinov2.py:281-297, dino.py:77-93 */
+  UCOD_EPI_BIAS_SCALE_RESID_F32 = 2, /* out f32[M,N] = resid + scale[n]*(C+bias[n])  out-proj/fc2 + LayerScale + residual:
+                                        modeling_dinov2.py:238-253,272-278,361-381 (scale = ones for DINOv1, dino.py:139-140) */
+  UCOD_EPI_PATCH_TOKENS_F32 = 3,     /* A = im2col patches [B*(tok-1),K]; out f32[B*tok,N] rows b*tok+1+p = C + bias[n] + pos[1+p][n]
+                                        patch-embed conv + position embedding: modeling_dinov2.py:97-116,139-149, dino.py:144-159,223-235 */
+  UCOD_EPI_KEY_NCHW_F32 = 4,         /* A = W_key [C,K], B = tokens [Bimg*tok,K]; out f32[Bimg,C,tok-1] = C + bias[m], CLS dropped:
+                                        the key hook, data/utils/feature_extractor.py:42,46-47,55-58 */
+  UCOD_EPI_BIAS_F32 = 5              /* out f32[M,N] = C + bias[n] (final LayerNorm consumers / tests) */
+};
+/* variant: 0 = LDS-DMA staging (default), 1 = register staging.  K % 64 == 0. */
+int ucod_gemm_bf16(int epilogue, const void* A_bf16, const void* B_bf16, void* out, int M, int N, int K,
+                   const float* bias, const float* scale, const float* resid, const float* pos,
+                   int tokens_per_image, int variant, void* stream);
+
+/* nn.LayerNorm over the last dim (modeling_dinov2.py:348,353,365,373,441; dino.py:127,131,184):
+ * x f32 [rows,D] -> y bf16 [rows,D] (or f32 when out_f32 != 0).  D % 128 == 0. */
+int ucod_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int D, float eps,
+                   int out_f32, void* stream);
+
+/* softmax(Q K^T * scale) V per (image, head), head_dim 64 (modeling_dinov2.py:153-179; dino.py:113-117).
+ * qkv bf16 [B*tok, 3*heads*64] rows = [q | k | v], heads contiguous; out bf16 [B*tok, heads*64].
+ * variant: 0 = V consumed through ds_read_b64_tr_b16, 1 = V transposed while staging. */
+int ucod_attention_fwd(const void* qkv_bf16, void* out_bf16, int B, int tok, int heads, float scale, int variant,
+                       void* stream);
+
+/* patch gather: img f32 [B,C,H,W] -> bf16 rows [B*(H/P)*(W/P), Kpad], k = c*P*P + py*P + px, zero padded
+ * (the im2col view of the stride-P conv, modeling_dinov2.py:139-149 / dino.py:154-158).  Kpad % 64 == 0. */
+int ucod_patch_im2col(const float* img, void* patches_bf16, int B, int C, int H, int W, int P, int Kpad, void* stream);
+
+/* x f32 [B*tok, D]: row b*tok = cls + pos[0]  (modeling_dinov2.py:107-112; dino.py:227-232) */
+int ucod_cls_rows(float* x, const float* cls, const float* pos, int B, int tok, int D, void* stream);
+
+/* f32 -> bf16 cast of n elements (weight preparation) */
+int ucod_cast_f32_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
+
+/* Whole frozen backbone forward up to the last layer's key projection: one call enqueues every kernel.
+ * Pointer table (HOST array of DEVICE pointers; "w" entries are bf16 [out,in], the rest f32):
+ *   [0] patch_w bf16 [D,Kpad] (zero padded k)  [1] patch_b [D]  [2] cls [D]  [3] pos [tok,D] (already interpolated)
+ *   layer l at base = 4 + UCOD_VIT_LAYER_STRIDE*l:
+ *     +0 ln1_g  +1 ln1_b  +2 qkv_w bf16 [3D,D] (rows q|k|v)  +3 qkv_b [3D]  +4 proj_w bf16 [D,D]  +5 proj_b
+ *     +6 ls1 [D] (LayerScale lambda1; ones for DINOv1)  +7 ln2_g  +8 ln2_b  +9 fc1_w bf16 [F,D]  +10 fc1_b [F]
+ *     +11 fc2_w bf16 [D,F]  +12 fc2_b [D]  +13 ls2 [D]
+ * The last layer uses only ln1 and the K slice (rows D..2D-1) of qkv_w / qkv_b: that projection, bias included and
+ * before the head split, is what the reference's forward hook captures (feature_extractor.py:42,46-47).
+ * key_out f32 [B, D, H/P, W/P].  full_last_layer != 0 additionally runs the rest of the last layer exactly as the
+ * reference does (its output is discarded there too); key_out is identical either way. */
+#define UCOD_VIT_LAYER_STRIDE 14
+typedef struct {
+  int B, C, H, W, P;      /* images */
+  int D, heads, F, L;     /* width, heads (head_dim = D/heads = 64), MLP width, layers */
+  int Kpad;               /* padded C*P*P */
+  float eps;              /* LayerNorm eps (1e-6 for DINOv2 / DINO) */
+  int full_last_layer;
+  int gemm_variant, attn_variant;
+} ucod_vit_desc;
+size_t ucod_vit_workspace_bytes(const ucod_vit_desc* d);
+int ucod_vit_forward(const ucod_vit_desc* d, const void* const* table_host, const float* img, float* key_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ decoder / APM path (rows A1-A8) */
+
+/* F.interpolate(mode='bilinear', align_corners=False) on `planes` independent [ih,iw] maps
+ * (engine/runner/loop_UCOD_DPL.py:153-154,236,241,305,315,356-358). */
+int ucod_bilinear_resize(const float* in, float* out, int planes, int ih, int iw, int oh, int ow, void* stream);
+
+/* 1x1 "decoupling" conv as an exact-f32 MFMA GEMM (models/modules/DBA.py:13,35):
+ * d[b][n][p] = sum_c W[n][c]*x[b][c][p] + bias[n];  x [B,C,HW], W [Nout,C], d [B,Nout,HW].
+ * Nout = 128 (one decoder) or 256 (student rows 0..127 | teacher rows 128..255 sharing the x read). */
+int ucod_dba_project(const float* x, const float* W, const float* bias, float* d, int B, int C, int HW, int Nout,
+                     void* stream);
+
+/* L2 norm over the PIXEL axis of (d * emb) per (image, channel), clamped at 1e-12
+ * (F.normalize(dim=1) on [B,HW,64], DBA.py:40-41).  d is a [B, ld_c, HW] buffer, channels c0..c0+127 used;
+ * emb [2,64] -> channel c scales by emb[c/64][c%64].  norm out [B,128]. */
+int ucod_dba_colnorm(const float* d, int ld_c, int c0, const float* emb, float* norm, int B, int HW, void* stream);
+
+/* gate + heads (DBA.py:48-52): a = sigmoid(f*d)+d, fg = w_fg.a1 + b_fg, bg = w_bg.a2 + b_bg, f = d*emb/norm.
+ * head_w [2,64] = (conv_out_fg.weight, conv_out_bg.weight), head_b [2].  fg,bg [B,HW] (bg may be NULL).
+ * sdiag (may be NULL) [B] receives sum_p (f1_p . f2_p)^2, the diagonal term of the orthogonality loss. */
+int ucod_dba_heads_fwd(const float* d, int ld_c, int c0, const float* emb, const float* norm, const float* head_w,
+                       const float* head_b, float* fg, float* bg, float* sdiag, int B, int HW, void* stream);
+
+/* Orthogonality loss in Gram form (DBA.py:25-29 rewritten):
+ * gram [B,2,64,64] (G1,G2 of the normalised features), sdiag [B] = sum_i (f1_i.f2_i)^2 from ucod_dba_heads_fwd,
+ * loss[0] = (sum_b tr(G1 G2) - sum_b sdiag[b]) / (B*HW*HW).  ws: ucod_orth_workspace_bytes. */
+size_t ucod_orth_workspace_bytes(int B, int HW);
+int ucod_orth_gram_fwd(const float* d, int ld_c, int c0, const float* emb, const float* norm, const float* sdiag,
+                       float* gram, float* loss, void* ws, int B, int HW, void* stream);
+
+/* Backward of heads + gate + HW-axis normalisation + Gram orthogonality loss w.r.t. d (closed form,
+ * SURVEY.md section 7).  gfg,gbg [B,HW] upstream logit grads, gextra = dL/d(extra_loss).
+ * Outputs: gd [B,128,HW]; g_head_w [2,64], g_head_b [2], g_dec_bias [128] (each zeroed inside, then accumulated).
+ * The gradient of learnable_embedding is analytically zero (its scale cancels under the HW-axis normalisation;
+ * the reference's autograd value is f32 cancellation noise) and is not produced. */
+size_t ucod_dba_bwd_workspace_bytes(int B, int HW);
+int ucod_dba_bwd(const float* d, int ld_c, int c0, const float* emb, const float* norm, const float* head_w,
+                 const float* gram, const float* gfg, const float* gbg, float gextra, float* gd, float* g_head_w,
+                 float* g_head_b, float* g_dec_bias, void* ws, int B, int HW, void* stream);
+
+/* weight gradient of the decoupling conv: gW[n][c] += sum_{b,p} gd[b][n][p]*x[b][c][p]  (f32 MFMA, split-K
+ * over (b, pixel chunks) with f32 atomics into gW [128,C], which is zeroed inside first). */
+int ucod_dba_wgrad(const float* gd, const float* x, float* gW, int B, int C, int HW, void* stream);
+
+/* APM discriminator forward, always train-mode BatchNorm (models/discriminator.py:60-70,86-95;
+ * dis_use_features=False).  params (f32, reference state_dict order):
+ *   w1 [32,1,3,3] g1 b1 [32]  w2 [16,32,3,3] g2 b2 [16]  w3 [8,16,3,3] g3 b3 [8]  lin_w [8*ceil(fs/4)^2] lin_b [1]
+ * running = (rm1,rv1,rm2,rv2,rm3,rv3) updated in place with momentum 0.1 when update_running != 0.
+ * mask [B,1,fs,fs] -> prob [B].  `saved` (ucod_disc_saved_bytes) keeps pre-BN activations + batch statistics
+ * for ucod_disc_bwd. */
+typedef struct {
+  const float *w1, *g1, *b1, *w2, *g2, *b2, *w3, *g3, *b3, *lin_w, *lin_b;
+  float *rm1, *rv1, *rm2, *rv2, *rm3, *rv3;
+} ucod_disc_params;
+size_t ucod_disc_saved_bytes(int B, int fs);
+int ucod_disc_fwd(const float* mask, const ucod_disc_params* p_host, float* prob, void* saved, int B, int fs,
+                  int update_running, void* stream);
+/* APM fusion + both BCE-with-logits losses + their logit gradients in one pass
+ * (engine/runner/loop_UCOD_DPL.py:257-272 and :161-173):
+ *   w[b] = clamp(0.5*(1+cos(pi*|p_s-p_p|)) + epoch_frac, 0, 1);  merged = pl*(1-w) + (sigmoid(teacher)>0.5)*w
+ *   losses[0] = mean BCEWithLogits(fg, merged), losses[1] = mean BCEWithLogits(bg, 1-merged),
+ *   losses[2] = dis_loss = mean BCE(p_s, 0);  gfg = (sigmoid(fg)-merged)/(B*HW)*gscale, gbg likewise.
+ * pl, teacher, fg, bg, merged, gfg, gbg: [B,HW]; p_s, p_p, w: [B].  losses [4] (zeroed inside; [3] unused). */
+int ucod_apm_bce(const float* pl, const float* teacher, const float* fg, const float* bg, const float* p_s,
+                 const float* p_p, float epoch_frac, float gscale, float* w, float* merged, float* gfg, float* gbg,
+                 float* losses, int B, int HW, void* stream);
+/* out[i] = (sigmoid(x[i]) > 0.5) when logits != 0, else (x[i] > 0.5), as 0/1 floats (loop_UCOD_DPL.py:240-241,258-261) */
+int ucod_binarize(const float* x, float* out, size_t n, int logits, void* stream);
+
+/* torch.optim.AdamW step + EMA teacher update over a flat f32 arena
+ * (engine/runner/runner.py:282-298; loop_UCOD_DPL.py:178,186-191).  ema may be NULL. */
+int ucod_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float ema_alpha, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,215 @@
+// Fused multi-head attention forward for the ViT backbone, head_dim 64, no mask, no dropout
+// (transformers modeling_dinov2.py:153-179 eager_attention_forward; models/backbones/dino.py:113-117).
+//
+// gfx950 structure (wave64, v_mfma_f32_32x32x16_bf16):
+//   * one workgroup = 4 waves = 128 query rows of one (image, head); each wave owns 32 query rows;
+//   * scores are computed TRANSPOSED, S^T = K Q^T, so a lane holds one query column: the online-softmax
+//     running max / sum and the O rescale are lane-local (one cross-half exchange with lane^32);
+//   * the S^T accumulator registers are converted to bf16 in place and fed as the B operand of
+//     O^T += V^T P^T (accumulator-as-operand: no LDS round trip for P);
+//   * K and V tiles (64 keys) are staged through LDS once per workgroup with register prefetch of the
+//     next tile (issue-early / write-late), double buffered, one barrier per tile; K is XOR-swizzled for
+//     conflict-free ds_read_b128, V is consumed through ds_read_b64_tr_b16 (hardware transpose).
+//   * N (=1370 tokens) is not a tile multiple: out-of-range keys are clamped on load and masked to -inf.
+#include "common.h"
+#include "../../include/ucod_dpl.h"
+
+namespace ucod {
+
+constexpr int HD = 64;        // head dim
+constexpr int QT = 128;       // query rows per workgroup
+constexpr int KT = 64;        // keys per tile
+constexpr int KV_BYTES = KT * HD * 2;  // 8 KiB
+constexpr int VT_STRIDE = 72;          // bf16 elements per row of the explicit-transpose V image (VMODE 1)
+constexpr int VT_BYTES = HD * VT_STRIDE * 2;
+
+__device__ __forceinline__ int swz_k(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+__device__ __forceinline__ int swz_v(int row, int chunk) { return chunk ^ (((row >> 1) & 1) << 2); }
+
+template <int VMODE>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N,
+                                                       int heads, float c /* scale*log2(e) */) {
+  constexpr int VB = (VMODE == 0) ? KV_BYTES : VT_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (KV_BYTES + VB)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h5 = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int D = heads * HD, ld = 3 * D;
+  const int q0 = blockIdx.x * QT + wave * 32;
+  const bf16_raw* base = qkv + (size_t)b * N * ld + head * HD;
+
+  // Q^T B-operand fragments: lane (q = l31, half h5) holds Q[q][16s + 8*h5 .. +7]
+  bf16x8 qf[4];
+  {
+    int qr = q0 + l31;
+    qr = qr < N ? qr : N - 1;
+    const bf16_raw* qp = base + (size_t)qr * ld + 8 * h5;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int nt = (N + KT - 1) / KT;
+  u32x4 rk[2], rv[2];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
+      int kr = t * KT + row;
+      kr = kr < N ? kr : N - 1;
+      const bf16_raw* p = base + (size_t)kr * ld + ch * 8;
+      rk[i] = *reinterpret_cast<const u32x4*>(p + D);
+      rv[i] = *reinterpret_cast<const u32x4*>(p + 2 * D);
+    }
+  };
+  auto lwrite = [&](int buf) {
+    char* kb = smem + buf * (KV_BYTES + VB);
+    char* vb = kb + KV_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
+      *reinterpret_cast<u32x4*>(kb + row * 128 + swz_k(row, ch) * 16) = rk[i];
+      if constexpr (VMODE == 0) {
+        *reinterpret_cast<u32x4*>(vb + row * 128 + swz_v(row, ch) * 16) = rv[i];
+      } else {
+        bf16_raw* vt = reinterpret_cast<bf16_raw*>(vb);
+        const unsigned w[4] = {rv[i][0], rv[i][1], rv[i][2], rv[i][3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bf16_raw val = (bf16_raw)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+          vt[(ch * 8 + e) * VT_STRIDE + row] = val;
+        }
+      }
+    }
+  };
+
+  gload(0);
+  lwrite(0);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    const bool more = (t + 1 < nt);
+    if (more) gload(t + 1);
+    const char* kb = smem + (t & 1) * (KV_BYTES + VB);
+    const char* vb = kb + KV_BYTES;
+
+    // ---- S^T = K Q^T  (keys on rows/registers, queries on lanes)
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
+      const int row = kt * 32 + l31;
+#pragma unroll
+      for (int sd = 0; sd < 4; ++sd) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + row * 128 + swz_k(row, 2 * sd + h5) * 16);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sd], s[kt], 0, 0, 0);
+      }
+    }
+    if (t == nt - 1) {  // wave-uniform: mask keys >= N
+      const int kbase = t * KT + 4 * h5;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + kt * 32 + (r & 3) + 8 * (r >> 2);
+          if (key >= N) s[kt][r] = -1e30f;
+        }
+    }
+
+    // ---- online softmax (per query = per lane; the other 32 keys of this query live in lane^32)
+    float mloc = s[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[1][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    const float mc = m_new * c;
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pb[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][8 * ks + j], c, -mc));
+          psum += p;
+          pb[kt][ks][j] = (__bf16)p;
+        }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+
+    // ---- O^T += V^T P^T : A = V^T fragment, element j of half h5 <-> key 16ks + 8(j>>2) + 4*h5 + (j&3)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int key0 = kt * 32 + ks * 16 + 4 * h5;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          bf16x8 vf;
+          if constexpr (VMODE == 0) {
+            // ds_read_b64_tr_b16: lane i of each 16-lane group addresses row (i>>2), columns 4*(i&3)..+3 of a
+            // 4 x 16 block and receives column i of the 4 rows.
+            const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+            const int key = key0 + (i16 >> 2);
+            const int dst = dt * 32 + g1 * 16 + 4 * (i16 & 3);  // first d column this lane addresses
+            const int ch = dst >> 3, sub = (dst & 7) * 2;
+            const char* p0 = vb + key * 128 + swz_v(key, ch) * 16 + sub;
+            const char* p1 = vb + (key + 8) * 128 + swz_v(key + 8, ch) * 16 + sub;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
+            vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          } else {
+            const bf16_raw* vt = reinterpret_cast<const bf16_raw*>(vb) + (dt * 32 + l31) * VT_STRIDE + key0;
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vt);
+            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vt + 8);
+            vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kt][ks], o[dt], 0, 0, 0);
+        }
+      }
+
+    if (more) lwrite((t + 1) & 1);
+  }
+
+  // ---- normalise and store: lane = query, registers = d (row map of the 32x32 accumulator)
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + l31;
+  if (q < N) {
+    bf16_raw* op = out + ((size_t)b * N + q) * D + head * HD + 4 * h5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w;
+        w[0] = pack_bf16x2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+        w[1] = pack_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
+      }
+  }
+}
+
+}  // namespace ucod
+
+extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, int heads, float scale, int variant, void* stream) {
+  using namespace ucod;
+  if (!qkv || !out || B <= 0 || tok <= 0 || heads <= 0) return UCOD_EINVAL;
+  dim3 grid(cdiv(tok, QT), heads, B), block(256);
+  const float c = scale * 1.4426950408889634f;
+  if (variant == 1)
+    hipLaunchKernelGGL((attn_fwd_kernel<1>), grid, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, c);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<0>), grid, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, c);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}

@@ -1,0 +1,336 @@
+// DBA decoder tail (models/modules/DBA.py:36-52): per-channel scale, L2 normalisation over the PIXEL axis,
+// sigmoid gate + residual, the two 64->1 heads; the orthogonality loss (DBA.py:25-29) in its exact Gram form
+// (no [B,HW,HW] tensor: SURVEY.md 8a row A3); and the closed-form backward of all of it w.r.t. the
+// decoupled features d (SURVEY.md section 7 "hard parts").
+//
+// d is addressed as a [B, ld_c, HW] f32 buffer of which channels c0..c0+127 belong to this decoder
+// (branch 1 = c0..c0+63, branch 2 = c0+64..c0+127), so the student and the EMA teacher can share one
+// 256-row projection.  All kernels stream d with pixel-contiguous (coalesced) accesses.
+#include "common.h"
+#include "../../include/ucod_dpl.h"
+
+namespace ucod {
+
+constexpr int E = 64;
+constexpr float NORM_EPS = 1e-12f;
+
+// ---------------------------------------------------------------------------------- column norms
+__global__ __launch_bounds__(256) void colnorm_kernel(const float* __restrict__ d, int ld_c, int c0, const float* __restrict__ emb,
+                                                      float* __restrict__ norm, int HW) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float e = emb[c];  // emb [2,64] flattened == channel index within this decoder
+  const float* row = d + ((long)b * ld_c + c0 + c) * HW;
+  float s = 0.f;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const float u = row[p] * e;
+    s = fmaf(u, u, s);
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) norm[b * 128 + c] = fmaxf(sqrtf(s), NORM_EPS);
+}
+
+// ---------------------------------------------------------------------------------- gate + heads (+ sdiag)
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ d, int ld_c, int c0, const float* __restrict__ emb,
+                                                        const float* __restrict__ norm, const float* __restrict__ head_w,
+                                                        const float* __restrict__ head_b, float* __restrict__ fg,
+                                                        float* __restrict__ bg, float* __restrict__ sdiag, int HW) {
+  __shared__ float kf[128], hw[128];
+  __shared__ float red[16];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (tid < 128) {
+    kf[tid] = emb[tid] / norm[b * 128 + tid];
+    hw[tid] = head_w[tid];
+  }
+  __syncthreads();
+  const int p = blockIdx.x * 256 + tid;
+  float s2 = 0.f;
+  if (p < HW) {
+    const float* dp = d + ((long)b * ld_c + c0) * HW + p;
+    float accf = head_b[0], accb = head_b[1], s = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < E; ++c) {
+      const float d1 = dp[(long)c * HW], d2 = dp[(long)(c + E) * HW];
+      const float f1 = d1 * kf[c], f2 = d2 * kf[c + E];
+      accf = fmaf(hw[c], sigmoid_acc(f1 * d1) + d1, accf);
+      accb = fmaf(hw[c + E], sigmoid_acc(f2 * d2) + d2, accb);
+      s = fmaf(f1, f2, s);
+    }
+    fg[(long)b * HW + p] = accf;
+    if (bg) bg[(long)b * HW + p] = accb;
+    s2 = s * s;
+  }
+  if (sdiag) {  // uniform branch
+    s2 = block_sum(s2, red);
+    if (tid == 0) atomicAdd(&sdiag[b], s2);
+  }
+}
+
+// ---------------------------------------------------------------------------------- Gram matrices (f32 MFMA)
+// grid (S pixel chunks, B); partial[b][s][branch][64][64] = sum over the chunk of f f^T.
+constexpr int GCH = 512;   // pixels per workgroup
+constexpr int GK = 16;     // pixels per K-tile
+constexpr int GLD = 129;
+__global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ d, int ld_c, int c0,
+                                                           const float* __restrict__ emb, const float* __restrict__ norm,
+                                                           float* __restrict__ partial, int HW, int S) {
+  __shared__ float Fs[2][GK * GLD];
+  __shared__ float kf[128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, ps = blockIdx.x * GCH, pe = min(ps + GCH, HW);
+  if (tid < 128) kf[tid] = emb[tid] / norm[b * 128 + tid];
+  __syncthreads();
+  const float* dbase = d + ((long)b * ld_c + c0) * HW;
+  const int sk = tid & 15, srow = tid >> 4;  // staging: 16 lanes = 64 contiguous bytes of one channel row
+  const int br = wave >> 1, rt = wave & 1;   // wave -> (branch, row tile); both column tiles
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+
+  float r[8];
+  auto gload = [&](int k0) {
+    const int k = k0 + sk;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = srow + 16 * i;
+      r[i] = (k < pe) ? dbase[(long)row * HW + k] * kf[row] : 0.f;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Fs[buf][sk * GLD + srow + 16 * i] = r[i];
+  };
+  const int nt = (pe - ps + GK - 1) / GK;
+  gload(ps);
+  lstore(0);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    const bool more = t + 1 < nt;
+    if (more) gload(ps + (t + 1) * GK);
+    const float* fs = Fs[t & 1];
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 2) {
+      const int k = kk + (lane >> 5);
+      const float a = fs[k * GLD + br * 64 + rt * 32 + (lane & 31)];
+      const float b0 = fs[k * GLD + br * 64 + (lane & 31)];
+      const float b1 = fs[k * GLD + br * 64 + 32 + (lane & 31)];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+    }
+    if (more) lstore((t + 1) & 1);
+  }
+  float* out = partial + (((long)b * S + blockIdx.x) * 2 + br) * (E * E);
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int i = rt * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+      const int j = ct * 32 + (lane & 31);
+      out[i * E + j] = acc[ct][rg];
+    }
+}
+
+// grid (B): gram[b] = sum_s partial[b][s]; trace[b] = sum_ij G1_ij G2_ij (= tr(G1 G2), both symmetric)
+__global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restrict__ partial, float* __restrict__ gram,
+                                                            float* __restrict__ trace, int S) {
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  float tr = 0.f;
+  for (int i = threadIdx.x; i < E * E; i += 256) {
+    float g1 = 0.f, g2 = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float* p = partial + (((long)b * S + s) * 2) * (E * E);
+      g1 += p[i];
+      g2 += p[E * E + i];
+    }
+    gram[((long)b * 2 + 0) * (E * E) + i] = g1;
+    gram[((long)b * 2 + 1) * (E * E) + i] = g2;
+    tr = fmaf(g1, g2, tr);
+  }
+  tr = block_sum(tr, red);
+  if (threadIdx.x == 0) trace[b] = tr;
+}
+
+__global__ void orth_loss_kernel(const float* __restrict__ trace, const float* __restrict__ sdiag, float* __restrict__ loss, int B,
+                                 double inv_z) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double t = 0.0;
+    for (int b = 0; b < B; ++b) t += (double)trace[b] - (double)sdiag[b];
+    loss[0] = (float)(t * inv_z);
+  }
+}
+
+// ---------------------------------------------------------------------------------- backward, pass A
+// thread = pixel.  gfeat[b][c][p] = dL/df = orth term + gate term, for both branches.
+__global__ __launch_bounds__(256) void dba_bwd_a_kernel(const float* __restrict__ d, int ld_c, int c0, const float* __restrict__ emb,
+                                                        const float* __restrict__ norm, const float* __restrict__ head_w,
+                                                        const float* __restrict__ gram, const float* __restrict__ gfg,
+                                                        const float* __restrict__ gbg, float coef /* 2*gextra/Z */,
+                                                        float* __restrict__ gfeat, int HW) {
+  __shared__ __attribute__((aligned(16))) float G[2][E * E];
+  __shared__ float kf[128], hw[128];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  for (int i = tid; i < 2 * E * E; i += 256) (&G[0][0])[i] = gram[(long)b * 2 * E * E + i];
+  if (tid < 128) {
+    kf[tid] = emb[tid] / norm[b * 128 + tid];
+    hw[tid] = head_w[tid];
+  }
+  __syncthreads();
+  const int p = blockIdx.x * 256 + tid;
+  if (p >= HW) return;
+  const float* dp = d + ((long)b * ld_c + c0) * HW + p;
+  float* gp = gfeat + (long)b * 128 * HW + p;
+  const float g1 = gfg[(long)b * HW + p], g2 = gbg[(long)b * HW + p];
+
+  float fin[E];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < E; ++c) {
+    fin[c] = dp[(long)c * HW] * kf[c];
+    s = fmaf(fin[c], dp[(long)(c + E) * HW] * kf[c + E], s);
+  }
+  // branch 1: go1 = coef * (G2 f1 - s f2)
+  for (int c = 0; c < E; ++c) {
+    const float4* grow = reinterpret_cast<const float4*>(&G[1][c * E]);
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < E / 4; ++q) {
+      const float4 g = grow[q];
+      acc = fmaf(g.x, fin[4 * q], acc);
+      acc = fmaf(g.y, fin[4 * q + 1], acc);
+      acc = fmaf(g.z, fin[4 * q + 2], acc);
+      acc = fmaf(g.w, fin[4 * q + 3], acc);
+    }
+    const float d1 = dp[(long)c * HW], f1 = d1 * kf[c];
+    const float f2 = dp[(long)(c + E) * HW] * kf[c + E];
+    const float sg = sigmoid_acc(f1 * d1);
+    gp[(long)c * HW] = coef * (acc - s * f2) + g1 * hw[c] * sg * (1.f - sg) * d1;
+  }
+  // branch 2: go2 = coef * (G1 f2 - s f1)
+#pragma unroll
+  for (int c = 0; c < E; ++c) fin[c] = dp[(long)(c + E) * HW] * kf[c + E];
+  for (int c = 0; c < E; ++c) {
+    const float4* grow = reinterpret_cast<const float4*>(&G[0][c * E]);
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < E / 4; ++q) {
+      const float4 g = grow[q];
+      acc = fmaf(g.x, fin[4 * q], acc);
+      acc = fmaf(g.y, fin[4 * q + 1], acc);
+      acc = fmaf(g.z, fin[4 * q + 2], acc);
+      acc = fmaf(g.w, fin[4 * q + 3], acc);
+    }
+    const float d2 = dp[(long)(c + E) * HW], f2 = d2 * kf[c + E];
+    const float f1 = dp[(long)c * HW] * kf[c];
+    const float sg = sigmoid_acc(f2 * d2);
+    gp[(long)(c + E) * HW] = coef * (acc - s * f1) + g2 * hw[c + E] * sg * (1.f - sg) * d2;
+  }
+}
+
+// ---------------------------------------------------------------------------------- backward, pass B
+// workgroup = one (image, channel) row: projection backward of f = u/max(||u||,eps) over the pixel axis,
+// then gd; plus the per-channel parameter-gradient reductions (atomics into `small`).
+__global__ __launch_bounds__(256) void dba_bwd_b_kernel(const float* __restrict__ d, int ld_c, int c0, const float* __restrict__ emb,
+                                                        const float* __restrict__ norm, const float* __restrict__ head_w,
+                                                        const float* __restrict__ gfg, const float* __restrict__ gbg,
+                                                        const float* __restrict__ gfeat, float* __restrict__ gd,
+                                                        float* __restrict__ g_head_w, float* __restrict__ g_head_b,
+                                                        float* __restrict__ g_dec_bias, int HW) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float e = emb[c], n = norm[b * 128 + c], k = e / n, w = head_w[c];
+  const float* drow = d + ((long)b * ld_c + c0 + c) * HW;
+  const float* grow = gfeat + ((long)b * 128 + c) * HW;
+  const float* gup = (c < E ? gfg : gbg) + (long)b * HW;
+  float* orow = gd + ((long)b * 128 + c) * HW;
+  float r = 0.f;
+  for (int p = tid; p < HW; p += 256) r = fmaf(drow[p] * k, grow[p], r);
+  r = block_sum(r, red);
+  const bool clamped = (n <= NORM_EPS);
+  float sgd = 0.f, sga = 0.f, sg_up = 0.f;
+  for (int p = tid; p < HW; p += 256) {
+    const float dv = drow[p], f = dv * k, gf = grow[p], g = gup[p];
+    const float sg = sigmoid_acc(f * dv);
+    const float gu = clamped ? gf / NORM_EPS : (gf - f * r) / n;
+    const float o = fmaf(gu, e, g * w * fmaf(sg * (1.f - sg), f, 1.f));
+    orow[p] = o;
+    sgd += o;
+    sga = fmaf(g, sg + dv, sga);
+    sg_up += g;
+  }
+  sgd = block_sum(sgd, red);
+  sga = block_sum(sga, red);
+  if (tid == 0) {
+    atomicAdd(&g_dec_bias[c], sgd);
+    atomicAdd(&g_head_w[c], sga);
+  }
+  if (c == 0 || c == E) {             // uniform per block
+    sg_up = block_sum(sg_up, red);
+    if (tid == 0) atomicAdd(&g_head_b[c == E ? 1 : 0], sg_up);
+  }
+}
+
+}  // namespace ucod
+
+using namespace ucod;
+
+extern "C" int ucod_dba_colnorm(const float* d, int ld_c, int c0, const float* emb, float* norm, int B, int HW, void* stream) {
+  if (!d || !emb || !norm || B <= 0 || HW <= 0 || c0 < 0 || c0 + 128 > ld_c) return UCOD_EINVAL;
+  hipLaunchKernelGGL(colnorm_kernel, dim3(128, B), dim3(256), 0, (hipStream_t)stream, d, ld_c, c0, emb, norm, HW);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_dba_heads_fwd(const float* d, int ld_c, int c0, const float* emb, const float* norm, const float* head_w,
+                                  const float* head_b, float* fg, float* bg, float* sdiag, int B, int HW, void* stream) {
+  if (!d || !emb || !norm || !head_w || !head_b || !fg || B <= 0 || HW <= 0 || c0 < 0 || c0 + 128 > ld_c) return UCOD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (sdiag) {
+    hipError_t e = hipMemsetAsync(sdiag, 0, sizeof(float) * B, s);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(heads_fwd_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, s, d, ld_c, c0, emb, norm, head_w, head_b, fg, bg, sdiag, HW);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" size_t ucod_orth_workspace_bytes(int B, int HW) {
+  const size_t S = (size_t)cdiv(HW, GCH);
+  return ((size_t)B * S * 2 * E * E + (size_t)B) * sizeof(float);
+}
+
+extern "C" int ucod_orth_gram_fwd(const float* d, int ld_c, int c0, const float* emb, const float* norm, const float* sdiag,
+                                  float* gram, float* loss, void* ws, int B, int HW, void* stream) {
+  if (!d || !emb || !norm || !sdiag || !gram || !loss || !ws || B <= 0 || HW <= 0 || c0 < 0 || c0 + 128 > ld_c) return UCOD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int S = cdiv(HW, GCH);
+  float* partial = (float*)ws;
+  float* trace = partial + (size_t)B * S * 2 * E * E;
+  hipLaunchKernelGGL(gram_partial_kernel, dim3(S, B), dim3(256), 0, s, d, ld_c, c0, emb, norm, partial, HW, S);
+  hipLaunchKernelGGL(gram_finalize_kernel, dim3(B), dim3(256), 0, s, partial, gram, trace, S);
+  const double inv_z = 1.0 / ((double)B * (double)HW * (double)HW);
+  hipLaunchKernelGGL(orth_loss_kernel, dim3(1), dim3(64), 0, s, trace, sdiag, loss, B, inv_z);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" size_t ucod_dba_bwd_workspace_bytes(int B, int HW) { return (size_t)B * 128 * HW * sizeof(float); }
+
+extern "C" int ucod_dba_bwd(const float* d, int ld_c, int c0, const float* emb, const float* norm, const float* head_w,
+                            const float* gram, const float* gfg, const float* gbg, float gextra, float* gd, float* g_head_w,
+                            float* g_head_b, float* g_dec_bias, void* ws, int B, int HW, void* stream) {
+  if (!d || !emb || !norm || !head_w || !gram || !gfg || !gbg || !gd || !g_head_w || !g_head_b || !g_dec_bias || !ws || B <= 0 ||
+      HW <= 0 || c0 < 0 || c0 + 128 > ld_c)
+    return UCOD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  float* gfeat = (float*)ws;
+  hipError_t e = hipMemsetAsync(g_head_w, 0, sizeof(float) * 128, s);
+  if (e == hipSuccess) e = hipMemsetAsync(g_head_b, 0, sizeof(float) * 2, s);
+  if (e == hipSuccess) e = hipMemsetAsync(g_dec_bias, 0, sizeof(float) * 128, s);
+  if (e != hipSuccess) return (int)e;
+  const float coef = (float)(2.0 * (double)gextra / ((double)B * (double)HW * (double)HW));
+  hipLaunchKernelGGL(dba_bwd_a_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, s, d, ld_c, c0, emb, norm, head_w, gram, gfg, gbg, coef, gfeat, HW);
+  hipLaunchKernelGGL(dba_bwd_b_kernel, dim3(128, B), dim3(256), 0, s, d, ld_c, c0, emb, norm, head_w, gfg, gbg, gfeat, gd, g_head_w, g_head_b, g_dec_bias, HW);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}

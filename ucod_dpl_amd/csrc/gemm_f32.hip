@@ -1,0 +1,236 @@
+// Exact-f32 MFMA GEMMs of the DBA decoder (models/modules/DBA.py:13,35 and its weight gradient).
+//
+// The decoder consumes f32 features and the parity bar is 1e-3 on the mask logits against the f32
+// reference, so these contractions use v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, bit-identical to an
+// fmaf chain; 1/16 of the bf16 MFMA rate, equal to the f32 VALU peak but with one VGPR per operand).
+//
+//   project: d[b][n][p] = sum_c W[n][c] * x[b][c][p] + bias[n]       (NCHW in, NCHW out, p contiguous)
+//   wgrad  : gW[n][c]  += sum_{b,p} gd[b][n][p] * x[b][c][p]          (split-K over (b, pixel chunk), f32 atomics)
+//
+// LDS images are [k][row] so that both MFMA operand reads (lane -> row, half-wave -> k) are conflict-free
+// ds_read_b32; K-contiguous operands are transposed while staging (global float4 along k -> 4 scalar LDS
+// writes with lanes on consecutive rows).  Next tile is prefetched into registers during the MFMAs.
+#include "common.h"
+#include "../../include/ucod_dpl.h"
+
+namespace ucod {
+
+constexpr int FK = 16;   // K-tile
+constexpr int LDP = 132; // row length of the [k][row] LDS images
+
+// rows x FK tile of a K-contiguous matrix (row stride ld) -> registers.  128 rows x 4 float4; lanes run along k
+// first (4 lanes = 64 contiguous bytes of one row), 2 float4 per thread.
+template <bool VEC>
+__device__ __forceinline__ void load_kcontig(const float* __restrict__ G, long ld, int row0, int nrows, int k0, int kend, int tid,
+                                             float4 (&r)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i, row = idx >> 2;
+    const int k = k0 + 4 * (idx & 3);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + row < nrows) {
+      const float* p = G + (long)(row0 + row) * ld + k;
+      if (VEC && k + 3 < kend) {
+        v = *reinterpret_cast<const float4*>(p);
+      } else {
+        if (k + 0 < kend) v.x = p[0];
+        if (k + 1 < kend) v.y = p[1];
+        if (k + 2 < kend) v.z = p[2];
+        if (k + 3 < kend) v.w = p[3];
+      }
+    }
+    r[i] = v;
+  }
+}
+// transposed store into a [k][row] image with row length LD = 132: writes are at most 2-way conflicted
+// (free for ds_write_b32), operand reads (lanes on consecutive rows) are conflict-free.
+template <int LD>
+__device__ __forceinline__ void store_kcontig(float* lds, int tid, const float4 (&r)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i, row = idx >> 2, k = 4 * (idx & 3);
+    lds[(k + 0) * LD + row] = r[i].x;
+    lds[(k + 1) * LD + row] = r[i].y;
+    lds[(k + 2) * LD + row] = r[i].z;
+    lds[(k + 3) * LD + row] = r[i].w;
+  }
+}
+
+// ------------------------------------------------------------------------------------------- project
+// block: 128 output channels x 64 pixels, K-tile 16 input channels; 4 waves, wave w -> channels 32w..32w+31
+template <bool VEC>
+__global__ __launch_bounds__(256) void dba_project_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ d, int C, int HW,
+                                                          int Nout) {
+  __shared__ float Ws[2][FK * LDP];
+  __shared__ float Xs[2][FK * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p0 = blockIdx.x * 64, n0 = blockIdx.y * 128, b = blockIdx.z;
+  const float* xb = x + (long)b * C * HW;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+
+  float4 rw[2];
+  float4 rx;
+  auto load_x = [&](int c0) {
+    if constexpr (VEC) {
+      const int k = tid >> 4, p = p0 + 4 * (tid & 15);
+      rx = (p < HW) ? *reinterpret_cast<const float4*>(xb + (long)(c0 + k) * HW + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      const int p = p0 + (tid & 63);
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = (tid >> 6) + 4 * i;
+        v[i] = (p < HW) ? xb[(long)(c0 + k) * HW + p] : 0.f;
+      }
+      rx = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto store_x = [&](int buf) {
+    if constexpr (VEC) {
+      *reinterpret_cast<float4*>(&Xs[buf][(tid >> 4) * 64 + 4 * (tid & 15)]) = rx;
+    } else {
+      const float v[4] = {rx.x, rx.y, rx.z, rx.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Xs[buf][((tid >> 6) + 4 * i) * 64 + (tid & 63)] = v[i];
+    }
+  };
+
+  const int nt = C / FK;
+  load_kcontig<true>(W, C, n0, Nout, 0, C, tid, rw);
+  load_x(0);
+  store_kcontig<LDP>(Ws[0], tid, rw);
+  store_x(0);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    const bool more = t + 1 < nt;
+    if (more) {
+      load_kcontig<true>(W, C, n0, Nout, (t + 1) * FK, C, tid, rw);
+      load_x((t + 1) * FK);
+    }
+    const float* ws = Ws[t & 1];
+    const float* xs = Xs[t & 1];
+#pragma unroll
+    for (int kk = 0; kk < FK; kk += 2) {
+      const int k = kk + (lane >> 5);
+      const float a = ws[k * LDP + wave * 32 + (lane & 31)];
+      const float b0 = xs[k * 64 + (lane & 31)];
+      const float b1 = xs[k * 64 + 32 + (lane & 31)];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+    }
+    if (more) {
+      store_kcontig<LDP>(Ws[(t + 1) & 1], tid, rw);
+      store_x((t + 1) & 1);
+    }
+  }
+  // C/D map of the 32x32 accumulator: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
+  float* db = d + (long)b * Nout * HW;
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const int p = p0 + pt * 32 + (lane & 31);
+    if (p >= HW) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (n < Nout) db[(long)n * HW + p] = acc[pt][r] + bias[n];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- wgrad
+// block: 128 (n) x 128 (c) output tile, reduction over one pixel chunk of one image; waves 2x2, 64x64 each
+constexpr int WG_CHUNK = 1024;
+template <bool VEC>
+__global__ __launch_bounds__(256) void dba_wgrad_kernel(const float* __restrict__ gd, const float* __restrict__ x,
+                                                        float* __restrict__ gW, int C, int HW) {
+  __shared__ float As[2][FK * LDP];
+  __shared__ float Bs[2][FK * LDP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int c0 = blockIdx.x * 128, b = blockIdx.z;
+  const int ps = blockIdx.y * WG_CHUNK;
+  const int pe = min(ps + WG_CHUNK, HW);
+  const float* gdb = gd + (long)b * 128 * HW;
+  const float* xb = x + (long)b * C * HW;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc[0][0][i] = 0.f; acc[0][1][i] = 0.f; acc[1][0][i] = 0.f; acc[1][1][i] = 0.f; }
+
+  float4 ra[2], rb[2];
+  const int nt = (pe - ps + FK - 1) / FK;
+  load_kcontig<VEC>(gdb, HW, 0, 128, ps, pe, tid, ra);
+  load_kcontig<VEC>(xb, HW, c0, C, ps, pe, tid, rb);
+  store_kcontig<LDP>(As[0], tid, ra);
+  store_kcontig<LDP>(Bs[0], tid, rb);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    const bool more = t + 1 < nt;
+    if (more) {
+      load_kcontig<VEC>(gdb, HW, 0, 128, ps + (t + 1) * FK, pe, tid, ra);
+      load_kcontig<VEC>(xb, HW, c0, C, ps + (t + 1) * FK, pe, tid, rb);
+    }
+    const float* as = As[t & 1];
+    const float* bs = Bs[t & 1];
+#pragma unroll
+    for (int kk = 0; kk < FK; kk += 2) {
+      const int k = kk + (lane >> 5);
+      const float a0 = as[k * LDP + wr * 64 + (lane & 31)];
+      const float a1 = as[k * LDP + wr * 64 + 32 + (lane & 31)];
+      const float b0 = bs[k * LDP + wc * 64 + (lane & 31)];
+      const float b1 = bs[k * LDP + wc * 64 + 32 + (lane & 31)];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) {
+      store_kcontig<LDP>(As[(t + 1) & 1], tid, ra);
+      store_kcontig<LDP>(Bs[(t + 1) & 1], tid, rb);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + wc * 64 + j * 32 + (lane & 31);
+      if (c >= C) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        atomicAdd(&gW[(long)n * C + c], acc[i][j][r]);
+      }
+    }
+}
+
+}  // namespace ucod
+
+extern "C" int ucod_dba_project(const float* x, const float* W, const float* bias, float* d, int B, int C, int HW, int Nout,
+                                void* stream) {
+  using namespace ucod;
+  if (!x || !W || !bias || !d || B <= 0 || C <= 0 || HW <= 0 || Nout <= 0 || (C % FK) != 0 || (((uintptr_t)W) % 16) != 0) return UCOD_EINVAL;
+  dim3 grid(cdiv(HW, 64), cdiv(Nout, 128), B), block(256);
+  if ((HW % 4) == 0 && (((uintptr_t)x) % 16) == 0)
+    hipLaunchKernelGGL((dba_project_kernel<true>), grid, block, 0, (hipStream_t)stream, x, W, bias, d, C, HW, Nout);
+  else
+    hipLaunchKernelGGL((dba_project_kernel<false>), grid, block, 0, (hipStream_t)stream, x, W, bias, d, C, HW, Nout);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_dba_wgrad(const float* gd, const float* x, float* gW, int B, int C, int HW, void* stream) {
+  using namespace ucod;
+  if (!gd || !x || !gW || B <= 0 || C <= 0 || HW <= 0) return UCOD_EINVAL;
+  dim3 grid(cdiv(C, 128), cdiv(HW, WG_CHUNK), B), block(256);
+  hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * 128 * (size_t)C, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if ((HW % 4) == 0 && (((uintptr_t)x) % 16) == 0 && (((uintptr_t)gd) % 16) == 0)
+    hipLaunchKernelGGL((dba_wgrad_kernel<true>), grid, block, 0, (hipStream_t)stream, gd, x, gW, C, HW);
+  else
+    hipLaunchKernelGGL((dba_wgrad_kernel<false>), grid, block, 0, (hipStream_t)stream, gd, x, gW, C, HW);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}

@@ -1,0 +1,90 @@
+// Host-side driver of the frozen ViT backbone forward (data/utils/feature_extractor.py:49-59 ->
+// transformers Dinov2Model / models/backbones/dino.py): one C call enqueues every kernel of the pass on the
+// caller's stream, from the NCHW image to the [B,C,h,w] last-layer key map.  No allocation, no sync: it can be
+// captured into a hipGraph by the caller.
+#include "common.h"
+#include "../../include/ucod_dpl.h"
+
+namespace {
+
+struct Plan {
+  size_t off_x, off_h, off_qkv, off_a, off_g, off_patch, total;
+  int M, tok;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+Plan make_plan(const ucod_vit_desc* d) {
+  Plan p;
+  const int gh = d->H / d->P, gw = d->W / d->P;
+  p.tok = gh * gw + 1;
+  p.M = d->B * p.tok;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+  p.off_x = take((size_t)p.M * d->D * 4);
+  p.off_h = take((size_t)p.M * d->D * 2);
+  p.off_qkv = take((size_t)p.M * 3 * d->D * 2);
+  p.off_a = take((size_t)p.M * d->D * 2);
+  p.off_g = take((size_t)p.M * d->F * 2);
+  p.off_patch = take((size_t)d->B * gh * gw * d->Kpad * 2);
+  p.total = o;
+  return p;
+}
+
+bool valid(const ucod_vit_desc* d) {
+  return d && d->B > 0 && d->C > 0 && d->P > 0 && d->H > 0 && d->W > 0 && d->H % d->P == 0 && d->W % d->P == 0 && d->D > 0 &&
+         d->heads > 0 && d->D == d->heads * 64 && d->D % 128 == 0 && d->F % 128 == 0 && d->L >= 1 && d->Kpad % 64 == 0 &&
+         d->Kpad >= d->C * d->P * d->P;
+}
+
+}  // namespace
+
+#define RUN(call)                \
+  do {                           \
+    int rc__ = (call);           \
+    if (rc__ != 0) return rc__;  \
+  } while (0)
+
+extern "C" size_t ucod_vit_workspace_bytes(const ucod_vit_desc* d) { return valid(d) ? make_plan(d).total : 0; }
+
+extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, const float* img, float* key_out, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  if (!valid(d) || !T || !img || !key_out || !workspace) return UCOD_EINVAL;
+  const Plan p = make_plan(d);
+  if (workspace_bytes < p.total) return UCOD_ENOMEM;
+  char* ws = (char*)workspace;
+  float* x = (float*)(ws + p.off_x);
+  void* h = ws + p.off_h;
+  void* qkv = ws + p.off_qkv;
+  void* a = ws + p.off_a;
+  void* g = ws + p.off_g;
+  void* patches = ws + p.off_patch;
+  const int M = p.M, tok = p.tok, D = d->D, F = d->F, gv = d->gemm_variant, av = d->attn_variant;
+  const float scale = 0.125f;  // head_dim^-0.5, head_dim = 64
+
+  // embeddings: patch conv as GEMM (+bias +pos), CLS rows
+  RUN(ucod_patch_im2col(img, patches, d->B, d->C, d->H, d->W, d->P, d->Kpad, stream));
+  RUN(ucod_gemm_bf16(UCOD_EPI_PATCH_TOKENS_F32, patches, T[0], x, d->B * (tok - 1), D, d->Kpad, (const float*)T[1], nullptr, nullptr,
+                     (const float*)T[3], tok, gv, stream));
+  RUN(ucod_cls_rows(x, (const float*)T[2], (const float*)T[3], d->B, tok, D, stream));
+
+  for (int l = 0; l < d->L; ++l) {
+    const void* const* W = T + 4 + UCOD_VIT_LAYER_STRIDE * l;
+    const bool last = (l == d->L - 1);
+    RUN(ucod_layernorm(x, (const float*)W[0], (const float*)W[1], h, M, D, d->eps, 0, stream));
+    if (last) {
+      // key hook: only the K slice (rows D..2D-1) of the fused qkv weight; output written as [B,D,h,w]
+      const char* wk = (const char*)W[2] + (size_t)D * D * 2;
+      const float* bk = (const float*)W[3] + D;
+      RUN(ucod_gemm_bf16(UCOD_EPI_KEY_NCHW_F32, wk, h, key_out, D, M, D, bk, nullptr, nullptr, nullptr, tok, gv, stream));
+      if (!d->full_last_layer) break;
+    }
+    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_BF16, h, W[2], qkv, M, 3 * D, D, (const float*)W[3], nullptr, nullptr, nullptr, tok, gv, stream));
+    RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, scale, av, stream));
+    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_SCALE_RESID_F32, a, W[4], x, M, D, D, (const float*)W[5], (const float*)W[6], x, nullptr, tok, gv, stream));
+    RUN(ucod_layernorm(x, (const float*)W[7], (const float*)W[8], h, M, D, d->eps, 0, stream));
+    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_GELU_BF16, h, W[9], g, M, F, D, (const float*)W[10], nullptr, nullptr, nullptr, tok, gv, stream));
+    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_SCALE_RESID_F32, g, W[11], x, M, D, F, (const float*)W[12], (const float*)W[13], x, nullptr, tok, gv, stream));
+  }
+  return UCOD_OK;
+}

@@ -1,0 +1,150 @@
+// Memory-bound helpers of the ViT backbone: LayerNorm, patch gather (im2col), CLS rows, casts.
+// All are HBM-bound streaming kernels: one wave per row with wave-shuffle reductions (LayerNorm),
+// vector loads/stores, no LDS.  SURVEY.md 8a rows B1,B2,B3.
+#include "common.h"
+#include "../../include/ucod_dpl.h"
+
+namespace ucod {
+
+// One wave per row, row resident in registers (NCH float2 chunks per lane, D = 128*NCH), two-pass
+// mean / variance like ATen's LayerNorm (modeling_dinov2.py:348,353; eps from the checkpoint config).
+template <int NCH, bool OUT_F32>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, void* __restrict__ y, int rows,
+                                                        int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float2* xr = reinterpret_cast<const float2*>(x + (size_t)row * D);
+  float2 v[NCH];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    v[i] = xr[lane + 64 * i];
+    s += v[i].x + v[i].y;
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean;
+    q += a * a + b * b;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  const float2* g2 = reinterpret_cast<const float2*>(gamma);
+  const float2* b2 = reinterpret_cast<const float2*>(beta);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const float2 g = g2[lane + 64 * i], b = b2[lane + 64 * i];
+    const float o0 = (v[i].x - mean) * rstd * g.x + b.x;
+    const float o1 = (v[i].y - mean) * rstd * g.y + b.y;
+    if constexpr (OUT_F32) {
+      reinterpret_cast<float2*>(reinterpret_cast<float*>(y) + (size_t)row * D)[lane + 64 * i] = make_float2(o0, o1);
+    } else {
+      reinterpret_cast<unsigned*>(reinterpret_cast<bf16_raw*>(y) + (size_t)row * D)[lane + 64 * i] = pack_bf16x2(o0, o1);
+    }
+  }
+}
+
+template <bool OUT_F32>
+static int launch_ln(const float* x, const float* g, const float* b, void* y, int rows, int D, float eps, hipStream_t s) {
+  dim3 grid(cdiv(rows, 4)), block(256);
+  switch (D / 128) {
+#define LN_CASE(n) \
+  case n: hipLaunchKernelGGL((layernorm_kernel<n, OUT_F32>), grid, block, 0, s, x, g, b, y, rows, D, eps); break;
+    LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(8) LN_CASE(10) LN_CASE(12)
+#undef LN_CASE
+    default: return UCOD_EINVAL;
+  }
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+// img [B,C,H,W] f32 -> patches bf16 [B*gh*gw, Kpad]; one thread per output pair (k, k+1).
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_raw* __restrict__ out, int B, int C,
+                                                     int H, int W, int P, int Kpad, int gh, int gw) {
+  const int kp = Kpad >> 1;
+  const size_t total = (size_t)B * gh * gw * kp;
+  const int K = C * P * P;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % kp) * 2;
+    const size_t m = idx / kp;
+    const int px = (int)(m % gw);
+    const int py = (int)((m / gw) % gh);
+    const int b = (int)(m / ((size_t)gw * gh));
+    float v[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kk = k + j;
+      if (kk < K) {
+        const int c = kk / (P * P), r = kk - c * P * P;
+        const int dy = r / P, dx = r - dy * P;
+        v[j] = img[(((size_t)b * C + c) * H + (py * P + dy)) * W + (px * P + dx)];
+      } else {
+        v[j] = 0.f;
+      }
+    }
+    reinterpret_cast<unsigned*>(out)[idx] = pack_bf16x2(v[0], v[1]);
+  }
+}
+
+__global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos, int B,
+                                int tok, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, j = i - b * D;
+  x[(size_t)b * tok * D + j] = cls[j] + pos[j];
+}
+
+__global__ void cast_kernel(const float* __restrict__ s, bf16_raw* __restrict__ d, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = f32_to_bf16(s[i]);
+}
+
+}  // namespace ucod
+
+extern "C" int ucod_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int D, float eps,
+                              int out_f32, void* stream) {
+  if (!x || !gamma || !beta || !y || rows <= 0 || D <= 0 || (D % 128) != 0) return UCOD_EINVAL;
+  return out_f32 ? ucod::launch_ln<true>(x, gamma, beta, y, rows, D, eps, (hipStream_t)stream)
+                 : ucod::launch_ln<false>(x, gamma, beta, y, rows, D, eps, (hipStream_t)stream);
+}
+
+extern "C" int ucod_patch_im2col(const float* img, void* patches, int B, int C, int H, int W, int P, int Kpad, void* stream) {
+  if (!img || !patches || B <= 0 || C <= 0 || P <= 0 || H % P || W % P || Kpad < C * P * P || (Kpad % 64) != 0) return UCOD_EINVAL;
+  const int gh = H / P, gw = W / P;
+  const size_t total = (size_t)B * gh * gw * (Kpad / 2);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(ucod::im2col_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, (bf16_raw*)patches, B, C, H, W, P,
+                     Kpad, gh, gw);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_cls_rows(float* x, const float* cls, const float* pos, int B, int tok, int D, void* stream) {
+  if (!x || !cls || !pos || B <= 0 || tok <= 0 || D <= 0) return UCOD_EINVAL;
+  hipLaunchKernelGGL(ucod::cls_rows_kernel, dim3(ucod::cdiv((long)B * D, 256)), dim3(256), 0, (hipStream_t)stream, x, cls, pos, B, tok, D);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_cast_f32_bf16(const float* src, void* dst, size_t n, void* stream) {
+  if (!src || !dst) return UCOD_EINVAL;
+  if (n == 0) return UCOD_OK;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(ucod::cast_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_raw*)dst, n);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_abi_version(void) { return UCOD_ABI_VERSION; }
+
+extern "C" int ucod_device_is_gfx950(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+  hipDeviceProp_t p;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+  const char* a = p.gcnArchName;
+  return (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 0;
+}

@@ -1,0 +1,96 @@
+"""ctypes binding of libucod_dpl.so (C ABI in include/ucod_dpl.h).
+
+There is deliberately NO fallback: if the shared library is missing, or a tensor is not on a
+gfx950 device, the call raises.  PyTorch is used only for device memory and streams.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_native", "libucod_dpl.so")
+
+EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_SCALE_RESID_F32, EPI_PATCH_TOKENS_F32, EPI_KEY_NCHW_F32, EPI_BIAS_F32 = range(6)
+VIT_LAYER_STRIDE = 14
+
+vp, ci, cf, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class VitDesc(C.Structure):
+    _fields_ = [(n, ci) for n in ("B", "C", "H", "W", "P", "D", "heads", "F", "L", "Kpad")] + [("eps", cf)] + \
+               [(n, ci) for n in ("full_last_layer", "gemm_variant", "attn_variant")]
+
+
+class DiscParams(C.Structure):
+    _fields_ = [(n, vp) for n in ("w1", "g1", "b1", "w2", "g2", "b2", "w3", "g3", "b3", "lin_w", "lin_b",
+                                  "rm1", "rv1", "rm2", "rv2", "rm3", "rv3")]
+
+
+class DiscGrads(C.Structure):
+    _fields_ = [(n, vp) for n in ("w1", "g1", "b1", "w2", "g2", "b2", "w3", "g3", "b3", "lin_w", "lin_b")]
+
+
+# name -> (restype, argtypes); must list EVERY symbol include/ucod_dpl.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    "ucod_abi_version": (ci, []),
+    "ucod_device_is_gfx950": (ci, []),
+    "ucod_gemm_bf16": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
+    "ucod_layernorm": (ci, [vp, vp, vp, vp, ci, ci, cf, ci, vp]),
+    "ucod_attention_fwd": (ci, [vp, vp, ci, ci, ci, cf, ci, vp]),
+    "ucod_patch_im2col": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "ucod_cls_rows": (ci, [vp, vp, vp, ci, ci, ci, vp]),
+    "ucod_cast_f32_bf16": (ci, [vp, vp, sz, vp]),
+    "ucod_vit_workspace_bytes": (sz, [C.POINTER(VitDesc)]),
+    "ucod_vit_forward": (ci, [C.POINTER(VitDesc), C.POINTER(vp), vp, vp, vp, sz, vp]),
+    "ucod_bilinear_resize": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ucod_dba_project": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "ucod_dba_colnorm": (ci, [vp, ci, ci, vp, vp, ci, ci, vp]),
+    "ucod_dba_heads_fwd": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]),
+    "ucod_orth_workspace_bytes": (sz, [ci, ci]),
+    "ucod_orth_gram_fwd": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci, vp]),
+    "ucod_dba_bwd_workspace_bytes": (sz, [ci, ci]),
+    "ucod_dba_bwd": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, ci, ci, vp]),
+    "ucod_dba_wgrad": (ci, [vp, vp, vp, ci, ci, ci, vp]),
+    "ucod_disc_saved_bytes": (sz, [ci, ci]),
+    "ucod_disc_fwd": (ci, [vp, C.POINTER(DiscParams), vp, vp, ci, ci, ci, vp]),
+    "ucod_apm_bce": (ci, [vp, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, ci, ci, vp]),
+    "ucod_binarize": (ci, [vp, vp, sz, ci, vp]),
+    "ucod_adamw_ema": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, ci, cf, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              f"or `make -C ucod_dpl_amd/csrc` (hipcc --offload-arch=gfx950). There is no fallback path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("ucod_dpl_amd: tensor is not on a GPU; the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("ucod_dpl_amd: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}" + (" (invalid argument)" if rc == -1 else ""))

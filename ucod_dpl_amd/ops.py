@@ -1,0 +1,188 @@
+"""Functional wrappers over the C ABI: allocate outputs with torch, launch on the current stream.
+
+Every function requires CUDA (ROCm) tensors and raises otherwise -- there is no CPU path here.
+"""
+import ctypes as C
+
+import torch
+
+from . import native as N
+from .native import ptr, stream, check
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    return t
+
+
+def _bf16(t):
+    if t.dtype != torch.bfloat16:
+        raise TypeError(f"expected bfloat16, got {t.dtype}")
+    return t
+
+
+# ----------------------------------------------------------------------------- backbone pieces
+def gemm_bf16(epilogue, A, Bm, out, M, Nn, K, bias=None, scale=None, resid=None, pos=None, tok=0, variant=0):
+    check(N.load().ucod_gemm_bf16(epilogue, ptr(_bf16(A)), ptr(_bf16(Bm)), ptr(out), M, Nn, K, ptr(bias), ptr(scale), ptr(resid),
+                                  ptr(pos), tok, variant, stream()), "ucod_gemm_bf16")
+    return out
+
+
+def linear_bf16(x, w, b, gelu=False, variant=0):
+    """x bf16 [M,K], w bf16 [N,K], b f32 [N] -> bf16 [M,N]."""
+    M, K = x.shape
+    out = torch.empty(M, w.shape[0], dtype=torch.bfloat16, device=x.device)
+    return gemm_bf16(N.EPI_BIAS_GELU_BF16 if gelu else N.EPI_BIAS_BF16, x, w, out, M, w.shape[0], K, bias=_f32(b), variant=variant)
+
+
+def linear_scale_resid(x, w, b, scale, resid, variant=0):
+    """resid f32 [M,N] + scale[n]*(x w^T + b) -> new f32 [M,N]."""
+    M, K = x.shape
+    out = torch.empty_like(resid)
+    return gemm_bf16(N.EPI_BIAS_SCALE_RESID_F32, x, w, out, M, w.shape[0], K, bias=b, scale=scale, resid=resid, variant=variant)
+
+
+def layernorm(x, gamma, beta, eps, out_f32=False):
+    rows, D = x.shape
+    y = torch.empty(rows, D, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    check(N.load().ucod_layernorm(ptr(_f32(x)), ptr(_f32(gamma)), ptr(_f32(beta)), ptr(y), rows, D, float(eps), int(out_f32), stream()),
+          "ucod_layernorm")
+    return y
+
+
+def attention(qkv, B, tok, heads, scale=0.125, variant=0):
+    out = torch.empty(B * tok, heads * 64, dtype=torch.bfloat16, device=qkv.device)
+    check(N.load().ucod_attention_fwd(ptr(_bf16(qkv)), ptr(out), B, tok, heads, float(scale), variant, stream()), "ucod_attention_fwd")
+    return out
+
+
+def patch_im2col(img, P, Kpad):
+    B, Cc, H, W = img.shape
+    out = torch.empty(B * (H // P) * (W // P), Kpad, dtype=torch.bfloat16, device=img.device)
+    check(N.load().ucod_patch_im2col(ptr(_f32(img)), ptr(out), B, Cc, H, W, P, Kpad, stream()), "ucod_patch_im2col")
+    return out
+
+
+def cast_bf16(t):
+    t = _f32(t).contiguous()
+    out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    check(N.load().ucod_cast_f32_bf16(ptr(t), ptr(out), t.numel(), stream()), "ucod_cast_f32_bf16")
+    return out
+
+
+# ----------------------------------------------------------------------------- decoder pieces
+def bilinear_resize(x, oh, ow):
+    x = _f32(x).contiguous()
+    *lead, ih, iw = x.shape
+    planes = 1
+    for v in lead:
+        planes *= v
+    out = torch.empty(*lead, oh, ow, dtype=torch.float32, device=x.device)
+    check(N.load().ucod_bilinear_resize(ptr(x), ptr(out), planes, ih, iw, oh, ow, stream()), "ucod_bilinear_resize")
+    return out
+
+
+def dba_project(x, W, bias):
+    """x [B,C,H,W] f32, W [Nout,C], bias [Nout] -> d [B,Nout,HW]."""
+    B, Cc, H, Wd = x.shape
+    Nout = W.shape[0]
+    d = torch.empty(B, Nout, H * Wd, dtype=torch.float32, device=x.device)
+    check(N.load().ucod_dba_project(ptr(_f32(x)), ptr(_f32(W)), ptr(_f32(bias)), ptr(d), B, Cc, H * Wd, Nout, stream()), "ucod_dba_project")
+    return d
+
+
+def dba_colnorm(d, c0, emb):
+    B, ld_c, HW = d.shape
+    norm = torch.empty(B, 128, dtype=torch.float32, device=d.device)
+    check(N.load().ucod_dba_colnorm(ptr(d), ld_c, c0, ptr(_f32(emb)), ptr(norm), B, HW, stream()), "ucod_dba_colnorm")
+    return norm
+
+
+def dba_heads(d, c0, emb, norm, head_w, head_b, want_bg=True, want_sdiag=False):
+    B, ld_c, HW = d.shape
+    fg = torch.empty(B, HW, dtype=torch.float32, device=d.device)
+    bg = torch.empty(B, HW, dtype=torch.float32, device=d.device) if want_bg else None
+    sdiag = torch.empty(B, dtype=torch.float32, device=d.device) if want_sdiag else None
+    check(N.load().ucod_dba_heads_fwd(ptr(d), ld_c, c0, ptr(emb), ptr(norm), ptr(_f32(head_w)), ptr(_f32(head_b)), ptr(fg), ptr(bg),
+                                      ptr(sdiag), B, HW, stream()), "ucod_dba_heads_fwd")
+    return fg, bg, sdiag
+
+
+def orth_gram(d, c0, emb, norm, sdiag):
+    B, ld_c, HW = d.shape
+    lib = N.load()
+    ws = torch.empty(lib.ucod_orth_workspace_bytes(B, HW), dtype=torch.uint8, device=d.device)
+    gram = torch.empty(B, 2, 64, 64, dtype=torch.float32, device=d.device)
+    loss = torch.empty(1, dtype=torch.float32, device=d.device)
+    check(lib.ucod_orth_gram_fwd(ptr(d), ld_c, c0, ptr(emb), ptr(norm), ptr(sdiag), ptr(gram), ptr(loss), ptr(ws), B, HW, stream()),
+          "ucod_orth_gram_fwd")
+    return loss, gram
+
+
+def dba_bwd(d, c0, emb, norm, head_w, gram, gfg, gbg, gextra, g_head_w=None, g_head_b=None, g_dec_bias=None):
+    B, ld_c, HW = d.shape
+    lib = N.load()
+    dev = d.device
+    ws = torch.empty(lib.ucod_dba_bwd_workspace_bytes(B, HW), dtype=torch.uint8, device=dev)
+    gd = torch.empty(B, 128, HW, dtype=torch.float32, device=dev)
+    g_head_w = torch.empty(2, 64, dtype=torch.float32, device=dev) if g_head_w is None else g_head_w
+    g_head_b = torch.empty(2, dtype=torch.float32, device=dev) if g_head_b is None else g_head_b
+    g_dec_bias = torch.empty(128, dtype=torch.float32, device=dev) if g_dec_bias is None else g_dec_bias
+    check(lib.ucod_dba_bwd(ptr(d), ld_c, c0, ptr(emb), ptr(norm), ptr(head_w), ptr(gram), ptr(_f32(gfg)), ptr(_f32(gbg)), float(gextra),
+                           ptr(gd), ptr(g_head_w), ptr(g_head_b), ptr(g_dec_bias), ptr(ws), B, HW, stream()), "ucod_dba_bwd")
+    return gd, g_head_w, g_head_b, g_dec_bias
+
+
+def dba_wgrad(gd, x, gW=None):
+    B, Cc = x.shape[0], x.shape[1]
+    HW = gd.shape[2]
+    gW = torch.empty(128, Cc, dtype=torch.float32, device=x.device) if gW is None else gW
+    check(N.load().ucod_dba_wgrad(ptr(gd), ptr(_f32(x)), ptr(gW), B, Cc, HW, stream()), "ucod_dba_wgrad")
+    return gW
+
+
+# ----------------------------------------------------------------------------- discriminator / APM / optimiser
+def disc_params_struct(tensors):
+    """tensors: dict with the 17 DiscParams field names -> CUDA f32 tensors."""
+    s = N.DiscParams()
+    for name, _ in N.DiscParams._fields_:
+        setattr(s, name, ptr(_f32(tensors[name])))
+    return s
+
+
+def disc_fwd(mask, tensors, update_running=True, saved=None):
+    B, _, fs, _ = mask.shape
+    lib = N.load()
+    if saved is None:
+        saved = torch.empty(lib.ucod_disc_saved_bytes(B, fs), dtype=torch.uint8, device=mask.device)
+    prob = torch.empty(B, dtype=torch.float32, device=mask.device)
+    ps = disc_params_struct(tensors)
+    check(lib.ucod_disc_fwd(ptr(_f32(mask)), C.byref(ps), ptr(prob), ptr(saved), B, fs, int(update_running), stream()), "ucod_disc_fwd")
+    return prob, saved
+
+
+def binarize(x, logits):
+    x = _f32(x).contiguous()
+    out = torch.empty_like(x)
+    check(N.load().ucod_binarize(ptr(x), ptr(out), x.numel(), int(logits), stream()), "ucod_binarize")
+    return out
+
+
+def apm_bce(pl, teacher, fg, bg, p_s, p_p, epoch_frac, gscale=1.0):
+    B = pl.shape[0]
+    HW = pl.numel() // B
+    dev = pl.device
+    w = torch.empty(B, dtype=torch.float32, device=dev)
+    merged = torch.empty(B, HW, dtype=torch.float32, device=dev)
+    gfg = torch.empty(B, HW, dtype=torch.float32, device=dev)
+    gbg = torch.empty(B, HW, dtype=torch.float32, device=dev)
+    losses = torch.empty(4, dtype=torch.float32, device=dev)
+    check(N.load().ucod_apm_bce(ptr(pl), ptr(teacher), ptr(fg), ptr(bg), ptr(p_s), ptr(p_p), float(epoch_frac), float(gscale), ptr(w),
+                                ptr(merged), ptr(gfg), ptr(gbg), ptr(losses), B, HW, stream()), "ucod_apm_bce")
+    return w, merged, gfg, gbg, losses
+
+
+def adamw_ema(p, g, m, v, ema, lr, step, ema_alpha=0.0, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01):
+    check(N.load().ucod_adamw_ema(ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), float(lr), beta1, beta2, eps, weight_decay, int(step),
+                                  float(ema_alpha), stream()), "ucod_adamw_ema")

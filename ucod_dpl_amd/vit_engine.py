@@ -1,0 +1,182 @@
+"""Frozen ViT backbone engine: owns bf16/f32 device copies of the weights, the pointer table the C driver
+walks, and a reusable workspace.  Accepts both checkpoint layouts the reference can meet:
+
+* HuggingFace ``Dinov2Model`` / ``ViTModel`` state dicts (data/utils/feature_extractor.py:20,25) with
+  ``attention.attention.{query,key,value}`` or (transformers>=5 ViT) ``attention.{q,k,v}_proj`` names;
+* the in-repo DINO ``VisionTransformer`` (models/backbones/dino.py) with fused ``attn.qkv``.
+
+Only what the key hook needs is computed by default (feature_extractor.py:46-47,55-58); see
+``ucod_vit_forward`` in include/ucod_dpl.h.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import native as N
+from . import ops
+
+
+def _interp_pos_dinov2(pos, gh, gw):
+    """transformers modeling_dinov2.py:57-95 (bicubic, size=, align_corners=False, computed in f32)."""
+    n0 = pos.shape[1] - 1
+    if n0 == gh * gw and gh == gw:
+        return pos
+    s = int(n0 ** 0.5)
+    pp = pos[:, 1:].reshape(1, s, s, -1).permute(0, 3, 1, 2).float()
+    pp = F.interpolate(pp, size=(gh, gw), mode="bicubic", align_corners=False)
+    return torch.cat((pos[:, :1], pp.permute(0, 2, 3, 1).reshape(1, gh * gw, -1)), 1)
+
+
+def _interp_pos_dinov1(pos, gh, gw):
+    """models/backbones/dino.py:202-221 (scale_factor + 0.1 trick)."""
+    n0 = pos.shape[1] - 1
+    if n0 == gh * gw and gh == gw:
+        return pos
+    s = int(math.sqrt(n0))
+    pp = pos[:, 1:].reshape(1, s, s, -1).permute(0, 3, 1, 2)
+    pp = F.interpolate(pp, scale_factor=((gh + 0.1) / math.sqrt(n0), (gw + 0.1) / math.sqrt(n0)), mode="bicubic")
+    assert pp.shape[-2] == gh and pp.shape[-1] == gw
+    return torch.cat((pos[:, :1], pp.permute(0, 2, 3, 1).reshape(1, gh * gw, -1)), 1)
+
+
+def normalize_state_dict(sd):
+    """Map any supported checkpoint layout to a canonical dict:
+    patch_w [D,C,P,P], patch_b, cls [D], pos [1,1+n,D], kind ('dinov2'|'dinov1'),
+    layers: list of dict(ln1_g, ln1_b, qkv_w [3D,D], qkv_b, proj_w, proj_b, ls1|None, ln2_g, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b, ls2|None)."""
+    sd = {k: v for k, v in sd.items()}
+    out = {"layers": []}
+    if "cls_token" in sd and "pos_embed" in sd:                      # in-repo DINO
+        out["kind"] = "dinov1"
+        out["patch_w"], out["patch_b"] = sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"]
+        out["cls"], out["pos"] = sd["cls_token"].reshape(-1), sd["pos_embed"]
+        L = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+        for i in range(L):
+            p = f"blocks.{i}."
+            out["layers"].append(dict(
+                ln1_g=sd[p + "norm1.weight"], ln1_b=sd[p + "norm1.bias"], qkv_w=sd[p + "attn.qkv.weight"], qkv_b=sd[p + "attn.qkv.bias"],
+                proj_w=sd[p + "attn.proj.weight"], proj_b=sd[p + "attn.proj.bias"], ls1=None,
+                ln2_g=sd[p + "norm2.weight"], ln2_b=sd[p + "norm2.bias"], fc1_w=sd[p + "mlp.fc1.weight"], fc1_b=sd[p + "mlp.fc1.bias"],
+                fc2_w=sd[p + "mlp.fc2.weight"], fc2_b=sd[p + "mlp.fc2.bias"], ls2=None))
+        return out
+    # HuggingFace: strip an optional model prefix ("dinov2." / "vit.")
+    pref = ""
+    for cand in ("", "dinov2.", "vit."):
+        if cand + "embeddings.cls_token" in sd:
+            pref = cand
+            break
+    g = lambda k: sd[pref + k]  # noqa: E731
+    out["patch_w"], out["patch_b"] = g("embeddings.patch_embeddings.projection.weight"), g("embeddings.patch_embeddings.projection.bias")
+    out["cls"], out["pos"] = g("embeddings.cls_token").reshape(-1), g("embeddings.position_embeddings")
+    has_ls = any("layer_scale1" in k for k in sd)
+    out["kind"] = "dinov2" if has_ls else "dinov1"
+    lay = "encoder.layer." if any(k.startswith(pref + "encoder.layer.") for k in sd) else "encoder.layers."
+    L = 1 + max(int(k[len(pref + lay):].split(".")[0]) for k in sd if k.startswith(pref + lay))
+    for i in range(L):
+        p = f"{lay}{i}."
+
+        def first(*names):
+            for n in names:
+                if pref + p + n in sd:
+                    return sd[pref + p + n]
+            raise KeyError(f"none of {names} under {pref + p}")
+
+        q_w, k_w, v_w = (first(f"attention.attention.{n}.weight", f"attention.{n[0]}_proj.weight") for n in ("query", "key", "value"))
+        q_b, k_b, v_b = (first(f"attention.attention.{n}.bias", f"attention.{n[0]}_proj.bias") for n in ("query", "key", "value"))
+        out["layers"].append(dict(
+            ln1_g=first("norm1.weight", "layernorm_before.weight"), ln1_b=first("norm1.bias", "layernorm_before.bias"),
+            qkv_w=torch.cat((q_w, k_w, v_w), 0), qkv_b=torch.cat((q_b, k_b, v_b), 0),
+            proj_w=first("attention.output.dense.weight", "attention.o_proj.weight"), proj_b=first("attention.output.dense.bias", "attention.o_proj.bias"),
+            ls1=first("layer_scale1.lambda1") if has_ls else None,
+            ln2_g=first("norm2.weight", "layernorm_after.weight"), ln2_b=first("norm2.bias", "layernorm_after.bias"),
+            fc1_w=first("mlp.fc1.weight", "intermediate.dense.weight"), fc1_b=first("mlp.fc1.bias", "intermediate.dense.bias"),
+            fc2_w=first("mlp.fc2.weight", "output.dense.weight"), fc2_b=first("mlp.fc2.bias", "output.dense.bias"),
+            ls2=first("layer_scale2.lambda1") if has_ls else None))
+    return out
+
+
+class ViTEngine:
+    """HIP ViT forward -> last-layer key map [B, D, H/P, W/P] (f32)."""
+
+    def __init__(self, state_dict, heads, eps=1e-6, device="cuda", full_last_layer=False, gemm_variant=0, attn_variant=0):
+        c = normalize_state_dict(state_dict)
+        self.kind = c["kind"]
+        self.device = torch.device(device)
+        self.D = c["patch_w"].shape[0]
+        self.C = c["patch_w"].shape[1]
+        self.P = c["patch_w"].shape[2]
+        self.heads = heads
+        if self.D != heads * 64:
+            raise ValueError(f"head_dim must be 64 (D={self.D}, heads={heads})")
+        self.L = len(c["layers"])
+        self.F = c["layers"][0]["fc1_w"].shape[0]
+        self.eps = float(eps)
+        self.full_last_layer = bool(full_last_layer)
+        self.gemm_variant, self.attn_variant = gemm_variant, attn_variant
+        K = self.C * self.P * self.P
+        self.Kpad = (K + 63) // 64 * 64
+        dev = self.device
+        f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()  # noqa: E731
+        bf = lambda t: ops.cast_bf16(f32(t))  # noqa: E731
+        pw = torch.zeros(self.D, self.Kpad, dtype=torch.float32, device=dev)
+        pw[:, :K] = f32(c["patch_w"]).reshape(self.D, K)
+        self._keep = []
+        self._pos_src = c["pos"].detach().float().cpu()
+        self._pos_cache = {}
+        self.patch_w, self.patch_b, self.cls = ops.cast_bf16(pw), f32(c["patch_b"]), f32(c["cls"])
+        ones = torch.ones(self.D, dtype=torch.float32, device=dev)
+        self.layers = []
+        for l in c["layers"]:
+            self.layers.append([f32(l["ln1_g"]), f32(l["ln1_b"]), bf(l["qkv_w"]), f32(l["qkv_b"]), bf(l["proj_w"]), f32(l["proj_b"]),
+                                f32(l["ls1"]) if l["ls1"] is not None else ones, f32(l["ln2_g"]), f32(l["ln2_b"]), bf(l["fc1_w"]),
+                                f32(l["fc1_b"]), bf(l["fc2_w"]), f32(l["fc2_b"]), f32(l["ls2"]) if l["ls2"] is not None else ones])
+        self._ws = None
+        self._ws_key = None
+
+    def param_bytes(self):
+        n = self.patch_w.numel() * 2
+        for l in self.layers:
+            n += sum(t.numel() * t.element_size() for t in l)
+        return n
+
+    def _pos(self, gh, gw):
+        key = (gh, gw)
+        if key not in self._pos_cache:
+            fn = _interp_pos_dinov2 if self.kind == "dinov2" else _interp_pos_dinov1
+            self._pos_cache[key] = fn(self._pos_src, gh, gw)[0].to(self.device, torch.float32).contiguous()
+        return self._pos_cache[key]
+
+    def _desc(self, B, H, W):
+        d = N.VitDesc()
+        d.B, d.C, d.H, d.W, d.P = B, self.C, H, W, self.P
+        d.D, d.heads, d.F, d.L, d.Kpad = self.D, self.heads, self.F, self.L, self.Kpad
+        d.eps = self.eps
+        d.full_last_layer = int(self.full_last_layer)
+        d.gemm_variant, d.attn_variant = self.gemm_variant, self.attn_variant
+        return d
+
+    def forward(self, img, out=None):
+        if not img.is_cuda:
+            raise RuntimeError("ViTEngine needs a CUDA(ROCm) tensor; there is no CPU path")
+        img = img.to(torch.float32).contiguous()
+        B, Cc, H, W = img.shape
+        gh, gw = H // self.P, W // self.P
+        lib = N.load()
+        d = self._desc(B, H, W)
+        need = lib.ucod_vit_workspace_bytes(C.byref(d))
+        if need == 0:
+            raise ValueError("unsupported ViT geometry")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        pos = self._pos(gh, gw)
+        ptrs = [self.patch_w, self.patch_b, self.cls, pos]
+        for l in self.layers:
+            ptrs += l
+        table = (C.c_void_p * len(ptrs))(*[t.data_ptr() for t in ptrs])
+        key = out if out is not None else torch.empty(B, self.D, gh, gw, dtype=torch.float32, device=self.device)
+        N.check(lib.ucod_vit_forward(C.byref(d), table, N.ptr(img), N.ptr(key), N.ptr(self._ws), self._ws.numel(), N.stream()),
+                "ucod_vit_forward")
+        return key
+
+    __call__ = forward
