@@ -150,6 +150,14 @@ typedef struct {
 size_t ucod_disc_saved_bytes(int B, int fs);
 int ucod_disc_fwd(const float* mask, const ucod_disc_params* p_host, float* prob, void* saved, int B, int fs,
                   int update_running, void* stream);
+/* gradient of sum_b gprob[b]*prob[b] w.r.t. the 11 parameter tensors, written (not accumulated unless
+ * accumulate != 0) into grads laid out in the same order/shapes as ucod_disc_params' const members.
+ * (engine/runner/loop_UCOD_DPL.py:244-251) */
+typedef struct { float *w1, *g1, *b1, *w2, *g2, *b2, *w3, *g3, *b3, *lin_w, *lin_b; } ucod_disc_grads;
+size_t ucod_disc_bwd_workspace_bytes(int B, int fs);
+int ucod_disc_bwd(const float* mask, const ucod_disc_params* p_host, const void* saved, const float* gprob,
+                  const ucod_disc_grads* g_host, int accumulate, void* ws, int B, int fs, void* stream);
+
 /* APM fusion + both BCE-with-logits losses + their logit gradients in one pass
  * (engine/runner/loop_UCOD_DPL.py:257-272 and :161-173):
  *   w[b] = clamp(0.5*(1+cos(pi*|p_s-p_p|)) + epoch_frac, 0, 1);  merged = pl*(1-w) + (sigmoid(teacher)>0.5)*w

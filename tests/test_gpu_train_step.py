@@ -1,0 +1,118 @@
+"""GPU: the fused HIP training step and discriminator step, driven through the reference-shaped TrainLoop /
+StandardRunner mirror, against vectors captured from the reference's own TrainLoop._process_batch (G5) and
+Discriminator_epoch (G6)."""
+import pytest
+import torch
+
+from conftest import load_golden, sub, maxdiff
+
+pytestmark = pytest.mark.gpu
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from ucod_dpl_amd.engine.config import CfgNode  # noqa: E402
+from ucod_dpl_amd.engine.runner import StandardRunner, TrainLoop  # noqa: E402
+
+
+def make_cfg(C=384, fs=28):
+    return CfgNode(dict(
+        model_cfg=dict(dim=C, feature_size=fs, ema_weight=0.99, dis_use_features=False),
+        train_cfg=dict(max_epoch=25, start_epoch=0, start_finetune=-5, lr0=6e-4, dis_lr0=1e-3, step_lr_size=2, dis_step_lr_size=2,
+                       step_lr_gamma=0.95, dis_step_lr_gamma=0.95, merge_alpha=0.5, merge_method="dis", dist_train=False, dis_epoch=1,
+                       dis_intertrain=2, save_cfg=dict(save_mode="model", save_interval=5, start_save=-50)),
+        val_cfg=dict(enable_val=False, val_interval=5, start_val=-50),
+        log_cfg=dict(log_interval=50, log_path="/tmp/ucod_test", multi_rank=[0]),
+    ))
+
+
+def build(g, prefix_model="model0.", prefix_disc="disc0."):
+    runner = StandardRunner.__new__(StandardRunner)
+    # construct without touching env/distributed twice: plain __init__ is fine on one GPU
+    StandardRunner.__init__(runner, make_cfg())
+    runner.model.load_state_dict({k: v.to(runner.device) for k, v in sub(g, prefix_model).items()}, strict=True)
+    runner.discriminator.load_state_dict({k: v.to(runner.device) for k, v in sub(g, prefix_disc).items()}, strict=True)
+    return runner, TrainLoop(runner.config, runner)
+
+
+def test_parameters_live_in_the_arena_and_keep_reference_names():
+    g = load_golden("g5_process_batch")
+    runner, _ = build(g)
+    sd = runner.model.state_dict()
+    assert sorted(sd.keys()) == sorted(sub(g, "model0.").keys())
+    for k, v in sub(g, "model0.").items():
+        assert maxdiff(sd[k].cpu(), v) == 0.0
+    # load_state_dict wrote through to the flat arena the kernels read
+    assert maxdiff(runner.arena.p[128:128 + 128 * 384].cpu(), g["model0.decoder.decoupling.weight"].reshape(-1)) == 0.0
+    assert maxdiff(runner.arena.ema[128:128 + 128 * 384].cpu(), g["model0.decoder_ema.decoupling.weight"].reshape(-1)) == 0.0
+
+
+def test_process_batch_three_steps_match_reference():
+    g = load_golden("g5_process_batch")
+    runner, loop = build(g)
+    for step in range(3):
+        batch = {"pseudo_label": g[f"pl{step}"], "label_tensor": torch.zeros(1), "features": g[f"features{step}"], "img_path": ["x"]}
+        assert abs(runner.optimizer.param_groups[0]["lr"] - float(g[f"lr_used{step}"])) < 1e-12
+        loss = loop._process_batch(batch)
+        loop.global_step += 1                                   # run_epoch's increment
+        assert abs(loss.item() - g[f"loss{step}"].item()) < 2e-5, (step, loss.item(), g[f"loss{step}"].item())
+        # gradients (flat arena) vs reference autograd
+        A = runner.arena
+        ref_gw = g[f"grad{step}.decoupling.weight"].reshape(-1)
+        assert maxdiff(A.g[A.o_W:A.o_b].cpu(), ref_gw) < 2e-3 * ref_gw.abs().max().item()
+        sd = {k: v.cpu() for k, v in runner.model.state_dict().items()}
+        for k, v in sub(g, f"model{step + 1}.").items():
+            if k.endswith("learnable_embedding"):
+                continue                                        # reference moves it with f32-noise gradients; analytically frozen
+            assert maxdiff(sd[k], v) < 5e-5, (step, k, maxdiff(sd[k], v))
+        dsd = {k: v.cpu() for k, v in runner.discriminator.state_dict().items()}
+        for k, v in sub(g, f"disc{step + 1}.").items():
+            assert maxdiff(dsd[k], v) < 2e-5, (step, k)
+
+
+def test_learnable_embedding_only_sees_weight_decay():
+    g = load_golden("g5_process_batch")
+    runner, loop = build(g)
+    e0 = runner.model.decoder.learnable_embedding.detach().clone()
+    batch = {"pseudo_label": g["pl0"], "label_tensor": torch.zeros(1), "features": g["features0"], "img_path": ["x"]}
+    loop._process_batch(batch)
+    e1 = runner.model.decoder.learnable_embedding.detach()
+    assert maxdiff((e0 * (1 - 6e-4 * 0.01)).cpu(), e1.cpu()) < 1e-7
+
+
+def test_discriminator_step_matches_reference():
+    g = load_golden("g6_discriminator_step")
+    runner, loop = build(g)
+    batch = {"pseudo_label": g["pl"], "label_tensor": torch.zeros(1), "features": g["features"], "img_path": ["x"]}
+    loss = loop._discriminator_batch(batch)
+    ref_loss = float(str(g["loss_str"][0]).split(":")[-1])
+    assert abs(loss.item() - ref_loss) < 1e-4
+    DA = runner.disc_arena
+    names = [n for n, _ in runner.discriminator.named_parameters()]
+    for n, gv in zip(names, DA.grad_views):
+        ref = g["grad." + n]
+        assert maxdiff(gv.cpu(), ref) < 1e-6 + 2e-3 * ref.abs().max().item(), n
+    dsd = {k: v.cpu() for k, v in runner.discriminator.state_dict().items()}
+    for k, v in sub(g, "disc1.").items():
+        tol = 2e-3 if ("running" not in k and "num_batches" not in k) else 2e-5
+        assert maxdiff(dsd[k], v) < tol, (k, maxdiff(dsd[k], v))
+
+
+def test_generic_autograd_path_matches_fused_path():
+    """baseline(...)(x) through torch autograd (the drop-in module interface) == the fused loop's gradients."""
+    g = load_golden("g1_decoder_c384")
+    from ucod_dpl_amd.models.uscod import baseline
+    m = baseline(CfgNode(dict(dim=384, feature_size=14, ema_weight=0.99, dis_use_features=False))).cuda()
+    m.load_state_dict({k: v for k, v in sub(g, "sd.").items()}, strict=True)
+    x = g["x"].cuda()
+    fg, bg, extra = m(x)
+    teacher = m(x, ema=True)
+    assert maxdiff(fg.cpu(), g["fg"]) < 1e-4 and maxdiff(teacher.cpu(), g["teacher"]) < 1e-4
+    loss = (fg * g["r1"].cuda()).sum() + (bg * g["r2"].cuda()).sum() + 1000.0 * extra
+    loss.backward()
+    for n, p in m.decoder.named_parameters():
+        if n == "learnable_embedding":
+            assert p.grad.abs().max().item() == 0.0
+            continue
+        ref = g["grad." + n]
+        assert maxdiff(p.grad.cpu(), ref) < 2e-3 * max(ref.abs().max().item(), 1e-6), n
+    assert all(p.grad is None for p in m.decoder_ema.parameters())

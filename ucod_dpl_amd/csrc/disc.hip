@@ -170,3 +170,215 @@ extern "C" int ucod_disc_fwd(const float* mask, const ucod_disc_params* p, float
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }
+
+// =====================================================================================================
+// Backward (discriminator phase, engine/runner/loop_UCOD_DPL.py:230-255): gradient of sum_b gprob[b]*prob[b]
+// w.r.t. every parameter.  Per block, from the top:  head -> [BN+LeakyReLU backward: per-channel sums of gh and
+// gh*xhat (f64), then gy = gamma*rstd*(gh - mean(gh) - xhat*mean(gh*xhat))] -> conv weight gradient
+// (recomputing the activated input on the fly) -> conv input gradient (-> gh of the block below).
+// =====================================================================================================
+namespace ucod {
+
+// head: gz = gprob*p*(1-p); g_lin_w += gz*a3; g_lin_b += gz; gh3 = gz*lin_w*lrelu'(h3)
+__global__ __launch_bounds__(256) void disc_head_bwd_kernel(const float* __restrict__ y3, const float* __restrict__ stats,
+                                                            const float* __restrict__ g, const float* __restrict__ bta,
+                                                            const float* __restrict__ lw, const float* __restrict__ lb,
+                                                            const float* __restrict__ gprob, float* __restrict__ gh3,
+                                                            float* __restrict__ g_lw, float* __restrict__ g_lb, int HW3) {
+  __shared__ float red[16];
+  const int b = blockIdx.x, tid = threadIdx.x, n = 8 * HW3;
+  float acc = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    const int c = i / HW3;
+    acc = fmaf(lw[i], bn_lrelu(y3[(long)b * n + i], stats[c], stats[8 + c], g[c], bta[c]), acc);
+  }
+  acc = block_sum(acc, red);
+  const float p = sigmoid_acc(acc + lb[0]);
+  const float gz = gprob[b] * p * (1.f - p);
+  for (int i = tid; i < n; i += 256) {
+    const int c = i / HW3;
+    const float h = (y3[(long)b * n + i] - stats[c]) * stats[8 + c] * g[c] + bta[c];
+    const float a = h >= 0.f ? h : h * LRELU;
+    atomicAdd(&g_lw[i], gz * a);
+    gh3[(long)b * n + i] = gz * lw[i] * (h >= 0.f ? 1.f : LRELU);
+  }
+  if (tid == 0) atomicAdd(g_lb, gz);
+}
+
+// one workgroup per channel: S1 = sum gh, S2 = sum gh*xhat (f64) -> g_beta, g_gamma (accumulated) and sums[c], sums[C+c]
+__global__ __launch_bounds__(1024) void bn_bwd_stats_kernel(const float* __restrict__ y, const float* __restrict__ gh, int C, int B,
+                                                            int HW, const float* __restrict__ stats, float* __restrict__ sums,
+                                                            float* __restrict__ g_gamma, float* __restrict__ g_beta) {
+  __shared__ double red[16];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const float mean = stats[c], rstd = stats[C + c];
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const long off = ((long)b * C + c) * HW;
+    for (int i = tid; i < HW; i += 1024) {
+      const double gv = (double)gh[off + i];
+      s1 += gv;
+      s2 += gv * (double)((y[off + i] - mean) * rstd);
+    }
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (tid == 0) {
+    const double n = (double)B * HW;
+    sums[c] = (float)(s1 / n);
+    sums[C + c] = (float)(s2 / n);
+    g_beta[c] += (float)s1;
+    g_gamma[c] += (float)s2;
+  }
+}
+
+// gh -> gy in place
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ y, float* __restrict__ gh, int C, int HW, long total,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)((i / HW) % C);
+    const float rstd = stats[C + c];
+    const float xh = (y[i] - stats[c]) * rstd;
+    gh[i] = gamma[c] * rstd * (gh[i] - sums[c] - xh * sums[C + c]);
+  }
+}
+
+// weight gradient: one workgroup per (co, ci); gW[co][ci][tap] += sum_{b,oy,ox} gy[b,co,oy,ox] * act_in[b,ci,iy,ix]
+template <int CIN, int COUT, int STRIDE, bool BN_IN>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ in_stats,
+                                                            const float* __restrict__ in_g, const float* __restrict__ in_b,
+                                                            const float* __restrict__ gy, float* __restrict__ gw, int B, int IH, int OH) {
+  __shared__ float red[16];
+  const int co = blockIdx.x / CIN, ci = blockIdx.x % CIN, tid = threadIdx.x;
+  float sc = 1.f, sh = 0.f;
+  if (BN_IN) {
+    const float mean = in_stats[ci], rstd = in_stats[CIN + ci];
+    sc = rstd * in_g[ci];
+    sh = in_b[ci] - mean * sc;
+  }
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  const long total = (long)B * OH * OH;
+  for (long idx = tid; idx < total; idx += 256) {
+    const int ox = (int)(idx % OH), oy = (int)((idx / OH) % OH), b = (int)(idx / ((long)OH * OH));
+    const float gv = gy[(((long)b * COUT + co) * OH + oy) * OH + ox];
+    const float* ib = in + ((long)b * CIN + ci) * IH * IH;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = oy * STRIDE - 1 + ky, ix = ox * STRIDE - 1 + kx;
+        if (iy >= 0 && iy < IH && ix >= 0 && ix < IH) {
+          float t = ib[(long)iy * IH + ix];
+          if (BN_IN) {
+            t = fmaf(t, sc, sh);
+            t = t >= 0.f ? t : t * LRELU;
+          }
+          acc[ky * 3 + kx] = fmaf(gv, t, acc[ky * 3 + kx]);
+        }
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float s = block_sum(acc[t], red);
+    if (tid == 0) gw[((long)co * CIN + ci) * 9 + t] += s;
+  }
+}
+
+// input gradient of a conv block, fused with the LeakyReLU' of the block BELOW: thread = input pixel (b,iy,ix),
+// gh_in[b,ci,iy,ix] = lrelu'(h_in) * sum_{co,ky,kx} gy[b,co,oy,ox] * w[co][ci][ky][kx],  oy = (iy+1-ky)/STRIDE
+template <int CIN, int COUT, int STRIDE>
+__global__ __launch_bounds__(256) void conv3x3_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                            const float* __restrict__ y_in, const float* __restrict__ in_stats,
+                                                            const float* __restrict__ in_g, const float* __restrict__ in_b,
+                                                            float* __restrict__ gh_in, int B, int IH, int OH) {
+  __shared__ float ws[COUT * 9 * CIN];  // [co][tap][ci]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < COUT * 9 * CIN; i += 256) {
+    const int ci = i % CIN, rest = i / CIN, tap = rest % 9, co = rest / 9;
+    ws[i] = w[(co * CIN + ci) * 9 + tap];
+  }
+  __syncthreads();
+  const long total = (long)B * IH * IH;
+  const long idx = (long)blockIdx.x * 256 + tid;
+  if (idx >= total) return;
+  const int ix = (int)(idx % IH), iy = (int)((idx / IH) % IH), b = (int)(idx / ((long)IH * IH));
+  float acc[CIN];
+#pragma unroll
+  for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.f;
+  for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ty = iy + 1 - ky, tx = ix + 1 - kx;
+        if (ty < 0 || tx < 0 || (ty % STRIDE) || (tx % STRIDE)) continue;
+        const int oy = ty / STRIDE, ox = tx / STRIDE;
+        if (oy >= OH || ox >= OH) continue;
+        const float gv = gy[(((long)b * COUT + co) * OH + oy) * OH + ox];
+        const float* wr = &ws[(co * 9 + ky * 3 + kx) * CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) acc[ci] = fmaf(gv, wr[ci], acc[ci]);
+      }
+  }
+#pragma unroll
+  for (int ci = 0; ci < CIN; ++ci) {
+    const long o = (((long)b * CIN + ci) * IH + iy) * IH + ix;
+    const float h = (y_in[o] - in_stats[ci]) * in_stats[CIN + ci] * in_g[ci] + in_b[ci];
+    gh_in[o] = acc[ci] * (h >= 0.f ? 1.f : LRELU);
+  }
+}
+
+}  // namespace ucod
+
+extern "C" size_t ucod_disc_bwd_workspace_bytes(int B, int fs) {
+  const DiscDims d = disc_dims(B, fs);
+  return (d.n1 + d.n2 + d.n3 + 2 * (32 + 16 + 8)) * sizeof(float);
+}
+
+extern "C" int ucod_disc_bwd(const float* mask, const ucod_disc_params* p, const void* saved, const float* gprob,
+                             const ucod_disc_grads* g, int accumulate, void* ws, int B, int fs, void* stream) {
+  if (!mask || !p || !saved || !gprob || !g || !ws || B <= 0 || fs < 4) return UCOD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const DiscDims d = disc_dims(B, fs);
+  const float* y1 = (const float*)saved;
+  const float* y2 = y1 + d.n1;
+  const float* y3 = y2 + d.n2;
+  const float* st1 = y1 + stats_off(d);
+  const float* st2 = st1 + 64;
+  const float* st3 = st2 + 32;
+  float* gh1 = (float*)ws;
+  float* gh2 = gh1 + d.n1;
+  float* gh3 = gh2 + d.n2;
+  float* su1 = gh3 + d.n3;
+  float* su2 = su1 + 64;
+  float* su3 = su2 + 32;
+  const int hw1 = d.s1 * d.s1, hw2 = d.s2 * d.s2, hw3 = d.s3 * d.s3;
+  if (!accumulate) {
+    hipError_t e = hipSuccess;
+    auto z = [&](float* ptr, size_t n) { if (e == hipSuccess) e = hipMemsetAsync(ptr, 0, n * sizeof(float), s); };
+    z(g->w1, 32 * 9); z(g->g1, 32); z(g->b1, 32); z(g->w2, 16 * 32 * 9); z(g->g2, 16); z(g->b2, 16);
+    z(g->w3, 8 * 16 * 9); z(g->g3, 8); z(g->b3, 8); z(g->lin_w, (size_t)8 * hw3); z(g->lin_b, 1);
+    if (e != hipSuccess) return (int)e;
+  }
+  auto blocks = [](size_t n) { return dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)); };
+  hipLaunchKernelGGL(disc_head_bwd_kernel, dim3(B), dim3(256), 0, s, y3, st3, p->g3, p->b3, p->lin_w, p->lin_b, gprob, gh3, g->lin_w, g->lin_b, hw3);
+  // block 3
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(8), dim3(1024), 0, s, y3, gh3, 8, B, hw3, st3, su3, g->g3, g->b3);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, blocks(d.n3), dim3(256), 0, s, y3, gh3, 8, hw3, (long)d.n3, st3, p->g3, su3);
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<16, 8, 2, true>), dim3(8 * 16), dim3(256), 0, s, y2, st2, p->g2, p->b2, gh3, g->w3, B, d.s2, d.s3);
+  hipLaunchKernelGGL((conv3x3_dgrad_kernel<16, 8, 2>), dim3(cdiv((long)B * hw2, 256)), dim3(256), 0, s, gh3, p->w3, y2, st2, p->g2, p->b2, gh2, B, d.s2, d.s3);
+  // block 2
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(16), dim3(1024), 0, s, y2, gh2, 16, B, hw2, st2, su2, g->g2, g->b2);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, blocks(d.n2), dim3(256), 0, s, y2, gh2, 16, hw2, (long)d.n2, st2, p->g2, su2);
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<32, 16, 2, true>), dim3(16 * 32), dim3(256), 0, s, y1, st1, p->g1, p->b1, gh2, g->w2, B, d.s1, d.s2);
+  hipLaunchKernelGGL((conv3x3_dgrad_kernel<32, 16, 2>), dim3(cdiv((long)B * hw1, 256)), dim3(256), 0, s, gh2, p->w2, y1, st1, p->g1, p->b1, gh1, B, d.s1, d.s2);
+  // block 1
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(32), dim3(1024), 0, s, y1, gh1, 32, B, hw1, st1, su1, g->g1, g->b1);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, blocks(d.n1), dim3(256), 0, s, y1, gh1, 32, hw1, (long)d.n1, st1, p->g1, su1);
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 32, 1, false>), dim3(32), dim3(256), 0, s, mask, nullptr, nullptr, nullptr, gh1, g->w1, B, fs, d.s1);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}

@@ -1,0 +1,108 @@
+"""Frozen backbone wrapper -- host-side mirror of data/utils/feature_extractor.py::backbone (:31-59).
+
+``backbone(fe_cfg)(img, reshape_keys=True) -> (outputs, key)`` where ``key`` is the LAST layer's key projection
+(bias included, before the head split), CLS dropped, reshaped to ``[B,C,h,w]`` (:46-47,55-58).  ``outputs`` is
+``None``: the reference's callers discard it (loop_UCOD_DPL.py:343, base_dataset.py:136-138) and the HIP engine
+does not compute the dead tail of the last layer unless ``full_last_layer`` is requested.
+
+Weights: the reference calls ``transformers.AutoModel.from_pretrained`` on ``fe_cfg.backbone_weights`` and falls
+back to downloading ``fe_cfg.backbone`` (:17-25).  Here the checkpoint is read straight from that local directory
+(``model.safetensors`` or ``pytorch_model.bin`` + ``config.json``) with no dependency on HF module attribute
+paths (they changed in transformers 5.x and broke the reference's DINOv1 hook); there is no
+network fallback.  ``backbone.from_state_dict`` / ``backbone.random_init`` cover tests and synthetic benchmarks.
+"""
+import json
+import os
+from pathlib import Path
+
+import torch
+from torch import nn
+
+from ...vit_engine import ViTEngine
+from ...engine.registry import BACKBONE_REGISTRY
+
+# name -> (width D, heads, layers, patch, pretrain image size, layerscale?)
+ARCHS = {
+    "dinov2_vits14": (384, 6, 12, 14, 518, True),
+    "dinov2_vitb14": (768, 12, 12, 14, 518, True),
+    "dinov2_vitl14": (1024, 16, 24, 14, 518, True),
+    "dino_vits8": (384, 6, 12, 8, 224, False),
+    "dino_vitb8": (768, 12, 12, 8, 224, False),
+}
+HUB_TO_ARCH = {"facebook/dinov2-small": "dinov2_vits14", "facebook/dinov2-base": "dinov2_vitb14", "facebook/dinov2-large": "dinov2_vitl14",
+               "facebook/dino-vits8": "dino_vits8", "facebook/dino-vitb8": "dino_vitb8"}
+
+
+def random_state_dict(arch, seed=0, image_size=None):
+    """Seeded HF-layout state dict with the architecture's shapes (trunc-normal sigma 0.02, HF init); throughput and
+    parity tests do not depend on trained weights."""
+    D, heads, L, P, img, ls = ARCHS[arch]
+    img = image_size or img
+    g = torch.Generator().manual_seed(seed)
+    tn = lambda *s: torch.nn.init.trunc_normal_(torch.empty(*s), std=0.02, a=-0.04, b=0.04, generator=g)  # noqa: E731
+    n = (img // P) ** 2
+    sd = {"embeddings.cls_token": tn(1, 1, D), "embeddings.position_embeddings": tn(1, n + 1, D),
+          "embeddings.patch_embeddings.projection.weight": tn(D, 3, P, P), "embeddings.patch_embeddings.projection.bias": torch.zeros(D)}
+    for i in range(L):
+        p = f"encoder.layer.{i}."
+        for nm in ("query", "key", "value"):
+            sd[p + f"attention.attention.{nm}.weight"], sd[p + f"attention.attention.{nm}.bias"] = tn(D, D), tn(D)
+        sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"] = tn(D, D), tn(D)
+        sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = tn(4 * D, D), tn(4 * D)
+        sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = tn(D, 4 * D), tn(D)
+        for nm in ("norm1", "norm2"):
+            sd[p + nm + ".weight"], sd[p + nm + ".bias"] = torch.ones(D) + tn(D), tn(D)
+        if ls:
+            sd[p + "layer_scale1.lambda1"], sd[p + "layer_scale2.lambda1"] = torch.ones(D), torch.ones(D)
+    sd["layernorm.weight"], sd["layernorm.bias"] = torch.ones(D), torch.zeros(D)
+    return sd
+
+
+def _read_checkpoint(folder):
+    folder = Path(folder).expanduser()
+    cfg = {}
+    if (folder / "config.json").exists():
+        cfg = json.loads((folder / "config.json").read_text())
+    if (folder / "model.safetensors").exists():
+        from safetensors.torch import load_file
+        return load_file(str(folder / "model.safetensors")), cfg
+    if (folder / "pytorch_model.bin").exists():
+        return torch.load(str(folder / "pytorch_model.bin"), map_location="cpu"), cfg
+    raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {folder} (and no network to download "
+                            f"one): place the HuggingFace checkpoint there or use backbone.from_state_dict")
+
+
+@BACKBONE_REGISTRY.register()
+class backbone(nn.Module):
+    def __init__(self, config=None, state_dict=None, heads=None, eps=None, device="cuda", **engine_kw):
+        super().__init__()
+        self.config = config
+        self.key = None
+        if state_dict is None:
+            if config is None:
+                raise ValueError("backbone needs a feature_extractor_cfg or a state_dict")
+            assert config.backbone_type == "huggingface"          # feature_extractor.py:16
+            if "dino" not in config.type:
+                raise ValueError(f"Unsupported model type: {config.type}")
+            state_dict, hf_cfg = _read_checkpoint(config.backbone_weights)
+            heads = heads or hf_cfg.get("num_attention_heads") or ARCHS[HUB_TO_ARCH[config.backbone]][1]
+            eps = eps or hf_cfg.get("layer_norm_eps", 1e-6)
+        if heads is None:
+            raise ValueError("heads is required with an explicit state_dict")
+        self.engine = ViTEngine(state_dict, heads=heads, eps=eps or 1e-6, device=device, **engine_kw)
+
+    @classmethod
+    def from_state_dict(cls, state_dict, heads, eps=1e-6, device="cuda", **kw):
+        return cls(None, state_dict=state_dict, heads=heads, eps=eps, device=device, **kw)
+
+    @classmethod
+    def random_init(cls, arch, seed=0, image_size=None, device="cuda", **kw):
+        return cls(None, state_dict=random_state_dict(arch, seed, image_size), heads=ARCHS[arch][1], eps=1e-6, device=device, **kw)
+
+    def forward(self, input, reshape_keys=True):
+        with torch.no_grad():
+            key = self.engine(input)                              # [B,C,h,w]
+        if not reshape_keys:                                      # the raw hook tensor minus CLS: [B,N-1,C]
+            key = key.flatten(2).transpose(1, 2)
+        self.key = key
+        return None, self.key

@@ -1,0 +1,2 @@
+from .runner import StandardRunner, create_runner  # noqa: F401
+from .loop_UCOD_DPL import TrainLoop  # noqa: F401

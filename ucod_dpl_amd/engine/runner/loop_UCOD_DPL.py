@@ -1,0 +1,347 @@
+"""Training / discriminator loops -- host-side mirror of engine/runner/loop_UCOD_DPL.py::TrainLoop.
+
+Same class and method names (``_process_batch``, ``merge_pseudo_label``, ``update_ema_decoder``,
+``Discriminator_train``, ``Discriminator_epoch``, ``run_epoch``, ``run``, ``decide_to_*``) and the same step
+semantics, including the reference's quirks: ``global_step`` advances twice per batch
+(:143,182) so the EMA ramp ``alpha = min(1 - 1/(global_step+1), ema_weight)`` (:187) is twice as fast; StepLR is
+stepped once per batch (:179); the APM weight denominator is ``max_epoch + start_finetune`` (:266);
+``loss -= dis_loss`` has no gradient path (:167-169); the discriminator's BatchNorm always uses batch
+statistics and mutates its running buffers on both APM calls (:260-261).
+
+What is different is *how* the step runs: one pass of fused HIP launches over flat parameter arenas, no
+autograd graph, no host synchronisation (the reference syncs four times per step to format log strings,
+:169,175,263-264,269 -- here scalars stay on the device unless ``log_scalars`` is on), one RCCL all-reduce of
+the flat gradient buffer per step when world_size > 1 (the reference's DDP wrapper is discarded and never
+reduces anything, engine/runner/runner.py:368-369 -- documented deviation).
+"""
+import math
+
+import torch
+
+from ... import ops
+from ...models.modules.DBA import EMB
+
+
+# ------------------------------------------------------------------------------------------------ arenas
+class DecoderArena:
+    """Flat f32 storage for the student decoder (params, grads, Adam moments) and the EMA teacher.
+    Layout: emb[128] | W[128*C] | bias[128] | head_w[128] (fg|bg) | head_b[2] (fg|bg)."""
+
+    def __init__(self, model, device):
+        dec, ema = model.decoder, model.decoder_ema
+        C = dec.decoupling.weight.shape[1]
+        self.C = C
+        self.o_emb, self.o_W, self.o_b = 0, 128, 128 + 128 * C
+        self.o_hw, self.o_hb = self.o_b + 128, self.o_b + 256
+        self.n = self.o_hb + 2
+        self.device = device
+        mk = lambda: torch.zeros(self.n, dtype=torch.float32, device=device)  # noqa: E731
+        self.p, self.g, self.m, self.v, self.ema = mk(), mk(), mk(), mk(), mk()
+        self._adopt(dec, self.p)
+        self._adopt(ema, self.ema)
+        self.Wcat = torch.empty(256, C, dtype=torch.float32, device=device)
+        self.bcat = torch.empty(256, dtype=torch.float32, device=device)
+
+    def _views(self, flat):
+        C = self.C
+        return {"learnable_embedding": flat[self.o_emb:self.o_W].view(2, EMB),
+                "decoupling.weight": flat[self.o_W:self.o_b].view(128, C, 1, 1),
+                "decoupling.bias": flat[self.o_b:self.o_hw],
+                "conv_out_fg.weight": flat[self.o_hw:self.o_hw + 64].view(1, EMB, 1, 1),
+                "conv_out_bg.weight": flat[self.o_hw + 64:self.o_hb].view(1, EMB, 1, 1),
+                "conv_out_fg.bias": flat[self.o_hb:self.o_hb + 1],
+                "conv_out_bg.bias": flat[self.o_hb + 1:self.o_hb + 2]}
+
+    def _adopt(self, decoder, flat):
+        """Copy the module's parameters into the arena and re-point them at arena views (state_dict, load_state_dict,
+        checkpoint names keep working; the arena is the storage)."""
+        params = dict(decoder.named_parameters())
+        for name, view in self._views(flat).items():
+            view.copy_(params[name].data.to(self.device))
+            params[name].data = view
+
+    def slices(self, flat):
+        return (flat[self.o_emb:self.o_W], flat[self.o_W:self.o_b].view(128, self.C), flat[self.o_b:self.o_hw],
+                flat[self.o_hw:self.o_hb], flat[self.o_hb:self.o_hb + 2])
+
+    def refresh_shared_projection(self):
+        """student rows 0..127 | teacher rows 128..255 of ONE projection (the 147 968 x 768 feature read is shared)."""
+        _, Ws, bs, _, _ = self.slices(self.p)
+        _, Wt, bt, _, _ = self.slices(self.ema)
+        self.Wcat[:128].copy_(Ws)
+        self.Wcat[128:].copy_(Wt)
+        self.bcat[:128].copy_(bs)
+        self.bcat[128:].copy_(bt)
+
+
+class DiscArena:
+    """Flat storage for the 11 discriminator parameters, their grads and Adam moments (reference order)."""
+
+    def __init__(self, disc, device):
+        self.disc = disc
+        plist = disc._param_list()
+        self.sizes = [p.numel() for p in plist]
+        self.n = sum(self.sizes)
+        mk = lambda: torch.zeros(self.n, dtype=torch.float32, device=device)  # noqa: E731
+        self.p, self.g, self.m, self.v = mk(), mk(), mk(), mk()
+        off = 0
+        self.grad_views = []
+        for p, n in zip(plist, self.sizes):
+            view = self.p[off:off + n].view(p.shape)
+            view.copy_(p.data.to(device))
+            p.data = view
+            self.grad_views.append(self.g[off:off + n].view(p.shape))
+            off += n
+        for b in (disc.maskConv, disc.convs[0], disc.convs[1]):      # buffers to the device too
+            bn = b.layers[1]
+            bn.running_mean.data = bn.running_mean.data.to(device)
+            bn.running_var.data = bn.running_var.data.to(device)
+            bn.num_batches_tracked.data = bn.num_batches_tracked.data.to(device)
+
+
+class FusedAdamW:
+    """torch.optim.AdamW(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0.01) over one arena, one launch
+    (engine/runner/runner.py:282-298).  ``step(ema=..., alpha=...)`` also applies the EMA update in the same pass."""
+
+    def __init__(self, arena_p, arena_g, arena_m, arena_v, lr):
+        self.p, self.g, self.m, self.v = arena_p, arena_g, arena_m, arena_v
+        self.param_groups = [{"lr": lr, "initial_lr": lr}]
+        self.t = 0
+
+    def zero_grad(self):
+        pass                                                  # every gradient kernel overwrites its slice
+
+    def step(self, ema=None, alpha=0.0):
+        self.t += 1
+        ops.adamw_ema(self.p, self.g, self.m, self.v, ema, self.param_groups[0]["lr"], self.t, ema_alpha=alpha)
+
+
+class StepLR:
+    def __init__(self, optimizer, step_size, gamma):
+        self.opt, self.step_size, self.gamma, self.n = optimizer, step_size, gamma, 0
+
+    def step(self):
+        self.n += 1
+        g = self.opt.param_groups[0]
+        g["lr"] = g["initial_lr"] * self.gamma ** (self.n // self.step_size)
+
+
+# ------------------------------------------------------------------------------------------------ loops
+class BaseLoop:
+    def __init__(self, config, runner):
+        self.cfg = config
+        self._runner = runner
+        self._dist_train = self.cfg.train_cfg.dist_train
+
+    @property
+    def runner(self):
+        return self._runner
+
+
+class TrainLoop(BaseLoop):
+    def __init__(self, config, runner):
+        super().__init__(config, runner)
+        self._mode = "train"
+        tc = self.cfg.train_cfg
+        self._start_epoch = tc.start_epoch
+        self._max_epoch = tc.max_epoch
+        self.global_step = 0
+        self._cur_epoch = 0
+        self._start_finetune = tc.start_finetune
+        self.finetune = False
+        self.merge_alpha = tc.merge_alpha
+        self.ema_alpha = self.cfg.model_cfg.ema_weight
+        vc = self.cfg.val_cfg
+        self.enable_val = vc.enable_val
+        self.val_interval = vc.val_interval
+        self.dis_intertrain = tc.dis_intertrain
+        self.val_start = (self._max_epoch + vc.start_val) if vc.start_val < 0 else vc.start_val
+        sc = tc.save_cfg
+        self.save_start = (self._max_epoch + sc.start_save) if sc.start_save < 0 else sc.start_save
+        self.save_interval = sc.save_interval
+        self.log_interval = self.cfg.log_cfg.log_interval
+        self.log_scalars = bool(self.cfg.log_cfg.get("log_scalars", False))   # build-only key: per-step .item() logging
+        self.best_mae = 1000.0
+        self.best_result = None
+        self.last = {}
+
+    # ------------------------------------------------------------------ one optimiser step (loop_UCOD_DPL.py:148-184)
+    def _process_batch(self, batch_data):
+        if isinstance(batch_data, dict):
+            pseudo_labels, _, features, _ = batch_data.values()
+        else:
+            pseudo_labels, features = batch_data
+        r = self.runner
+        A = r.arena
+        world = r.world_size
+        dev = A.device
+        fs = self.cfg.model_cfg.feature_size
+        features = features.to(dev, torch.float32)
+        pseudo_labels = pseudo_labels.to(dev, torch.float32)
+        B = features.shape[0]
+        feats = features.contiguous() if features.shape[-2:] == (fs, fs) else ops.bilinear_resize(features, fs, fs)     # :153
+        pl = ops.bilinear_resize(pseudo_labels, fs, fs)                                                               # :154
+
+        # teacher (no grad) and student share one projection (:156-158)
+        A.refresh_shared_projection()
+        emb_s, _, _, hw_s, hb_s = A.slices(A.p)
+        emb_t, _, _, hw_t, hb_t = A.slices(A.ema)
+        d = ops.dba_project(feats, A.Wcat, A.bcat)
+        norm_s = ops.dba_colnorm(d, 0, emb_s)
+        norm_t = ops.dba_colnorm(d, 128, emb_t)
+        fg, bg, sdiag = ops.dba_heads(d, 0, emb_s, norm_s, hw_s, hb_s, want_bg=True, want_sdiag=True)
+        teacher, _, _ = ops.dba_heads(d, 128, emb_t, norm_t, hw_t, hb_t, want_bg=False)
+        extra, gram = ops.orth_gram(d, 0, emb_s, norm_s, sdiag)
+
+        # APM (:257-272) + both BCE losses and their gradients (:161-173)
+        disc_t = r.discriminator.tensor_table()
+        p_s, _ = ops.disc_fwd(ops.binarize(fg, logits=True).view(B, 1, fs, fs), disc_t, update_running=True, saved=r.disc_saved(B, fs))
+        r.discriminator._bump_num_batches()
+        p_p, _ = ops.disc_fwd(ops.binarize(pl, logits=False), disc_t, update_running=True, saved=r.disc_saved(B, fs))
+        r.discriminator._bump_num_batches()
+        epoch_frac = self._cur_epoch / (self._max_epoch + self._start_finetune)
+        w, merged, gfg, gbg, losses = ops.apm_bce(pl.view(B, -1), teacher, fg, bg, p_s, p_p, epoch_frac, gscale=1.0 / world)
+
+        # backward through heads / gate / normalisation / orthogonality loss, then the 1x1 conv weight gradient
+        g_emb, g_W, g_b, g_hw, g_hb = A.slices(A.g)
+        gd, _, _, _ = ops.dba_bwd(d, 0, emb_s, norm_s, hw_s, gram, gfg, gbg, 1.0 / world, g_head_w=g_hw, g_head_b=g_hb, g_dec_bias=g_b)
+        ops.dba_wgrad(gd, feats, gW=g_W)
+        if world > 1:
+            torch.distributed.all_reduce(A.g)                 # RCCL, one flat 128C+386-float buffer (grads pre-scaled by 1/world)
+
+        # AdamW + StepLR + EMA (:178-181,186-191)
+        alpha = min(1 - 1 / (self.global_step + 1), self.ema_alpha)
+        r.optimizer.step(ema=A.ema, alpha=alpha)
+        r.lr_scheduler.step()
+        self.global_step += 1
+
+        loss = losses[0] + losses[1] + extra[0]
+        if not self.finetune:
+            loss = loss - losses[2]
+        self.last = dict(loss=loss, dis_loss=losses[2], extra=extra[0], w=w, merged=merged, fg=fg, bg=bg, teacher=teacher, p_s=p_s, p_p=p_p)
+        if self.log_scalars:
+            r.logger.log("train/dis_loss:{:.4f}".format(losses[2].item()))
+            r.logger.log("iter{}:loss:{:.4f}".format(self.global_step - 1, loss.item()))
+        return loss
+
+    def merge_pseudo_label(self, pseudo_labels, p_teachers, p_students, features=None):
+        """Stand-alone APM fusion with the reference's signature (:257-272) -> (merged [B,1,H,W], dis_loss)."""
+        r = self.runner
+        B, _, H, W = pseudo_labels.shape
+        t = r.discriminator.tensor_table()
+        p_s, _ = ops.disc_fwd(ops.binarize(p_students.contiguous(), logits=True), t, update_running=True)
+        r.discriminator._bump_num_batches()
+        p_p, _ = ops.disc_fwd(ops.binarize(pseudo_labels.contiguous(), logits=False), t, update_running=True)
+        r.discriminator._bump_num_batches()
+        frac = self._cur_epoch / (self._max_epoch + self._start_finetune)
+        zeros = torch.zeros(B, H * W, device=pseudo_labels.device)
+        _, merged, _, _, losses = ops.apm_bce(pseudo_labels.reshape(B, -1).contiguous(), p_teachers.reshape(B, -1).contiguous(), zeros, zeros, p_s, p_p, frac)
+        return merged.view(B, 1, H, W), losses[2]
+
+    def update_ema_decoder(self):
+        """:186-191 as a separate call (the fused step applies it inside the optimiser launch)."""
+        A = self.runner.arena
+        alpha = min(1 - 1 / (self.global_step + 1), self.ema_alpha)
+        A.ema.mul_(alpha).add_(A.p, alpha=1 - alpha)
+
+    # ------------------------------------------------------------------ discriminator phase (:215-255)
+    def Discriminator_train(self):
+        for p in self.runner.discriminator.parameters():
+            p.requires_grad = True
+        for p in self.runner.model.decoder.parameters():
+            p.requires_grad = False
+        for _ in range(self.cfg.train_cfg.dis_epoch):
+            self.Discriminator_epoch()
+        for p in self.runner.discriminator.parameters():
+            p.requires_grad = False
+        for p in self.runner.model.decoder.parameters():
+            p.requires_grad = True
+
+    def Discriminator_epoch(self):
+        for batch in self.runner.train_dataloader:
+            self._discriminator_batch(batch)
+
+    def _discriminator_batch(self, batch):
+        if isinstance(batch, dict):
+            pseudo_labels, _, features, _ = batch.values()
+        else:
+            pseudo_labels, features = batch
+        r = self.runner
+        A, DA = r.arena, r.disc_arena
+        dev = A.device
+        fs = self.cfg.model_cfg.feature_size
+        features = features.to(dev, torch.float32)
+        B = features.shape[0]
+        feats = features.contiguous() if features.shape[-2:] == (fs, fs) else ops.bilinear_resize(features, fs, fs)
+        emb_s, W_s, b_s, hw_s, hb_s = A.slices(A.p)
+        d = ops.dba_project(feats, W_s, b_s)                  # student only, no grad (:238-240)
+        norm = ops.dba_colnorm(d, 0, emb_s)
+        fg, _, _ = ops.dba_heads(d, 0, emb_s, norm, hw_s, hb_s, want_bg=False)
+        preds = ops.binarize(fg, logits=True).view(B, 1, fs, fs)
+        pl = ops.binarize(ops.bilinear_resize(pseudo_labels.to(dev, torch.float32), fs, fs), logits=False)           # :241
+        t = r.discriminator.tensor_table()
+        world = r.world_size
+        probs_pseudo, saved_p = ops.disc_fwd(pl, t, update_running=True)                                              # :244
+        r.discriminator._bump_num_batches()
+        probs_student, saved_s = ops.disc_fwd(preds, t, update_running=True)                                          # :245
+        r.discriminator._bump_num_batches()
+        # BCELoss(cat(student, pseudo), [0..0, 1..1]) mean over 2B (:246-247); torch clamps log at -100
+        eps_guard = 1e-43
+        g_student = (1.0 / (2 * B * world)) / (1.0 - probs_student).clamp_min(eps_guard)
+        g_pseudo = (-1.0 / (2 * B * world)) / probs_pseudo.clamp_min(eps_guard)
+        loss = (-(torch.log(1 - probs_student).clamp_min(-100.0).sum() + torch.log(probs_pseudo).clamp_min(-100.0).sum())) / (2 * B)
+        ops.disc_bwd(pl, t, saved_p, g_pseudo, grads=DA.grad_views, accumulate=False)
+        ops.disc_bwd(preds, t, saved_s, g_student, grads=DA.grad_views, accumulate=True)
+        if world > 1:
+            torch.distributed.all_reduce(DA.g)
+        r.dis_optimizer.step()
+        r.dis_lr_scheduler.step()
+        self.last = dict(dis_phase_loss=loss, probs_student=probs_student, probs_pseudo=probs_pseudo)
+        if self.log_scalars:
+            r.logger.log("dis:loss:{:.4f}".format(loss.item()))
+        return loss
+
+    # ------------------------------------------------------------------ epoch / schedule (:94-146,193-213)
+    def run_epoch(self):
+        self.runner.model.train()
+        for batch_data in self.runner.train_dataloader:
+            loss = self._process_batch(batch_data)
+            if self.log_scalars and self._cur_epoch % self.log_interval == 0:
+                self.runner.logger.log(f"iter{self.global_step}:loss:{loss.item():.4f}")
+            self.global_step += 1                             # second increment per batch (:143)
+
+    def run(self):
+        self.runner.logger.log(self.cfg)
+        while self._cur_epoch < self._max_epoch:
+            if self.decide_to_finetune():
+                self.runner.start_finetune()
+                self.global_step = 0
+            if self.decide_to_train_dis():
+                self.Discriminator_train()
+            self.run_epoch()
+            self._cur_epoch += 1
+            if self.decide_to_save():
+                self.runner.save_checkpoint(self._cur_epoch)
+            if self.decide_to_val():
+                self._update_best_result(self.runner.launch_val_look_twice())
+
+    def _update_best_result(self, result):
+        if result is not None and result["MAE"] < self.best_mae:
+            self.best_mae, self.best_result = result["MAE"], result
+            self.runner.logger.log("best result:")
+            self.runner.logger.log_table({k: [round(v, 4)] for k, v in result.items()})
+
+    def decide_to_train_dis(self):
+        return self.cfg.train_cfg.merge_method == "dis" and self._cur_epoch % self.dis_intertrain == 0 and not self.finetune
+
+    def decide_to_finetune(self):
+        if self._cur_epoch == self._max_epoch + self._start_finetune:
+            self.finetune = True
+            return True
+        return False
+
+    def decide_to_save(self):
+        return self._cur_epoch >= self.save_start and self._cur_epoch % self.save_interval == 0
+
+    def decide_to_val(self):
+        return self.enable_val and self._cur_epoch >= self.val_start and self._cur_epoch % self.val_interval == 0

@@ -1,0 +1,128 @@
+"""Thin runner -- host-side mirror of engine/runner/runner.py::StandardRunner (:242-397) for the hot path.
+
+Builds what the loops need (``model``, ``discriminator``, ``optimizer``/``lr_scheduler``, ``dis_optimizer``/
+``dis_lr_scheduler``, ``train_dataloader``, ``logger``) and the MI355X-specific state (flat arenas, reusable
+buffers, the process group).  One process per GPU: ``torch.distributed`` with backend ``nccl`` (= RCCL over xGMI
+on ROCm) is initialised from the torchrun environment; parameters are broadcast from rank 0 once (what the DDP
+constructor did in the reference, runner.py:357-365) and the loop all-reduces the flat gradient buffer.
+``accelerate`` is not used: the reference unwraps the DDP module right after ``prepare`` (:368-369), so the only
+behaviour it contributed on this path was device placement and that initial broadcast.
+Checkpoints keep the reference's format: a directory ``epochN.pth/`` containing ``model.safetensors`` with the
+``decoder.*`` / ``decoder_ema.*`` names (:165-185); ``load_checkpoint`` raises on failure instead of swallowing it
+(:201-207, documented deviation).
+"""
+import os
+
+import torch
+
+from ... import ops, native
+from ...models.uscod import baseline
+from ...models.discriminator import Discriminator
+from .loop_UCOD_DPL import DecoderArena, DiscArena, FusedAdamW, StepLR, TrainLoop
+
+
+class Logger:
+    """log / info / error / log_table on the ranks listed in ``log_cfg.multi_rank`` (engine/utils/logger.py:85-171 surface)."""
+
+    def __init__(self, rank=0, ranks=(0,)):
+        self.enabled = rank in tuple(ranks)
+
+    def log(self, msg, *a, **k):
+        if self.enabled:
+            print(msg, flush=True)
+
+    info = log
+    warning = log
+    error = log
+
+    def log_table(self, table, *a, **k):
+        if self.enabled:
+            print(" | ".join(f"{k}={v}" for k, v in table.items()), flush=True)
+
+
+class StandardRunner:
+    def __init__(self, config, train_dataloader=None, val_dataloader=None, device=None):
+        self.config = config
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        if not torch.cuda.is_available():
+            raise RuntimeError("StandardRunner needs a GPU: the hot path is HIP-only (no CPU fallback)")
+        native.load()
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank) if device is None else torch.device(device)
+        if self.world_size > 1 and not torch.distributed.is_initialized():
+            torch.distributed.init_process_group(backend="nccl")          # RCCL
+        self.logger = Logger(self.rank, config.log_cfg.get("multi_rank", [0]))
+        self.train_dataloader = train_dataloader if train_dataloader is not None else []
+        self.val_dataloader = val_dataloader if val_dataloader is not None else []
+        self._saved = {}
+        self._build_model()
+        self._build_optimizer()
+
+    # ------------------------------------------------------------------ builders (runner.py:266-308)
+    def _build_model(self):
+        self.model = baseline(self.config.model_cfg)
+        self.discriminator = Discriminator(self.config.model_cfg)
+        ckpt = self.config.train_cfg.get("checkpoint", None)
+        if ckpt:
+            self.load_checkpoint(ckpt)
+        self.arena = DecoderArena(self.model, self.device)
+        self.disc_arena = DiscArena(self.discriminator, self.device)
+        if self.world_size > 1:                               # the DDP-constructor broadcast of the reference
+            for t in (self.arena.p, self.arena.ema, self.disc_arena.p):
+                torch.distributed.broadcast(t, src=0)
+            for b in (self.discriminator.maskConv, self.discriminator.convs[0], self.discriminator.convs[1]):
+                torch.distributed.broadcast(b.layers[1].running_mean, src=0)
+                torch.distributed.broadcast(b.layers[1].running_var, src=0)
+
+    def _build_optimizer(self):
+        tc = self.config.train_cfg
+        A, DA = self.arena, self.disc_arena
+        A.m.zero_(); A.v.zero_(); DA.m.zero_(); DA.v.zero_()
+        self.optimizer = FusedAdamW(A.p, A.g, A.m, A.v, tc.lr0)
+        self.dis_optimizer = FusedAdamW(DA.p, DA.g, DA.m, DA.v, tc.dis_lr0)
+        self.lr_scheduler = StepLR(self.optimizer, tc.step_lr_size, tc.step_lr_gamma)
+        self.dis_lr_scheduler = StepLR(self.dis_optimizer, tc.dis_step_lr_size, tc.dis_step_lr_gamma)
+
+    def start_finetune(self):                                 # runner.py:378-379
+        self._build_optimizer()
+
+    def disc_saved(self, B, fs):
+        key = (B, fs)
+        if key not in self._saved:
+            self._saved[key] = torch.empty(native.load().ucod_disc_saved_bytes(B, fs), dtype=torch.uint8, device=self.device)
+        return self._saved[key]
+
+    # ------------------------------------------------------------------ checkpoints (runner.py:165-240)
+    def save_checkpoint(self, epoch, save_mode="model"):
+        from safetensors.torch import save_file
+        if self.world_size > 1:
+            torch.distributed.barrier()
+        if self.rank == 0:
+            path = os.path.join(self.config.log_cfg.log_path, "ckp", f"epoch{epoch}.pth")
+            os.makedirs(path, exist_ok=True)
+            save_file({k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()}, os.path.join(path, "model.safetensors"))
+
+    def load_checkpoint(self, checkpoint_path):
+        from safetensors.torch import load_file
+        if os.path.isdir(checkpoint_path):
+            checkpoint_path = os.path.join(checkpoint_path, "model.safetensors")
+        self.model.load_state_dict(load_file(checkpoint_path), strict=True)
+        self.logger.info("Successfully loaded checkpoint weights from {}".format(checkpoint_path))
+
+    # ------------------------------------------------------------------ launchers (runner.py:381-397)
+    def launch_train(self):
+        self.trainloop = TrainLoop(self.config, self)
+        self.trainloop.run()
+
+    def launch_val_look_twice(self):
+        from .loop_look_twice import ValLoop_Look_Twice
+        return ValLoop_Look_Twice(self.config, self).run()
+
+
+def create_runner(config, **kw):
+    """engine/runner/runner.py:688-699 surface; only the first-stage (UCOD-DPL) runner is on the hot path."""
+    if config.model_cfg.get("window_size", None) is not None or config.train_cfg.get("refiner_path", None):
+        raise NotImplementedError("CORAL second stage (LocalRefineRunner) is a 'next' row of SURVEY.md 8(f)")
+    return StandardRunner(config, **kw)

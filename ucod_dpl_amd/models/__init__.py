@@ -1,0 +1,2 @@
+from .uscod import baseline  # noqa: F401
+from .discriminator import Discriminator  # noqa: F401

@@ -54,6 +54,8 @@ SIGNATURES = {
     "ucod_dba_wgrad": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "ucod_disc_saved_bytes": (sz, [ci, ci]),
     "ucod_disc_fwd": (ci, [vp, C.POINTER(DiscParams), vp, vp, ci, ci, ci, vp]),
+    "ucod_disc_bwd_workspace_bytes": (sz, [ci, ci]),
+    "ucod_disc_bwd": (ci, [vp, C.POINTER(DiscParams), vp, vp, C.POINTER(DiscGrads), ci, vp, ci, ci, vp]),
     "ucod_apm_bce": (ci, [vp, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, ci, ci, vp]),
     "ucod_binarize": (ci, [vp, vp, sz, ci, vp]),
     "ucod_adamw_ema": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, ci, cf, vp]),

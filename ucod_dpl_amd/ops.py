@@ -186,3 +186,25 @@ def apm_bce(pl, teacher, fg, bg, p_s, p_p, epoch_frac, gscale=1.0):
 def adamw_ema(p, g, m, v, ema, lr, step, ema_alpha=0.0, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01):
     check(N.load().ucod_adamw_ema(ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), float(lr), beta1, beta2, eps, weight_decay, int(step),
                                   float(ema_alpha), stream()), "ucod_adamw_ema")
+
+
+DISC_GRAD_SHAPES = (("w1", (32, 1, 3, 3)), ("g1", (32,)), ("b1", (32,)), ("w2", (16, 32, 3, 3)), ("g2", (16,)), ("b2", (16,)),
+                    ("w3", (8, 16, 3, 3)), ("g3", (8,)), ("b3", (8,)), ("lin_w", None), ("lin_b", (1,)))
+
+
+def disc_bwd(mask, tensors, saved, gprob, grads=None, accumulate=False):
+    """Gradients of sum_b gprob[b]*prob[b] w.r.t. the 11 discriminator parameters (reference order)."""
+    B, _, fs, _ = mask.shape
+    lib = N.load()
+    dev = mask.device
+    if grads is None:
+        grads = [torch.zeros(tensors["lin_w"].shape if shp is None else shp, dtype=torch.float32, device=dev) for _, shp in DISC_GRAD_SHAPES]
+        accumulate = True                                   # freshly zeroed
+    gs = N.DiscGrads()
+    for (name, _), t in zip(DISC_GRAD_SHAPES, grads):
+        setattr(gs, name, ptr(_f32(t)))
+    ws = torch.empty(lib.ucod_disc_bwd_workspace_bytes(B, fs), dtype=torch.uint8, device=dev)
+    ps = disc_params_struct(tensors)
+    check(lib.ucod_disc_bwd(ptr(_f32(mask)), C.byref(ps), ptr(saved), ptr(_f32(gprob)), C.byref(gs), int(accumulate), ptr(ws), B, fs,
+                            stream()), "ucod_disc_bwd")
+    return grads
