@@ -29,6 +29,14 @@ int ucod_abi_version(void);
 /* 1 when a gfx950 device is visible to this process (hipGetDeviceProperties().gcnArchName) */
 int ucod_device_is_gfx950(void);
 
+/* Optional per-op timing with HIP events recorded on the launch stream around every launcher below (off by default;
+ * bench.py turns it on over its timed region to price each kernel class against its roofline).
+ * ucod_prof_collect synchronises the recorded events, fills total_ms[ncls] / count[ncls] and clears the log. */
+int ucod_prof_enable(int on);
+int ucod_prof_num_classes(void);
+const char* ucod_prof_class_name(int cls);
+int ucod_prof_collect(double* total_ms_host, long long* count_host);
+
 /* ------------------------------------------------------------------ ViT backbone (rows B1-B8) */
 
 /* GEMM epilogues: C[m][n] = sum_k A[m][k]*B[n][k], A:[M,K] B:[N,K] bf16, K contiguous (y = x W^T) */

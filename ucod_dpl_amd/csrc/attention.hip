@@ -206,6 +206,7 @@ extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, in
   if (!qkv || !out || B <= 0 || tok <= 0 || heads <= 0) return UCOD_EINVAL;
   dim3 grid(cdiv(tok, QT), heads, B), block(256);
   const float c = scale * 1.4426950408889634f;
+  UCOD_PROF(PROF_ATTN, stream);
   if (variant == 1)
     hipLaunchKernelGGL((attn_fwd_kernel<1>), grid, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, c);
   else

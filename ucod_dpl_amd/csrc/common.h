@@ -73,4 +73,18 @@ __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + ex
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// op classes for the optional event profiler (prof.hip); the first six follow the UCOD_EPI_* numbering
+enum ProfClass {
+  PROF_GEMM_EPI0 = 0, PROF_GEMM_EPI1, PROF_GEMM_EPI2, PROF_GEMM_EPI3, PROF_GEMM_EPI4, PROF_GEMM_EPI5, PROF_ATTN, PROF_LN,
+  PROF_IM2COL, PROF_CLS, PROF_BILINEAR, PROF_DBA_PROJECT, PROF_DBA_COLNORM, PROF_DBA_HEADS, PROF_ORTH, PROF_DBA_BWD,
+  PROF_DBA_WGRAD, PROF_DISC_FWD, PROF_DISC_BWD, PROF_APM, PROF_BINARIZE, PROF_ADAMW, PROF_CROP, PROF_CAST, PROF_NUM
+};
+struct ProfScope {
+  int idx;
+  hipStream_t stream;
+  ProfScope(int cls, hipStream_t s);
+  ~ProfScope();
+};
+#define UCOD_PROF(cls, stream) ucod::ProfScope prof_scope__((cls), (hipStream_t)(stream))
+
 }  // namespace ucod

@@ -276,6 +276,7 @@ using namespace ucod;
 
 extern "C" int ucod_dba_colnorm(const float* d, int ld_c, int c0, const float* emb, float* norm, int B, int HW, void* stream) {
   if (!d || !emb || !norm || B <= 0 || HW <= 0 || c0 < 0 || c0 + 128 > ld_c) return UCOD_EINVAL;
+  UCOD_PROF(PROF_DBA_COLNORM, stream);
   hipLaunchKernelGGL(colnorm_kernel, dim3(128, B), dim3(256), 0, (hipStream_t)stream, d, ld_c, c0, emb, norm, HW);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
@@ -285,6 +286,7 @@ extern "C" int ucod_dba_heads_fwd(const float* d, int ld_c, int c0, const float*
                                   const float* head_b, float* fg, float* bg, float* sdiag, int B, int HW, void* stream) {
   if (!d || !emb || !norm || !head_w || !head_b || !fg || B <= 0 || HW <= 0 || c0 < 0 || c0 + 128 > ld_c) return UCOD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  UCOD_PROF(PROF_DBA_HEADS, s);
   if (sdiag) {
     hipError_t e = hipMemsetAsync(sdiag, 0, sizeof(float) * B, s);
     if (e != hipSuccess) return (int)e;
@@ -303,6 +305,7 @@ extern "C" int ucod_orth_gram_fwd(const float* d, int ld_c, int c0, const float*
                                   float* gram, float* loss, void* ws, int B, int HW, void* stream) {
   if (!d || !emb || !norm || !sdiag || !gram || !loss || !ws || B <= 0 || HW <= 0 || c0 < 0 || c0 + 128 > ld_c) return UCOD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  UCOD_PROF(PROF_ORTH, s);
   const int S = cdiv(HW, GCH);
   float* partial = (float*)ws;
   float* trace = partial + (size_t)B * S * 2 * E * E;
@@ -324,6 +327,7 @@ extern "C" int ucod_dba_bwd(const float* d, int ld_c, int c0, const float* emb, 
     return UCOD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   float* gfeat = (float*)ws;
+  UCOD_PROF(PROF_DBA_BWD, s);
   hipError_t e = hipMemsetAsync(g_head_w, 0, sizeof(float) * 128, s);
   if (e == hipSuccess) e = hipMemsetAsync(g_head_b, 0, sizeof(float) * 2, s);
   if (e == hipSuccess) e = hipMemsetAsync(g_dec_bias, 0, sizeof(float) * 128, s);

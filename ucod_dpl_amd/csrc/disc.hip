@@ -160,6 +160,7 @@ extern "C" int ucod_disc_fwd(const float* mask, const ucod_disc_params* p, float
   float* st1 = y1 + stats_off(d);
   float* st2 = st1 + 64;
   float* st3 = st2 + 32;
+  UCOD_PROF(PROF_DISC_FWD, s);
   hipLaunchKernelGGL((conv3x3_kernel<1, 32, 1, false>), dim3(cdiv((long)B * d.s1 * d.s1, 256)), dim3(256), 0, s, mask, p->w1, nullptr, nullptr, nullptr, y1, B, fs, d.s1);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(32), dim3(1024), 0, s, y1, 32, B, d.s1 * d.s1, st1, p->rm1, p->rv1, update_running);
   hipLaunchKernelGGL((conv3x3_kernel<32, 16, 2, true>), dim3(cdiv((long)B * d.s2 * d.s2, 256)), dim3(256), 0, s, y1, p->w2, st1, p->g1, p->b1, y2, B, d.s1, d.s2);
@@ -356,6 +357,7 @@ extern "C" int ucod_disc_bwd(const float* mask, const ucod_disc_params* p, const
   float* su2 = su1 + 64;
   float* su3 = su2 + 32;
   const int hw1 = d.s1 * d.s1, hw2 = d.s2 * d.s2, hw3 = d.s3 * d.s3;
+  UCOD_PROF(PROF_DISC_BWD, s);
   if (!accumulate) {
     hipError_t e = hipSuccess;
     auto z = [&](float* ptr, size_t n) { if (e == hipSuccess) e = hipMemsetAsync(ptr, 0, n * sizeof(float), s); };

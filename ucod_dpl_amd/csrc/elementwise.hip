@@ -114,6 +114,7 @@ extern "C" int ucod_bilinear_resize(const float* in, float* out, int planes, int
   if (!in || !out || planes <= 0 || ih <= 0 || iw <= 0 || oh <= 0 || ow <= 0) return UCOD_EINVAL;
   const size_t total = (size_t)planes * oh * ow;
   const float sh = (float)ih / (float)oh, sw = (float)iw / (float)ow;   // area_pixel_compute_scale<float>
+  UCOD_PROF(PROF_BILINEAR, stream);
   hipLaunchKernelGGL(bilinear_kernel, dim3(nblocks(total, 16384)), dim3(256), 0, (hipStream_t)stream, in, out, (long)planes, ih, iw, oh, ow, sh, sw);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
@@ -122,6 +123,7 @@ extern "C" int ucod_bilinear_resize(const float* in, float* out, int planes, int
 extern "C" int ucod_binarize(const float* x, float* out, size_t n, int logits, void* stream) {
   if (!x || !out) return UCOD_EINVAL;
   if (n == 0) return UCOD_OK;
+  UCOD_PROF(PROF_BINARIZE, stream);
   hipLaunchKernelGGL(binarize_kernel, dim3(nblocks(n, 4096)), dim3(256), 0, (hipStream_t)stream, x, out, n, logits);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
@@ -132,6 +134,7 @@ extern "C" int ucod_apm_bce(const float* pl, const float* teacher, const float* 
                             float* losses, int B, int HW, void* stream) {
   if (!pl || !teacher || !fg || !bg || !p_s || !p_p || !w || !merged || !gfg || !gbg || !losses || B <= 0 || HW <= 0) return UCOD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  UCOD_PROF(PROF_APM, s);
   hipError_t e = hipMemsetAsync(losses, 0, 4 * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(apm_bce_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, s, pl, teacher, fg, bg, p_s, p_p, epoch_frac, gscale, w, merged, gfg, gbg, losses, B, HW);
@@ -147,6 +150,7 @@ extern "C" int ucod_adamw_ema(float* p, const float* g, float* m, float* v, floa
   const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
   const float step_size = (float)((double)lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
+  UCOD_PROF(PROF_ADAMW, stream);
   hipLaunchKernelGGL(adamw_ema_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, n, decay, beta1, beta2, step_size, bc2_sqrt, eps, ema_alpha);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;

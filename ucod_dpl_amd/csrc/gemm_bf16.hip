@@ -203,6 +203,7 @@ extern "C" int ucod_gemm_bf16(int epilogue, const void* A, const void* B, void* 
   a.tiles_m = cdiv(M, BM);
   a.tiles_n = cdiv(N, BN);
   hipStream_t s = (hipStream_t)stream;
+  UCOD_PROF(epilogue >= 0 && epilogue <= 5 ? epilogue : 5, s);
   switch (epilogue) {
     case UCOD_EPI_BIAS_BF16: if (!bias) return UCOD_EINVAL; return launch<UCOD_EPI_BIAS_BF16>(a, variant, s);
     case UCOD_EPI_BIAS_GELU_BF16: if (!bias) return UCOD_EINVAL; return launch<UCOD_EPI_BIAS_GELU_BF16>(a, variant, s);

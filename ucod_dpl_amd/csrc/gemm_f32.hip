@@ -213,6 +213,7 @@ extern "C" int ucod_dba_project(const float* x, const float* W, const float* bia
   using namespace ucod;
   if (!x || !W || !bias || !d || B <= 0 || C <= 0 || HW <= 0 || Nout <= 0 || (C % FK) != 0 || (((uintptr_t)W) % 16) != 0) return UCOD_EINVAL;
   dim3 grid(cdiv(HW, 64), cdiv(Nout, 128), B), block(256);
+  UCOD_PROF(PROF_DBA_PROJECT, stream);
   if ((HW % 4) == 0 && (((uintptr_t)x) % 16) == 0)
     hipLaunchKernelGGL((dba_project_kernel<true>), grid, block, 0, (hipStream_t)stream, x, W, bias, d, C, HW, Nout);
   else
@@ -225,6 +226,7 @@ extern "C" int ucod_dba_wgrad(const float* gd, const float* x, float* gW, int B,
   using namespace ucod;
   if (!gd || !x || !gW || B <= 0 || C <= 0 || HW <= 0) return UCOD_EINVAL;
   dim3 grid(cdiv(C, 128), cdiv(HW, WG_CHUNK), B), block(256);
+  UCOD_PROF(PROF_DBA_WGRAD, stream);
   hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * 128 * (size_t)C, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   if ((HW % 4) == 0 && (((uintptr_t)x) % 16) == 0 && (((uintptr_t)gd) % 16) == 0)

@@ -105,6 +105,7 @@ __global__ void cast_kernel(const float* __restrict__ s, bf16_raw* __restrict__ 
 extern "C" int ucod_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int D, float eps,
                               int out_f32, void* stream) {
   if (!x || !gamma || !beta || !y || rows <= 0 || D <= 0 || (D % 128) != 0) return UCOD_EINVAL;
+  UCOD_PROF(ucod::PROF_LN, stream);
   return out_f32 ? ucod::launch_ln<true>(x, gamma, beta, y, rows, D, eps, (hipStream_t)stream)
                  : ucod::launch_ln<false>(x, gamma, beta, y, rows, D, eps, (hipStream_t)stream);
 }
@@ -113,6 +114,7 @@ extern "C" int ucod_patch_im2col(const float* img, void* patches, int B, int C, 
   if (!img || !patches || B <= 0 || C <= 0 || P <= 0 || H % P || W % P || Kpad < C * P * P || (Kpad % 64) != 0) return UCOD_EINVAL;
   const int gh = H / P, gw = W / P;
   const size_t total = (size_t)B * gh * gw * (Kpad / 2);
+  UCOD_PROF(ucod::PROF_IM2COL, stream);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(ucod::im2col_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, (bf16_raw*)patches, B, C, H, W, P,
                      Kpad, gh, gw);
@@ -122,6 +124,7 @@ extern "C" int ucod_patch_im2col(const float* img, void* patches, int B, int C, 
 
 extern "C" int ucod_cls_rows(float* x, const float* cls, const float* pos, int B, int tok, int D, void* stream) {
   if (!x || !cls || !pos || B <= 0 || tok <= 0 || D <= 0) return UCOD_EINVAL;
+  UCOD_PROF(ucod::PROF_CLS, stream);
   hipLaunchKernelGGL(ucod::cls_rows_kernel, dim3(ucod::cdiv((long)B * D, 256)), dim3(256), 0, (hipStream_t)stream, x, cls, pos, B, tok, D);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
@@ -130,6 +133,7 @@ extern "C" int ucod_cls_rows(float* x, const float* cls, const float* pos, int B
 extern "C" int ucod_cast_f32_bf16(const float* src, void* dst, size_t n, void* stream) {
   if (!src || !dst) return UCOD_EINVAL;
   if (n == 0) return UCOD_OK;
+  UCOD_PROF(ucod::PROF_CAST, stream);
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(ucod::cast_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_raw*)dst, n);
   UCOD_CHECK_LAUNCH();

@@ -35,6 +35,10 @@ class DiscGrads(C.Structure):
 SIGNATURES = {
     "ucod_abi_version": (ci, []),
     "ucod_device_is_gfx950": (ci, []),
+    "ucod_prof_enable": (ci, [ci]),
+    "ucod_prof_num_classes": (ci, []),
+    "ucod_prof_class_name": (C.c_char_p, [ci]),
+    "ucod_prof_collect": (ci, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ucod_gemm_bf16": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
     "ucod_layernorm": (ci, [vp, vp, vp, vp, ci, ci, cf, ci, vp]),
     "ucod_attention_fwd": (ci, [vp, vp, ci, ci, ci, cf, ci, vp]),
