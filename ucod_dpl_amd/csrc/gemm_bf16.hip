@@ -91,6 +91,56 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& a, int m, int n, 
   }
 }
 
+// Four consecutive columns n..n+3 of output row m (n % 4 == 0, N % 4 == 0): vector loads / stores.
+template <int EPI>
+__device__ __forceinline__ void epilogue_store4(const GemmArgs& a, int m, int n, f32x4 v) {
+  if (m >= a.M || n >= a.N) return;
+  if constexpr (EPI == UCOD_EPI_KEY_NCHW_F32) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) epilogue_store<EPI>(a, m, n + e, v[e]);
+  } else {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
+    if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) {
+      f32x4 o = v + b;
+      if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
+      }
+      u32x2 w;
+      w[0] = pack_bf16x2(o[0], o[1]);
+      w[1] = pack_bf16x2(o[2], o[3]);
+      *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_raw*>(a.out) + (size_t)m * a.N + n) = w;
+    } else if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) {
+      const size_t i = (size_t)m * a.N + n;
+      const f32x4 r = *reinterpret_cast<const f32x4*>(a.resid + i);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + i) = r + sc * (v + b);
+    } else if constexpr (EPI == UCOD_EPI_PATCH_TOKENS_F32) {
+      const int np = a.tok - 1;
+      const int bi = m / np, p = m - bi * np;
+      const f32x4 ps = *reinterpret_cast<const f32x4*>(a.pos + (size_t)(1 + p) * a.N + n);
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + ((size_t)bi * a.tok + 1 + p) * a.N + n) = v + b + ps;
+    } else {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.N + n) = v + b;
+    }
+  }
+}
+
+// Epilogue of one wave's RxWCOLS f32 sub-tile through a wave-private LDS region: accumulators are written with the
+// MFMA C layout (lane -> column), read back row-major 16 B per lane, so global traffic is whole 64..256-byte row
+// segments (4x fewer, wider instructions than storing straight from the accumulator layout).
+template <int EPI, int WCOLS, int ROWS>
+__device__ __forceinline__ void drain_rows(const GemmArgs& a, const char* wbase, int m_first, int n_first, int lane) {
+  constexpr int CH = WCOLS / 4;                       // 16-byte chunks per row
+  static_assert((ROWS * CH) % 64 == 0, "whole wave instructions");
+#pragma unroll
+  for (int it = 0; it < ROWS * CH / 64; ++it) {
+    const int idx = it * 64 + lane, r = idx / CH, c = idx - r * CH;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + r * (WCOLS * 4) + c * 16);
+    epilogue_store4<EPI>(a, m_first + r, n_first + c * 4, v);
+  }
+}
+
 template <int EPI, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [stage][A|B]
@@ -157,26 +207,226 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
     }
   }
 
-  // C/D map of v_mfma_f32_16x16x32: col = lane&15, row = (lane>>4)*4 + reg
+  // C/D map of v_mfma_f32_16x16x32: col = lane&15, row = (lane>>4)*4 + reg.  Drain through LDS (see drain_rows).
+  __syncthreads();
+  if ((a.N & 3) == 0) {
+    char* wbase = smem + wave * (64 * 64 * 4);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int m = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + rg;
-        const int n = n0 + wc * 64 + j * 16 + (lane & 15);
-        epilogue_store<EPI>(a, m, n, acc[i][j][rg]);
-      }
+        for (int rg = 0; rg < 4; ++rg)
+          *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * 256 + (j * 16 + (lane & 15)) * 4) = acc[i][j][rg];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    drain_rows<EPI, 64, 64>(a, wbase, m0 + wr * 64, n0 + wc * 64, lane);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          epilogue_store<EPI>(a, m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + rg, n0 + wc * 64 + j * 16 + (lane & 15), acc[i][j][rg]);
+  }
 }
 
+// =====================================================================================================
+// Large-tile kernel: 256 x (64*NT) x 64 block tile, 8 waves (2 in M x 4 in N), one workgroup per CU.
+//   * per wave 128 x 16*NT outputs; a K-tile is consumed in FOUR phases of 32 rows each (2 x NT tiles x 2 k-steps
+//     = 4*NT MFMAs per phase); the wave's B fragments are read once per K-tile (phase 1) and stay in registers;
+//   * LDS = two K-tile buffers {A0 | A1 | B}; operands arrive by 16-byte LDS-DMA that stays IN FLIGHT across the
+//     phase barriers: phase 1/2 stage A0/A1 of tile t+1 into the other buffer, phase 3/4 stage B of tile t+2 into
+//     THIS buffer (its B slot is dead after phase 1), and the only wait is a counted `s_waitcnt vmcnt(BN/64)` at
+//     phase 4 that leaves exactly the B(t+2) DMAs outstanding; raw s_barrier (a __syncthreads would drain vmcnt);
+//   * 256-row tiles halve the L2->LDS traffic per FLOP of the 128x128 kernel, which is L2-bandwidth bound
+//     (2 WGs/CU x 32 KB per 1024 MFMA cycles ~ 39 TB/s chip-wide, above the ~34.5 TB/s L2 ceiling).
+// Hazards: RAW -- every wave waits for its own DMAs (vmcnt) BEFORE the phase-4 barrier, reads happen after it;
+//          WAR -- B slot of buffer b: last ds_read in phase 1 (retired before its MFMAs), first restaged in phase 3;
+//                 A slots of buffer b^1: last read in phase 4 of tile t-1, first restaged in phase 1 of tile t,
+//                 with the phase-4 barrier in between.
+// =====================================================================================================
+constexpr int SLOT_A = 128 * 128;  // bytes: 128 rows x 64 bf16
+
+template <int NT>
+struct BigCfg {
+  static constexpr int BN_ = 64 * NT;
+  static constexpr int NB = BN_ / 64;                 // LDS-DMA instructions per thread for the B tile
+  static constexpr int BUF = 2 * SLOT_A + BN_ * 128;  // bytes per K-tile buffer
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+}
+
+template <int EPI, int NT>
+__global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
+  using Cfg = BigCfg<NT>;
+  __shared__ __attribute__((aligned(16))) char smem[2 * Cfg::BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+  const int tm = wg / a.tiles_n, tn = wg - tm * a.tiles_n;
+  const int m0 = tm * 256, n0 = tn * Cfg::BN_;
+  const int K = a.K, nt = K / BK;
+
+  // per-thread LDS-DMA source rows (fixed for the whole K loop): A0,A1 -> 2 instructions each; B -> NB instructions
+  const bf16_raw* srcA[2][2];
+  const bf16_raw* srcB[Cfg::NB];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (i * 8 + wave) * 8 + (lane >> 3);
+      int gr = m0 + h * 128 + r;
+      gr = gr < a.M ? gr : a.M - 1;
+      srcA[h][i] = a.A + (size_t)gr * K + swz(r, lane & 7) * 8;
+    }
+#pragma unroll
+  for (int i = 0; i < Cfg::NB; ++i) {
+    const int r = (i * 8 + wave) * 8 + (lane >> 3);
+    int gr = n0 + r;
+    gr = gr < a.N ? gr : a.N - 1;
+    srcB[i] = a.B + (size_t)gr * K + swz(r, lane & 7) * 8;
+  }
+  auto dma = [&](const bf16_raw* src, char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto stageA = [&](int t, int h) {
+    char* slot = smem + (t & 1) * Cfg::BUF + h * SLOT_A;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma(srcA[h][i] + t * BK, slot + (i * 8 + wave) * 1024);
+  };
+  auto stageB = [&](int t, int i0, int i1) {
+    char* slot = smem + (t & 1) * Cfg::BUF + 2 * SLOT_A;
+#pragma unroll
+    for (int i = 0; i < Cfg::NB; ++i)
+      if (i >= i0 && i < i1) dma(srcB[i] + t * BK, slot + (i * 8 + wave) * 1024);
+  };
+  constexpr int B_SPLIT = Cfg::NB >= 2 ? 2 : 1;   // phase 3 issues [0,B_SPLIT), phase 4 the rest
+
+  f32x4 acc[8][NT];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // prologue: tile 0 complete, B of tile 1 in flight
+  stageA(0, 0);
+  stageA(0, 1);
+  stageB(0, 0, Cfg::NB);
+  if (nt > 1) {
+    stageB(1, 0, Cfg::NB);
+    wait_vmcnt<Cfg::NB>();
+  } else {
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+
+  for (int t = 0; t < nt; ++t) {
+    const char* bufA = smem + (t & 1) * Cfg::BUF + wm * SLOT_A;
+    const char* bufB = smem + (t & 1) * Cfg::BUF + 2 * SLOT_A;
+    const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+    bf16x8 fb[NT][2];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      if (ph == 0 && more1) stageA(t + 1, 0);
+      if (ph == 1 && more1) stageA(t + 1, 1);
+      if (ph == 2 && more2) stageB(t + 2, 0, B_SPLIT);
+      if (ph == 3 && more2) stageB(t + 2, B_SPLIT, Cfg::NB);
+      if (ph == 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int r = wn * 16 * NT + j * 16 + (lane & 15);
+            fb[j][ks] = *reinterpret_cast<const bf16x8*>(bufB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+          }
+      }
+      bf16x8 fa[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int r = ph * 32 + i * 16 + (lane & 15);
+          fa[i][ks] = *reinterpret_cast<const bf16x8*>(bufA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+        }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[ph * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[ph * 2 + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (ph == 3) {
+        if (more2) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  // epilogue: two passes of 64 rows through a wave-private LDS region (operand tiles are dead: last barrier passed)
+  constexpr int WCOLS = 16 * NT;
+  char* wbase = smem + wave * (64 * WCOLS * 4);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * (WCOLS * 4) + (j * 16 + (lane & 15)) * 4) = acc[pass * 4 + i][j][rg];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    drain_rows<EPI, WCOLS, 64>(a, wbase, m0 + wm * 128 + pass * 64, n0 + wn * WCOLS, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// variant: 0 auto | 1 128^2 register staging | 2 128^2 LDS-DMA | 3 256x256 | 4 256x192
 template <int EPI>
-static int launch(const GemmArgs& a, int variant, hipStream_t s) {
-  dim3 grid(a.tiles_m * a.tiles_n), block(256);
-  if (variant == 1)
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, false>), grid, block, 0, s, a);
-  else
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, true>), grid, block, 0, s, a);
+static int launch(GemmArgs a, int variant, hipStream_t s) {
+  if (variant == 0) {
+    variant = 2;
+    if (a.M >= 2048 && a.K >= 128 && (a.N & 3) == 0) {
+      // cost in "rounds x tile area" on 256 CUs (one large-tile workgroup per CU)
+      auto cost = [&](int bn) { return (double)cdiv((long)cdiv(a.M, 256) * cdiv(a.N, bn), 256) * bn; };
+      const double c4 = cost(256), c3 = cost(192);
+      const double c128 = (double)cdiv((long)cdiv(a.M, 128) * cdiv(a.N, 128), 512) * 64 * 1.6;   // measured ~1.6x slower per FLOP
+      variant = (c3 <= c4) ? 4 : 3;
+      if (c128 < (c3 <= c4 ? c3 : c4)) variant = 2;
+    }
+  }
+  if ((variant == 3 || variant == 4) && (a.N & 3) != 0) return UCOD_EINVAL;
+  if (variant == 3 || variant == 4) {
+    const int bn = variant == 3 ? 256 : 192;
+    a.tiles_m = cdiv(a.M, 256);
+    a.tiles_n = cdiv(a.N, bn);
+    dim3 grid(a.tiles_m * a.tiles_n), block(512);
+    if (variant == 3)
+      hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3>), grid, block, 0, s, a);
+  } else {
+    dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    if (variant == 1)
+      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, false>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, true>), grid, block, 0, s, a);
+  }
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }
