@@ -64,7 +64,19 @@ __device__ __forceinline__ void write_tile(char* lds_tile, int wave, int lane, c
   }
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (transformers ACT2FN["gelu"], modeling_dinov2.py:289).  erf by Abramowitz-Stegun 7.1.26
+// (|abs err| <= 1.5e-7, far below the bf16 output resolution): 1 rcp + 1 exp + 6 fma instead of libm erff's
+// ~40 instructions -- the fc1 epilogue applies it 134 M times per launch.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& a, int m, int n, float v) {
@@ -264,7 +276,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 }
 
-template <int EPI, int NT>
+template <int EPI, int NT, bool STAGGER>
 __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   using Cfg = BigCfg<NT>;
   __shared__ __attribute__((aligned(16))) char smem[2 * Cfg::BUF];
@@ -333,6 +345,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
     wait_vmcnt<0>();
   }
   __builtin_amdgcn_s_barrier();
+  // STAGGER: the wm==1 waves run one barrier interval behind the wm==0 waves, so on every SIMD one wave is in its
+  // MFMA interval while its partner is in its LDS-read / DMA-issue interval (two barriers per phase: R | M).
+  // All waves execute the same number of barriers (extra one here for wm==1, extra one after the loop for wm==0).
+  if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();
 
   for (int t = 0; t < nt; ++t) {
     const char* bufA = smem + (t & 1) * Cfg::BUF + wm * SLOT_A;
@@ -362,6 +378,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
           const int r = ph * 32 + i * 16 + (lane & 15);
           fa[i][ks] = *reinterpret_cast<const bf16x8*>(bufA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
         }
+      if constexpr (STAGGER) {
+        // RAW: every wave retires its tile-(t+1) DMAs BEFORE the barrier that precedes the leading group's first read
+        if (ph == 3) {
+          if (more2) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -371,12 +396,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
           for (int j = 0; j < NT; ++j)
             acc[ph * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[ph * 2 + i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
-      if (ph == 3) {
-        if (more2) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
+      if constexpr (!STAGGER) {
+        if (ph == 3) {
+          if (more2) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();
 
   // epilogue: two passes of 64 rows through a wave-private LDS region (operand tiles are dead: last barrier passed)
   constexpr int WCOLS = 16 * NT;
@@ -396,30 +426,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   }
 }
 
-// variant: 0 auto | 1 128^2 register staging | 2 128^2 LDS-DMA | 3 256x256 | 4 256x192
+// variant: 0 auto | 1 128^2 register staging | 2 128^2 LDS-DMA | 3 256x256 | 4 256x192 | 5,6 = 3,4 with staggered wave groups
 template <int EPI>
 static int launch(GemmArgs a, int variant, hipStream_t s) {
   if (variant == 0) {
     variant = 2;
     if (a.M >= 2048 && a.K >= 128 && (a.N & 3) == 0) {
-      // cost in "rounds x tile area" on 256 CUs (one large-tile workgroup per CU)
+      // makespan in (rounds x tile width) on 256 CUs, one large-tile workgroup per CU
       auto cost = [&](int bn) { return (double)cdiv((long)cdiv(a.M, 256) * cdiv(a.N, bn), 256) * bn; };
-      const double c4 = cost(256), c3 = cost(192);
-      const double c128 = (double)cdiv((long)cdiv(a.M, 128) * cdiv(a.N, 128), 512) * 64 * 1.6;   // measured ~1.6x slower per FLOP
-      variant = (c3 <= c4) ? 4 : 3;
-      if (c128 < (c3 <= c4 ? c3 : c4)) variant = 2;
+      variant = (cost(192) <= cost(256)) ? 6 : 5;
     }
   }
-  if ((variant == 3 || variant == 4) && (a.N & 3) != 0) return UCOD_EINVAL;
-  if (variant == 3 || variant == 4) {
-    const int bn = variant == 3 ? 256 : 192;
+  if (variant >= 3 && variant <= 6 && (a.N & 3) != 0) return UCOD_EINVAL;
+  if (variant >= 3 && variant <= 6) {
+    const bool wide = (variant == 3 || variant == 5);
     a.tiles_m = cdiv(a.M, 256);
-    a.tiles_n = cdiv(a.N, bn);
+    a.tiles_n = cdiv(a.N, wide ? 256 : 192);
     dim3 grid(a.tiles_m * a.tiles_n), block(512);
-    if (variant == 3)
-      hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4>), grid, block, 0, s, a);
-    else
-      hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3>), grid, block, 0, s, a);
+    switch (variant) {
+      case 3: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4, false>), grid, block, 0, s, a); break;
+      case 4: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3, false>), grid, block, 0, s, a); break;
+      case 5: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4, true>), grid, block, 0, s, a); break;
+      default: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3, true>), grid, block, 0, s, a); break;
+    }
   } else {
     dim3 grid(a.tiles_m * a.tiles_n), block(256);
     if (variant == 1)
