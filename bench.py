@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=2)
     ap.add_argument("--gemm-variant", type=int, default=0)
-    ap.add_argument("--attn-variant", type=int, default=0)
+    ap.add_argument("--attn-variant", type=int, default=2)
     return ap.parse_args()
 
 

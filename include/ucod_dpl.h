@@ -51,7 +51,9 @@ enum {
                                         the key hook, data/utils/feature_extractor.py:42,46-47,55-58 */
   UCOD_EPI_BIAS_F32 = 5              /* out f32[M,N] = C + bias[n] (final LayerNorm consumers / tests) */
 };
-/* variant: 0 = LDS-DMA staging (default), 1 = register staging.  K % 64 == 0. */
+/* variant: 0 = auto, 1 = 128x128 register staging, 2 = 128x128 LDS-DMA, 3/4 = 256x256 / 256x192 large tile,
+ * 5/6 = 3/4 with staggered wave groups.  K % 64 == 0.  For UCOD_EPI_BIAS_BF16 a non-NULL `scale` [N] multiplies
+ * (C + bias) per column before the bf16 rounding (used to fold the softmax scale into Q). */
 int ucod_gemm_bf16(int epilogue, const void* A_bf16, const void* B_bf16, void* out, int M, int N, int K,
                    const float* bias, const float* scale, const float* resid, const float* pos,
                    int tokens_per_image, int variant, void* stream);
@@ -63,7 +65,9 @@ int ucod_layernorm(const float* x, const float* gamma, const float* beta, void* 
 
 /* softmax(Q K^T * scale) V per (image, head), head_dim 64 (modeling_dinov2.py:153-179; dino.py:113-117).
  * qkv bf16 [B*tok, 3*heads*64] rows = [q | k | v], heads contiguous; out bf16 [B*tok, heads*64].
- * variant: 0 = V consumed through ds_read_b64_tr_b16, 1 = V transposed while staging. */
+ * variant: 0 = V consumed through ds_read_b64_tr_b16, 1 = V transposed while staging.
+ * scale == 0 selects the VALU-lean kernel and declares that Q already carries head_dim^-0.5 * log2(e)
+ * (ucod_fill_qscale + the QKV epilogue scale do that inside ucod_vit_forward when attn_variant == 2). */
 int ucod_attention_fwd(const void* qkv_bf16, void* out_bf16, int B, int tok, int heads, float scale, int variant,
                        void* stream);
 
@@ -73,6 +77,9 @@ int ucod_patch_im2col(const float* img, void* patches_bf16, int B, int C, int H,
 
 /* x f32 [B*tok, D]: row b*tok = cls + pos[0]  (modeling_dinov2.py:107-112; dino.py:227-232) */
 int ucod_cls_rows(float* x, const float* cls, const float* pos, int B, int tok, int D, void* stream);
+
+/* v[0..D) = c, v[D..3D) = 1: the per-column factor of the fused QKV epilogue */
+int ucod_fill_qscale(float* v, int D, float c, void* stream);
 
 /* f32 -> bf16 cast of n elements (weight preparation) */
 int ucod_cast_f32_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
@@ -182,6 +189,26 @@ int ucod_binarize(const float* x, float* out, size_t n, int logits, void* stream
  * (engine/runner/runner.py:282-298; loop_UCOD_DPL.py:178,186-191).  ema may be NULL. */
 int ucod_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float ema_alpha, void* stream);
+
+/* ------------------------------------------------------------------ Look-Twice (rows L1-L3) */
+
+/* 8-connected component labelling of a HOST uint8 [H,W] mask (non-zero = foreground) into HOST int32 labels
+ * (0 = background, k = k-th component in raster order of its first pixel); returns the number of labels INCLUDING
+ * the background, like cv2.connectedComponents(connectivity=8) (engine/runner/loop_UCOD_DPL.py:366).  < 0 on error. */
+int ucod_ccl8_host(const uint8_t* mask_host, int H, int W, int32_t* labels_host);
+
+/* Pillow Image.resize on an 8-bit single-channel HOST image: antialiased separable resample with 22-bit fixed-point
+ * coefficients, horizontal then vertical pass (filter 0 = BILINEAR, 1 = BICUBIC, the Pillow default used for the
+ * 'L' mask at loop_UCOD_DPL.py:350).  Bit-identical to Pillow. */
+int ucod_pil_resize_u8_host(const uint8_t* src_host, int h, int w, uint8_t* dst_host, int oh, int ow, int filter);
+
+/* Batched crop + Pillow-BILINEAR resize + ToTensor + ImageNet Normalize on the GPU
+ * (PIL crop + torchvision Resize/ToTensor/Normalize, loop_UCOD_DPL.py:282-286,341-342).
+ * img u8 [H,W,3] (HWC, device); boxes_host int32 [nbox,4] = (x,y,w,h) in source pixels (regions outside the image read
+ * as zero, as PIL's crop does); out f32 [nbox,3,oh,ow].  The 8-bit intermediate is bit-identical to Pillow's. */
+size_t ucod_crop_workspace_bytes(int nbox, int max_crop_h, int max_crop_w, int oh, int ow);
+int ucod_crop_resize_norm(const uint8_t* img, int H, int W, const int32_t* boxes_host, int nbox, float* out, int oh, int ow,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,88 @@
+"""CPU, world_size 2 (gloo): the data-parallel plumbing of the product path (ucod_dpl_amd/parallel.py) -- parameter
+broadcast from rank 0 and ONE all-reduce of the pre-scaled flat gradient buffer -- reproduces a single process that
+sees the global batch as two per-rank BatchNorm groups (the parity definition of SURVEY.md 8e)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+from conftest import load_golden, sub, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _flat(d, keys):
+    return torch.cat([d[k].reshape(-1) for k in keys])
+
+
+KEYS = ["learnable_embedding", "decoupling.weight", "decoupling.bias", "conv_out_fg.weight", "conv_out_bg.weight", "conv_out_fg.bias", "conv_out_bg.bias"]
+CFG = dict(feature_size=28, ema_weight=0.99, lr0=6e-4, dis_lr0=1e-3, step_lr_size=2, step_lr_gamma=0.95, dis_step_lr_size=2,
+           dis_step_lr_gamma=0.95, max_epoch=25, start_finetune=-5)
+
+
+def _rank_grads(dec, ema, disc, feats, pl, scale):
+    """Per-rank gradients of the (1/world)-scaled loss, as the HIP kernels produce them (gscale = gextra = 1/world)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import decoder as OD, train_step as OT
+    from oracle.apm import merge_pseudo_label, bce_with_logits_mean
+    from oracle.resize import torch_bilinear
+    f = torch_bilinear(feats, 28, 28)
+    p_l = torch_bilinear(pl, 28, 28)
+    with torch.no_grad():
+        t, _, _ = OD.rev_decoder_forward(f, ema, ema=True)
+    p = {k: v.clone().requires_grad_(True) for k, v in dec.items()}
+    fg, bg, extra = OD.rev_decoder_forward(f, p, orth="gram")
+    with torch.no_grad():
+        merged, _, _, _, _ = merge_pseudo_label(p_l, t, fg.detach(), disc, 0, 25, -5)
+    loss = (bce_with_logits_mean(fg, merged) + bce_with_logits_mean(bg, 1 - merged) + extra) * scale
+    g = torch.autograd.grad(loss, [p[k] for k in KEYS], allow_unused=True)
+    return torch.cat([(torch.zeros_like(p[k]) if gi is None else gi).reshape(-1) for k, gi in zip(KEYS, g)])
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ucod_dpl_amd import parallel
+    parallel.init_from_env("gloo")
+    assert parallel.world_size() == world and abs(parallel.grad_prescale() - 1.0 / world) < 1e-15
+    g = load_golden("g5_process_batch")
+    dec, ema, disc = sub(g, "model0.decoder."), sub(g, "model0.decoder_ema."), sub(g, "disc0.")
+    # rank 1 starts from garbage: the broadcast must overwrite it with rank 0's parameters
+    flat_p = _flat(dec, KEYS).clone()
+    if rank != 0:
+        flat_p.normal_()
+    parallel.broadcast_state([flat_p])
+    assert torch.equal(flat_p, _flat(dec, KEYS))
+    feats, pl = g["features0"], g["pl0"]
+    lo, hi = rank * 2, rank * 2 + 2                     # images [r*B, (r+1)*B)
+    grads = _rank_grads(dec, ema, {k: v.clone() for k, v in disc.items()}, feats[lo:hi], pl[lo:hi], parallel.grad_prescale())
+    parallel.allreduce_prescaled_(grads)
+    t = parallel.max_over_ranks(float(rank), "cpu")
+    assert t == world - 1
+    parallel.barrier()
+    if rank == 0:
+        torch.save(grads, out)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_equals_global_batch_with_per_rank_bn(tmp_path):
+    out = str(tmp_path / "grads.pt")
+    port = _free_port()
+    mp.start_processes(_worker, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
+    got = torch.load(out)
+    g = load_golden("g5_process_batch")
+    dec, ema, disc = sub(g, "model0.decoder."), sub(g, "model0.decoder_ema."), sub(g, "disc0.")
+    ref = sum(_rank_grads(dec, ema, {k: v.clone() for k, v in disc.items()}, g["features0"][r * 2:r * 2 + 2], g["pl0"][r * 2:r * 2 + 2], 0.5)
+              for r in range(2))
+    assert torch.allclose(got, ref, rtol=0, atol=1e-9)
+    assert got.abs().max() > 1e-4

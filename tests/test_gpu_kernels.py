@@ -127,6 +127,45 @@ def test_attention(variant, B, tok, heads):
     assert rel_l2(out, ref) < 1e-2
 
 
+@pytest.mark.parametrize("B,tok,heads", [(1, 26, 2), (2, 64, 1), (1, 200, 3), (2, 1370, 2), (1, 1, 1)])
+def test_attention_prescaled_q_kernel(B, tok, heads):
+    """VALU-lean kernel: Q carries head_dim^-0.5*log2(e) already (scale=0 in the ABI)."""
+    g = torch.Generator().manual_seed(tok * 3 + heads)
+    D = heads * 64
+    qkv = torch.randn(B * tok, 3 * D, generator=g) * 1.5
+    qkv[:, :D] *= 0.125 * math.log2(math.e)
+    qkv = bf(qkv)
+    q, k, v = (qkv.float()[:, i * D:(i + 1) * D].reshape(B, tok, heads, 64).transpose(1, 2) for i in range(3))
+    p = torch.softmax(torch.matmul(q, k.transpose(2, 3)) * math.log(2.0), dim=-1)
+    ref = torch.matmul(p, v).transpose(1, 2).reshape(B * tok, D)
+    out = ops.attention(qkv.to(DEV), B, tok, heads, scale=0.0, variant=2).float().cpu()
+    assert maxdiff(out, ref) < 3e-2, maxdiff(out, ref)
+    assert rel_l2(out, ref) < 1e-2
+
+
+def test_attention_prescaled_deferred_max_branches():
+    """Force both branches of the deferred-max logic: (a) a late key that beats the running max by far more than THR
+    (rescale must fire and rescale O, the denominator and the pending scores exactly once); (b) scores that creep up by
+    less than THR per tile (no rescale: P > 1 must still normalise correctly); (c) everything far BELOW the first tile."""
+    D, tok = 64, 400
+    c = 0.125 * math.log2(math.e)
+    g = torch.Generator().manual_seed(21)
+    base = torch.randn(tok, 3 * D, generator=g) * 0.3
+    cases = []
+    a = base.clone(); a[5, :D] = 2.0; a[333, D:2 * D] = 6.0; cases.append(a)                       # (a) jump of ~96*... in a late tile
+    b_ = base.clone(); b_[:, D:2 * D] += torch.linspace(0, 1.2, tok).view(-1, 1) * 0.5; b_[:, :D] = 0.5; cases.append(b_)   # (b) slow creep
+    c_ = base.clone(); c_[:64, D:2 * D] += 3.0; c_[:, :D] = 1.0; cases.append(c_)                  # (c) first tile dominates
+    for x in cases:
+        x = x.clone()
+        x[:, :D] *= c
+        x = bf(x)
+        q, k, v = (x.float()[:, i * D:(i + 1) * D] for i in range(3))
+        p = torch.softmax((q @ k.t()) * math.log(2.0), dim=-1)
+        ref = p @ v
+        out = ops.attention(x.to(DEV), 1, tok, 1, scale=0.0, variant=2).float().cpu()
+        assert maxdiff(out, ref) < 3e-2, maxdiff(out, ref)
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_attention_spiked_row_forces_rescale(variant):
     """One key far above the rest in a LATE tile: the running max jumps and every earlier tile must be rescaled."""
@@ -167,11 +206,11 @@ def test_patch_embed_matches_conv():
 # ----------------------------------------------------------------------------------------- ViT end to end
 @pytest.mark.parametrize("name,heads,fn", [("g8_dinov2_native", 2, "dinov2"), ("g8_dinov2_interp", 2, "dinov2"),
                                            ("g8_dinov1_native", 2, "dinov1"), ("g8_dinov1_interp", 2, "dinov1")])
-@pytest.mark.parametrize("full", [False, True])
-def test_vit_key_against_reference_golden(name, heads, fn, full):
+@pytest.mark.parametrize("full,av", [(False, 0), (True, 0), (False, 2)])
+def test_vit_key_against_reference_golden(name, heads, fn, full, av):
     from ucod_dpl_amd.vit_engine import ViTEngine
     gd = load_golden(name)
-    eng = ViTEngine(sub(gd, "sd."), heads=heads, eps=1e-6, device=DEV, full_last_layer=full)
+    eng = ViTEngine(sub(gd, "sd."), heads=heads, eps=1e-6, device=DEV, full_last_layer=full, attn_variant=av)
     key = eng(gd["x"].to(DEV)).cpu()
     ref = gd["key"]
     # bf16 operands through 3 layers: report-level tolerance (f32 reference); structure errors are O(1)

@@ -27,7 +27,7 @@ __device__ __forceinline__ int swz_k(int row, int chunk) { return chunk ^ ((row 
 __device__ __forceinline__ int swz_v(int row, int chunk) { return chunk ^ (((row >> 1) & 1) << 2); }
 
 template <int VMODE>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N,
                                                        int heads, float c /* scale*log2(e) */) {
   constexpr int VB = (VMODE == 0) ? KV_BYTES : VT_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[2 * (KV_BYTES + VB)];
@@ -199,6 +199,199 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_raw* __restric
   }
 }
 
+
+// =====================================================================================================
+// v2: VALU-lean variant (the first kernel spends 2/3 of its issue slots on softmax VALU work, 25 % MFMA busy).
+//   * Q arrives PRE-SCALED by head_dim^-0.5 * log2(e) (folded into the QKV GEMM epilogue before its bf16
+//     rounding), so probabilities are a bare v_exp_f32 of the score;
+//   * the score accumulator is initialised with -m (running max, per query = per lane), so S' = S - m leaves the
+//     MFMA chain ready: no per-element subtract;
+//   * deferred max: the running max moves only when a tile's max exceeds it by more than THR (log2 units); until then
+//     there is no O rescale and no exponent bookkeeping (P <= 2^THR, f32 accumulation);
+//   * the softmax denominator is accumulated on the matrix pipe: O_sum += 1^T P^T (an all-ones A fragment), 4 extra
+//     MFMAs per tile instead of 32 v_add (MFMA has slack, VALU does not);
+//   * P is packed to bf16 with v_cvt_pk_bf16_f32 (one instruction per register pair).
+// =====================================================================================================
+// two f32 -> one packed bf16x2 register: the vector convert lowers to a single v_cvt_pk_bf16_f32.  (No inline asm: the
+// compiler inserts no VALU->MFMA-operand wait states behind an asm statement, and the first MFMA that consumes P would
+// read stale registers.)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+constexpr float DEFER_THR = 8.0f;
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N,
+                                                              int heads) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (KV_BYTES + KV_BYTES)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h5 = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int D = heads * HD, ld = 3 * D;
+  const int q0 = blockIdx.x * QT + wave * 32;
+  const bf16_raw* base = qkv + (size_t)b * N * ld + head * HD;
+
+  bf16x8 qf[4];
+  {
+    int qr = q0 + l31;
+    qr = qr < N ? qr : N - 1;
+    const bf16_raw* qp = base + (size_t)qr * ld + 8 * h5;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  const u32x4_t ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+
+  f32x16 o[2], osum;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; osum[i] = 0.f; }
+  float m_run = 0.f;
+
+  const int nt = (N + KT - 1) / KT;
+  u32x4 rk[2], rv[2];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
+      int kr = t * KT + row;
+      kr = kr < N ? kr : N - 1;
+      const bf16_raw* p = base + (size_t)kr * ld + ch * 8;
+      rk[i] = *reinterpret_cast<const u32x4*>(p + D);
+      rv[i] = *reinterpret_cast<const u32x4*>(p + 2 * D);
+    }
+  };
+  auto lwrite = [&](int buf) {
+    char* kb = smem + buf * (2 * KV_BYTES);
+    char* vb = kb + KV_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
+      *reinterpret_cast<u32x4*>(kb + row * 128 + swz_k(row, ch) * 16) = rk[i];
+      *reinterpret_cast<u32x4*>(vb + row * 128 + swz_v(row, ch) * 16) = rv[i];
+    }
+  };
+
+  // loop-invariant LDS byte offsets of this lane's fragments (relative to the tile buffer)
+  int koff[2][4], voff[2][2][2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int sd = 0; sd < 4; ++sd) {
+      const int row = kt * 32 + l31;
+      koff[kt][sd] = row * 128 + swz_k(row, 2 * sd + h5) * 16;
+    }
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+        const int key = kt * 32 + ks * 16 + 4 * h5 + (i16 >> 2);
+        const int dst = dt * 32 + g1 * 16 + 4 * (i16 & 3);
+        voff[kt][ks][dt] = KV_BYTES + key * 128 + swz_v(key, dst >> 3) * 16 + (dst & 7) * 2;   // key+8 keeps the swizzle: +1024
+      }
+
+  gload(0);
+  lwrite(0);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    const bool more = (t + 1 < nt);
+    if (more) gload(t + 1);
+    const char* kb = smem + (t & 1) * (2 * KV_BYTES);
+
+    // S' = K Q^T - m_run  (accumulator initialised with the row constant)
+    f32x16 s[2];
+    const float neg_m = -m_run;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kt][i] = neg_m;
+#pragma unroll
+      for (int sd = 0; sd < 4; ++sd) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + koff[kt][sd]);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sd], s[kt], 0, 0, 0);
+      }
+    }
+    if (t == nt - 1 && (N & (KT - 1)) != 0) {
+      const int kbase = t * KT + 4 * h5;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + kt * 32 + (r & 3) + 8 * (r >> 2);
+          if (key >= N) s[kt][r] = -1e30f;
+        }
+    }
+    float mloc = s[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[1][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    // rescale only when some query's max ran away by more than THR (always on the first tile: m_run is a guess)
+    if (t == 0 || __any(mloc > DEFER_THR)) {
+      const float delta = (t == 0) ? mloc : fmaxf(mloc, 0.f);
+      const float alpha = (t == 0) ? 1.f : __builtin_amdgcn_exp2f(-delta);
+      m_run += delta;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s[0][i] -= delta;
+        s[1][i] -= delta;
+        o[0][i] *= alpha;
+        o[1][i] *= alpha;
+      }
+      osum[0] *= alpha;
+    }
+    bf16x8 pb[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4_t w;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          w[jj] = cvt_pk_bf16(__builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj + 1]));
+        pb[kt][ks] = __builtin_bit_cast(bf16x8, w);
+      }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[kt][ks], osum, 0, 0, 0);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const char* p0 = kb + voff[kt][ks][dt];
+          const char* p1 = p0 + 8 * 128;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
+          const bf16x8 vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kt][ks], o[dt], 0, 0, 0);
+        }
+      }
+    if (more) lwrite((t + 1) & 1);
+  }
+
+  const float inv = 1.0f / osum[0];
+  const int q = q0 + l31;
+  if (q < N) {
+    bf16_raw* op = out + ((size_t)b * N + q) * D + head * HD + 4 * h5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w;
+        w[0] = cvt_pk_bf16(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+        w[1] = cvt_pk_bf16(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
+      }
+  }
+}
+
 }  // namespace ucod
 
 extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, int heads, float scale, int variant, void* stream) {
@@ -207,6 +400,11 @@ extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, in
   dim3 grid(cdiv(tok, QT), heads, B), block(256);
   const float c = scale * 1.4426950408889634f;
   UCOD_PROF(PROF_ATTN, stream);
+  if (scale == 0.f) {   // Q pre-scaled by head_dim^-0.5 * log2(e): the VALU-lean kernel
+    hipLaunchKernelGGL(attn_fwd_v2_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads);
+    UCOD_CHECK_LAUNCH();
+    return UCOD_OK;
+  }
   if (variant == 1)
     hipLaunchKernelGGL((attn_fwd_kernel<1>), grid, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, c);
   else

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
 constexpr int GCH = 512;   // pixels per workgroup
 constexpr int GK = 16;     // pixels per K-tile
 constexpr int GLD = 129;
-__global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ d, int ld_c, int c0,
+__global__ __launch_bounds__(256, 2) void gram_partial_kernel(const float* __restrict__ d, int ld_c, int c0,
                                                            const float* __restrict__ emb, const float* __restrict__ norm,
                                                            float* __restrict__ partial, int HW, int S) {
   __shared__ float Fs[2][GK * GLD];

@@ -82,7 +82,7 @@ template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& a, int m, int n, float v) {
   if (m >= a.M || n >= a.N) return;
   if constexpr (EPI == UCOD_EPI_BIAS_BF16) {
-    reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_bf16(v + a.bias[n]);
+    reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_bf16((v + a.bias[n]) * (a.scale ? a.scale[n] : 1.f));
   } else if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) {
     reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_bf16(gelu_erf(v + a.bias[n]));
   } else if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) {
@@ -114,6 +114,9 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& a, int m, int n,
     const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
     if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) {
       f32x4 o = v + b;
+      if constexpr (EPI == UCOD_EPI_BIAS_BF16) {
+        if (a.scale) o = o * *reinterpret_cast<const f32x4*>(a.scale + n);
+      }
       if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
@@ -154,7 +157,7 @@ __device__ __forceinline__ void drain_rows(const GemmArgs& a, const char* wbase,
 }
 
 template <int EPI, bool GLDS>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [stage][A|B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -432,9 +435,13 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
   if (variant == 0) {
     variant = 2;
     if (a.M >= 2048 && a.K >= 128 && (a.N & 3) == 0) {
-      // makespan in (rounds x tile width) on 256 CUs, one large-tile workgroup per CU
-      auto cost = [&](int bn) { return (double)cdiv((long)cdiv(a.M, 256) * cdiv(a.N, bn), 256) * bn; };
-      variant = (cost(192) <= cost(256)) ? 6 : 5;
+      // Makespan model on 256 CUs (one large-tile workgroup per CU), fitted to tools/gemm_bench.py on MI355X:
+      // a tile costs a fixed part (A-panel DMA, prologue, epilogue set-up) plus a part proportional to its width.
+      auto cost = [&](int bn) {
+        const double rounds = (double)cdiv((long)cdiv(a.M, 256) * cdiv(a.N, bn), 256);
+        return rounds * (0.45 * 256 + 0.55 * bn);
+      };
+      variant = (cost(192) < cost(256)) ? 6 : 5;
     }
   }
   if (variant >= 3 && variant <= 6 && (a.N & 3) != 0) return UCOD_EINVAL;

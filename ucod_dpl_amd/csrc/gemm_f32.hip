@@ -59,7 +59,7 @@ __device__ __forceinline__ void store_kcontig(float* lds, int tid, const float4 
 // ------------------------------------------------------------------------------------------- project
 // block: 128 output channels x 64 pixels, K-tile 16 input channels; 4 waves, wave w -> channels 32w..32w+31
 template <bool VEC>
-__global__ __launch_bounds__(256) void dba_project_kernel(const float* __restrict__ x, const float* __restrict__ W,
+__global__ __launch_bounds__(256, 2) void dba_project_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                           const float* __restrict__ bias, float* __restrict__ d, int C, int HW,
                                                           int Nout) {
   __shared__ float Ws[2][FK * LDP];
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void dba_project_kernel(const float* __restric
 // block: 128 (n) x 128 (c) output tile, reduction over one pixel chunk of one image; waves 2x2, 64x64 each
 constexpr int WG_CHUNK = 1024;
 template <bool VEC>
-__global__ __launch_bounds__(256) void dba_wgrad_kernel(const float* __restrict__ gd, const float* __restrict__ x,
+__global__ __launch_bounds__(256, 2) void dba_wgrad_kernel(const float* __restrict__ gd, const float* __restrict__ x,
                                                         float* __restrict__ gW, int C, int HW) {
   __shared__ float As[2][FK * LDP];
   __shared__ float Bs[2][FK * LDP];

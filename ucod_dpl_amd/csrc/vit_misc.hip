@@ -140,6 +140,17 @@ extern "C" int ucod_cast_f32_bf16(const float* src, void* dst, size_t n, void* s
   return UCOD_OK;
 }
 
+__global__ void fill_qscale_kernel(float* __restrict__ v, int D, float c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3 * D) v[i] = i < D ? c : 1.f;
+}
+extern "C" int ucod_fill_qscale(float* v, int D, float c, void* stream) {
+  if (!v || D <= 0) return UCOD_EINVAL;
+  hipLaunchKernelGGL(fill_qscale_kernel, dim3(ucod::cdiv(3L * D, 256)), dim3(256), 0, (hipStream_t)stream, v, D, c);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
 extern "C" int ucod_abi_version(void) { return UCOD_ABI_VERSION; }
 
 extern "C" int ucod_device_is_gfx950(void) {

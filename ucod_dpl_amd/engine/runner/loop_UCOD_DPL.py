@@ -18,7 +18,7 @@ import math
 
 import torch
 
-from ... import ops
+from ... import ops, parallel
 from ...models.modules.DBA import EMB
 
 
@@ -206,8 +206,7 @@ class TrainLoop(BaseLoop):
         g_emb, g_W, g_b, g_hw, g_hb = A.slices(A.g)
         gd, _, _, _ = ops.dba_bwd(d, 0, emb_s, norm_s, hw_s, gram, gfg, gbg, 1.0 / world, g_head_w=g_hw, g_head_b=g_hb, g_dec_bias=g_b)
         ops.dba_wgrad(gd, feats, gW=g_W)
-        if world > 1:
-            torch.distributed.all_reduce(A.g)                 # RCCL, one flat 128C+386-float buffer (grads pre-scaled by 1/world)
+        parallel.allreduce_prescaled_(A.g)                    # RCCL: one flat 128C+386-float buffer, pre-scaled by 1/world
 
         # AdamW + StepLR + EMA (:178-181,186-191)
         alpha = min(1 - 1 / (self.global_step + 1), self.ema_alpha)
@@ -292,8 +291,7 @@ class TrainLoop(BaseLoop):
         loss = (-(torch.log(1 - probs_student).clamp_min(-100.0).sum() + torch.log(probs_pseudo).clamp_min(-100.0).sum())) / (2 * B)
         ops.disc_bwd(pl, t, saved_p, g_pseudo, grads=DA.grad_views, accumulate=False)
         ops.disc_bwd(preds, t, saved_s, g_student, grads=DA.grad_views, accumulate=True)
-        if world > 1:
-            torch.distributed.all_reduce(DA.g)
+        parallel.allreduce_prescaled_(DA.g)
         r.dis_optimizer.step()
         r.dis_lr_scheduler.step()
         self.last = dict(dis_phase_loss=loss, probs_student=probs_student, probs_pseudo=probs_pseudo)

@@ -1,0 +1,207 @@
+"""Look-Twice validation -- host-side mirror of engine/runner/loop_UCOD_DPL.py::ValLoop_Look_Twice (:276-417).
+
+Same method names and semantics (``run``, ``process_preds``, ``look_twice``, ``resize_bbox``, ``expand_bbox``), with the
+integer box logic reproduced bit-for-bit, quirks included: ``process_preds`` passes (h, w) into
+``expand_bbox``'s (img_width, img_height) slots (:379), ``br = (h*y)/(H*W)`` (:404), ``sqrt(1 - br/fr + 1)`` raises
+ValueError when br/fr > 2 (:405), ``int()`` truncates toward zero (:392-395,417), ``new_x`` may go negative (:412-416).
+
+What moved to the GPU: the 68->518 bilinear upsample + threshold (one pass), the crop + Pillow-BILINEAR resize +
+ToTensor + Normalize of EVERY box of an image in one batched launch pair (the reference loops PIL crop/resize per box on
+the host), one batched backbone forward over all crops and one decoder pass at the native 37x37 grid (:343-345).  What
+stays on the host, as in the reference: connected components (C++ in libucod_dpl.so instead of OpenCV), the float box
+arithmetic, and the Pillow-BICUBIC resize + paste of the small refined masks (C++ restatement of Pillow's resampler).
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import torch
+
+from ... import native as N, ops
+from .loop_UCOD_DPL import BaseLoop
+
+DEFAULT_BOX = [129, 129, 259, 259]
+
+
+# ---------------------------------------------------------------------------------------------- host helpers
+def connected_components(mask_u8):
+    """cv2.connectedComponents(mask, connectivity=8) -> (num_labels, labels int32)."""
+    m = np.ascontiguousarray(mask_u8, dtype=np.uint8)
+    labels = np.empty(m.shape, np.int32)
+    n = N.load().ucod_ccl8_host(m.ctypes.data, m.shape[0], m.shape[1], labels.ctypes.data)
+    if n < 0:
+        raise RuntimeError("ucod_ccl8_host failed")
+    return n, labels
+
+
+def bounding_rect(mask):
+    """cv2.boundingRect -> (x, y, w, h)."""
+    ys, xs = np.nonzero(mask)
+    return int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)
+
+
+def pil_resize_u8(src, out_w, out_h, bicubic=True):
+    """Pillow Image.resize((out_w,out_h)) on an 'L' image (default BICUBIC), bit-identical."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.empty((out_h, out_w), np.uint8)
+    N.check(N.load().ucod_pil_resize_u8_host(src.ctypes.data, src.shape[0], src.shape[1], dst.ctypes.data, out_h, out_w, 1 if bicubic else 0),
+            "ucod_pil_resize_u8_host")
+    return dst
+
+
+class MAEStatistics:
+    """The MAE part of engine/utils/metrics/metric.py::statistics (_prepare_data :125-133, MAEmeasure :187-207)."""
+
+    def __init__(self):
+        self.maes = []
+
+    def step(self, gt_tensor, pred_tensor):
+        gt = gt_tensor.detach().to("cpu").numpy().astype(float)
+        pred = pred_tensor.detach().to("cpu").numpy().astype(float)
+        for g, p in zip(gt, pred):
+            g, p = np.squeeze(g), np.squeeze(p)
+            if g.max() != g.min():
+                g = (g - g.min()) / (g.max() - g.min())
+            g = g > 0.5
+            if p.max() != p.min():
+                p = (p - p.min()) / (p.max() - p.min())
+            else:
+                p = p.astype(int)
+            self.maes.append(np.mean(np.abs(p - g)))
+
+    def get_result(self):
+        return {"MAE": float(np.mean(np.array(self.maes, np.float64)))}
+
+
+# ---------------------------------------------------------------------------------------------- the loop
+class ValLoop_Look_Twice(BaseLoop):
+    def __init__(self, config, runner, feature_extractor=None):
+        super().__init__(config, runner)
+        self._mode = "val"
+        self.img_size = tuple(self.cfg.dataset_cfg.valset_cfg.image_size)
+        if feature_extractor is None:
+            from ...data.utils.feature_extractor import backbone
+            feature_extractor = backbone(self.cfg.dataset_cfg.feature_extractor_cfg, device=runner.device)
+        self.feature_extractor = feature_extractor
+        self.device = runner.device
+        self._ws = None
+
+    # ------------------------------------------------------------------ integer box logic (bit-exact)
+    @staticmethod
+    def resize_bbox(bbox, original_width, original_height, new_width, new_height):
+        x, y, w, h = bbox
+        width_scale = new_width / original_width
+        height_scale = new_height / original_height
+        return [int(x * width_scale), int(y * height_scale), int(w * width_scale), int(h * height_scale)]
+
+    @staticmethod
+    def expand_bbox(mask, bbox, img_width, img_height, expand_type="const", scale=1.3):
+        x, y, w, h = bbox
+        if expand_type == "dynamic":
+            fr = mask[y:y + h, x:x + w].sum() / (h * w)
+            br = (h * y) / (mask.shape[-2] * mask.shape[-1])
+            scale = math.sqrt(1 - br / fr + 1)
+        new_w = w * scale
+        new_h = h * scale
+        new_x = x - (new_w - w) / 2
+        new_y = y - (new_h - h) / 2
+        new_x = max(0, new_x)
+        if new_x + new_w > img_width:
+            new_x = img_width - new_w
+        new_y = max(0, new_y)
+        if new_y + new_h > img_height:
+            new_y = img_height - new_h
+        return [int(new_x), int(new_y), int(new_w), int(new_h)]
+
+    def boxes_from_mask(self, mask_u8):
+        """Integer tail of process_preds (:366-384) on a 0/255 uint8 [h,w] mask."""
+        h, w = self.img_size
+        num_labels, labels = connected_components(mask_u8)
+        p = [(labels == i).sum() / (h * w) for i in range(1, num_labels)]
+        if len(p) == 0:
+            return [list(DEFAULT_BOX)]
+        if max(p) < self.cfg.val_cfg.look_twice_th:
+            bboxes = []
+            for i in range(1, num_labels):
+                if p[i - 1] > 0.01:
+                    binary_mask = (labels == i).astype(np.uint8)
+                    bboxes.append(self.expand_bbox(binary_mask, bounding_rect(binary_mask), h, w, expand_type=self.cfg.val_cfg.expand_type))
+            return sorted(bboxes, key=lambda b: -1 * b[2] * b[3])
+        return None
+
+    def process_preds(self, preds, label_tensor=None):
+        """:354-384.  preds [1,1,fs,fs] logits -> (preds_up float [1,h,w] on the GPU, boxes | None)."""
+        h, w = self.img_size
+        up = ops.binarize(ops.bilinear_resize(preds.to(self.device, torch.float32), h, w), logits=True)     # one resize + threshold
+        preds_up = up.reshape(-1, h, w)[:1]
+        mask = (preds_up[0].cpu().numpy() * 255).astype(np.uint8)
+        return preds_up, self.boxes_from_mask(mask)
+
+    # ------------------------------------------------------------------ crop / re-encode / paste (:326-352)
+    def crop_batch(self, img_u8, boxes_xywh):
+        """img_u8: uint8 [H,W,3] (numpy or CUDA tensor); boxes in source pixels -> normalised crops [nbox,3,ih,iw] on the GPU."""
+        ih, iw = self.img_size
+        img = torch.as_tensor(img_u8).to(self.device).contiguous()
+        H, W = img.shape[:2]
+        nb = len(boxes_xywh)
+        boxes = np.ascontiguousarray(np.asarray(boxes_xywh, np.int32).reshape(nb, 4))
+        lib = N.load()
+        need = lib.ucod_crop_workspace_bytes(nb, int(boxes[:, 3].max()), int(boxes[:, 2].max()), ih, iw)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = torch.empty(nb, 3, ih, iw, dtype=torch.float32, device=self.device)
+        N.check(lib.ucod_crop_resize_norm(N.ptr(img), H, W, boxes.ctypes.data, nb, N.ptr(out), ih, iw, N.ptr(self._ws), self._ws.numel(), N.stream()),
+                "ucod_crop_resize_norm")
+        return out
+
+    def look_twice(self, path, bboxes, old_mask):
+        """path: image file or uint8 [H,W,3] array.  old_mask float [1,h,w] in {0,1}.  Returns ToTensor(new_mask) [1,h,w] (CPU)."""
+        ih, iw = self.img_size
+        if isinstance(path, (str, os.PathLike)):
+            from PIL import Image
+            Image.MAX_IMAGE_PIXELS = None
+            img = np.asarray(Image.open(path).convert("RGB"))
+        else:
+            img = np.asarray(path)
+        H, W = img.shape[:2]
+        canvas = (old_mask.squeeze(0).cpu().numpy() * 255).astype(np.uint8)
+        src_boxes = [self.resize_bbox(b, iw, ih, W, H) for b in bboxes]          # img.size = (W, H) (:335)
+        crops = self.crop_batch(img, src_boxes)
+        _, key = self.feature_extractor(crops)                                   # [nbox,C,37,37], all boxes in one pass
+        with torch.no_grad():
+            preds = self.runner.model(key)[0]                                    # decoder at the native grid, no 68x68 resize
+        pred01 = ops.binarize(preds.contiguous(), logits=True).reshape(len(bboxes), preds.shape[-2], preds.shape[-1]).cpu().numpy()
+        for b, m in zip(bboxes, pred01):
+            bx, by, bw, bh = b
+            if bw <= 0 or bh <= 0:
+                raise ValueError("height and width must be > 0")                  # what PIL's resize raises
+            rs = pil_resize_u8((m * 255).astype(np.uint8), bw, bh, bicubic=True)
+            x0, y0, x1, y1 = max(bx, 0), max(by, 0), min(bx + bw, canvas.shape[1]), min(by + bh, canvas.shape[0])
+            if x1 > x0 and y1 > y0:
+                canvas[y0:y1, x0:x1] = rs[y0 - by:y1 - by, x0 - bx:x1 - bx]
+        return torch.from_numpy(canvas.astype(np.float32) / 255.0).unsqueeze(0)
+
+    # ------------------------------------------------------------------ :297-324
+    def run(self):
+        stats = MAEStatistics()
+        self.runner.model.eval()
+        fs = self.cfg.model_cfg.feature_size
+        world = self.runner.world_size
+        for batch in self.runner.val_dataloader:
+            _, label_tensor, features, img_path = batch.values()
+            features = ops.bilinear_resize(features.to(self.device, torch.float32), fs, fs)
+            with torch.no_grad():
+                preds = self.runner.model(features)[0]
+            if world > 1:                                                         # accelerator.gather_for_metrics (:310)
+                gathered = [torch.empty_like(preds) for _ in range(world)]
+                torch.distributed.all_gather(gathered, preds.contiguous())
+                preds = gathered[self.runner.rank]
+            preds_up, bboxes = self.process_preds(preds, label_tensor)
+            if bboxes is not None and self.cfg.val_cfg.look_twice:
+                preds_up = self.look_twice(img_path[0], bboxes, preds_up).to(self.device)
+            out = ops.bilinear_resize(preds_up.reshape(1, 1, *preds_up.shape[-2:]).to(self.device), label_tensor.shape[-2], label_tensor.shape[-1])
+            stats.step(label_tensor, (out.reshape(1, *out.shape[-2:]) > 0.5))
+        result = stats.get_result()
+        self.runner.logger.log_table({k: [round(v, 4)] for k, v in result.items()})
+        return result

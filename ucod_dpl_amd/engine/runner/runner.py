@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from ... import ops, native
+from ... import ops, native, parallel
 from ...models.uscod import baseline
 from ...models.discriminator import Discriminator
 from .loop_UCOD_DPL import DecoderArena, DiscArena, FusedAdamW, StepLR, TrainLoop
@@ -43,16 +43,13 @@ class Logger:
 class StandardRunner:
     def __init__(self, config, train_dataloader=None, val_dataloader=None, device=None):
         self.config = config
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         if not torch.cuda.is_available():
             raise RuntimeError("StandardRunner needs a GPU: the hot path is HIP-only (no CPU fallback)")
         native.load()
+        self.rank, self.local_rank, self.world_size = parallel.env_world()
         torch.cuda.set_device(self.local_rank)
         self.device = torch.device("cuda", self.local_rank) if device is None else torch.device(device)
-        if self.world_size > 1 and not torch.distributed.is_initialized():
-            torch.distributed.init_process_group(backend="nccl")          # RCCL
+        parallel.init_from_env("nccl")                         # RCCL over xGMI; no-op on one GPU
         self.logger = Logger(self.rank, config.log_cfg.get("multi_rank", [0]))
         self.train_dataloader = train_dataloader if train_dataloader is not None else []
         self.val_dataloader = val_dataloader if val_dataloader is not None else []
@@ -69,12 +66,8 @@ class StandardRunner:
             self.load_checkpoint(ckpt)
         self.arena = DecoderArena(self.model, self.device)
         self.disc_arena = DiscArena(self.discriminator, self.device)
-        if self.world_size > 1:                               # the DDP-constructor broadcast of the reference
-            for t in (self.arena.p, self.arena.ema, self.disc_arena.p):
-                torch.distributed.broadcast(t, src=0)
-            for b in (self.discriminator.maskConv, self.discriminator.convs[0], self.discriminator.convs[1]):
-                torch.distributed.broadcast(b.layers[1].running_mean, src=0)
-                torch.distributed.broadcast(b.layers[1].running_var, src=0)
+        bn = [b.layers[1] for b in (self.discriminator.maskConv, self.discriminator.convs[0], self.discriminator.convs[1])]
+        parallel.broadcast_state([self.arena.p, self.arena.ema, self.disc_arena.p] + [m.running_mean for m in bn] + [m.running_var for m in bn])
 
     def _build_optimizer(self):
         tc = self.config.train_cfg
@@ -97,8 +90,7 @@ class StandardRunner:
     # ------------------------------------------------------------------ checkpoints (runner.py:165-240)
     def save_checkpoint(self, epoch, save_mode="model"):
         from safetensors.torch import save_file
-        if self.world_size > 1:
-            torch.distributed.barrier()
+        parallel.barrier()
         if self.rank == 0:
             path = os.path.join(self.config.log_cfg.log_path, "ckp", f"epoch{epoch}.pth")
             os.makedirs(path, exist_ok=True)

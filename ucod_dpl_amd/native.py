@@ -44,6 +44,7 @@ SIGNATURES = {
     "ucod_attention_fwd": (ci, [vp, vp, ci, ci, ci, cf, ci, vp]),
     "ucod_patch_im2col": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "ucod_cls_rows": (ci, [vp, vp, vp, ci, ci, ci, vp]),
+    "ucod_fill_qscale": (ci, [vp, ci, cf, vp]),
     "ucod_cast_f32_bf16": (ci, [vp, vp, sz, vp]),
     "ucod_vit_workspace_bytes": (sz, [C.POINTER(VitDesc)]),
     "ucod_vit_forward": (ci, [C.POINTER(VitDesc), C.POINTER(vp), vp, vp, vp, sz, vp]),
@@ -62,6 +63,10 @@ SIGNATURES = {
     "ucod_disc_bwd": (ci, [vp, C.POINTER(DiscParams), vp, vp, C.POINTER(DiscGrads), ci, vp, ci, ci, vp]),
     "ucod_apm_bce": (ci, [vp, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, ci, ci, vp]),
     "ucod_binarize": (ci, [vp, vp, sz, ci, vp]),
+    "ucod_ccl8_host": (ci, [vp, ci, ci, vp]),
+    "ucod_pil_resize_u8_host": (ci, [vp, ci, ci, vp, ci, ci, ci]),
+    "ucod_crop_workspace_bytes": (sz, [ci, ci, ci, ci, ci]),
+    "ucod_crop_resize_norm": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, vp, sz, vp]),
     "ucod_adamw_ema": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, ci, cf, vp]),
 }
 
