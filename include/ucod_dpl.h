@@ -113,6 +113,10 @@ int ucod_vit_forward(const ucod_vit_desc* d, const void* const* table_host, cons
 /* F.interpolate(mode='bilinear', align_corners=False) on `planes` independent [ih,iw] maps
  * (engine/runner/loop_UCOD_DPL.py:153-154,236,241,305,315,356-358). */
 int ucod_bilinear_resize(const float* in, float* out, int planes, int ih, int iw, int oh, int ow, void* stream);
+/* Transpose of the above: gin [planes,ih,iw] = U^T gout [planes,oh,ow] (same taps and weights as the forward).  The
+ * training step runs the 1x1 decoupling conv and its weight gradient on the backbone's native 37x37 grid and moves
+ * d / gd across the resize instead of the 768-channel features (conv and resize commute). */
+int ucod_bilinear_resize_adjoint(const float* gout, float* gin, int planes, int ih, int iw, int oh, int ow, void* stream);
 
 /* 1x1 "decoupling" conv as an exact-f32 MFMA GEMM (models/modules/DBA.py:13,35):
  * d[b][n][p] = sum_c W[n][c]*x[b][c][p] + bias[n];  x [B,C,HW], W [Nout,C], d [B,Nout,HW].

@@ -230,6 +230,19 @@ def test_bilinear_matches_aten_semantics():
     assert torch.equal(a > 0.5, torch_bilinear(pl, 68, 68) > 0.5)
 
 
+def test_bilinear_adjoint_is_the_transpose():
+    g = torch.Generator().manual_seed(8)
+    for (ih, oh) in ((37, 68), (14, 28), (68, 37), (5, 12)):
+        x = torch.randn(3, 4, ih, ih, generator=g)
+        y = torch.randn(3, 4, oh, oh, generator=g)
+        xr = x.clone().requires_grad_(True)
+        (torch.nn.functional.interpolate(xr, size=(oh, oh), mode="bilinear") * y).sum().backward()
+        got = ops.bilinear_resize_adjoint(y.to(DEV), ih, ih).cpu()
+        assert maxdiff(got, xr.grad) < 2e-5
+        ux = ops.bilinear_resize(x.to(DEV), oh, oh).cpu()
+        assert abs((ux * y).sum().item() - (x * got).sum().item()) < 1e-3          # <Ux, y> == <x, U^T y>
+
+
 @pytest.mark.parametrize("B,C,H,Nout", [(2, 384, 28, 128), (1, 768, 37, 256), (3, 768, 68, 256), (2, 128, 5, 128)])
 def test_dba_project(B, C, H, Nout):
     g = torch.Generator().manual_seed(C + H)

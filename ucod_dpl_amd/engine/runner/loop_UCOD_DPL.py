@@ -179,14 +179,20 @@ class TrainLoop(BaseLoop):
         features = features.to(dev, torch.float32)
         pseudo_labels = pseudo_labels.to(dev, torch.float32)
         B = features.shape[0]
-        feats = features.contiguous() if features.shape[-2:] == (fs, fs) else ops.bilinear_resize(features, fs, fs)     # :153
         pl = ops.bilinear_resize(pseudo_labels, fs, fs)                                                               # :154
 
-        # teacher (no grad) and student share one projection (:156-158)
+        # teacher (no grad) and student share one projection (:156-158).  The reference resizes the 768-channel features to
+        # fs x fs first (:153) and then applies the 1x1 conv; both are linear and act on different axes, so they commute:
+        # project on the native h x w grid (3.4x fewer FLOPs at 37->68) and resize the 256-channel result instead.
         A.refresh_shared_projection()
         emb_s, _, _, hw_s, hb_s = A.slices(A.p)
         emb_t, _, _, hw_t, hb_t = A.slices(A.ema)
-        d = ops.dba_project(feats, A.Wcat, A.bcat)
+        features = features.contiguous()
+        fh, fw = features.shape[-2:]
+        native_grid = (fh, fw) != (fs, fs)
+        d = ops.dba_project(features, A.Wcat, A.bcat)
+        if native_grid:
+            d = ops.bilinear_resize(d.view(B, 256, fh, fw), fs, fs).view(B, 256, fs * fs)
         norm_s = ops.dba_colnorm(d, 0, emb_s)
         norm_t = ops.dba_colnorm(d, 128, emb_t)
         fg, bg, sdiag = ops.dba_heads(d, 0, emb_s, norm_s, hw_s, hb_s, want_bg=True, want_sdiag=True)
@@ -205,7 +211,9 @@ class TrainLoop(BaseLoop):
         # backward through heads / gate / normalisation / orthogonality loss, then the 1x1 conv weight gradient
         g_emb, g_W, g_b, g_hw, g_hb = A.slices(A.g)
         gd, _, _, _ = ops.dba_bwd(d, 0, emb_s, norm_s, hw_s, gram, gfg, gbg, 1.0 / world, g_head_w=g_hw, g_head_b=g_hb, g_dec_bias=g_b)
-        ops.dba_wgrad(gd, feats, gW=g_W)
+        if native_grid:                                       # pull the gradient back through the resize (its transpose)
+            gd = ops.bilinear_resize_adjoint(gd.view(B, 128, fs, fs), fh, fw).view(B, 128, fh * fw)
+        ops.dba_wgrad(gd, features, gW=g_W)
         parallel.allreduce_prescaled_(A.g)                    # RCCL: one flat 128C+386-float buffer, pre-scaled by 1/world
 
         # AdamW + StepLR + EMA (:178-181,186-191)
@@ -271,9 +279,11 @@ class TrainLoop(BaseLoop):
         fs = self.cfg.model_cfg.feature_size
         features = features.to(dev, torch.float32)
         B = features.shape[0]
-        feats = features.contiguous() if features.shape[-2:] == (fs, fs) else ops.bilinear_resize(features, fs, fs)
+        features = features.contiguous()
         emb_s, W_s, b_s, hw_s, hb_s = A.slices(A.p)
-        d = ops.dba_project(feats, W_s, b_s)                  # student only, no grad (:238-240)
+        d = ops.dba_project(features, W_s, b_s)               # student only, no grad (:238-240); conv before resize (they commute)
+        if features.shape[-2:] != (fs, fs):
+            d = ops.bilinear_resize(d.view(B, 128, *features.shape[-2:]), fs, fs).view(B, 128, fs * fs)
         norm = ops.dba_colnorm(d, 0, emb_s)
         fg, _, _ = ops.dba_heads(d, 0, emb_s, norm, hw_s, hb_s, want_bg=False)
         preds = ops.binarize(fg, logits=True).view(B, 1, fs, fs)

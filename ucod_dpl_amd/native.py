@@ -49,6 +49,7 @@ SIGNATURES = {
     "ucod_vit_workspace_bytes": (sz, [C.POINTER(VitDesc)]),
     "ucod_vit_forward": (ci, [C.POINTER(VitDesc), C.POINTER(vp), vp, vp, vp, sz, vp]),
     "ucod_bilinear_resize": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ucod_bilinear_resize_adjoint": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "ucod_dba_project": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "ucod_dba_colnorm": (ci, [vp, ci, ci, vp, vp, ci, ci, vp]),
     "ucod_dba_heads_fwd": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]),

@@ -83,6 +83,17 @@ def bilinear_resize(x, oh, ow):
     return out
 
 
+def bilinear_resize_adjoint(gout, ih, iw):
+    gout = _f32(gout).contiguous()
+    *lead, oh, ow = gout.shape
+    planes = 1
+    for v in lead:
+        planes *= v
+    gin = torch.empty(*lead, ih, iw, dtype=torch.float32, device=gout.device)
+    check(N.load().ucod_bilinear_resize_adjoint(ptr(gout), ptr(gin), planes, ih, iw, oh, ow, stream()), "ucod_bilinear_resize_adjoint")
+    return gin
+
+
 def dba_project(x, W, bias):
     """x [B,C,H,W] f32, W [Nout,C], bias [Nout] -> d [B,Nout,HW]."""
     B, Cc, H, Wd = x.shape
