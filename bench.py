@@ -62,8 +62,8 @@ def algorithmic_work(name, B, tok, D, F, heads, Kpad, C_dec, HW):
         "gemm_bf16_patch_embed": 2.0 * B * (tok - 1) * D * Kpad,
         "gemm_bf16_key_nchw": 2.0 * M * D * D,
         "attention_fwd": 4.0 * B * heads * tok * tok * 64,
-        "dba_project_f32": 2.0 * B * HW * C_dec * 256,
-        "dba_wgrad_f32": 2.0 * B * HW * C_dec * 128,
+        "dba_project_f32": 2.0 * B * (tok - 1) * C_dec * 256,   # on the backbone's native grid (conv and resize commute)
+        "dba_wgrad_f32": 2.0 * B * (tok - 1) * C_dec * 128,
     }
     return f.get(name)
 

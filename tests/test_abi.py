@@ -52,7 +52,7 @@ def test_workspace_size_helpers(lib):
     assert need >= M * 768 * 4 + M * 768 * 2 * 2 + M * 2304 * 2 + M * 3072 * 2
     d.heads = 11                                           # head_dim != 64 -> rejected
     assert lib.ucod_vit_workspace_bytes(ctypes.byref(d)) == 0
-    assert lib.ucod_disc_saved_bytes(32, 68) == (32 * (32 * 68 * 68 + 16 * 34 * 34 + 8 * 17 * 17) + 112) * 4
+    assert lib.ucod_disc_saved_bytes(32, 68) == (32 * (32 * 68 * 68 + 16 * 34 * 34 + 8 * 17 * 17) + 112) * 4 + 112 * 8
     assert lib.ucod_dba_bwd_workspace_bytes(2, 100) == 2 * 128 * 100 * 4
 
 

@@ -29,8 +29,9 @@ static inline DiscDims disc_dims(int B, int fs) {
   d.n3 = (size_t)B * 8 * d.s3 * d.s3;
   return d;
 }
-// saved layout (floats): y1 | y2 | y3 | stats[2*(32+16+8)] (mean, rstd per channel, layer after layer)
+// saved layout (floats): y1 | y2 | y3 | stats[2*(32+16+8)] (mean, rstd per channel, layer after layer) | f64 sums[2*(32+16+8)]
 static inline size_t stats_off(const DiscDims& d) { return d.n1 + d.n2 + d.n3; }
+static inline size_t acc_off_bytes(const DiscDims& d) { return ((stats_off(d) + 112) * sizeof(float) + 7) / 8 * 8; }
 
 __device__ __forceinline__ float bn_lrelu(float y, float mean, float rstd, float g, float b) {
   const float h = (y - mean) * rstd * g + b;
@@ -41,11 +42,14 @@ __device__ __forceinline__ float bn_lrelu(float y, float mean, float rstd, float
 template <int CIN, int COUT, int STRIDE, bool BN_IN>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                       const float* __restrict__ in_stats, const float* __restrict__ in_g,
-                                                      const float* __restrict__ in_b, float* __restrict__ out, int B, int IH,
+                                                      const float* __restrict__ in_b, float* __restrict__ out,
+                                                      double* __restrict__ gacc /* [2*COUT]: sum, sum of squares */, int B, int IH,
                                                       int OH) {
   __shared__ __attribute__((aligned(16))) float ws[CIN * 9 * COUT];  // [ci][tap][co]
   __shared__ float sc[CIN > 1 ? CIN : 1], sh[CIN > 1 ? CIN : 1];
+  __shared__ float ssum[COUT], ssq[COUT];
   const int tid = threadIdx.x;
+  if (tid < COUT) { ssum[tid] = 0.f; ssq[tid] = 0.f; }
   for (int i = tid; i < CIN * 9 * COUT; i += 256) {
     const int co = i % COUT, rest = i / COUT, tap = rest % 9, ci = rest / 9;
     ws[i] = w[(co * CIN + ci) * 9 + tap];
@@ -57,8 +61,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
   }
   __syncthreads();
   const long total = (long)B * OH * OH;
-  const long idx = (long)blockIdx.x * 256 + tid;
-  if (idx >= total) return;
+  const long idx0 = (long)blockIdx.x * 256 + tid;
+  const bool valid = idx0 < total;
+  const long idx = valid ? idx0 : total - 1;
   const int ox = (int)(idx % OH), oy = (int)((idx / OH) % OH), b = (int)(idx / ((long)OH * OH));
   float acc[COUT];
 #pragma unroll
@@ -89,38 +94,38 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     }
   }
   float* ob = out + (long)b * COUT * OH * OH + (long)oy * OH + ox;
+  // pre-BN output + this workgroup's share of the batch statistics (wave shuffle -> LDS atomics -> one f64 atomic per channel)
 #pragma unroll
-  for (int co = 0; co < COUT; ++co) ob[(long)co * OH * OH] = acc[co];
-}
-
-// one workgroup per channel: mean / biased var in f64 over (B, H, W); writes mean, rstd; updates running buffers
-__global__ __launch_bounds__(1024) void bn_stats_kernel(const float* __restrict__ y, int C, int B, int HW, float* __restrict__ stats,
-                                                        float* __restrict__ rmean, float* __restrict__ rvar, int update) {
-  __shared__ double red[16];
-  const int c = blockIdx.x, tid = threadIdx.x;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < B; ++b) {
-    const float* p = y + ((long)b * C + c) * HW;
-    for (int i = tid; i < HW; i += 1024) {
-      const double v = (double)p[i];
-      s += v;
-      q += v * v;
+  for (int co = 0; co < COUT; ++co) {
+    const float v = valid ? acc[co] : 0.f;
+    if (valid) ob[(long)co * OH * OH] = v;
+    const float s1 = wave_sum(v), s2 = wave_sum(v * v);
+    if ((tid & 63) == 0) {
+      atomicAdd(&ssum[co], s1);
+      atomicAdd(&ssq[co], s2);
     }
   }
-  s = block_sum(s, red);
-  q = block_sum(q, red);
-  if (tid == 0) {
-    const double n = (double)B * HW;
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    stats[c] = (float)mean;
-    stats[C + c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
-    if (update) {
-      const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-      rmean[c] = (1.f - BN_MOM) * rmean[c] + BN_MOM * (float)mean;
-      rvar[c] = (1.f - BN_MOM) * rvar[c] + BN_MOM * (float)unb;
-    }
+  __syncthreads();
+  if (tid < COUT) {
+    atomicAdd(&gacc[tid], (double)ssum[tid]);
+    atomicAdd(&gacc[COUT + tid], (double)ssq[tid]);
+  }
+}
+
+// mean / biased variance from the f64 sums the conv kernel accumulated; writes (mean, rstd), updates the running buffers
+__global__ void bn_finalize_kernel(const double* __restrict__ gacc, int C, double n, float* __restrict__ stats,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, int update) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const double mean = gacc[c] / n;
+  double var = gacc[C + c] / n - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  stats[c] = (float)mean;
+  stats[C + c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+  if (update) {
+    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+    rmean[c] = (1.f - BN_MOM) * rmean[c] + BN_MOM * (float)mean;
+    rvar[c] = (1.f - BN_MOM) * rvar[c] + BN_MOM * (float)unb;
   }
 }
 
@@ -146,7 +151,7 @@ using namespace ucod;
 
 extern "C" size_t ucod_disc_saved_bytes(int B, int fs) {
   const DiscDims d = disc_dims(B, fs);
-  return (stats_off(d) + 2 * (32 + 16 + 8)) * sizeof(float);
+  return acc_off_bytes(d) + 112 * sizeof(double);
 }
 
 extern "C" int ucod_disc_fwd(const float* mask, const ucod_disc_params* p, float* prob, void* saved, int B, int fs,
@@ -161,12 +166,17 @@ extern "C" int ucod_disc_fwd(const float* mask, const ucod_disc_params* p, float
   float* st2 = st1 + 64;
   float* st3 = st2 + 32;
   UCOD_PROF(PROF_DISC_FWD, s);
-  hipLaunchKernelGGL((conv3x3_kernel<1, 32, 1, false>), dim3(cdiv((long)B * d.s1 * d.s1, 256)), dim3(256), 0, s, mask, p->w1, nullptr, nullptr, nullptr, y1, B, fs, d.s1);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(32), dim3(1024), 0, s, y1, 32, B, d.s1 * d.s1, st1, p->rm1, p->rv1, update_running);
-  hipLaunchKernelGGL((conv3x3_kernel<32, 16, 2, true>), dim3(cdiv((long)B * d.s2 * d.s2, 256)), dim3(256), 0, s, y1, p->w2, st1, p->g1, p->b1, y2, B, d.s1, d.s2);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(16), dim3(1024), 0, s, y2, 16, B, d.s2 * d.s2, st2, p->rm2, p->rv2, update_running);
-  hipLaunchKernelGGL((conv3x3_kernel<16, 8, 2, true>), dim3(cdiv((long)B * d.s3 * d.s3, 256)), dim3(256), 0, s, y2, p->w3, st2, p->g2, p->b2, y3, B, d.s2, d.s3);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(8), dim3(1024), 0, s, y3, 8, B, d.s3 * d.s3, st3, p->rm3, p->rv3, update_running);
+  double* ac1 = (double*)((char*)saved + acc_off_bytes(d));
+  double* ac2 = ac1 + 64;
+  double* ac3 = ac2 + 32;
+  hipError_t e = hipMemsetAsync(ac1, 0, 112 * sizeof(double), s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((conv3x3_kernel<1, 32, 1, false>), dim3(cdiv((long)B * d.s1 * d.s1, 256)), dim3(256), 0, s, mask, p->w1, nullptr, nullptr, nullptr, y1, ac1, B, fs, d.s1);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, ac1, 32, (double)B * d.s1 * d.s1, st1, p->rm1, p->rv1, update_running);
+  hipLaunchKernelGGL((conv3x3_kernel<32, 16, 2, true>), dim3(cdiv((long)B * d.s2 * d.s2, 256)), dim3(256), 0, s, y1, p->w2, st1, p->g1, p->b1, y2, ac2, B, d.s1, d.s2);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, ac2, 16, (double)B * d.s2 * d.s2, st2, p->rm2, p->rv2, update_running);
+  hipLaunchKernelGGL((conv3x3_kernel<16, 8, 2, true>), dim3(cdiv((long)B * d.s3 * d.s3, 256)), dim3(256), 0, s, y2, p->w3, st2, p->g2, p->b2, y3, ac3, B, d.s2, d.s3);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, ac3, 8, (double)B * d.s3 * d.s3, st3, p->rm3, p->rv3, update_running);
   hipLaunchKernelGGL(disc_head_kernel, dim3(B), dim3(256), 0, s, y3, st3, p->g3, p->b3, p->lin_w, p->lin_b, prob, d.s3 * d.s3);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;

@@ -143,10 +143,9 @@ __global__ __launch_bounds__(256, 2) void dba_project_kernel(const float* __rest
 
 // ------------------------------------------------------------------------------------------- wgrad
 // block: 128 (n) x 128 (c) output tile, reduction over one pixel chunk of one image; waves 2x2, 64x64 each
-constexpr int WG_CHUNK = 1024;
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void dba_wgrad_kernel(const float* __restrict__ gd, const float* __restrict__ x,
-                                                        float* __restrict__ gW, int C, int HW) {
+                                                        float* __restrict__ gW, int C, int HW, int WG_CHUNK) {
   __shared__ float As[2][FK * LDP];
   __shared__ float Bs[2][FK * LDP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
@@ -225,14 +224,17 @@ extern "C" int ucod_dba_project(const float* x, const float* W, const float* bia
 extern "C" int ucod_dba_wgrad(const float* gd, const float* x, float* gW, int B, int C, int HW, void* stream) {
   using namespace ucod;
   if (!gd || !x || !gW || B <= 0 || C <= 0 || HW <= 0) return UCOD_EINVAL;
+  // split-K granularity: enough workgroups to fill 256 CUs a few times over (chunk a multiple of the 16-pixel K-tile)
+  int WG_CHUNK = 1024;
+  while (WG_CHUNK > 128 && (long)cdiv(C, 128) * cdiv(HW, WG_CHUNK) * B < 1024) WG_CHUNK >>= 1;
   dim3 grid(cdiv(C, 128), cdiv(HW, WG_CHUNK), B), block(256);
   UCOD_PROF(PROF_DBA_WGRAD, stream);
   hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * 128 * (size_t)C, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   if ((HW % 4) == 0 && (((uintptr_t)x) % 16) == 0 && (((uintptr_t)gd) % 16) == 0)
-    hipLaunchKernelGGL((dba_wgrad_kernel<true>), grid, block, 0, (hipStream_t)stream, gd, x, gW, C, HW);
+    hipLaunchKernelGGL((dba_wgrad_kernel<true>), grid, block, 0, (hipStream_t)stream, gd, x, gW, C, HW, WG_CHUNK);
   else
-    hipLaunchKernelGGL((dba_wgrad_kernel<false>), grid, block, 0, (hipStream_t)stream, gd, x, gW, C, HW);
+    hipLaunchKernelGGL((dba_wgrad_kernel<false>), grid, block, 0, (hipStream_t)stream, gd, x, gW, C, HW, WG_CHUNK);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }
