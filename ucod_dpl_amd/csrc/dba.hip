@@ -161,69 +161,86 @@ __global__ void orth_loss_kernel(const float* __restrict__ trace, const float* _
 }
 
 // ---------------------------------------------------------------------------------- backward, pass A
-// thread = pixel.  gfeat[b][c][p] = dL/df = orth term + gate term, for both branches.
-__global__ __launch_bounds__(256) void dba_bwd_a_kernel(const float* __restrict__ d, int ld_c, int c0, const float* __restrict__ emb,
-                                                        const float* __restrict__ norm, const float* __restrict__ head_w,
-                                                        const float* __restrict__ gram, const float* __restrict__ gfg,
-                                                        const float* __restrict__ gbg, float coef /* 2*gextra/Z */,
-                                                        float* __restrict__ gfeat, int HW) {
-  __shared__ __attribute__((aligned(16))) float G[2][E * E];
+// gfeat[b][c][p] = dL/df for both branches = orthogonality term + gate term:
+//   gfeat1 = coef*(G2 f1 - s f2) + g_fg*w_fg*sig'(f1 d1)*d1 ,  gfeat2 = coef*(G1 f2 - s f1) + g_bg*w_bg*sig'(f2 d2)*d2 ,
+//   s_p = f1_p . f2_p.  The two 64x64 mat-vecs per pixel are run as exact-f32 MFMA products G[64x64] x F[64 x 256 px]:
+// A operand = Gram matrix from LDS (symmetric, so row-major IS the [k][row] image), B operand = normalised features read
+// straight from global memory (lane = pixel: coalesced; each element is used by exactly one MFMA, so no LDS staging).
+// Workgroup = 256 pixels of one image, wave = 64 pixels, both branches in one k loop (s_p falls out of the same loads).
+__global__ __launch_bounds__(256, 2) void dba_bwd_a_kernel(const float* __restrict__ d, int ld_c, int c0, const float* __restrict__ emb,
+                                                           const float* __restrict__ norm, const float* __restrict__ head_w,
+                                                           const float* __restrict__ gram, const float* __restrict__ gfg,
+                                                           const float* __restrict__ gbg, float coef /* 2*gextra/Z */,
+                                                           float* __restrict__ gfeat, int HW) {
+  __shared__ float G[2][E * E];
   __shared__ float kf[128], hw[128];
-  const int b = blockIdx.y, tid = threadIdx.x;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h5 = lane >> 5;
   for (int i = tid; i < 2 * E * E; i += 256) (&G[0][0])[i] = gram[(long)b * 2 * E * E + i];
   if (tid < 128) {
     kf[tid] = emb[tid] / norm[b * 128 + tid];
     hw[tid] = head_w[tid];
   }
   __syncthreads();
-  const int p = blockIdx.x * 256 + tid;
-  if (p >= HW) return;
-  const float* dp = d + ((long)b * ld_c + c0) * HW + p;
-  float* gp = gfeat + (long)b * 128 * HW + p;
-  const float g1 = gfg[(long)b * HW + p], g2 = gbg[(long)b * HW + p];
+  const int pbase = blockIdx.x * 256 + wave * 64;
+  int px[2];
+  bool ok[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int p = pbase + ct * 32 + l31;
+    ok[ct] = p < HW;
+    px[ct] = ok[ct] ? p : HW - 1;
+  }
+  const float* dp = d + ((long)b * ld_c + c0) * HW;
 
-  float fin[E];
-  float s = 0.f;
+  f32x16 a1[2][2], a2[2][2];   // [row tile][pixel tile]: G2 f1 and G1 f2
 #pragma unroll
-  for (int c = 0; c < E; ++c) {
-    fin[c] = dp[(long)c * HW] * kf[c];
-    s = fmaf(fin[c], dp[(long)(c + E) * HW] * kf[c + E], s);
+  for (int i = 0; i < 16; ++i) {
+    a1[0][0][i] = a1[0][1][i] = a1[1][0][i] = a1[1][1][i] = 0.f;
+    a2[0][0][i] = a2[0][1][i] = a2[1][0][i] = a2[1][1][i] = 0.f;
   }
-  // branch 1: go1 = coef * (G2 f1 - s f2)
-  for (int c = 0; c < E; ++c) {
-    const float4* grow = reinterpret_cast<const float4*>(&G[1][c * E]);
-    float acc = 0.f;
+  float spart[2] = {0.f, 0.f};
+#pragma unroll 4
+  for (int kk = 0; kk < E; kk += 2) {
+    const int k = kk + h5;
+    const float k1 = kf[k], k2 = kf[E + k];
+    float f1[2], f2[2];
 #pragma unroll
-    for (int q = 0; q < E / 4; ++q) {
-      const float4 g = grow[q];
-      acc = fmaf(g.x, fin[4 * q], acc);
-      acc = fmaf(g.y, fin[4 * q + 1], acc);
-      acc = fmaf(g.z, fin[4 * q + 2], acc);
-      acc = fmaf(g.w, fin[4 * q + 3], acc);
+    for (int ct = 0; ct < 2; ++ct) {
+      f1[ct] = dp[(long)k * HW + px[ct]] * k1;
+      f2[ct] = dp[(long)(k + E) * HW + px[ct]] * k2;
+      spart[ct] = fmaf(f1[ct], f2[ct], spart[ct]);
     }
-    const float d1 = dp[(long)c * HW], f1 = d1 * kf[c];
-    const float f2 = dp[(long)(c + E) * HW] * kf[c + E];
-    const float sg = sigmoid_acc(f1 * d1);
-    gp[(long)c * HW] = coef * (acc - s * f2) + g1 * hw[c] * sg * (1.f - sg) * d1;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const float g2 = G[1][k * E + rt * 32 + l31];
+      const float g1 = G[0][k * E + rt * 32 + l31];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        a1[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g2, f1[ct], a1[rt][ct], 0, 0, 0);
+        a2[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, f2[ct], a2[rt][ct], 0, 0, 0);
+      }
+    }
   }
-  // branch 2: go2 = coef * (G1 f2 - s f1)
+  float* gp = gfeat + (long)b * 128 * HW;
 #pragma unroll
-  for (int c = 0; c < E; ++c) fin[c] = dp[(long)(c + E) * HW] * kf[c + E];
-  for (int c = 0; c < E; ++c) {
-    const float4* grow = reinterpret_cast<const float4*>(&G[0][c * E]);
-    float acc = 0.f;
+  for (int ct = 0; ct < 2; ++ct) {
+    const float s = spart[ct] + __shfl_xor(spart[ct], 32, 64);
+    const long gi = (long)b * HW + px[ct];
+    const float g1 = gfg[gi], g2 = gbg[gi];
 #pragma unroll
-    for (int q = 0; q < E / 4; ++q) {
-      const float4 g = grow[q];
-      acc = fmaf(g.x, fin[4 * q], acc);
-      acc = fmaf(g.y, fin[4 * q + 1], acc);
-      acc = fmaf(g.z, fin[4 * q + 2], acc);
-      acc = fmaf(g.w, fin[4 * q + 3], acc);
-    }
-    const float d2 = dp[(long)(c + E) * HW], f2 = d2 * kf[c + E];
-    const float f1 = dp[(long)c * HW] * kf[c];
-    const float sg = sigmoid_acc(f2 * d2);
-    gp[(long)(c + E) * HW] = coef * (acc - s * f1) + g2 * hw[c + E] * sg * (1.f - sg) * d2;
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h5;
+        const float d1 = dp[(long)c * HW + px[ct]], d2 = dp[(long)(c + E) * HW + px[ct]];
+        const float f1 = d1 * kf[c], f2 = d2 * kf[c + E];
+        const float s1 = sigmoid_acc(f1 * d1), s2 = sigmoid_acc(f2 * d2);
+        if (ok[ct]) {
+          gp[(long)c * HW + px[ct]] = coef * (a1[rt][ct][r] - s * f2) + g1 * hw[c] * s1 * (1.f - s1) * d1;
+          gp[(long)(c + E) * HW + px[ct]] = coef * (a2[rt][ct][r] - s * f1) + g2 * hw[c + E] * s2 * (1.f - s2) * d2;
+        }
+      }
   }
 }
 

@@ -42,39 +42,50 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__
 // src_index() as the forward, so forward and adjoint agree tap for tap.  Used to pull the decoder's gradient back from the
 // 68x68 grid to the backbone's native 37x37 grid, where the 1x1-conv weight gradient is 3.4x cheaper (the conv and the
 // resize commute: both are linear, one acts on channels, the other on pixels).
+// taps of source index i along one axis: the (at most MAXT) output indices whose bilinear footprint touches i, with
+// their weights.  Scans the candidate range with the SAME src_index() as the forward.
+constexpr int MAXT = 8;
+__device__ __forceinline__ int adjoint_taps(int i, float scale, int in_size, int out_size, int (&idx)[MAXT], float (&w)[MAXT]) {
+  int lo = (int)floorf((float)(i - 1) / scale) - 1, hi = (int)ceilf((float)(i + 1) / scale) + 1;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > out_size - 1 ? out_size - 1 : hi;
+  int n = 0;
+  for (int o = lo; o <= hi; ++o) {
+    int i0, i1;
+    float l1;
+    src_index(o, scale, in_size, i0, i1, l1);
+    float wt = 0.f;
+    if (i0 == i) wt += 1.f - l1;
+    if (i1 == i) wt += l1;
+    if (wt != 0.f && n < MAXT) { idx[n] = o; w[n] = wt; ++n; }
+  }
+  return n;
+}
+
+// grid (cdiv(ih*iw,256), plane-chunks): each thread owns one source pixel, computes its taps ONCE and then sweeps planes.
 __global__ __launch_bounds__(256) void bilinear_adjoint_kernel(const float* __restrict__ gout, float* __restrict__ gin, long planes,
                                                                int ih, int iw, int oh, int ow, float sh, float sw) {
-  const long total = planes * ih * iw;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int ix = (int)(idx % iw);
-    const int iy = (int)((idx / iw) % ih);
-    const long pl = idx / ((long)iw * ih);
-    // output indices that can reference source index i lie in [ (i-1)/scale - 1, (i+1)/scale + 1 ]
-    int ylo = (int)floorf((float)(iy - 1) / sh) - 1, yhi = (int)ceilf((float)(iy + 1) / sh) + 1;
-    int xlo = (int)floorf((float)(ix - 1) / sw) - 1, xhi = (int)ceilf((float)(ix + 1) / sw) + 1;
-    ylo = ylo < 0 ? 0 : ylo; xlo = xlo < 0 ? 0 : xlo;
-    yhi = yhi > oh - 1 ? oh - 1 : yhi; xhi = xhi > ow - 1 ? ow - 1 : xhi;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= ih * iw) return;
+  const int iy = p / iw, ix = p - iy * iw;
+  int yi[MAXT], xi[MAXT];
+  float yw[MAXT], xw[MAXT];
+  const int ny = adjoint_taps(iy, sh, ih, oh, yi, yw);
+  const int nx = adjoint_taps(ix, sw, iw, ow, xi, xw);
+  for (long pl = blockIdx.y; pl < planes; pl += gridDim.y) {
     const float* g = gout + pl * oh * ow;
     float acc = 0.f;
-    for (int oy = ylo; oy <= yhi; ++oy) {
-      int y0, y1; float ly;
-      src_index(oy, sh, ih, y0, y1, ly);
-      float wy = 0.f;
-      if (y0 == iy) wy += 1.f - ly;
-      if (y1 == iy) wy += ly;
-      if (wy == 0.f) continue;
-      float row = 0.f;
-      for (int ox = xlo; ox <= xhi; ++ox) {
-        int x0, x1; float lx;
-        src_index(ox, sw, iw, x0, x1, lx);
-        float wx = 0.f;
-        if (x0 == ix) wx += 1.f - lx;
-        if (x1 == ix) wx += lx;
-        if (wx != 0.f) row = fmaf(wx, g[oy * ow + ox], row);
+#pragma unroll
+    for (int a = 0; a < MAXT; ++a) {
+      if (a < ny) {
+        float row = 0.f;
+#pragma unroll
+        for (int b = 0; b < MAXT; ++b)
+          if (b < nx) row = fmaf(xw[b], g[yi[a] * ow + xi[b]], row);
+        acc = fmaf(yw[a], row, acc);
       }
-      acc = fmaf(wy, row, acc);
     }
-    gin[idx] = acc;
+    gin[pl * ih * iw + p] = acc;
   }
 }
 
@@ -166,7 +177,10 @@ extern "C" int ucod_bilinear_resize_adjoint(const float* gout, float* gin, int p
   const size_t total = (size_t)planes * ih * iw;
   const float sh = (float)ih / (float)oh, sw = (float)iw / (float)ow;
   UCOD_PROF(PROF_BILINEAR, stream);
-  hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(nblocks(total, 16384)), dim3(256), 0, (hipStream_t)stream, gout, gin, (long)planes, ih, iw, oh, ow, sh, sw);
+  (void)total;
+  if (ceilf(2.f / fminf(sh, sw)) + 1.f > (float)MAXT) return UCOD_EINVAL;   // more than MAXT taps per axis (upsampling beyond ~3.5x)
+  const int py = planes < 1024 ? planes : 1024;
+  hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(cdiv((long)ih * iw, 256), py), dim3(256), 0, (hipStream_t)stream, gout, gin, (long)planes, ih, iw, oh, ow, sh, sw);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }
