@@ -47,9 +47,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
                                                       int OH) {
   __shared__ __attribute__((aligned(16))) float ws[CIN * 9 * COUT];  // [ci][tap][co]
   __shared__ float sc[CIN > 1 ? CIN : 1], sh[CIN > 1 ? CIN : 1];
-  __shared__ float ssum[COUT], ssq[COUT];
+  constexpr int PARTS = 256 / COUT;                     // threads cooperating on one channel in the statistics pass
+  __shared__ float red[256 * (COUT + 1)];
+  __shared__ float psum[PARTS][COUT], psq[PARTS][COUT];
   const int tid = threadIdx.x;
-  if (tid < COUT) { ssum[tid] = 0.f; ssq[tid] = 0.f; }
   for (int i = tid; i < CIN * 9 * COUT; i += 256) {
     const int co = i % COUT, rest = i / COUT, tap = rest % 9, ci = rest / 9;
     ws[i] = w[(co * CIN + ci) * 9 + tap];
@@ -94,21 +95,34 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     }
   }
   float* ob = out + (long)b * COUT * OH * OH + (long)oy * OH + ox;
-  // pre-BN output + this workgroup's share of the batch statistics (wave shuffle -> LDS atomics -> one f64 atomic per channel)
+  // pre-BN output + this workgroup's share of the batch statistics: transpose through LDS (thread-major -> channel-major),
+  // PARTS threads per channel sum 256/PARTS pixels each, then one f64 atomic per channel per workgroup.
 #pragma unroll
   for (int co = 0; co < COUT; ++co) {
     const float v = valid ? acc[co] : 0.f;
     if (valid) ob[(long)co * OH * OH] = v;
-    const float s1 = wave_sum(v), s2 = wave_sum(v * v);
-    if ((tid & 63) == 0) {
-      atomicAdd(&ssum[co], s1);
-      atomicAdd(&ssq[co], s2);
+    red[tid * (COUT + 1) + co] = v;
+  }
+  __syncthreads();
+  {
+    const int ch = tid % COUT, part = tid / COUT;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+    for (int r = part; r < 256; r += PARTS) {
+      const float v = red[r * (COUT + 1) + ch];
+      s1 += v;
+      s2 = fmaf(v, v, s2);
     }
+    psum[part][ch] = s1;
+    psq[part][ch] = s2;
   }
   __syncthreads();
   if (tid < COUT) {
-    atomicAdd(&gacc[tid], (double)ssum[tid]);
-    atomicAdd(&gacc[COUT + tid], (double)ssq[tid]);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < PARTS; ++q) { s1 += psum[q][tid]; s2 += psq[q][tid]; }
+    atomicAdd(&gacc[tid], (double)s1);
+    atomicAdd(&gacc[COUT + tid], (double)s2);
   }
 }
 
