@@ -327,42 +327,42 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __r
           if (key >= N) s[kt][r] = -1e30f;
         }
     }
-    float mloc = s[0][0];
+    // The 64-key tile is consumed as two independent 32-key halves, each with its own (cheap) deferred-max check:
+    // while the VALU runs max/exp/cvt of half 0 the matrix pipe is still executing the QK^T MFMAs of half 1, and while it
+    // runs half 1's softmax the pipe executes half 0's PV products -- MFMA || VALU overlap inside ONE wave.
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[0][r]);
+    for (int kt = 0; kt < 2; ++kt) {
+      float mloc = s[kt][0];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[1][r]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    // rescale only when some query's max ran away by more than THR (always on the first tile: m_run is a guess)
-    if (t == 0 || __any(mloc > DEFER_THR)) {
-      const float delta = (t == 0) ? mloc : fmaxf(mloc, 0.f);
-      const float alpha = (t == 0) ? 1.f : __builtin_amdgcn_exp2f(-delta);
-      m_run += delta;
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[kt][r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      // rescale only when some query's max ran away by more than THR (always on the very first half: m_run is a guess)
+      const bool first = (t == 0 && kt == 0);
+      if (first || __any(mloc > DEFER_THR)) {
+        const float delta = first ? mloc : fmaxf(mloc, 0.f);
+        const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+        m_run += delta;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        s[0][i] -= delta;
-        s[1][i] -= delta;
-        o[0][i] *= alpha;
-        o[1][i] *= alpha;
+        for (int i = 0; i < 16; ++i) {
+          s[kt][i] -= delta;
+          if (kt == 0) s[1][i] -= delta;       // half 1 was accumulated against the old running max
+          o[0][i] *= alpha;
+          o[1][i] *= alpha;
+        }
+        osum[0] *= alpha;
       }
-      osum[0] *= alpha;
-    }
-    bf16x8 pb[2][2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      bf16x8 pb[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         u32x4_t w;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
           w[jj] = cvt_pk_bf16(__builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj + 1]));
-        pb[kt][ks] = __builtin_bit_cast(bf16x8, w);
+        pb[ks] = __builtin_bit_cast(bf16x8, w);
       }
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[kt][ks], osum, 0, 0, 0);
+        osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[ks], osum, 0, 0, 0);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const char* p0 = kb + voff[kt][ks][dt];
@@ -370,9 +370,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __r
           const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
           const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
           const bf16x8 vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kt][ks], o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[ks], o[dt], 0, 0, 0);
         }
       }
+    }
     if (more) lwrite((t + 1) & 1);
   }
 
