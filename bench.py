@@ -156,8 +156,12 @@ def main():
         kernels["layernorm"]["gbs"] = round(B * tok * D * 6 / (kernels["layernorm"]["avg_us"] * 1e-6) / 1e9, 1)
     dom = max((n for n in kernels if "tflops" in kernels[n] and n.startswith(("gemm_bf16", "attention"))),
               key=lambda n: kernels[n]["ms_per_step"])
+    traffic = None                                            # HBM-side bytes per launch from committed PMC passes (see the file's "source")
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath) and a.arch == "dinov2_vitb14" and B == 32 and a.image == 518:
+        traffic = json.load(open(tpath)).get("kernels", {}).get(dom, {}).get("traffic_bytes")
     roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(kernels[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(kernels[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                 "avg_launch_us": kernels[dom]["avg_us"], "share_of_step": round(kernels[dom]["ms_per_step"] / (dt / a.steps * 1e3), 3)}
     if "layernorm" in kernels:
         roofline["hbm_row"] = {"kernel": "layernorm", "achieved": kernels["layernorm"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

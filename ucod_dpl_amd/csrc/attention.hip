@@ -225,13 +225,20 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 constexpr float DEFER_THR = 8.0f;
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N,
-                                                              int heads) {
+                                                              int heads, int npairs) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (KV_BYTES + KV_BYTES)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h5 = lane >> 5, l31 = lane & 31;
-  const int head = blockIdx.y, b = blockIdx.z;
+  // XCD-aware 1-D grid: blocks i and i+8 share an XCD (and its 4 MiB L2), so all query tiles of one (image, head) are
+  // given to ONE XCD back to back -- its K/V (350 KB at N=1370) is then re-read from that L2 instead of the fabric
+  // (rocprofv3 FETCH_SIZE was 5.6x the algorithmic bytes with the natural (q-tile, head, image) order).
+  const int nq = (N + QT - 1) / QT;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pair = (slot / nq) * 8 + xcd, qt = slot - (slot / nq) * nq;
+  if (pair >= npairs) return;
+  const int head = pair % heads, b = pair / heads;
   const int D = heads * HD, ld = 3 * D;
-  const int q0 = blockIdx.x * QT + wave * 32;
+  const int q0 = qt * QT + wave * 32;
   const bf16_raw* base = qkv + (size_t)b * N * ld + head * HD;
 
   bf16x8 qf[4];
@@ -402,7 +409,9 @@ extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, in
   const float c = scale * 1.4426950408889634f;
   UCOD_PROF(PROF_ATTN, stream);
   if (scale == 0.f) {   // Q pre-scaled by head_dim^-0.5 * log2(e): the VALU-lean kernel
-    hipLaunchKernelGGL(attn_fwd_v2_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads);
+    const int npairs = B * heads, nq = cdiv(tok, QT);
+    dim3 grid1(cdiv(npairs, 8) * 8 * nq);
+    hipLaunchKernelGGL(attn_fwd_v2_kernel, grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs);
     UCOD_CHECK_LAUNCH();
     return UCOD_OK;
   }
