@@ -330,7 +330,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   const int orig = blockIdx.x;
   const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
   const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-  const int tm = wg / a.tiles_n, tn = wg - tm * a.tiles_n;
+  // grouped order inside each XCD's chunk: GROUP_M row-tiles x all column-tiles, row-tile fastest -- the workgroups that are
+  // resident together on an XCD then share a few B (weight) panels and GROUP_M A panels that fit its 4 MiB L2, instead of
+  // every row-tile streaming the whole weight matrix through L2 (FETCH_SIZE was 5x the algorithmic bytes on fc1).
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * a.tiles_n;
+  const int grp = wg / per_group, first_m = grp * GROUP_M;
+  const int gsz = (a.tiles_m - first_m) < GROUP_M ? (a.tiles_m - first_m) : GROUP_M;
+  const int in_grp = wg - grp * per_group;
+  const int tm = first_m + in_grp % gsz, tn = in_grp / gsz;
   const int m0 = tm * 256, n0 = tn * Cfg::BN_;
   const int K = a.K, nt = K / BK;
 
