@@ -214,6 +214,40 @@ size_t ucod_crop_workspace_bytes(int nbox, int max_crop_h, int max_crop_w, int o
 int ucod_crop_resize_norm(const uint8_t* img, int H, int W, const int32_t* boxes_host, int nbox, float* out, int oh, int ow,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ CORAL SparseRefiner (rows R1-R4), inference */
+
+/* Cross-attention core of nn.MultiheadAttention with head_dim 96 (models/modules/mlp.py:122,143; 8 heads on C=768):
+ * softmax(Q K^T) V per (window, head).  q bf16 [B*Nq, ldq] (head h at columns h*96.., PRE-SCALED by 96^-0.5*log2(e));
+ * k, v bf16 rows of stride ldkv (may point into one [k|v] buffer); out bf16 [B*Nq, heads*96]. */
+int ucod_cross_attention96_fwd(const void* q_bf16, int ldq, const void* k_bf16, const void* v_bf16, int ldkv, void* out_bf16,
+                               int B, int Nq, int Nk, int heads, void* stream);
+
+/* out[(i*HW + p)*C + c] = src[(src_idx[i]*C + c)*HW + p]: window gather (models/modules/ASR.py:13-20) fused with
+ * CSF._BCHW_to_BLC (models/modules/CSF.py:29-31).  src f32 [*,C,HW], src_idx int32 [n] (device), out f32 [n*HW, C]. */
+int ucod_gather_tokens(const float* src, const int* src_idx, float* out, int n, int C, int HW, void* stream);
+
+/* EntropySelector scores (models/modules/ASR.py:42-48): entropy = -p*log(max(p,1e-5)) with p = preds (use_sigmoid == 0) or
+ * sigmoid(preds); scores = adaptive_avg_pool2d(entropy, (ws,ws)).  preds, entropy f32 [B,1,H,W]; scores f32 [B,ws,ws]. */
+int ucod_entropy_scores(const float* preds, int use_sigmoid, float* entropy, float* scores, int B, int H, int W, int ws, void* stream);
+
+/* depthwise 7x7 conv (padding 3, bias) + 1x1 mask head (models/modules/CSF.py:13-25,41-42) on token-major activations:
+ * x f32 [n,H,W,C]; dw_tapmajor f32 [49,C] (= depthwise_conv.weight [C,1,7,7] transposed), dw_bias [C], w1 [C], b1;
+ * out f32 [n,1,H,W]. */
+int ucod_dwconv7_maskdec(const float* x_tokens, const float* dw_tapmajor, const float* dw_bias, const float* w1, float b1, float* out,
+                         int n, int H, int W, int C, void* stream);
+
+/* HRE.concate_windows (models/modules/HRE.py:18-39): out f32 [B,1,ws*H,ws*W] = 0, then window i [H,W] placed at
+ * (coords[i][0]*H, coords[i][1]*W) of image win_img[i], divided by (1 + 1e-6).  coords int32 [n,2], win_img int32 [n] (device). */
+int ucod_window_scatter(const float* windows, const int* coords, const int* win_img, float* out, int n, int B, int H, int W, int ws,
+                        void* stream);
+
+/* GatedEnsembler (models/modules/GE_pix_level.py:16-25) after the bilinear resize of l1: 19x19 zero-padded average of
+ * sigmoid(l1), its entropy normalised by the maximum over the WHOLE batch, gate = ((1 - en/en_max) + mean sigmoid(l1))/2,
+ * y = l1*gate + l2*(1-gate), out = fuser(y) (1x1 conv 1->64, ReLU, 1x1 conv 64->1).  All maps f32 [B,1,h,w]. */
+size_t ucod_gated_ensemble_workspace_bytes(int B, int h, int w);
+int ucod_gated_ensemble(const float* l1_up, const float* l2, const float* fuser0_w, const float* fuser0_b, const float* fuser2_w,
+                        float fuser2_b, float* out, float* weight_out, void* workspace, int B, int h, int w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -398,7 +398,26 @@ def g8():
         save("g8_dinov1_" + tag, **d)
 
 
+# ----------------------------------------------------------------------------- G9: CORAL SparseRefiner (eval forward)
+def g9():
+    from models.UDLR import SparseRefiner
+    sys.path.insert(0, OUT)
+    import refiner_init as RI
+    torch.manual_seed(RI.SEED)
+    m = RI.perturb_(SparseRefiner.from_config(CfgNode(dict(window_size=3, threshold=0.0015, dim=768)))).eval()
+    out = {"chk." + k: v for k, v in RI.checksums(m).items()}
+    for tag, partial in (("full", False), ("partial", True)):
+        l, h, preds = RI.make_inputs(partial)
+        with torch.no_grad():
+            outputs, ex, opt = m(l, h, preds)
+        out[tag + ".outputs"] = outputs
+        for k in ("mask", "entropy", "h_preds", "window_preds", "GE_w", "coords_list"):
+            out[f"{tag}.{k}"] = opt[k].float() if opt[k].dtype == torch.bool else opt[k]
+        out[tag + ".ex_loss"] = np.float64(ex)
+    save("g9_refiner", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for w in which:
         globals()[w]()

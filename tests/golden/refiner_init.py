@@ -1,0 +1,32 @@
+"""Deterministic weights for the SparseRefiner fixture (G9), shared by make_golden.py (applied to the REFERENCE module)
+and the tests (applied to the build's mirror).  Seeded default init (both modules build identical nn sub-modules in the
+same order, so they consume the RNG identically) plus a closed-form perturbation so that the zero-initialised biases of
+nn.MultiheadAttention and the LayerNorm affine terms take part in the check."""
+import torch
+
+SEED = 9
+
+
+def perturb_(module):
+    with torch.no_grad():
+        for i, (name, p) in enumerate(module.named_parameters()):
+            n = p.numel()
+            t = torch.arange(n, dtype=torch.float32)
+            p.add_((0.02 * torch.sin(0.37 * t + i)).reshape(p.shape))
+    return module
+
+
+def checksums(module):
+    return {name: torch.stack([p.detach().double().sum(), p.detach().double().abs().sum()]) for name, p in module.named_parameters()}
+
+
+def make_inputs(partial):
+    g = torch.Generator().manual_seed(90 + int(partial))
+    B, H = 2, 6
+    l = torch.randn(B, 768, H, H, generator=g)
+    h = torch.randn(B, 9, 768, H, H, generator=g)
+    preds = torch.randn(B, 1, H, H, generator=g) * 2
+    if partial:                                    # confident (low-entropy) regions: only some windows pass the threshold
+        preds[0, :, :4, :] = 14.0
+        preds[1, :, :, 2:] = -14.0
+    return l, h, preds

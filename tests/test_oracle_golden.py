@@ -159,3 +159,28 @@ def test_g8_dinov1(tag):
     last, key = OV.dinov1_forward(g["x"], sub(g, "sd."), heads=2, patch=8, eps=1e-6)
     assert maxdiff(key, g["key"]) < 2e-5
     assert maxdiff(last, g["last_hidden_state"]) < 5e-5
+
+
+@pytest.mark.parametrize("tag", ["full", "partial"])
+def test_g9_sparse_refiner(tag):
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import refiner_init as RI
+    from oracle import refiner as OR
+    from ucod_dpl_amd.models.UDLR import SparseRefiner
+    from ucod_dpl_amd.engine.config import CfgNode
+    g = load_golden("g9_refiner")
+    torch.manual_seed(RI.SEED)
+    m = RI.perturb_(SparseRefiner.from_config(CfgNode(dict(window_size=3, threshold=0.0015)))).eval()
+    for k, v in RI.checksums(m).items():                     # the mirror's seeded init IS the reference's
+        assert maxdiff(v, g["chk." + k]) < 1e-9 * max(1.0, g["chk." + k].abs().max().item()), k
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    l, h, preds = RI.make_inputs(tag == "partial")
+    out, opt = OR.sparse_refiner_forward(l, h, preds, sd)
+    assert torch.equal(opt["mask"].float(), g[tag + ".mask"])
+    assert torch.equal(opt["coords_list"], g[tag + ".coords_list"])
+    if tag == "partial":
+        assert 0 < int(opt["mask"].sum()) < 18
+    for k in ("entropy", "window_preds", "h_preds", "GE_w"):
+        assert maxdiff(opt[k], g[f"{tag}.{k}"]) < 2e-4, (k, maxdiff(opt[k], g[f"{tag}.{k}"]))
+    assert maxdiff(out, g[tag + ".outputs"]) < 2e-4

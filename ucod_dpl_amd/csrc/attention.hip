@@ -400,6 +400,180 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __r
   }
 }
 
+
+// =====================================================================================================
+// Cross-attention, head_dim 96 (CORAL refiner: nn.MultiheadAttention with 8 heads on C=768, models/modules/mlp.py:122,143).
+// Same structure as attn_fwd_v2_kernel (pre-scaled Q, accumulator initialised with -m, per-half deferred max, denominator on
+// the matrix pipe, V through ds_read_b64_tr_b16) with separate query / key-value sources and lengths.  LDS rows are padded
+// to 256 B (16 slots of 16 B, 12 used): K slot = chunk ^ (row & 15), V slot = chunk ^ ((row & 3) << 2).
+// =====================================================================================================
+constexpr int HDX = 96;
+constexpr int XROW = 256;                 // padded LDS row bytes
+constexpr int XTILE = KT * XROW;          // 16 KiB per K or V tile
+
+__global__ __launch_bounds__(256, 2) void attn_cross96_kernel(const bf16_raw* __restrict__ qp_, int ldq, const bf16_raw* __restrict__ kp_,
+                                                               const bf16_raw* __restrict__ vp_, int ldkv, bf16_raw* __restrict__ out,
+                                                               int Nq, int Nk, int heads) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * XTILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h5 = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int D = heads * HDX;
+  const int q0 = blockIdx.x * QT + wave * 32;
+  const bf16_raw* qb = qp_ + (size_t)b * Nq * ldq + head * HDX;
+  const bf16_raw* kbase = kp_ + (size_t)b * Nk * ldkv + head * HDX;
+  const bf16_raw* vbase = vp_ + (size_t)b * Nk * ldkv + head * HDX;
+
+  bf16x8 qf[6];
+  {
+    int qr = q0 + l31;
+    qr = qr < Nq ? qr : Nq - 1;
+    const bf16_raw* qp = qb + (size_t)qr * ldq + 8 * h5;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  const u32x4_t ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+
+  f32x16 o[3], osum;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; o[2][i] = 0.f; osum[i] = 0.f; }
+  float m_run = 0.f;
+
+  const int nt = (Nk + KT - 1) / KT;
+  u32x4 rk[3], rv[3];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = tid + 256 * i, row = idx / 12, ch = idx - row * 12;
+      int kr = t * KT + row;
+      kr = kr < Nk ? kr : Nk - 1;
+      rk[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)kr * ldkv + ch * 8);
+      rv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)kr * ldkv + ch * 8);
+    }
+  };
+  auto lwrite = [&](int buf) {
+    char* kb = smem + buf * (2 * XTILE);
+    char* vb = kb + XTILE;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = tid + 256 * i, row = idx / 12, ch = idx - row * 12;
+      *reinterpret_cast<u32x4*>(kb + row * XROW + (ch ^ (row & 15)) * 16) = rk[i];
+      *reinterpret_cast<u32x4*>(vb + row * XROW + (ch ^ ((row & 3) << 2)) * 16) = rv[i];
+    }
+  };
+  int koff[2][6], voff[2][2][3];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int sd = 0; sd < 6; ++sd) {
+      const int row = kt * 32 + l31;
+      koff[kt][sd] = row * XROW + ((2 * sd + h5) ^ (row & 15)) * 16;
+    }
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) {
+        const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+        const int key = kt * 32 + ks * 16 + 4 * h5 + (i16 >> 2);
+        const int dst = dt * 32 + g1 * 16 + 4 * (i16 & 3);
+        voff[kt][ks][dt] = XTILE + key * XROW + (((dst >> 3)) ^ ((key & 3) << 2)) * 16 + (dst & 7) * 2;   // key+8: same (key&3) -> +8*XROW
+      }
+
+  gload(0);
+  lwrite(0);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    const bool more = (t + 1 < nt);
+    if (more) gload(t + 1);
+    const char* kb = smem + (t & 1) * (2 * XTILE);
+    f32x16 s[2];
+    const float neg_m = -m_run;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kt][i] = neg_m;
+#pragma unroll
+      for (int sd = 0; sd < 6; ++sd) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + koff[kt][sd]);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sd], s[kt], 0, 0, 0);
+      }
+    }
+    if (t == nt - 1 && (Nk & (KT - 1)) != 0) {
+      const int kbase_i = t * KT + 4 * h5;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase_i + kt * 32 + (r & 3) + 8 * (r >> 2);
+          if (key >= Nk) s[kt][r] = -1e30f;
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      float mloc = s[kt][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[kt][r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const bool first = (t == 0 && kt == 0);
+      if (first || __any(mloc > DEFER_THR)) {
+        const float delta = first ? mloc : fmaxf(mloc, 0.f);
+        const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+        m_run += delta;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          s[kt][i] -= delta;
+          if (kt == 0) s[1][i] -= delta;
+          o[0][i] *= alpha;
+          o[1][i] *= alpha;
+          o[2][i] *= alpha;
+        }
+        osum[0] *= alpha;
+      }
+      bf16x8 pb[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4_t w;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          w[jj] = cvt_pk_bf16(__builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj + 1]));
+        pb[ks] = __builtin_bit_cast(bf16x8, w);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[ks], osum, 0, 0, 0);
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+          const char* p0 = kb + voff[kt][ks][dt];
+          const char* p1 = p0 + 8 * XROW;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
+          const bf16x8 vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[ks], o[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (more) lwrite((t + 1) & 1);
+  }
+  const float inv = 1.0f / osum[0];
+  const int q = q0 + l31;
+  if (q < Nq) {
+    bf16_raw* op = out + ((size_t)b * Nq + q) * D + head * HDX + 4 * h5;
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w;
+        w[0] = cvt_pk_bf16(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+        w[1] = cvt_pk_bf16(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
+      }
+  }
+}
+
 }  // namespace ucod
 
 extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, int heads, float scale, int variant, void* stream) {
@@ -419,6 +593,18 @@ extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, in
     hipLaunchKernelGGL((attn_fwd_kernel<1>), grid, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, c);
   else
     hipLaunchKernelGGL((attn_fwd_kernel<0>), grid, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, c);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_cross_attention96_fwd(const void* q, int ldq, const void* k, const void* v, int ldkv, void* out, int B, int Nq, int Nk,
+                                          int heads, void* stream) {
+  using namespace ucod;
+  if (!q || !k || !v || !out || B <= 0 || Nq <= 0 || Nk <= 0 || heads <= 0 || (ldq % 8) || (ldkv % 8)) return UCOD_EINVAL;
+  UCOD_PROF(PROF_ATTN, stream);
+  dim3 grid(cdiv(Nq, QT), heads, B), block(256);
+  hipLaunchKernelGGL(attn_cross96_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_raw*)q, ldq, (const bf16_raw*)k, (const bf16_raw*)v,
+                     ldkv, (bf16_raw*)out, Nq, Nk, heads);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }

@@ -31,14 +31,14 @@ ProfScope::ProfScope(int cls, hipStream_t s) : idx(-1), stream(s) {
   std::lock_guard<std::mutex> lk(g_mu);
   Rec r{cls, get_event(), get_event()};
   if (!r.a || !r.b) return;
-  hipEventRecord(r.a, s);
+  (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
   idx = (int)g_recs.size() - 1;
 }
 ProfScope::~ProfScope() {
   if (idx < 0) return;
   std::lock_guard<std::mutex> lk(g_mu);
-  hipEventRecord(g_recs[idx].b, stream);
+  (void)hipEventRecord(g_recs[idx].b, stream);
 }
 
 }  // namespace ucod

@@ -68,6 +68,13 @@ SIGNATURES = {
     "ucod_pil_resize_u8_host": (ci, [vp, ci, ci, vp, ci, ci, ci]),
     "ucod_crop_workspace_bytes": (sz, [ci, ci, ci, ci, ci]),
     "ucod_crop_resize_norm": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, vp, sz, vp]),
+    "ucod_cross_attention96_fwd": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, vp]),
+    "ucod_gather_tokens": (ci, [vp, vp, vp, ci, ci, ci, vp]),
+    "ucod_entropy_scores": (ci, [vp, ci, vp, vp, ci, ci, ci, ci, vp]),
+    "ucod_dwconv7_maskdec": (ci, [vp, vp, vp, vp, cf, vp, ci, ci, ci, ci, vp]),
+    "ucod_window_scatter": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ucod_gated_ensemble_workspace_bytes": (sz, [ci, ci, ci]),
+    "ucod_gated_ensemble": (ci, [vp, vp, vp, vp, vp, cf, vp, vp, vp, ci, ci, ci, vp]),
     "ucod_adamw_ema": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, ci, cf, vp]),
 }
 
