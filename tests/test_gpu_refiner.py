@@ -76,7 +76,8 @@ def test_refiner_small_kernels_exact_f32():
     src = torch.randn(5, 768, 30, generator=g)
     idx = torch.tensor([3, 0, 4], dtype=torch.int32)
     out = torch.empty(3 * 30, 768, device="cuda")
-    N.check(lib.ucod_gather_tokens(N.ptr(src.cuda()), N.ptr(idx.cuda()), N.ptr(out), 3, 768, 30, N.stream()), "gather")
+    src_d, idx_d = src.cuda(), idx.cuda()                   # keep the device buffers alive across the asynchronous launch
+    N.check(lib.ucod_gather_tokens(N.ptr(src_d), N.ptr(idx_d), N.ptr(out), 3, 768, 30, N.stream()), "gather")
     assert torch.equal(out.cpu(), src[idx.long()].permute(0, 2, 1).reshape(90, 768))
     # depthwise conv + mask head on token-major activations
     x = torch.randn(2, 9, 9, 768, generator=g)
@@ -85,7 +86,8 @@ def test_refiner_small_kernels_exact_f32():
     mc = m.cuda()
     P = mc._prepare(torch.device("cuda", 0))
     win = torch.empty(2, 1, 9, 9, device="cuda")
-    N.check(lib.ucod_dwconv7_maskdec(N.ptr(x.cuda().contiguous()), N.ptr(P["dwT"]), N.ptr(P["dwb"]), N.ptr(P["mw"]), P["mb"], N.ptr(win), 2, 9, 9, 768, N.stream()), "dw")
+    x_d = x.cuda().contiguous()
+    N.check(lib.ucod_dwconv7_maskdec(N.ptr(x_d), N.ptr(P["dwT"]), N.ptr(P["dwb"]), N.ptr(P["mw"]), P["mb"], N.ptr(win), 2, 9, 9, 768, N.stream()), "dw")
     assert maxdiff(win.cpu(), ref) < 2e-4
     # gated ensembling
     l1 = torch.randn(2, 1, 7, 7, generator=g) * 2
@@ -94,5 +96,6 @@ def test_refiner_small_kernels_exact_f32():
     l1u = ops.bilinear_resize(l1.cuda(), 21, 21)
     o, w = torch.empty(2, 1, 21, 21, device="cuda"), torch.empty(2, 1, 21, 21, device="cuda")
     wsb = torch.empty(lib.ucod_gated_ensemble_workspace_bytes(2, 21, 21), dtype=torch.uint8, device="cuda")
-    N.check(lib.ucod_gated_ensemble(N.ptr(l1u), N.ptr(l2.cuda()), N.ptr(P["f0w"]), N.ptr(P["f0b"]), N.ptr(P["f2w"]), P["f2b"], N.ptr(o), N.ptr(w), N.ptr(wsb), 2, 21, 21, N.stream()), "ge")
+    l2_d = l2.cuda()
+    N.check(lib.ucod_gated_ensemble(N.ptr(l1u), N.ptr(l2_d), N.ptr(P["f0w"]), N.ptr(P["f0b"]), N.ptr(P["f2w"]), P["f2b"], N.ptr(o), N.ptr(w), N.ptr(wsb), 2, 21, 21, N.stream()), "ge")
     assert maxdiff(w.cpu(), ref_w) < 2e-5 and maxdiff(o.cpu(), ref_out) < 2e-5
