@@ -39,7 +39,7 @@ def test_library_is_native_and_device_is_gfx950():
 
 
 # ----------------------------------------------------------------------------------------- bf16 GEMM
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,Nn,K", [(128, 128, 64), (200, 256, 128), (1370 * 2, 384, 768), (333, 128, 3072), (2500, 768, 128), (4111, 2304, 768)])
 def test_gemm_bf16_bias(variant, M, Nn, K):
     g = torch.Generator().manual_seed(M + Nn + K)
@@ -52,7 +52,7 @@ def test_gemm_bf16_bias(variant, M, Nn, K):
     assert maxdiff(out, ref) < 2e-2 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm_bf16_asymmetric_identity(variant):
     """A = I with an asymmetric B catches a transposed C write (guide: always A=I-check with asymmetric B)."""
     M = Nn = K = 128
@@ -67,7 +67,8 @@ def test_gemm_bf16_large_tile_is_race_free_and_deterministic():
     wrong tiles, so hammer it -- many launches, full-size K, every output compared, results bitwise repeatable."""
     g = torch.Generator().manual_seed(77)
     for variant, (M, Nn, K) in ((3, (5000, 768, 3072)), (4, (5000, 768, 3072)), (5, (5000, 768, 3072)), (6, (5000, 768, 3072)),
-                               (6, (4384, 2304, 768)), (5, (3000, 3072, 768)), (6, (2100, 768, 64)), (5, (2100, 768, 128))):
+                               (6, (4384, 2304, 768)), (5, (3000, 3072, 768)), (6, (2100, 768, 64)), (5, (2100, 768, 128)),
+                               (7, (43840, 768, 768)), (8, (43840, 768, 3072)), (8, (43840, 2304, 64)), (7, (43840, 768, 128)), (8, (70000, 768, 192))):
         A = bf(torch.randn(M, K, generator=g)).to(DEV)
         W = bf(torch.randn(Nn, K, generator=g) * 0.05).to(DEV)
         b = torch.randn(Nn, generator=g).to(DEV)
@@ -82,7 +83,7 @@ def test_gemm_bf16_large_tile_is_race_free_and_deterministic():
                 assert torch.equal(out, first), (variant, it)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm_bf16_epilogues(variant):
     g = torch.Generator().manual_seed(5)
     M, Nn, K = 300, 256, 192

@@ -476,6 +476,183 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   }
 }
 
+// =====================================================================================================
+// Persistent form of the large-tile kernel: one workgroup per CU walks tiles vt = blockIdx.x, +gridDim.x, ...
+// What it buys: the first K-tile of the NEXT output tile (A0|A1|B, 9-11 LDS-DMAs per thread) is issued BEFORE the epilogue of
+// the current tile, into the K-tile buffer the main loop has just vacated, so the ~3 us of first-tile HBM/L2 latency that every
+// tile of the one-shot kernel pays up front (13 % of a K=768 tile) hides under the epilogue's stores.  The epilogue stages
+// through the OTHER buffer (4 passes of 32 rows, 8 KB per wave) so the two never touch the same LDS bytes.
+// Hazards on top of the one-shot kernel's:
+//   * next-tile DMAs target buffer free_buf = (last K-tile's buffer)^1, last read during K-tile nt-2: dead long before;
+//   * epilogue staging lives in last_buf, whose operand reads all retired before the stagger-out barrier;
+//   * after the epilogue: every wave `vmcnt(0)` (its DMAs landed; also its stores) -> barrier -> only then may B(1) of the next
+//     tile be DMA'd into last_buf (it overlaps other waves' staging areas) and the next main loop read free_buf.
+// =====================================================================================================
+template <int EPI, int NT>
+__global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
+  using Cfg = BigCfg<NT>;
+  __shared__ __attribute__((aligned(16))) char smem[2 * Cfg::BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntiles = a.tiles_m * a.tiles_n;
+  const int K = a.K, nt = K / BK;
+  constexpr int GROUP_M = 8;
+  constexpr int WCOLS = 16 * NT;
+
+  auto decode = [&](int vt, int& m0, int& n0) {
+    const int q = ntiles >> 3, r8 = ntiles & 7, xcd = vt & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (vt >> 3);
+    const int per_group = GROUP_M * a.tiles_n;
+    const int grp = wg / per_group, first_m = grp * GROUP_M;
+    const int gsz = (a.tiles_m - first_m) < GROUP_M ? (a.tiles_m - first_m) : GROUP_M;
+    const int in_grp = wg - grp * per_group;
+    m0 = (first_m + in_grp % gsz) * 256;
+    n0 = (in_grp / gsz) * Cfg::BN_;
+  };
+  const bf16_raw* srcA[2][2];
+  const bf16_raw* srcB[Cfg::NB];
+  auto set_src = [&](int m0, int n0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = (i * 8 + wave) * 8 + (lane >> 3);
+        int gr = m0 + h * 128 + r;
+        gr = gr < a.M ? gr : a.M - 1;
+        srcA[h][i] = a.A + (size_t)gr * K + swz(r, lane & 7) * 8;
+      }
+#pragma unroll
+    for (int i = 0; i < Cfg::NB; ++i) {
+      const int r = (i * 8 + wave) * 8 + (lane >> 3);
+      int gr = n0 + r;
+      gr = gr < a.N ? gr : a.N - 1;
+      srcB[i] = a.B + (size_t)gr * K + swz(r, lane & 7) * 8;
+    }
+  };
+  auto dma = [&](const bf16_raw* src, char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto stageA = [&](int t, int h, int pb) {
+    char* slot = smem + ((t + pb) & 1) * Cfg::BUF + h * SLOT_A;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma(srcA[h][i] + t * BK, slot + (i * 8 + wave) * 1024);
+  };
+  auto stageB = [&](int t, int i0, int i1, int pb) {
+    char* slot = smem + ((t + pb) & 1) * Cfg::BUF + 2 * SLOT_A;
+#pragma unroll
+    for (int i = 0; i < Cfg::NB; ++i)
+      if (i >= i0 && i < i1) dma(srcB[i] + t * BK, slot + (i * 8 + wave) * 1024);
+  };
+  constexpr int B_SPLIT = Cfg::NB >= 2 ? 2 : 1;
+
+  int vt = blockIdx.x, pb = 0, m0, n0;
+  decode(vt, m0, n0);
+  set_src(m0, n0);
+  stageA(0, 0, pb);
+  stageA(0, 1, pb);
+  stageB(0, 0, Cfg::NB, pb);
+  if (nt > 1) {
+    stageB(1, 0, Cfg::NB, pb);
+    wait_vmcnt<Cfg::NB>();
+  } else {
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+
+  while (true) {
+    f32x4 acc[8][NT];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (wm == 1) __builtin_amdgcn_s_barrier();               // stagger in (see the one-shot kernel)
+
+    for (int t = 0; t < nt; ++t) {
+      const char* bufA = smem + ((t + pb) & 1) * Cfg::BUF + wm * SLOT_A;
+      const char* bufB = smem + ((t + pb) & 1) * Cfg::BUF + 2 * SLOT_A;
+      const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+      bf16x8 fb[NT][2];
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        if (ph == 0 && more1) stageA(t + 1, 0, pb);
+        if (ph == 1 && more1) stageA(t + 1, 1, pb);
+        if (ph == 2 && more2) stageB(t + 2, 0, B_SPLIT, pb);
+        if (ph == 3 && more2) stageB(t + 2, B_SPLIT, Cfg::NB, pb);
+        if (ph == 0) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const int r = wn * 16 * NT + j * 16 + (lane & 15);
+              fb[j][ks] = *reinterpret_cast<const bf16x8*>(bufB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+            }
+        }
+        bf16x8 fa[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int r = ph * 32 + i * 16 + (lane & 15);
+            fa[i][ks] = *reinterpret_cast<const bf16x8*>(bufA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+          }
+        if (ph == 3) {
+          if (more2) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[ph * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[ph * 2 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();               // stagger out: every wave is past its last LDS operand read
+
+    const int last_buf = (nt - 1 + pb) & 1, free_buf = last_buf ^ 1;
+    const int vnext = vt + gridDim.x;
+    const bool has_next = vnext < ntiles;
+    const int em0 = m0, en0 = n0;
+    if (has_next) {                                           // first K-tile of the next tile, in flight under the epilogue
+      decode(vnext, m0, n0);
+      set_src(m0, n0);
+      stageA(0, 0, free_buf);
+      stageA(0, 1, free_buf);
+      stageB(0, 0, Cfg::NB, free_buf);
+    }
+    char* wbase = smem + last_buf * Cfg::BUF + wave * (32 * WCOLS * 4);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+            *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * (WCOLS * 4) + (j * 16 + (lane & 15)) * 4) = acc[pass * 2 + i][j][rg];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      drain_rows<EPI, WCOLS, 32>(a, wbase, em0 + wm * 128 + pass * 32, en0 + wn * WCOLS, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (!has_next) break;
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    vt = vnext;
+    pb = free_buf;
+    if (nt > 1) stageB(1, 0, Cfg::NB, pb);
+  }
+}
+
 // variant: 0 auto | 1 128^2 register staging | 2 128^2 LDS-DMA | 3 256x256 | 4 256x192 | 5,6 = 3,4 with staggered wave groups
 template <int EPI>
 static int launch(GemmArgs a, int variant, hipStream_t s) {
@@ -491,9 +668,9 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
       variant = (cost(192) < cost(256)) ? 6 : 5;
     }
   }
-  if (variant >= 3 && variant <= 6 && (a.N & 3) != 0) return UCOD_EINVAL;
-  if (variant >= 3 && variant <= 6) {
-    const bool wide = (variant == 3 || variant == 5);
+  if (variant >= 3 && variant <= 8 && (a.N & 3) != 0) return UCOD_EINVAL;
+  if (variant >= 3 && variant <= 8) {
+    const bool wide = (variant == 3 || variant == 5 || variant == 7);
     a.tiles_m = cdiv(a.M, 256);
     a.tiles_n = cdiv(a.N, wide ? 256 : 192);
     dim3 grid(a.tiles_m * a.tiles_n), block(512);
@@ -501,7 +678,14 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
       case 3: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4, false>), grid, block, 0, s, a); break;
       case 4: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3, false>), grid, block, 0, s, a); break;
       case 5: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4, true>), grid, block, 0, s, a); break;
-      default: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3, true>), grid, block, 0, s, a); break;
+      case 6: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3, true>), grid, block, 0, s, a); break;
+      default: {                                             // 7, 8: persistent, one workgroup per CU
+        static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+        const int ntiles = a.tiles_m * a.tiles_n;
+        dim3 pgrid(ntiles < n_cu ? ntiles : n_cu);
+        if (variant == 7) hipLaunchKernelGGL((gemm_bf16_pers_kernel<EPI, 4>), pgrid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_bf16_pers_kernel<EPI, 3>), pgrid, block, 0, s, a);
+      }
     }
   } else {
     dim3 grid(a.tiles_m * a.tiles_n), block(256);
