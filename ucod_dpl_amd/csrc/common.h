@@ -34,8 +34,11 @@ __device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
   return __builtin_bit_cast(bf16_raw, b);
 }
 
+// two round-to-nearest-even conversions in ONE v_cvt_pk_bf16_f32 (the scalar form costs cvt, cvt, shift, or)
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+  typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((pk_f32x2){lo, hi}, pk_bf16x2));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

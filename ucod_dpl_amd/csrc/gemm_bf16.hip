@@ -11,6 +11,7 @@
 // (global_load_lds_dwordx4; the LDS image is lane-linear, so the bank swizzle is applied to the
 // per-lane SOURCE address and again on the ds_read_b128 side), double buffered, one barrier per
 // K-tile.  The workgroup->tile map is XCD-aware (bijective remap: blocks b and b+8 share an XCD/L2).
+#include <cstdlib>
 #include "common.h"
 #include "../../include/ucod_dpl.h"
 
@@ -20,6 +21,7 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 
 struct GemmArgs {
+  unsigned long long* stamps;   // diagnostic builds only (UCOD_GEMM_STAMPS): per-workgroup segment cycle sums, never read by kernels
   const bf16_raw* A;
   const bf16_raw* B;
   void* out;
@@ -64,19 +66,25 @@ __device__ __forceinline__ void write_tile(char* lds_tile, int wave, int lane, c
   }
 }
 
-// exact-erf GELU (transformers ACT2FN["gelu"], modeling_dinov2.py:289).  erf by Abramowitz-Stegun 7.1.26
-// (|abs err| <= 1.5e-7, far below the bf16 output resolution): 1 rcp + 1 exp + 6 fma instead of libm erff's
-// ~40 instructions -- the fc1 epilogue applies it 134 M times per launch.
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = 1.0f - p * t * __expf(-z * z);
-  return 0.5f * x * (1.0f + copysignf(e, x));
+// exact-erf GELU (transformers ACT2FN["gelu"], modeling_dinov2.py:289), two elements per call so the polynomial runs
+// on v_pk_fma_f32.  With a = |x|:  0.5*erfc(a/sqrt2) = exp2(-(1 + a*(d1 + d2 a + d3 a^2 + d4 a^3 + d5 a^4)))  (weighted
+// minimax fit of -log2 erfc, |erfc err| <= 5e-6 and RELATIVE in the tail), and  gelu(x) = max(x,0) - a * 0.5*erfc(a/sqrt2).
+// Max |gelu err| = 7.1e-7 over [-30,30] in fp32 -- the same as the Abramowitz-Stegun 7.1.26 form it replaces, at one
+// transcendental and ~9 issue slots per element instead of two and ~22 (the fc1 epilogue runs it 134 M times per
+// launch and was VALU-bound: 6.3 k of its 18.1 k cycles per 256x256 tile).  d5 > 0, so large |x| underflows to t = 0.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  const f32x2 a = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+  f32x2 p = a * 4.881021588e-04f + (-7.198718842e-03f);
+  p = p * a + 5.214663086e-02f;
+  p = p * a + 4.595958292e-01f;
+  p = p * a + 1.151000509e+00f;
+  p = p * a + 1.0f;
+  const f32x2 t = {__builtin_amdgcn_exp2f(-p[0]), __builtin_amdgcn_exp2f(-p[1])};
+  const f32x2 pos = {__builtin_fmaxf(x[0], 0.f), __builtin_fmaxf(x[1], 0.f)};
+  return pos - a * t;
 }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f32x2){x, x})[0]; }
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& a, int m, int n, float v) {
@@ -118,8 +126,8 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& a, int m, int n,
         if (a.scale) o = o * *reinterpret_cast<const f32x4*>(a.scale + n);
       }
       if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
+        const f32x2 g0 = gelu_erf2((f32x2){o[0], o[1]}), g1 = gelu_erf2((f32x2){o[2], o[3]});
+        o = (f32x4){g0[0], g0[1], g1[0], g1[1]};
       }
       u32x2 w;
       w[0] = pack_bf16x2(o[0], o[1]);
@@ -155,8 +163,10 @@ __device__ __forceinline__ void epilogue_store8_bf16(const GemmArgs& a, int m, i
       o1 = o1 * *reinterpret_cast<const f32x4*>(a.scale + n + 4);
     }
   } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { o0[e] = gelu_erf(o0[e]); o1[e] = gelu_erf(o1[e]); }
+    const f32x2 g0 = gelu_erf2((f32x2){o0[0], o0[1]}), g1 = gelu_erf2((f32x2){o0[2], o0[3]});
+    const f32x2 g2 = gelu_erf2((f32x2){o1[0], o1[1]}), g3 = gelu_erf2((f32x2){o1[2], o1[3]});
+    o0 = (f32x4){g0[0], g0[1], g1[0], g1[1]};
+    o1 = (f32x4){g2[0], g2[1], g3[0], g3[1]};
   }
   u32x4 w;
   w[0] = pack_bf16x2(o0[0], o0[1]);
@@ -285,6 +295,172 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
   }
 }
 
+// ---- large-tile epilogue (one-shot and persistent kernels) ------------------------------------------------------
+// s_memtime stamps (tools/gemm_stamps.py) showed the old epilogue costing 12 k (bf16 out) to 40 k (f32 residual) cycles per
+// 256-wide tile INDEPENDENT of how many CUs were active: not bandwidth, but a latency chain -- every 16-byte store was
+// preceded by bias / scale / residual loads whose `s_waitcnt vmcnt(0)` also drained the stores issued just before (vmcnt
+// counts stores on gfx9), i.e. one ~700-cycle store round trip per store instruction.  So, for the three hot epilogues:
+//   * the bias is the accumulator's INITIAL value and the per-column scale (Q pre-scale, LayerScale gamma) is applied in the
+//     MFMA C layout, where a lane owns one column per 16-wide tile: NT + NT registers, loaded once per output tile;
+//   * GELU runs in the C layout too, so the row-major drain of a bf16 tile is ds_read -> cvt -> 16-byte store, no loads;
+//   * the f32 residual is double buffered: the loads of pass p+1 are issued BEFORE the stores of pass p, and vmcnt retires
+//     in order, so the wait for them leaves pass p's stores in flight.  (out may alias resid: passes touch disjoint rows.)
+template <int EPI>
+constexpr bool kColFused = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32);
+
+template <int EPI, int NT>
+__device__ __forceinline__ void load_col_consts(const GemmArgs& a, int ncol0, float (&cb)[NT], float (&cs)[NT]) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    cb[j] = 0.f;
+    cs[j] = 1.f;
+    if constexpr (kColFused<EPI>) {
+      int n = ncol0 + j * 16;
+      n = n < a.N ? n : a.N - 1;
+      cb[j] = a.bias[n];
+      if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) cs[j] = a.scale[n];
+      // optional scale: unconditional load now (a branch here costs a vmcnt(0) at the join, ahead of the operand DMAs),
+      // select at the point of use (finish_col_consts) so nothing waits on the load before the DMAs are out
+      if constexpr (EPI == UCOD_EPI_BIAS_BF16) cs[j] = (a.scale ? a.scale : a.bias)[n];
+    }
+  }
+}
+
+template <int EPI, int NT>
+__device__ __forceinline__ void finish_col_consts(const GemmArgs& a, float (&cs)[NT]) {
+  if constexpr (EPI == UCOD_EPI_BIAS_BF16) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) cs[j] = a.scale ? cs[j] : 1.f;
+  }
+}
+
+// acc: the wave's 128 x 16*NT tile (8 row-tiles x NT column-tiles, C layout col = lane&15, row = (lane>>4)*4 + reg), bias
+// already inside for the fused epilogues; cs = per-column scale.  wbase: wave-private 32 x WCOLS f32 staging area.  Four passes of 32 rows.
+template <int EPI, int NT>
+__device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][NT], const float (&cs)[NT], char* wbase,
+                                             int m_first, int n_first, int lane) {
+  constexpr int WCOLS = 16 * NT, PR = 32;
+  auto stage = [&](int pass) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f32x4 v = acc[pass * 2 + i][j];
+        if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) v = v * cs[j];
+        if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) {
+          const f32x2 g0 = gelu_erf2((f32x2){v[0], v[1]}), g1 = gelu_erf2((f32x2){v[2], v[3]});
+          v = (f32x4){g0[0], g0[1], g1[0], g1[1]};
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * (WCOLS * 4) + (j * 16 + (lane & 15)) * 4) = v[rg];
+      }
+  };
+  if constexpr (!kColFused<EPI>) {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      stage(pass);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      drain_rows<EPI, WCOLS, PR>(a, wbase, m_first + pass * PR, n_first, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  } else {
+    // Row / column guards without branches (a branch per access makes hipcc fall back to vmcnt(0) before every store):
+    // buffer descriptors over [first row of this wave's tile, end of the matrix) -- rows past M fail the range check and
+    // are dropped (loads return 0) -- and columns past N get an offset beyond any descriptor.
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    constexpr int ELT = (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) ? 4 : 2;
+    const long rows_left = (long)a.M - m_first;
+    const unsigned long left = rows_left > 0 ? (unsigned long)rows_left * a.N * ELT : 0ul;
+    const unsigned records = left > 0xFFFFFFFFul ? 0xFFFFFFFFu : (unsigned)left;
+    const size_t base = (size_t)(m_first < a.M ? m_first : 0) * a.N * ELT;
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + base, 0, records, 0x00020000);
+    const unsigned row_bytes = (unsigned)a.N * ELT;
+    if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) {
+      constexpr int CH = WCOLS / 4, ITS = PR * CH / 64;          // 16-byte chunks per row; wave instructions per pass
+      static_assert((PR * CH) % 64 == 0, "whole wave instructions");
+      const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.resid)) + base, 0, records, 0x00020000);
+      unsigned off[ITS];                                          // byte offset of (row, chunk) of pass 0; + pass * 32 rows
+      int lrow[ITS], lchk[ITS];
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) {
+        const int idx = it * 64 + lane;
+        lrow[it] = idx / CH;
+        lchk[it] = idx - lrow[it] * CH;
+        const int n = n_first + lchk[it] * 4;
+        off[it] = n < a.N ? (unsigned)lrow[it] * row_bytes + (unsigned)n * 4u : OOB;
+      }
+      const unsigned pass_bytes = PR * row_bytes;
+      u32x4 rb[2][ITS];
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) rb[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off[it], 0, 0);
+      // (the pass offset goes into the VGPR offset, not soffset: the range check covers only voffset + inst_offset)
+      auto at = [&](int it, int pass) { return off[it] == OOB ? OOB : off[it] + (unsigned)pass * pass_bytes; };
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        stage(pass);
+        if (pass + 1 < 4) {
+#pragma unroll
+          for (int it = 0; it < ITS; ++it)
+            rb[(pass + 1) & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, at(it, pass + 1), 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + lrow[it] * (WCOLS * 4) + lchk[it] * 16);
+          const f32x4 o = __builtin_bit_cast(f32x4, rb[pass & 1][it]) + v;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, at(it, pass), 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    } else {
+      if ((a.N & 7) == 0) {                                       // 16-byte stores need 8-column alignment of every row
+        constexpr int CH = WCOLS / 8, ITS = PR * CH / 64;
+        static_assert((PR * CH) % 64 == 0, "whole wave instructions");
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          stage(pass);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int it = 0; it < ITS; ++it) {
+            const int idx = it * 64 + lane, row = idx / CH, c = idx - row * CH;
+            const int n = n_first + c * 8;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(wbase + row * (WCOLS * 4) + c * 32);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(wbase + row * (WCOLS * 4) + c * 32 + 16);
+            u32x4 w;
+            w[0] = pack_bf16x2(v0[0], v0[1]);
+            w[1] = pack_bf16x2(v0[2], v0[3]);
+            w[2] = pack_bf16x2(v1[0], v1[1]);
+            w[3] = pack_bf16x2(v1[2], v1[3]);
+            const unsigned o = n < a.N ? (unsigned)(pass * PR + row) * row_bytes + (unsigned)n * 2u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, o, 0, 0);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      } else {
+        constexpr int CH = WCOLS / 4, ITS = PR * CH / 64;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          stage(pass);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int it = 0; it < ITS; ++it) {
+            const int idx = it * 64 + lane, row = idx / CH, c = idx - row * CH;
+            const int n = n_first + c * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + row * (WCOLS * 4) + c * 16);
+            u32x2 w;
+            w[0] = pack_bf16x2(v[0], v[1]);
+            w[1] = pack_bf16x2(v[2], v[3]);
+            const unsigned o = n < a.N ? (unsigned)(pass * PR + row) * row_bytes + (unsigned)n * 2u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b64(w, rs_out, o, 0, 0);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+    }
+  }
+}
+
 // =====================================================================================================
 // Large-tile kernel: 256 x (64*NT) x 64 block tile, 8 waves (2 in M x 4 in N), one workgroup per CU.
 //   * per wave 128 x 16*NT outputs; a K-tile is consumed in FOUR phases of 32 rows each (2 x NT tiles x 2 k-steps
@@ -378,11 +554,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   };
   constexpr int B_SPLIT = Cfg::NB >= 2 ? 2 : 1;   // phase 3 issues [0,B_SPLIT), phase 4 the rest
 
-  f32x4 acc[8][NT];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // per-column epilogue constants first (oldest in the vmcnt queue: landed long before the accumulators are initialised)
+  float cb[NT], cs[NT];
+  load_col_consts<EPI, NT>(a, n0 + wn * 16 * NT + (lane & 15), cb, cs);
 
   // prologue: tile 0 complete, B of tile 1 in flight
   stageA(0, 0);
@@ -394,6 +568,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   } else {
     wait_vmcnt<0>();
   }
+  f32x4 acc[8][NT];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){cb[j], cb[j], cb[j], cb[j]};
+  finish_col_consts<EPI, NT>(a, cs);
   __builtin_amdgcn_s_barrier();
   // STAGGER: the wm==1 waves run one barrier interval behind the wm==0 waves, so on every SIMD one wave is in its
   // MFMA interval while its partner is in its LDS-read / DMA-issue interval (two barriers per phase: R | M).
@@ -458,22 +638,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   }
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();
 
-  // epilogue: two passes of 64 rows through a wave-private LDS region (operand tiles are dead: last barrier passed)
-  constexpr int WCOLS = 16 * NT;
-  char* wbase = smem + wave * (64 * WCOLS * 4);
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * (WCOLS * 4) + (j * 16 + (lane & 15)) * 4) = acc[pass * 4 + i][j][rg];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    drain_rows<EPI, WCOLS, 64>(a, wbase, m0 + wm * 128 + pass * 64, n0 + wn * WCOLS, lane);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
+  // epilogue through a wave-private LDS region (operand tiles are dead: last barrier passed)
+  big_epilogue<EPI, NT>(a, acc, cs, smem + wave * (32 * 16 * NT * 4), m0 + wm * 128, n0 + wn * 16 * NT, lane);
 }
 
 // =====================================================================================================
@@ -510,24 +676,27 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
     m0 = (first_m + in_grp % gsz) * 256;
     n0 = (in_grp / gsz) * Cfg::BN_;
   };
-  const bf16_raw* srcA[2][2];
-  const bf16_raw* srcB[Cfg::NB];
+  // DMA source rows as 32-bit element offsets from the tile's first A / B row (64-bit per-tile bases stay in SGPRs): the
+  // persistent kernel keeps the next tile's sources live across the epilogue, and 64-bit pointers there spilled VGPRs.
+  unsigned srcA[2][2], srcB[Cfg::NB];
+  const bf16_raw *baseA, *baseB;
   auto set_src = [&](int m0, int n0) {
+    baseA = a.A + (size_t)m0 * K;
+    baseB = a.B + (size_t)n0 * K;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int r = (i * 8 + wave) * 8 + (lane >> 3);
-        int gr = m0 + h * 128 + r;
-        gr = gr < a.M ? gr : a.M - 1;
-        srcA[h][i] = a.A + (size_t)gr * K + swz(r, lane & 7) * 8;
+        int lr = h * 128 + r;
+        lr = (m0 + lr) < a.M ? lr : a.M - 1 - m0;
+        srcA[h][i] = (unsigned)lr * (unsigned)K + swz(r, lane & 7) * 8;
       }
 #pragma unroll
     for (int i = 0; i < Cfg::NB; ++i) {
       const int r = (i * 8 + wave) * 8 + (lane >> 3);
-      int gr = n0 + r;
-      gr = gr < a.N ? gr : a.N - 1;
-      srcB[i] = a.B + (size_t)gr * K + swz(r, lane & 7) * 8;
+      int lr = (n0 + r) < a.N ? r : a.N - 1 - n0;
+      srcB[i] = (unsigned)lr * (unsigned)K + swz(r, lane & 7) * 8;
     }
   };
   auto dma = [&](const bf16_raw* src, char* dst) {
@@ -537,18 +706,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
   auto stageA = [&](int t, int h, int pb) {
     char* slot = smem + ((t + pb) & 1) * Cfg::BUF + h * SLOT_A;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma(srcA[h][i] + t * BK, slot + (i * 8 + wave) * 1024);
+    for (int i = 0; i < 2; ++i) dma(baseA + t * BK + srcA[h][i], slot + (i * 8 + wave) * 1024);
   };
   auto stageB = [&](int t, int i0, int i1, int pb) {
     char* slot = smem + ((t + pb) & 1) * Cfg::BUF + 2 * SLOT_A;
 #pragma unroll
     for (int i = 0; i < Cfg::NB; ++i)
-      if (i >= i0 && i < i1) dma(srcB[i] + t * BK, slot + (i * 8 + wave) * 1024);
+      if (i >= i0 && i < i1) dma(baseB + t * BK + srcB[i], slot + (i * 8 + wave) * 1024);
   };
   constexpr int B_SPLIT = Cfg::NB >= 2 ? 2 : 1;
 
+#ifdef UCOD_GEMM_STAMPS
+  unsigned long long st_loop = 0, st_epi = 0, st_wait = 0, st_tiles = 0, t0s, t1s, t2s, t3s;
+#define STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#else
+#define STAMP(v)
+#endif
   int vt = blockIdx.x, pb = 0, m0, n0;
   decode(vt, m0, n0);
+  float cb[NT], cs[NT];
+  load_col_consts<EPI, NT>(a, n0 + wn * WCOLS + (lane & 15), cb, cs);
   set_src(m0, n0);
   stageA(0, 0, pb);
   stageA(0, 1, pb);
@@ -566,7 +743,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){cb[j], cb[j], cb[j], cb[j]};
+    finish_col_consts<EPI, NT>(a, cs);
+    STAMP(t0s);
     if (wm == 1) __builtin_amdgcn_s_barrier();               // stagger in (see the one-shot kernel)
 
     for (int t = 0; t < nt; ++t) {
@@ -618,6 +797,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
       }
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();               // stagger out: every wave is past its last LDS operand read
+    STAMP(t1s);
 
     const int last_buf = (nt - 1 + pb) & 1, free_buf = last_buf ^ 1;
     const int vnext = vt + gridDim.x;
@@ -630,22 +810,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
       stageA(0, 1, free_buf);
       stageB(0, 0, Cfg::NB, free_buf);
     }
-    char* wbase = smem + last_buf * Cfg::BUF + wave * (32 * WCOLS * 4);
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg)
-            *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * (WCOLS * 4) + (j * 16 + (lane & 15)) * 4) = acc[pass * 2 + i][j][rg];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      drain_rows<EPI, WCOLS, 32>(a, wbase, em0 + wm * 128 + pass * 32, en0 + wn * WCOLS, lane);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    big_epilogue<EPI, NT>(a, acc, cs, smem + last_buf * Cfg::BUF + wave * (32 * WCOLS * 4), em0 + wm * 128, en0 + wn * WCOLS, lane);
+    if (has_next) load_col_consts<EPI, NT>(a, n0 + wn * WCOLS + (lane & 15), cb, cs);   // retired by the vmcnt(0) below, with the stores
+    STAMP(t2s);
+#ifdef UCOD_GEMM_STAMPS
+    wait_vmcnt<0>();
+    STAMP(t3s);
+    st_loop += t1s - t0s; st_epi += t2s - t1s; st_wait += t3s - t2s; st_tiles += 1;
+    if (!has_next) {
+      if (tid == 0 && a.stamps) { a.stamps[blockIdx.x * 4 + 0] = st_loop; a.stamps[blockIdx.x * 4 + 1] = st_epi; a.stamps[blockIdx.x * 4 + 2] = st_wait; a.stamps[blockIdx.x * 4 + 3] = st_tiles; }
+      break;
     }
+#else
     if (!has_next) break;
     wait_vmcnt<0>();
+#endif
     __builtin_amdgcn_s_barrier();
     vt = vnext;
     pb = free_buf;
@@ -683,6 +862,9 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
         static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
         const int ntiles = a.tiles_m * a.tiles_n;
         dim3 pgrid(ntiles < n_cu ? ntiles : n_cu);
+#ifdef UCOD_GEMM_STAMPS
+        if (const char* g = getenv("UCOD_PERS_GRID")) pgrid.x = atoi(g) < ntiles ? atoi(g) : ntiles;   // diagnostic: fewer active CUs
+#endif
         if (variant == 7) hipLaunchKernelGGL((gemm_bf16_pers_kernel<EPI, 4>), pgrid, block, 0, s, a);
         else hipLaunchKernelGGL((gemm_bf16_pers_kernel<EPI, 3>), pgrid, block, 0, s, a);
       }
@@ -706,6 +888,10 @@ extern "C" int ucod_gemm_bf16(int epilogue, const void* A, const void* B, void* 
   using namespace ucod;
   if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0) return UCOD_EINVAL;
   GemmArgs a;
+  a.stamps = nullptr;
+#ifdef UCOD_GEMM_STAMPS
+  a.stamps = (unsigned long long*)pos;   // diagnostic build: the (otherwise unused here) `pos` argument carries the stamp buffer
+#endif
   a.A = (const bf16_raw*)A;
   a.B = (const bf16_raw*)B;
   a.out = out;
