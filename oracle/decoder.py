@@ -84,7 +84,7 @@ def rev_decoder_forward(x, p, ema=False, orth="naive"):
     return fg.view(B, 1, H, W), bg.view(B, 1, H, W), extra
 
 
-def rev_decoder_backward(x, p, gfg, gbg, gextra):
+def rev_decoder_backward(x, p, gfg, gbg, gextra, with_dx=False):
     """Closed-form backward used by the HIP kernels (validated against autograd in tests).
 
     gfg,gbg: [B,1,H,W] upstream grads of the logits; gextra: python float, upstream grad of
@@ -137,4 +137,9 @@ def rev_decoder_backward(x, p, gfg, gbg, gextra):
     out["conv_out_fg.bias"] = gbf.reshape(1)
     out["conv_out_bg.weight"] = gwb.reshape(1, EMB, 1, 1)
     out["conv_out_bg.bias"] = gbb.reshape(1)
+    if with_dx:
+        # gradient w.r.t. the input features (backbone-backward mode; pinned by g12_decoder_dx):
+        # the 1x1 decoupling conv transposed, dX[b] = W^T gd[b]
+        Wd = p["decoupling.weight"].reshape(2 * EMB, C)
+        out["dx"] = torch.einsum("nc,bnp->bcp", Wd, gd).reshape(B, C, H, W)
     return out

@@ -57,7 +57,18 @@ def dinov2_pos_embed(pos, n_h, n_w):
     return torch.cat((pos[:, :1], pp.permute(0, 2, 3, 1).reshape(1, n_h * n_w, -1)), 1)
 
 
-def dinov2_forward(img, sd, heads, patch=14, eps=1e-6, n_layers=None, full_last_layer=True):
+def _lora_linear(h, sd, name, lora_scale):
+    """nn.Linear, plus -- when the state dict carries ``<name>.lora_A.weight`` [r,D] / ``<name>.lora_B.weight`` [D,r] -- the
+    peft LoRA branch the reference wraps query/key/value in (models/modules/full_model.py:47-72: r=2, lora_alpha=4,
+    bias='none'; peft is not installed here, its published forward is ``base(x) + lora_B(lora_A(dropout(x))) * alpha/r``;
+    dropout is the identity in this restatement -- SURVEY.md 8a row B9)."""
+    y = h @ sd[name + ".weight"].t() + sd[name + ".bias"]
+    if name + ".lora_A.weight" in sd:
+        y = y + (h @ sd[name + ".lora_A.weight"].t()) @ sd[name + ".lora_B.weight"].t() * lora_scale
+    return y
+
+
+def dinov2_forward(img, sd, heads, patch=14, eps=1e-6, n_layers=None, full_last_layer=True, lora_scale=2.0):
     """Returns (last_hidden_state [B,N,D] after the final LayerNorm, key [B,D,h,w])."""
     B, _, H, W = img.shape
     pre = "embeddings."
@@ -70,13 +81,13 @@ def dinov2_forward(img, sd, heads, patch=14, eps=1e-6, n_layers=None, full_last_
         p = f"encoder.layer.{i}."
         h = layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
         a = p + "attention.attention."
-        k = h @ sd[a + "key.weight"].t() + sd[a + "key.bias"]
+        k = _lora_linear(h, sd, a + "key", lora_scale)
         if i == L - 1:
             key = k
             if not full_last_layer:
                 break
-        q = h @ sd[a + "query.weight"].t() + sd[a + "query.bias"]
-        v = h @ sd[a + "value.weight"].t() + sd[a + "value.bias"]
+        q = _lora_linear(h, sd, a + "query", lora_scale)
+        v = _lora_linear(h, sd, a + "value", lora_scale)
         o = attention(q, k, v, heads)
         o = o @ sd[p + "attention.output.dense.weight"].t() + sd[p + "attention.output.dense.bias"]
         x = o * sd[p + "layer_scale1.lambda1"] + x
@@ -131,3 +142,16 @@ def dinov1_forward(img, sd, heads, patch=8, eps=1e-6, full_last_layer=True):
     gh, gw = H // patch, W // patch
     key_map = key[:, 1:, :].reshape(B, gh, gw, -1).permute(0, 3, 1, 2)
     return last, key_map
+
+
+def dinov2_lora_grads(img, sd, heads, dkey, patch=14, eps=1e-6, lora_scale=2.0):
+    """Backbone-backward mode: gradients of <key map, dkey> w.r.t. every LoRA matrix in ``sd``, by
+    autograd over the restated forward.  ``dkey`` [B,D,h,w] is the cotangent arriving at the key hook
+    (models/modules/full_model.py:95-106).  Returns (key [B,D,h,w], {param name: grad})."""
+    names = [k for k in sd if ".lora_" in k]
+    leaf = {k: sd[k].detach().clone().requires_grad_(True) for k in names}
+    sd2 = dict(sd)
+    sd2.update(leaf)
+    _, key = dinov2_forward(img, sd2, heads, patch=patch, eps=eps, full_last_layer=False, lora_scale=lora_scale)
+    grads = torch.autograd.grad((key * dkey).sum(), [leaf[k] for k in names], allow_unused=True)
+    return key.detach(), {k: (torch.zeros_like(leaf[k]) if g is None else g) for k, g in zip(names, grads)}

@@ -417,7 +417,82 @@ def g9():
     save("g9_refiner", **out)
 
 
+# ----------------------------------------------------------------------------- G12: backbone backward (LoRA mode, row B9)
+class _LoRALinear(nn.Module):
+    """What peft's LoRA wrapper computes for the LoraConfig of models/modules/full_model.py:47-72 (r, lora_alpha, bias='none';
+    peft is not installed here, so its published forward is restated; dropout left out = eval / p=0):
+    base(x) + lora_B(lora_A(x)) * lora_alpha / r, lora_A kaiming_uniform(a=sqrt(5)), lora_B zeros."""
+
+    def __init__(self, base, r, alpha):
+        super().__init__()
+        self.base = base
+        self.lora_A = nn.Linear(base.in_features, r, bias=False)
+        self.lora_B = nn.Linear(r, base.out_features, bias=False)
+        nn.init.kaiming_uniform_(self.lora_A.weight, a=5 ** 0.5)
+        nn.init.zeros_(self.lora_B.weight)
+        self.scaling = alpha / r
+
+    def forward(self, x):
+        return self.base(x) + self.lora_B(self.lora_A(x)) * self.scaling
+
+
+def g12():
+    import torch.nn.functional as F
+    # (a) HF Dinov2 + LoRA on query/key/value, the hook of full_model.py:95-106 (key -> drop CLS -> NCHW -> bilinear), autograd
+    torch.manual_seed(12)
+    cfg = Dinov2Config(hidden_size=128, num_hidden_layers=3, num_attention_heads=2, image_size=70, patch_size=14, mlp_ratio=4,
+                       layerscale_value=1.0)
+    m = Dinov2Model(cfg).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+            if "position_embeddings" in n or "cls_token" in n:
+                p.mul_(0.05)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    r, alpha = 2, 4
+    for layer in m.encoder.layer:
+        att = layer.attention.attention
+        for name in ("query", "key", "value"):
+            w = _LoRALinear(getattr(att, name), r, alpha)
+            with torch.no_grad():
+                w.lora_B.weight.copy_(0.05 * torch.randn_like(w.lora_B.weight))     # non-zero B: every LoRA gradient is exercised
+            setattr(att, name, w)
+    keys = {}
+    m.encoder.layer[-1].attention.attention.key.register_forward_hook(lambda mod_, i, o: keys.__setitem__("k", o))
+    x = torch.randn(2, 3, 70, 70)
+    m(x)
+    k = keys["k"]
+    B, Ntok, C = k.shape
+    g = int((Ntok - 1) ** 0.5)
+    kmap = k[:, 1:, :].reshape(B, g, g, C).permute(0, 3, 1, 2)
+    kmap.retain_grad()
+    up = F.interpolate(kmap, size=(8, 8), mode="bilinear")
+    R = torch.randn_like(up)
+    (up * R).sum().backward()
+    d = dict(x=x, R=R, key=kmap.detach(), dkey=kmap.grad, lora_scale=np.float64(alpha / r))
+    for n, v in m.state_dict().items():
+        n = n.replace(".base.", ".")
+        d["sd." + n] = v
+    for n, p in m.named_parameters():
+        if "lora_" in n:
+            d["grad." + n] = p.grad if p.grad is not None else torch.zeros_like(p)
+    save("g12_lora_backbone", **d)
+    # (b) the REAL reference decoder: gradient w.r.t. its input features (what flows back into the key hook)
+    torch.manual_seed(1200)
+    C_, H_ = 768, 8
+    dec = baseline(model_cfg(C_, H_))
+    feat = torch.randn(2, C_, H_, H_, requires_grad=True)
+    r1, r2 = torch.randn(2, 1, H_, H_), torch.randn(2, 1, H_, H_)
+    fg, bg, extra = dec(feat)
+    ((fg * r1).sum() + (bg * r2).sum() + 1000.0 * extra).backward()
+    out = dict(x=feat.detach(), r1=r1, r2=r2, dx=feat.grad)
+    out.update(sd_flat("sd.", dec))
+    save("g12_decoder_dx", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g12"]
     for w in which:
         globals()[w]()

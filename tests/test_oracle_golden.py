@@ -184,3 +184,29 @@ def test_g9_sparse_refiner(tag):
     for k in ("entropy", "window_preds", "h_preds", "GE_w"):
         assert maxdiff(opt[k], g[f"{tag}.{k}"]) < 2e-4, (k, maxdiff(opt[k], g[f"{tag}.{k}"]))
     assert maxdiff(out, g[tag + ".outputs"]) < 2e-4
+
+
+def test_g12_lora_backbone_grads():
+    """Row B9: oracle forward with the LoRA branch + autograd == HF Dinov2Model with LoRA-wrapped q/k/v (the reference's
+    full_model.py is unimportable; SURVEY.md 8c pins this row on HF autograd)."""
+    g = load_golden("g12_lora_backbone")
+    sd = sub(g, "sd.")
+    key, grads = OV.dinov2_lora_grads(g["x"], sd, heads=2, dkey=g["dkey"], lora_scale=float(g["lora_scale"]))
+    assert maxdiff(key, g["key"]) < 2e-5
+    n_checked = 0
+    for k, v in grads.items():
+        ref = g["grad." + k]
+        assert maxdiff(v, ref) < 1e-6 + 2e-4 * ref.abs().max().item(), (k, maxdiff(v, ref))
+        n_checked += 1
+    assert n_checked == 3 * 3 * 2
+    last = "encoder.layer.2.attention.attention."
+    assert float(g["grad." + last + "query.lora_A.weight"].abs().max()) == 0.0      # last layer: only the key hook is used
+    assert float(g["grad." + last + "key.lora_A.weight"].abs().max()) > 0.0
+
+
+def test_g12_decoder_input_gradient():
+    g = load_golden("g12_decoder_dx")
+    p = {k: v.double() for k, v in sub(g, "sd.decoder.").items()}
+    out = OD.rev_decoder_backward(g["x"].double(), p, g["r1"].double(), g["r2"].double(), 1000.0, with_dx=True)
+    ref = g["dx"].double()
+    assert maxdiff(out["dx"], ref) < 2e-4 * ref.abs().max().item()
