@@ -49,7 +49,10 @@ enum {
                                         patch-embed conv + position embedding: modeling_dinov2.py:97-116,139-149, dino.py:144-159,223-235 */
   UCOD_EPI_KEY_NCHW_F32 = 4,         /* A = W_key [C,K], B = tokens [Bimg*tok,K]; out f32[Bimg,C,tok-1] = C + bias[m], CLS dropped:
                                         the key hook, data/utils/feature_extractor.py:42,46-47,55-58 */
-  UCOD_EPI_BIAS_F32 = 5              /* out f32[M,N] = C + bias[n] (final LayerNorm consumers / tests) */
+  UCOD_EPI_BIAS_F32 = 5,             /* out f32[M,N] = C + bias[n] (final LayerNorm consumers / tests; dgrad GEMMs with bias NULL) */
+  /* backbone-backward mode (row B9), ucod_gemm_bf16_train only: */
+  UCOD_EPI_GELU_BWD_BF16 = 6,        /* out bf16[M,N] = C * gelu'(aux[m][n]), aux = saved fc1 pre-activation (fc2 dgrad) */
+  UCOD_EPI_BIAS_GELU_SAVE_BF16 = 7   /* out bf16 = gelu_erf(C + bias[n]) and out2 bf16 = C + bias[n] (training-mode fc1) */
 };
 /* variant: 0 = auto, 1 = 128x128 register staging, 2 = 128x128 LDS-DMA, 3/4 = 256x256 / 256x192 large tile,
  * 5/6 = 3/4 with staggered wave groups.  K % 64 == 0.  For UCOD_EPI_BIAS_BF16 a non-NULL `scale` [N] multiplies
@@ -84,6 +87,54 @@ int ucod_fill_qscale(float* v, int D, float c, void* stream);
 /* f32 -> bf16 cast of n elements (weight preparation) */
 int ucod_cast_f32_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Backbone-backward mode.  The reference describes it in models/modules/full_model.py:47-72,79-126
+ * (peft LoRA r=2, lora_alpha=4 on query/key/value of every encoder layer, all other weights frozen, key hook of the
+ * last layer feeds the decoder); that file is not importable, so parity is pinned on HuggingFace Dinov2Model autograd
+ * with the LoRA forward restated (tests/golden/g12_lora_backbone.npz).  LoRA rides on the GEMMs as UCOD_LORA_AUG
+ * extra K columns -- see ucod_dpl_amd/csrc/vit_train.hip for the operand formats.
+ * One layer's LoRA parameters / gradients (f32): [A_q (r x D) | B_q (D x r) | A_k | B_k | A_v | B_v], 3r <= UCOD_LORA_AUG. */
+#define UCOD_LORA_AUG 64
+
+/* ucod_gemm_bf16 with the two training epilogues (large-tile kernels; N % 8 == 0, K >= 128).  For UCOD_EPI_BIAS_BF16 and
+ * UCOD_EPI_BIAS_F32 (either entry point) a NULL bias means a plain product (K >= 128, N % 4 == 0, variant not 1/2). */
+int ucod_gemm_bf16_train(int epilogue, const void* A, const void* B, void* out, int M, int N, int K, const float* bias,
+                         const void* aux_bf16, void* out2_bf16, int variant, void* stream);
+
+/* y_aug bf16 [rows, D+64] = [ LayerNorm(x) | LayerNorm(x) A_q^T, A_k^T, A_v^T (3r values) | 0 ] */
+int ucod_layernorm_lora(const float* x, const float* gamma, const float* beta, const float* lora_layer, int r, void* y_aug_bf16,
+                        int rows, int D, float eps, void* stream);
+
+/* LayerNorm backward w.r.t. its input (frozen gamma/beta), fused with the residual add and the next GEMM's A operand:
+ * dx f32 [rows,D] = dres (nullable) + dLN(dy; x, gamma);  s bf16 [rows,D] = next_scale (nullable: ones) * dx.
+ * dx may alias dres or dy; either output may be NULL. */
+int ucod_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
+                       void* s_bf16, int rows, int D, float eps, void* stream);
+
+/* Attention forward that also returns the base-2 log-sum-exp of the scaled scores, lse f32 [B, heads, tok]
+ * (Q must carry head_dim^-0.5 * log2(e), as for ucod_attention_fwd with scale == 0). */
+int ucod_attention_fwd_lse(const void* qkv_bf16, void* out_bf16, float* lse, int B, int tok, int heads, void* stream);
+
+/* Attention backward (eager_attention_forward of modeling_dinov2.py:153-179 differentiated): qkv as in the forward
+ * (Q pre-scaled), out/dout bf16 [B*tok, D], lse from ucod_attention_fwd_lse; delta f32 [B, heads, tok] is scratch.
+ * dqkv bf16 rows of length ld_dqkv (>= 3D) = gradient w.r.t. the UNSCALED q | k | v projections. */
+int ucod_attention_bwd(const void* qkv_bf16, const void* out_bf16, const void* dout_bf16, const float* lse, float* delta,
+                       void* dqkv_bf16, int ld_dqkv, int B, int tok, int heads, void* stream);
+
+/* dkey f32 [B, D, tok-1] (cotangent of the key hook) -> rows of dqkv_aug bf16 [B*tok, 3D+64]: k third = dkey^T (CLS row 0),
+ * q and v thirds and the aug columns zero. */
+int ucod_key_grad_tokens(const float* dkey, void* dqkv_aug_bf16, int B, int tok, int D, void* stream);
+
+/* Fill the aug columns of Wqkv_aug bf16 [3D, D+64] (alpha/r * B_q|B_k|B_v on the block diagonal) and of WqkvT_aug bf16
+ * [D, 3D+64] (A_q^T|A_k^T|A_v^T) from one layer's LoRA parameters.  Either matrix may be NULL. */
+int ucod_lora_pack(const float* lora_layer, int r, float scaling, void* w_aug_bf16, void* wt_aug_bf16, int D, void* stream);
+
+/* One layer's LoRA gradients from dqkv_aug [rows, 3D+64] and h_aug [rows, D+64]; also writes t = alpha/r * dqkv B into the
+ * aug columns of dqkv_aug (consumed by the dgrad GEMM).  grad_layer has the parameter layout; accumulate != 0 adds. */
+size_t ucod_lora_grad_workspace_bytes(int D);
+int ucod_lora_grad(void* dqkv_aug_bf16, const void* h_aug_bf16, const float* lora_layer, int r, float scaling, float* grad_layer,
+                   int accumulate, void* workspace, size_t workspace_bytes, int rows, int D, void* stream);
+
 /* Whole frozen backbone forward up to the last layer's key projection: one call enqueues every kernel.
  * Pointer table (HOST array of DEVICE pointers; "w" entries are bf16 [out,in], the rest f32):
  *   [0] patch_w bf16 [D,Kpad] (zero padded k)  [1] patch_b [D]  [2] cls [D]  [3] pos [tok,D] (already interpolated)
@@ -107,6 +158,27 @@ typedef struct {
 size_t ucod_vit_workspace_bytes(const ucod_vit_desc* d);
 int ucod_vit_forward(const ucod_vit_desc* d, const void* const* table_host, const float* img, float* key_out,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backbone-backward mode, whole passes (row B9; operand formats in ucod_dpl_amd/csrc/vit_train.hip).
+ * T = the table of ucod_vit_forward; TT = per-layer training table (HOST array of DEVICE pointers), layer l at
+ * UCOD_VIT_TRAIN_STRIDE*l:
+ *   +0 qkv_w_aug bf16 [3D, D+64]   +1 qkv_wT_aug bf16 [D, 3D+64]   (aug columns maintained by ucod_lora_pack)
+ *   +2 proj_w^T bf16 [D,D]   +3 fc1_w^T bf16 [D,F]   +4 fc2_w^T bf16 [F,D]   (frozen; transposed once by the host)
+ *   +5 LoRA parameters f32 [6*r*D]   +6 LoRA gradients f32 [6*r*D] (overwritten by ucod_vit_backward)
+ * forward_train saves its activations in `workspace`; backward must be given the same, untouched workspace.
+ * dkey f32 [B, D, H/P, W/P] = cotangent of key_out.  gemm_variant of the embedded desc applies; attention is the
+ * pre-scaled kernel.  Dropout of the reference's LoraConfig (0.05) is not applied (documented deviation). */
+#define UCOD_VIT_TRAIN_STRIDE 7
+typedef struct {
+  ucod_vit_desc vit;
+  int lora_r;           /* models/modules/full_model.py:48: r = 2 */
+  float lora_scaling;   /* lora_alpha / r = 4 / 2 */
+} ucod_vit_train_desc;
+size_t ucod_vit_train_workspace_bytes(const ucod_vit_train_desc* t);
+int ucod_vit_forward_train(const ucod_vit_train_desc* t, const void* const* table_host, const void* const* train_table_host,
+                           const float* img, float* key_out, void* workspace, size_t workspace_bytes, void* stream);
+int ucod_vit_backward(const ucod_vit_train_desc* t, const void* const* table_host, const void* const* train_table_host,
+                      const float* dkey, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ decoder / APM path (rows A1-A8) */
 

@@ -1,0 +1,308 @@
+"""GPU parity tests of the backbone-backward mode, every call through the C ABI.
+
+Reference = oracle/vit.py + torch autograd on the CPU (pinned against HuggingFace Dinov2Model autograd by
+tests/golden/g12_lora_backbone.npz; the reference's own full_model.py is not importable).  bf16 kernels are compared
+with an f32/f64 evaluation of the same bf16-rounded operands; the end-to-end LoRA gradients carry the accumulated
+bf16 error of a full forward + backward and are held to a relative-L2 bar instead (stated per test).
+"""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden, sub, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from ucod_dpl_amd import native as N, ops  # noqa: E402
+from ucod_dpl_amd.vit_engine import ViTLoRAEngine  # noqa: E402
+from oracle import vit as OV  # noqa: E402
+
+DEV = "cuda"
+AUG = N.LORA_AUG
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def lora_arena(r, D, g, b_scale=0.05):
+    """one layer: [A_q | B_q | A_k | B_k | A_v | B_v]"""
+    parts, mats = [], []
+    for _ in range(3):
+        A = torch.randn(r, D, generator=g) / math.sqrt(D)
+        Bm = torch.randn(D, r, generator=g) * b_scale
+        parts += [A.reshape(-1), Bm.reshape(-1)]
+        mats.append((A, Bm))
+    return torch.cat(parts), mats
+
+
+# ------------------------------------------------------------------------------------------------ row-wise kernels
+@pytest.mark.parametrize("M,D,r", [(37, 128, 2), (300, 768, 2), (64, 1024, 4), (50, 384, 1)])
+def test_layernorm_lora(M, D, r):
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D, generator=g) * 2 + 0.3
+    gam, bet = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    flat, mats = lora_arena(r, D, g)
+    out = torch.full((M, D + AUG), 7.0, dtype=torch.bfloat16, device=DEV)
+    xs, gs, bs, fs = x.to(DEV), gam.to(DEV), bet.to(DEV), flat.to(DEV)
+    N.check(N.load().ucod_layernorm_lora(N.ptr(xs), N.ptr(gs), N.ptr(bs), N.ptr(fs), r, N.ptr(out), M, D, 1e-6, N.stream()), "ln_lora")
+    out = out.float().cpu()
+    h = OV.layer_norm(x.double(), gam.double(), bet.double(), 1e-6)
+    assert maxdiff(out[:, :D], h) < 2e-2 * max(1.0, h.abs().max().item())
+    u = torch.cat([h @ A.double().t() for A, _ in mats], 1)
+    assert maxdiff(out[:, D:D + 3 * r], u) < 1e-2 * max(1.0, u.abs().max().item())
+    assert float(out[:, D + 3 * r:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,D", [(37, 128), (300, 768), (20, 1024)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_layernorm_bwd(M, D, with_res):
+    g = torch.Generator().manual_seed(M * 3 + D)
+    x = (torch.randn(M, D, generator=g) * 2 + 0.3).requires_grad_(True)
+    gam = torch.randn(D, generator=g)
+    dy = torch.randn(M, D, generator=g)
+    dres = torch.randn(M, D, generator=g) if with_res else None
+    sc = torch.rand(D, generator=g) + 0.5
+    y = OV.layer_norm(x.double(), gam.double(), torch.zeros(D).double(), 1e-6)
+    (gx,) = torch.autograd.grad((y * dy.double()).sum(), x)
+    ref = gx + (dres.double() if with_res else 0)
+    dx = torch.empty(M, D, device=DEV)
+    s = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    dys, xs, gs, scs = dy.to(DEV), x.detach().to(DEV), gam.to(DEV), sc.to(DEV)
+    drs = dres.to(DEV) if with_res else None
+    N.check(N.load().ucod_layernorm_bwd(N.ptr(dys), N.ptr(xs), N.ptr(gs), N.ptr(drs) if with_res else None, N.ptr(scs), N.ptr(dx), N.ptr(s), M, D,
+                                        1e-6, N.stream()), "ln_bwd")
+    assert maxdiff(dx.cpu(), ref) < 2e-5 * max(1.0, ref.abs().max().item())
+    assert maxdiff(s.float().cpu(), ref * sc.double()) < 1e-2 * max(1.0, (ref * sc.double()).abs().max().item())
+
+
+def test_key_grad_tokens_and_lora_pack():
+    B, tok, D, r = 2, 26, 128, 2
+    g = torch.Generator().manual_seed(5)
+    dkey = torch.randn(B, D, tok - 1, generator=g)
+    out = torch.full((B * tok, 3 * D + AUG), 3.0, dtype=torch.bfloat16, device=DEV)
+    dks = dkey.to(DEV)
+    N.check(N.load().ucod_key_grad_tokens(N.ptr(dks), N.ptr(out), B, tok, D, N.stream()), "key_grad")
+    o = out.float().cpu().reshape(B, tok, 3 * D + AUG)
+    assert float(o[:, :, :D].abs().max()) == 0 and float(o[:, :, 2 * D:].abs().max()) == 0 and float(o[:, 0].abs().max()) == 0
+    assert maxdiff(o[:, 1:, D:2 * D], bf(dkey.transpose(1, 2)).float()) == 0
+    flat, mats = lora_arena(r, D, g)
+    w = torch.zeros(3 * D, D + AUG, dtype=torch.bfloat16, device=DEV)
+    wt = torch.zeros(D, 3 * D + AUG, dtype=torch.bfloat16, device=DEV)
+    fs = flat.to(DEV)
+    N.check(N.load().ucod_lora_pack(N.ptr(fs), r, 2.0, N.ptr(w), N.ptr(wt), D, N.stream()), "lora_pack")
+    w, wt = w.float().cpu(), wt.float().cpu()
+    for p, (A, Bm) in enumerate(mats):
+        blk = w[p * D:(p + 1) * D, D:]
+        assert maxdiff(blk[:, p * r:(p + 1) * r], bf(2.0 * Bm).float()) == 0
+        blk = blk.clone()
+        blk[:, p * r:(p + 1) * r] = 0
+        assert float(blk.abs().max()) == 0
+        assert maxdiff(wt[:, 3 * D + p * r:3 * D + (p + 1) * r], bf(A.t()).float()) == 0
+    assert float(wt[:, 3 * D + 3 * r:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,D,r", [(52, 128, 2), (3000, 768, 2), (500, 256, 3), (700, 384, 1)])
+def test_lora_grad(M, D, r):
+    g = torch.Generator().manual_seed(M + r)
+    scaling = 2.0
+    flat, mats = lora_arena(r, D, g)
+    dqkv = bf(torch.randn(M, 3 * D, generator=g))
+    h = bf(torch.randn(M, D, generator=g))
+    u = bf(torch.cat([h.float() @ A.t() for A, _ in mats], 1))
+    d_aug = torch.zeros(M, 3 * D + AUG, dtype=torch.bfloat16)
+    d_aug[:, :3 * D] = dqkv
+    h_aug = torch.zeros(M, D + AUG, dtype=torch.bfloat16)
+    h_aug[:, :D] = h
+    h_aug[:, D:D + 3 * r] = u
+    lib = N.load()
+    wsb = lib.ucod_lora_grad_workspace_bytes(D)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    grad = torch.full((6 * r * D,), 9.0, device=DEV)
+    ds, hs, fs = d_aug.to(DEV), h_aug.to(DEV), flat.to(DEV)
+    N.check(lib.ucod_lora_grad(N.ptr(ds), N.ptr(hs), N.ptr(fs), r, scaling, N.ptr(grad), 0, N.ptr(ws), wsb, M, D, N.stream()), "lora_grad")
+    grad, t_out = grad.cpu(), ds.float().cpu()[:, 3 * D:]
+    off = 0
+    for p, (A, Bm) in enumerate(mats):
+        dq = dqkv[:, p * D:(p + 1) * D].double()
+        t = scaling * dq @ Bm.double()
+        assert maxdiff(t_out[:, p * r:(p + 1) * r], t) < 1e-2 * max(1.0, t.abs().max().item())
+        tb = t_out[:, p * r:(p + 1) * r].double()                        # the kernel uses the bf16-rounded t for dA
+        dA = tb.t() @ h.double()
+        dB = scaling * dq.t() @ u[:, p * r:(p + 1) * r].double()
+        gA, gB = grad[off:off + r * D].reshape(r, D), grad[off + r * D:off + 2 * r * D].reshape(D, r)
+        off += 2 * r * D
+        assert maxdiff(gA, dA) < 2e-4 * max(1.0, dA.abs().max().item()), p
+        assert maxdiff(gB, dB) < 2e-4 * max(1.0, dB.abs().max().item()), p
+    assert float(t_out[:, 3 * r:].abs().max()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ GEMM epilogues
+def _gelu_grad(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+@pytest.mark.parametrize("variant", [0, 5, 6, 7, 8])
+@pytest.mark.parametrize("M,Nn,K", [(300, 512, 128), (2740, 3072, 768)])
+def test_gemm_train_epilogues(variant, M, Nn, K):
+    g = torch.Generator().manual_seed(M + Nn)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(Nn, K, generator=g) * 0.05)
+    b = torch.randn(Nn, generator=g)
+    pre_ref = A.double() @ W.double().t() + b.double()
+    lib = N.load()
+    As, Ws, bs = A.to(DEV), W.to(DEV), b.to(DEV)
+    out = torch.empty(M, Nn, dtype=torch.bfloat16, device=DEV)
+    pre = torch.empty(M, Nn, dtype=torch.bfloat16, device=DEV)
+    N.check(lib.ucod_gemm_bf16_train(N.EPI_BIAS_GELU_SAVE_BF16, N.ptr(As), N.ptr(Ws), N.ptr(out), M, Nn, K, N.ptr(bs), None, N.ptr(pre), variant,
+                                     N.stream()), "gelu_save")
+    assert rel_l2(pre.float(), pre_ref) < 4e-3
+    assert rel_l2(out.float(), OV.gelu_erf(pre_ref)) < 5e-3
+    # fc2-dgrad style: out = (A W^T) * gelu'(aux)
+    aux = bf(torch.randn(M, Nn, generator=g) * 1.5)
+    auxs = aux.to(DEV)
+    N.check(lib.ucod_gemm_bf16_train(N.EPI_GELU_BWD_BF16, N.ptr(As), N.ptr(Ws), N.ptr(out), M, Nn, K, None, N.ptr(auxs), None, variant, N.stream()),
+            "gelu_bwd")
+    ref = (A.double() @ W.double().t()) * _gelu_grad(aux.double())
+    assert rel_l2(out.float(), ref) < 5e-3
+    # plain products (NULL bias) in both output types
+    o32 = torch.empty(M, Nn, device=DEV)
+    N.check(lib.ucod_gemm_bf16(N.EPI_BIAS_F32, N.ptr(As), N.ptr(Ws), N.ptr(o32), M, Nn, K, None, None, None, None, 0, variant, N.stream()), "plain f32")
+    assert rel_l2(o32, A.double() @ W.double().t()) < 1e-5
+    N.check(lib.ucod_gemm_bf16(N.EPI_BIAS_BF16, N.ptr(As), N.ptr(Ws), N.ptr(out), M, Nn, K, None, None, None, None, 0, variant, N.stream()), "plain bf16")
+    assert rel_l2(out.float(), A.double() @ W.double().t()) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, heads):
+    B, T, D = q.shape
+    hd = D // heads
+    qh, kh, vh = (t.view(B, T, heads, hd).transpose(1, 2) for t in (q, k, v))
+    s = qh @ kh.transpose(2, 3) * hd ** -0.5
+    p = torch.softmax(s, -1)
+    return (p @ vh).transpose(1, 2).reshape(B, T, D), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,tok,heads", [(1, 26, 2), (2, 200, 3), (1, 1370, 2), (2, 129, 1)])
+def test_attention_backward(B, tok, heads):
+    g = torch.Generator().manual_seed(B * 1000 + tok)
+    D = heads * 64
+    c = 0.125 * 1.4426950408889634
+    q = bf(torch.randn(B, tok, D, generator=g) * 1.5)
+    k = bf(torch.randn(B, tok, D, generator=g) * 1.5)
+    v = bf(torch.randn(B, tok, D, generator=g))
+    qs = bf(q.float() * c)                                              # what the QKV epilogue stores
+    q_eff = (qs.double() / c).requires_grad_(True)                      # the unscaled q the gradient refers to
+    kd, vd = k.double().requires_grad_(True), v.double().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(q_eff, kd, vd, heads)
+    do = bf(torch.randn(B, tok, D, generator=g))
+    gq, gk, gv = torch.autograd.grad((o_ref * do.double()).sum(), (q_eff, kd, vd))
+    lib = N.load()
+    qkv = torch.cat((qs, k, v), -1).reshape(B * tok, 3 * D).contiguous().to(DEV)
+    out = torch.empty(B * tok, D, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, heads, tok, device=DEV)
+    N.check(lib.ucod_attention_fwd_lse(N.ptr(qkv), N.ptr(out), N.ptr(lse), B, tok, heads, N.stream()), "fwd_lse")
+    assert rel_l2(out.float().reshape(B, tok, D), o_ref) < 8e-3
+    assert maxdiff(lse.cpu() / 1.4426950408889634, lse_ref.detach()) < 2e-3 * max(1.0, lse_ref.abs().max().item())
+    ld = 3 * D + AUG
+    dqkv = torch.full((B * tok, ld), 5.0, dtype=torch.bfloat16, device=DEV)
+    delta = torch.empty(B, heads, tok, device=DEV)
+    dos = do.reshape(B * tok, D).contiguous().to(DEV)
+    N.check(lib.ucod_attention_bwd(N.ptr(qkv), N.ptr(out), N.ptr(dos), N.ptr(lse), N.ptr(delta), N.ptr(dqkv), ld, B, tok, heads, N.stream()), "bwd")
+    d = dqkv.float().cpu().reshape(B, tok, ld)
+    assert float((d[..., 3 * D:] - 5.0).abs().max()) == 0              # aug columns untouched
+    for name, got, ref in (("dq", d[..., :D], gq), ("dk", d[..., D:2 * D], gk), ("dv", d[..., 2 * D:3 * D], gv)):
+        assert rel_l2(got, ref) < 1.5e-2, (name, rel_l2(got, ref))
+
+
+# ------------------------------------------------------------------------------------------------ whole passes
+def _engine_from_golden(g):
+    sd = sub(g, "sd.")
+    base = {k: v for k, v in sd.items() if ".lora_" not in k}
+    eng = ViTLoRAEngine(base, heads=2, r=2, lora_alpha=4, device=DEV)
+    eng.load_lora_state_dict(sd)
+    return eng, sd
+
+
+def test_g12_end_to_end_lora_gradients():
+    """HF Dinov2Model + LoRA autograd (golden) vs ucod_vit_forward_train / ucod_vit_backward.  bf16 operands through 3 layers
+    forward and backward: key within 3e-2 abs (O(3) values), every LoRA gradient within 4e-2 relative L2."""
+    g = load_golden("g12_lora_backbone")
+    eng, sd = _engine_from_golden(g)
+    key = eng.forward_train(g["x"].to(DEV))
+    assert maxdiff(key.cpu(), g["key"]) < 3e-2 * max(1.0, g["key"].abs().max().item())
+    eng.backward(g["dkey"].to(DEV))
+    grads = eng.lora_state_dict(grads=True)
+    worst = 0.0
+    for k, v in grads.items():
+        ref = g["grad." + k]
+        if float(ref.abs().max()) == 0.0:
+            assert float(v.abs().max()) == 0.0, k                       # last layer's query / value LoRA: exactly zero
+            continue
+        worst = max(worst, rel_l2(v, ref))
+        assert rel_l2(v, ref) < 4e-2, (k, rel_l2(v, ref))
+    assert worst > 0
+
+
+def test_forward_train_matches_inference_forward():
+    """Same weights, LoRA B = 0: the training forward's key map must equal the inference engine's bit for bit up to the
+    different GEMM K extent (aug columns are zero) -- here: identical within bf16 noise, and deterministic across calls."""
+    from ucod_dpl_amd.vit_engine import ViTEngine
+    g = load_golden("g8_dinov2_native")
+    base = sub(g, "sd.")
+    inf = ViTEngine(base, heads=2, device=DEV, attn_variant=2)
+    eng = ViTLoRAEngine(base, heads=2, device=DEV)
+    x = g["x"].to(DEV)
+    k0 = inf(x)
+    k1 = eng.forward_train(x)
+    k2 = eng.forward_train(x)
+    assert torch.equal(k1, k2)
+    assert maxdiff(k0.cpu(), k1.cpu()) < 1e-2 * max(1.0, k0.abs().max().item())
+    assert maxdiff(k1.cpu(), g["key"]) < 3e-2 * max(1.0, g["key"].abs().max().item())
+
+
+def test_medium_model_lora_gradients_vs_oracle_autograd():
+    """D=256, 4 heads, 4 layers, 9x9 patches (82 tokens), batch 3: HIP passes vs oracle/vit.py + torch autograd (CPU, f32)."""
+    from transformers import Dinov2Config, Dinov2Model
+    torch.manual_seed(21)
+    cfg = Dinov2Config(hidden_size=256, num_hidden_layers=4, num_attention_heads=4, image_size=126, patch_size=14, mlp_ratio=4,
+                       layerscale_value=1.0)
+    m = Dinov2Model(cfg).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+            if "position_embeddings" in n or "cls_token" in n:
+                p.mul_(0.05)
+    base = {k: v.detach() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(4)
+    eng = ViTLoRAEngine(base, heads=4, r=2, lora_alpha=4, device=DEV, generator=gen)
+    lsd = eng.lora_state_dict()
+    for k in lsd:
+        if "lora_B" in k:
+            lsd[k] = 0.05 * torch.randn(lsd[k].shape, generator=gen)
+    eng.load_lora_state_dict(lsd)
+    x = torch.randn(3, 3, 126, 126, generator=gen)
+    dkey = torch.randn(3, 256, 9, 9, generator=gen)
+    sd = dict(base)
+    sd.update({k: v.cpu() for k, v in eng.lora_state_dict().items()})
+    key_ref, gref = OV.dinov2_lora_grads(x, sd, heads=4, dkey=dkey, lora_scale=2.0)
+    key = eng.forward_train(x.to(DEV))
+    assert maxdiff(key.cpu(), key_ref) < 3e-2 * max(1.0, key_ref.abs().max().item())
+    eng.backward(dkey.to(DEV))
+    got = eng.lora_state_dict(grads=True)
+    for k, ref in gref.items():
+        if float(ref.abs().max()) == 0.0:
+            assert float(got[k].abs().max()) == 0.0, k
+        else:
+            assert rel_l2(got[k], ref) < 5e-2, (k, rel_l2(got[k], ref))

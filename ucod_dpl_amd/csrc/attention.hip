@@ -225,7 +225,7 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 constexpr float DEFER_THR = 8.0f;
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N,
-                                                              int heads, int npairs) {
+                                                              int heads, int npairs, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (KV_BYTES + KV_BYTES)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h5 = lane >> 5, l31 = lane & 31;
@@ -387,6 +387,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __r
   const float inv = 1.0f / osum[0];
   const int q = q0 + l31;
   if (q < N) {
+    // training mode: base-2 log-sum-exp of the scaled scores, consumed by ucod_attention_bwd
+    if (lse && h5 == 0) lse[((size_t)b * heads + head) * N + q] = m_run + __builtin_amdgcn_logf(osum[0]);
     bf16_raw* op = out + ((size_t)b * N + q) * D + head * HD + 4 * h5;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -585,7 +587,7 @@ extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, in
   if (scale == 0.f) {   // Q pre-scaled by head_dim^-0.5 * log2(e): the VALU-lean kernel
     const int npairs = B * heads, nq = cdiv(tok, QT);
     dim3 grid1(cdiv(npairs, 8) * 8 * nq);
-    hipLaunchKernelGGL(attn_fwd_v2_kernel, grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs);
+    hipLaunchKernelGGL(attn_fwd_v2_kernel, grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
     UCOD_CHECK_LAUNCH();
     return UCOD_OK;
   }
@@ -605,6 +607,17 @@ extern "C" int ucod_cross_attention96_fwd(const void* q, int ldq, const void* k,
   dim3 grid(cdiv(Nq, QT), heads, B), block(256);
   hipLaunchKernelGGL(attn_cross96_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_raw*)q, ldq, (const bf16_raw*)k, (const bf16_raw*)v,
                      ldkv, (bf16_raw*)out, Nq, Nk, heads);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_attention_fwd_lse(const void* qkv, void* out, float* lse, int B, int tok, int heads, void* stream) {
+  using namespace ucod;
+  if (!qkv || !out || !lse || B <= 0 || tok <= 0 || heads <= 0) return UCOD_EINVAL;
+  UCOD_PROF(PROF_ATTN, stream);
+  const int npairs = B * heads, nq = cdiv(tok, QT);
+  hipLaunchKernelGGL(attn_fwd_v2_kernel, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok,
+                     heads, npairs, lse);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }

@@ -1,0 +1,365 @@
+// Multi-head attention backward, head_dim 64 (backbone-backward mode, SURVEY.md 8a row B9: eager_attention_forward of
+// transformers modeling_dinov2.py:153-179 differentiated; dropout 0, no mask).
+//
+// Same transposed-score scheme as attention.hip: v_mfma_f32_32x32x16_bf16, a lane owns one column of every 32x32 tile, the
+// C registers are converted to bf16 in place and reused as the B operand of the next product.  With Q' = Q * hd^-0.5 * log2(e)
+// (what the forward stored), L = base-2 log-sum-exp of the scaled scores, P = exp2(Q'K^T - L), dP = dO V^T,
+// delta = rowsum(dO * O), dS = P * (dP - delta):
+//     dQ = hd^-0.5 * dS K          dK = ln(2) * dS^T Q'          dV = P^T dO
+// Two kernels, no atomics (bitwise reproducible):
+//   attn_bwd_dq_kernel   a wave owns 32 QUERIES (lane = query), walks the key tiles: 8 MFMAs for S^T and dP^T, 4 for dQ^T
+//                        per 32 keys; L and delta are per-lane scalars folded into the accumulator initial values; also
+//                        writes delta for the second kernel;
+//   attn_bwd_dkv_kernel  a wave owns 32 KEYS (lane = key), walks the query tiles: S and dP (A operand = Q' / dO rows from
+//                        LDS, B operand = the wave's K / V fragments in registers), then dV^T += dO^T P and
+//                        dK^T += Q'^T dS with dO^T / Q'^T read through ds_read_b64_tr_b16; -L[q] and -delta[q] vary
+//                        along the accumulator ROWS here, so they are staged in LDS and loaded as the initial values.
+// Tiles that are needed both row-major (A operand of the score products) and transposed (A operand of the gradient
+// products) are staged twice, once per bank swizzle.
+#include "common.h"
+#include "../../include/ucod_dpl.h"
+
+namespace ucod {
+namespace {
+
+constexpr int HD = 64;
+constexpr int WT = 128;                 // rows (queries or keys) owned by one workgroup: 4 waves x 32
+constexpr int ST = 64;                  // rows per streamed tile
+constexpr int TILE = ST * HD * 2;       // 8 KiB
+
+__device__ __forceinline__ int swz_k(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+__device__ __forceinline__ int swz_v(int row, int chunk) { return chunk ^ (((row >> 1) & 1) << 2); }
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+// C registers 8*ks .. 8*ks+7 of a 32x32 tile -> bf16 B operand of the next product (k index = the C row permutation)
+__device__ __forceinline__ bf16x8 pack_b(const f32x16& s, int ks) {
+  u32x4_t w;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) w[jj] = pack_bf16x2(s[8 * ks + 2 * jj], s[8 * ks + 2 * jj + 1]);
+  return __builtin_bit_cast(bf16x8, w);
+}
+
+// A operand X^T[32 d of block dt][16 rows of block (half, ks) in the C row permutation] from a swz_v-staged [64][64] tile
+__device__ __forceinline__ bf16x8 read_tr(const char* tile, int off) {
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(tile + off));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(tile + off + 8 * 128));
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+struct Map {            // XCD-aware 1-D grid -> (image, head, row block): all blocks of one (image, head) on one XCD
+  int b, head, blk;
+  bool ok;
+};
+__device__ __forceinline__ Map decode(int N, int heads, int npairs) {
+  const int nb = (N + WT - 1) / WT;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pair = (slot / nb) * 8 + xcd;
+  Map m;
+  m.blk = slot - (slot / nb) * nb;
+  m.ok = pair < npairs;
+  m.head = pair % heads;
+  m.b = pair / heads;
+  return m;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_raw* __restrict__ qkv, const bf16_raw* __restrict__ out,
+                                                              const bf16_raw* __restrict__ dout, const float* __restrict__ lse,
+                                                              float* __restrict__ delta, bf16_raw* __restrict__ dqkv, int ldd, int N,
+                                                              int heads, int npairs, float qscale) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE];      // per stage: K (swz_k) | K (swz_v) | V (swz_k)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h5 = lane >> 5, l31 = lane & 31;
+  const Map mp = decode(N, heads, npairs);
+  if (!mp.ok) return;
+  const int D = heads * HD, ld = 3 * D;
+  const int q0 = mp.blk * WT + wave * 32;
+  const bf16_raw* base = qkv + (size_t)mp.b * N * ld + mp.head * HD;
+  const int q = q0 + l31, qc = q < N ? q : N - 1;
+
+  bf16x8 qf[4], dof[4];
+  float dl = 0.f;
+  {
+    const bf16_raw* qp = base + (size_t)qc * ld + 8 * h5;
+    const bf16_raw* op = out + ((size_t)mp.b * N + qc) * D + mp.head * HD + 8 * h5;
+    const bf16_raw* dp = dout + ((size_t)mp.b * N + qc) * D + mp.head * HD + 8 * h5;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+      dof[s] = *reinterpret_cast<const bf16x8*>(dp + 16 * s);
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(op + 16 * s);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += (float)dof[s][e] * (float)of[e];
+    }
+  }
+  dl += __shfl_xor(dl, 32, 64);
+  const size_t stat = ((size_t)mp.b * heads + mp.head) * N + qc;
+  const float L = lse[stat];
+  if (h5 == 0 && q < N) delta[stat] = dl;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+
+  const int nt = (N + ST - 1) / ST;
+  u32x4 rk[2], rv[2];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
+      int kr = t * ST + row;
+      kr = kr < N ? kr : N - 1;
+      const bf16_raw* p = base + (size_t)kr * ld + ch * 8;
+      rk[i] = *reinterpret_cast<const u32x4*>(p + D);
+      rv[i] = *reinterpret_cast<const u32x4*>(p + 2 * D);
+    }
+  };
+  auto lwrite = [&](int buf) {
+    char* kb = smem + buf * (3 * TILE);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
+      *reinterpret_cast<u32x4*>(kb + row * 128 + swz_k(row, ch) * 16) = rk[i];
+      *reinterpret_cast<u32x4*>(kb + TILE + row * 128 + swz_v(row, ch) * 16) = rk[i];
+      *reinterpret_cast<u32x4*>(kb + 2 * TILE + row * 128 + swz_k(row, ch) * 16) = rv[i];
+    }
+  };
+  int roff[2][4], toff[2][2][2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int sd = 0; sd < 4; ++sd) {
+      const int row = kt * 32 + l31;
+      roff[kt][sd] = row * 128 + swz_k(row, 2 * sd + h5) * 16;
+    }
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+        const int row = kt * 32 + ks * 16 + 4 * h5 + (i16 >> 2);
+        const int dst = dt * 32 + g1 * 16 + 4 * (i16 & 3);
+        toff[kt][ks][dt] = row * 128 + swz_v(row, dst >> 3) * 16 + (dst & 7) * 2;
+      }
+
+  gload(0);
+  lwrite(0);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    const bool more = (t + 1 < nt);
+    if (more) gload(t + 1);
+    const char* kb = smem + (t & 1) * (3 * TILE);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = -L; dp[i] = -dl; }
+#pragma unroll
+      for (int sd = 0; sd < 4; ++sd) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + roff[kt][sd]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sd], s, 0, 0, 0);
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(kb + 2 * TILE + roff[kt][sd]);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[sd], dp, 0, 0, 0);
+      }
+      const bool tail = (t == nt - 1) && (N & (ST - 1)) != 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = __builtin_amdgcn_exp2f(s[r]);
+        if (tail) {
+          const int key = t * ST + kt * 32 + 4 * h5 + (r & 3) + 8 * (r >> 2);
+          if (key >= N) p = 0.f;
+        }
+        s[r] = p * dp[r];                                            // dS^T
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 dsb = pack_b(s, ks);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr(kb + TILE, toff[kt][ks][dt]), dsb, acc[dt], 0, 0, 0);
+      }
+    }
+    if (more) lwrite((t + 1) & 1);
+  }
+  if (q < N) {
+    bf16_raw* op = dqkv + ((size_t)mp.b * N + q) * ldd + mp.head * HD + 4 * h5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w;
+        w[0] = pack_bf16x2(acc[dt][4 * g + 0] * qscale, acc[dt][4 * g + 1] * qscale);
+        w[1] = pack_bf16x2(acc[dt][4 * g + 2] * qscale, acc[dt][4 * g + 3] * qscale);
+        *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_raw* __restrict__ qkv, const bf16_raw* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               bf16_raw* __restrict__ dqkv, int ldd, int N, int heads, int npairs) {
+  // per stage: Q' (swz_k) | Q' (swz_v) | dO (swz_k) | dO (swz_v) | -L [64] | -delta [64]
+  constexpr int STAGE = 4 * TILE + 2 * ST * 4;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h5 = lane >> 5, l31 = lane & 31;
+  const Map mp = decode(N, heads, npairs);
+  if (!mp.ok) return;
+  const int D = heads * HD, ld = 3 * D;
+  const int k0 = mp.blk * WT + wave * 32;
+  const bf16_raw* base = qkv + (size_t)mp.b * N * ld + mp.head * HD;
+  const bf16_raw* dob = dout + (size_t)mp.b * N * D + mp.head * HD;
+  const float* lseb = lse + ((size_t)mp.b * heads + mp.head) * N;
+  const float* dlb = delta + ((size_t)mp.b * heads + mp.head) * N;
+  const int key = k0 + l31, kc = key < N ? key : N - 1;
+
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16_raw* kp = base + (size_t)kc * ld + D + 8 * h5;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
+      vf[s] = *reinterpret_cast<const bf16x8*>(kp + D + 16 * s);
+    }
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+
+  const int nt = (N + ST - 1) / ST;
+  u32x4 rq[2], rd[2];
+  float rl = 0.f, rdl = 0.f;
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
+      int qr = t * ST + row;
+      qr = qr < N ? qr : N - 1;
+      rq[i] = *reinterpret_cast<const u32x4*>(base + (size_t)qr * ld + ch * 8);
+      rd[i] = *reinterpret_cast<const u32x4*>(dob + (size_t)qr * D + ch * 8);
+    }
+    if (tid < ST) {
+      const int qr = t * ST + tid;
+      rl = qr < N ? -lseb[qr] : -1e30f;                              // out-of-range queries: P = exp2(-huge) = 0
+      rdl = qr < N ? -dlb[qr] : 0.f;
+    }
+  };
+  auto lwrite = [&](int buf) {
+    char* sb = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
+      *reinterpret_cast<u32x4*>(sb + row * 128 + swz_k(row, ch) * 16) = rq[i];
+      *reinterpret_cast<u32x4*>(sb + TILE + row * 128 + swz_v(row, ch) * 16) = rq[i];
+      *reinterpret_cast<u32x4*>(sb + 2 * TILE + row * 128 + swz_k(row, ch) * 16) = rd[i];
+      *reinterpret_cast<u32x4*>(sb + 3 * TILE + row * 128 + swz_v(row, ch) * 16) = rd[i];
+    }
+    if (tid < ST) {
+      reinterpret_cast<float*>(sb + 4 * TILE)[tid] = rl;
+      reinterpret_cast<float*>(sb + 4 * TILE + ST * 4)[tid] = rdl;
+    }
+  };
+  int roff[2][4], toff[2][2][2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int sd = 0; sd < 4; ++sd) {
+      const int row = qt * 32 + l31;
+      roff[qt][sd] = row * 128 + swz_k(row, 2 * sd + h5) * 16;
+    }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+        const int row = qt * 32 + ks * 16 + 4 * h5 + (i16 >> 2);
+        const int dst = dt * 32 + g1 * 16 + 4 * (i16 & 3);
+        toff[qt][ks][dt] = row * 128 + swz_v(row, dst >> 3) * 16 + (dst & 7) * 2;
+      }
+
+  gload(0);
+  lwrite(0);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    const bool more = (t + 1 < nt);
+    if (more) gload(t + 1);
+    const char* sb = smem + (t & 1) * STAGE;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      // accumulator rows r <-> query qt*32 + 4*h5 + (r&3) + 8*(r>>2): initial values -L[q], -delta[q] (four float4 each)
+      f32x16 s, dp;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(sb + 4 * TILE + (qt * 32 + 8 * g + 4 * h5) * 4);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sb + 4 * TILE + ST * 4 + (qt * 32 + 8 * g + 4 * h5) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[4 * g + e] = l4[e]; dp[4 * g + e] = d4[e]; }
+      }
+#pragma unroll
+      for (int sd = 0; sd < 4; ++sd) {
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sb + roff[qt][sd]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[sd], s, 0, 0, 0);
+        const bf16x8 da = *reinterpret_cast<const bf16x8*>(sb + 2 * TILE + roff[qt][sd]);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[sd], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __builtin_amdgcn_exp2f(s[r]);                         // P
+        dp[r] = s[r] * dp[r];                                        // dS
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pb = pack_b(s, ks), dsb = pack_b(dp, ks);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr(sb + 3 * TILE, toff[qt][ks][dt]), pb, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr(sb + TILE, toff[qt][ks][dt]), dsb, dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (more) lwrite((t + 1) & 1);
+  }
+  if (key < N) {
+    bf16_raw* op = dqkv + ((size_t)mp.b * N + key) * ldd + D + mp.head * HD + 4 * h5;
+    constexpr float LN2 = 0.69314718055994531f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w;
+        w[0] = pack_bf16x2(dk[dt][4 * g + 0] * LN2, dk[dt][4 * g + 1] * LN2);
+        w[1] = pack_bf16x2(dk[dt][4 * g + 2] * LN2, dk[dt][4 * g + 3] * LN2);
+        *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
+        w[0] = pack_bf16x2(dv[dt][4 * g + 0], dv[dt][4 * g + 1]);
+        w[1] = pack_bf16x2(dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
+        *reinterpret_cast<u32x2*>(op + D + dt * 32 + 8 * g) = w;
+      }
+  }
+}
+
+}  // namespace ucod
+
+extern "C" int ucod_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                                  int ld_dqkv, int B, int tok, int heads, void* stream) {
+  using namespace ucod;
+  if (!qkv || !out || !dout || !lse || !delta || !dqkv || B <= 0 || tok <= 0 || heads <= 0 || ld_dqkv < 3 * heads * HD || (ld_dqkv & 3))
+    return UCOD_EINVAL;
+  UCOD_PROF(PROF_ATTN_BWD, stream);
+  const int npairs = B * heads, nb = cdiv(tok, WT);
+  dim3 grid(cdiv(npairs, 8) * 8 * nb), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, s, (const bf16_raw*)qkv, (const bf16_raw*)out, (const bf16_raw*)dout, lse, delta,
+                     (bf16_raw*)dqkv, ld_dqkv, tok, heads, npairs, 0.125f);
+  UCOD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, s, (const bf16_raw*)qkv, (const bf16_raw*)dout, lse, delta, (bf16_raw*)dqkv, ld_dqkv, tok,
+                     heads, npairs);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}

@@ -29,6 +29,8 @@ struct GemmArgs {
   const float* scale;
   const float* resid;
   const float* pos;
+  const void* aux;    // GELU_BWD: bf16 [M,N] pre-activation of the forward fc1
+  void* out2;         // BIAS_GELU_SAVE: bf16 [M,N] pre-activation output
   int M, N, K;
   int tok;   // tokens per image incl. CLS (PATCH / KEY epilogues)
   int tiles_m, tiles_n;
@@ -85,6 +87,20 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
   return pos - a * t;
 }
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f32x2){x, x})[0]; }
+// d/dx gelu(x) = Phi(x) + x * phi(x), Phi from the same 0.5*erfc fit (backbone-backward mode, fc1 dgrad epilogue)
+__device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
+  const f32x2 a = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+  f32x2 p = a * 4.881021588e-04f + (-7.198718842e-03f);
+  p = p * a + 5.214663086e-02f;
+  p = p * a + 4.595958292e-01f;
+  p = p * a + 1.151000509e+00f;
+  p = p * a + 1.0f;
+  const f32x2 t = {__builtin_amdgcn_exp2f(-p[0]), __builtin_amdgcn_exp2f(-p[1])};          // 0.5 * erfc(|x| / sqrt 2)
+  const f32x2 cdf = {x[0] >= 0.f ? 1.f - t[0] : t[0], x[1] >= 0.f ? 1.f - t[1] : t[1]};
+  const f32x2 xx = x * x * (-0.72134752044448170f);                                         // -x^2/2 * log2(e)
+  const f32x2 pdf = {__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
+  return cdf + x * pdf * 0.39894228040143268f;
+}
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& a, int m, int n, float v) {
@@ -306,7 +322,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
 //   * the f32 residual is double buffered: the loads of pass p+1 are issued BEFORE the stores of pass p, and vmcnt retires
 //     in order, so the wait for them leaves pass p's stores in flight.  (out may alias resid: passes touch disjoint rows.)
 template <int EPI>
-constexpr bool kColFused = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32);
+constexpr bool kColFused = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 ||
+                            EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
+template <int EPI>
+constexpr bool kF32Out = (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_BIAS_F32);
 
 template <int EPI, int NT>
 __device__ __forceinline__ void load_col_consts(const GemmArgs& a, int ncol0, float (&cb)[NT], float (&cs)[NT]) {
@@ -317,20 +336,28 @@ __device__ __forceinline__ void load_col_consts(const GemmArgs& a, int ncol0, fl
     if constexpr (kColFused<EPI>) {
       int n = ncol0 + j * 16;
       n = n < a.N ? n : a.N - 1;
-      cb[j] = a.bias[n];
+      if constexpr (EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_BIAS_BF16) {
+        cb[j] = (a.bias ? a.bias : reinterpret_cast<const float*>(a.B))[n];   // NULL bias = plain product (dgrad GEMMs): selected in finish_col_consts
+      } else if constexpr (EPI != UCOD_EPI_GELU_BWD_BF16) {
+        cb[j] = a.bias[n];
+      }
       if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) cs[j] = a.scale[n];
       // optional scale: unconditional load now (a branch here costs a vmcnt(0) at the join, ahead of the operand DMAs),
       // select at the point of use (finish_col_consts) so nothing waits on the load before the DMAs are out
-      if constexpr (EPI == UCOD_EPI_BIAS_BF16) cs[j] = (a.scale ? a.scale : a.bias)[n];
+      if constexpr (EPI == UCOD_EPI_BIAS_BF16) cs[j] = (a.scale ? a.scale : reinterpret_cast<const float*>(a.B))[n];
     }
   }
 }
 
 template <int EPI, int NT>
-__device__ __forceinline__ void finish_col_consts(const GemmArgs& a, float (&cs)[NT]) {
+__device__ __forceinline__ void finish_col_consts(const GemmArgs& a, float (&cb)[NT], float (&cs)[NT]) {
   if constexpr (EPI == UCOD_EPI_BIAS_BF16) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) cs[j] = a.scale ? cs[j] : 1.f;
+  }
+  if constexpr (EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_BIAS_BF16) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) cb[j] = a.bias ? cb[j] : 0.f;
   }
 }
 
@@ -369,17 +396,20 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][
     // buffer descriptors over [first row of this wave's tile, end of the matrix) -- rows past M fail the range check and
     // are dropped (loads return 0) -- and columns past N get an offset beyond any descriptor.
     constexpr unsigned OOB = 0xFFFFFFF0u;
-    constexpr int ELT = (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) ? 4 : 2;
+    constexpr int ELT = kF32Out<EPI> ? 4 : 2;
     const long rows_left = (long)a.M - m_first;
     const unsigned long left = rows_left > 0 ? (unsigned long)rows_left * a.N * ELT : 0ul;
     const unsigned records = left > 0xFFFFFFFFul ? 0xFFFFFFFFu : (unsigned)left;
     const size_t base = (size_t)(m_first < a.M ? m_first : 0) * a.N * ELT;
     const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + base, 0, records, 0x00020000);
     const unsigned row_bytes = (unsigned)a.N * ELT;
-    if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) {
+    const unsigned pass_bytes = PR * row_bytes;
+    if constexpr (kF32Out<EPI>) {
+      constexpr bool RESID = (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32);
       constexpr int CH = WCOLS / 4, ITS = PR * CH / 64;          // 16-byte chunks per row; wave instructions per pass
       static_assert((PR * CH) % 64 == 0, "whole wave instructions");
-      const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.resid)) + base, 0, records, 0x00020000);
+      const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(RESID ? (const void*)a.resid : (const void*)a.out)) + base, 0, RESID ? records : 0u, 0x00020000);
       unsigned off[ITS];                                          // byte offset of (row, chunk) of pass 0; + pass * 32 rows
       int lrow[ITS], lchk[ITS];
 #pragma unroll
@@ -390,72 +420,119 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][
         const int n = n_first + lchk[it] * 4;
         off[it] = n < a.N ? (unsigned)lrow[it] * row_bytes + (unsigned)n * 4u : OOB;
       }
-      const unsigned pass_bytes = PR * row_bytes;
-      u32x4 rb[2][ITS];
-#pragma unroll
-      for (int it = 0; it < ITS; ++it) rb[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off[it], 0, 0);
       // (the pass offset goes into the VGPR offset, not soffset: the range check covers only voffset + inst_offset)
       auto at = [&](int it, int pass) { return off[it] == OOB ? OOB : off[it] + (unsigned)pass * pass_bytes; };
+      u32x4 rb[2][ITS];
+      if constexpr (RESID) {
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) rb[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off[it], 0, 0);
+      }
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
         stage(pass);
-        if (pass + 1 < 4) {
+        if constexpr (RESID) {
+          if (pass + 1 < 4) {
 #pragma unroll
-          for (int it = 0; it < ITS; ++it)
-            rb[(pass + 1) & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, at(it, pass + 1), 0, 0);
+            for (int it = 0; it < ITS; ++it)
+              rb[(pass + 1) & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, at(it, pass + 1), 0, 0);
+          }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + lrow[it] * (WCOLS * 4) + lchk[it] * 16);
-          const f32x4 o = __builtin_bit_cast(f32x4, rb[pass & 1][it]) + v;
+          f32x4 o = *reinterpret_cast<const f32x4*>(wbase + lrow[it] * (WCOLS * 4) + lchk[it] * 16);
+          if constexpr (RESID) o = o + __builtin_bit_cast(f32x4, rb[pass & 1][it]);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, at(it, pass), 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-    } else {
-      if ((a.N & 7) == 0) {                                       // 16-byte stores need 8-column alignment of every row
-        constexpr int CH = WCOLS / 8, ITS = PR * CH / 64;
-        static_assert((PR * CH) % 64 == 0, "whole wave instructions");
+    } else if ((a.N & 7) == 0) {                                  // 16-byte stores need 8-column alignment of every row
+      constexpr bool GBWD = (EPI == UCOD_EPI_GELU_BWD_BF16), SAVE = (EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
+      constexpr int CH = WCOLS / 8, ITS = PR * CH / 64;
+      static_assert((PR * CH) % 64 == 0, "whole wave instructions");
+      // second bf16 [M,N] matrix with the same geometry: the saved pre-activation, read (GELU_BWD) or written (GELU_SAVE)
+      const void* second = GBWD ? a.aux : (SAVE ? (const void*)a.out2 : (const void*)a.out);
+      const auto rs_2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(second)) + base, 0,
+                                                          (GBWD || SAVE) ? records : 0u, 0x00020000);
+      unsigned off[ITS];
+      int lrow[ITS], lchk[ITS];
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          stage(pass);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int it = 0; it < ITS; ++it) {
+        const int idx = it * 64 + lane;
+        lrow[it] = idx / CH;
+        lchk[it] = idx - lrow[it] * CH;
+        const int n = n_first + lchk[it] * 8;
+        off[it] = n < a.N ? (unsigned)lrow[it] * row_bytes + (unsigned)n * 2u : OOB;
+      }
+      auto at = [&](int it, int pass) { return off[it] == OOB ? OOB : off[it] + (unsigned)pass * pass_bytes; };
+      u32x4 pre[2][ITS];
+      if constexpr (GBWD) {
 #pragma unroll
-          for (int it = 0; it < ITS; ++it) {
-            const int idx = it * 64 + lane, row = idx / CH, c = idx - row * CH;
-            const int n = n_first + c * 8;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(wbase + row * (WCOLS * 4) + c * 32);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(wbase + row * (WCOLS * 4) + c * 32 + 16);
+        for (int it = 0; it < ITS; ++it) pre[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_2, off[it], 0, 0);
+      }
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        stage(pass);
+        if constexpr (GBWD) {
+          if (pass + 1 < 4) {
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) pre[(pass + 1) & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_2, at(it, pass + 1), 0, 0);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          f32x4 v0 = *reinterpret_cast<const f32x4*>(wbase + lrow[it] * (WCOLS * 4) + lchk[it] * 32);
+          f32x4 v1 = *reinterpret_cast<const f32x4*>(wbase + lrow[it] * (WCOLS * 4) + lchk[it] * 32 + 16);
+          if constexpr (SAVE) {                                   // pre-activation out first, GELU in the row-major layout
             u32x4 w;
             w[0] = pack_bf16x2(v0[0], v0[1]);
             w[1] = pack_bf16x2(v0[2], v0[3]);
             w[2] = pack_bf16x2(v1[0], v1[1]);
             w[3] = pack_bf16x2(v1[2], v1[3]);
-            const unsigned o = n < a.N ? (unsigned)(pass * PR + row) * row_bytes + (unsigned)n * 2u : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, o, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs_2, at(it, pass), 0, 0);
+            const f32x2 g0 = gelu_erf2((f32x2){v0[0], v0[1]}), g1 = gelu_erf2((f32x2){v0[2], v0[3]});
+            const f32x2 g2 = gelu_erf2((f32x2){v1[0], v1[1]}), g3 = gelu_erf2((f32x2){v1[2], v1[3]});
+            v0 = (f32x4){g0[0], g0[1], g1[0], g1[1]};
+            v1 = (f32x4){g2[0], g2[1], g3[0], g3[1]};
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-      } else {
-        constexpr int CH = WCOLS / 4, ITS = PR * CH / 64;
+          if constexpr (GBWD) {
+            const u32x4 pw = pre[pass & 1][it];
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          stage(pass);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int it = 0; it < ITS; ++it) {
-            const int idx = it * 64 + lane, row = idx / CH, c = idx - row * CH;
-            const int n = n_first + c * 4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + row * (WCOLS * 4) + c * 16);
-            u32x2 w;
-            w[0] = pack_bf16x2(v[0], v[1]);
-            w[1] = pack_bf16x2(v[2], v[3]);
-            const unsigned o = n < a.N ? (unsigned)(pass * PR + row) * row_bytes + (unsigned)n * 2u : OOB;
-            __builtin_amdgcn_raw_buffer_store_b64(w, rs_out, o, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+              const f32x2 x = {__uint_as_float(pw[e] << 16), __uint_as_float(pw[e] & 0xFFFF0000u)};
+              const f32x2 g = gelu_grad2(x);
+              if (e < 2) { v0[2 * e] *= g[0]; v0[2 * e + 1] *= g[1]; }
+              else { v1[2 * (e - 2)] *= g[0]; v1[2 * (e - 2) + 1] *= g[1]; }
+            }
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          u32x4 w;
+          w[0] = pack_bf16x2(v0[0], v0[1]);
+          w[1] = pack_bf16x2(v0[2], v0[3]);
+          w[2] = pack_bf16x2(v1[0], v1[1]);
+          w[3] = pack_bf16x2(v1[2], v1[3]);
+          __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, at(it, pass), 0, 0);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    } else if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) {
+      constexpr int CH = WCOLS / 4, ITS = PR * CH / 64;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        stage(pass);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          const int idx = it * 64 + lane, row = idx / CH, c = idx - row * CH;
+          const int n = n_first + c * 4;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + row * (WCOLS * 4) + c * 16);
+          u32x2 w;
+          w[0] = pack_bf16x2(v[0], v[1]);
+          w[1] = pack_bf16x2(v[2], v[3]);
+          const unsigned o = n < a.N ? (unsigned)(pass * PR + row) * row_bytes + (unsigned)n * 2u : OOB;
+          __builtin_amdgcn_raw_buffer_store_b64(w, rs_out, o, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     }
   }
@@ -568,12 +645,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   } else {
     wait_vmcnt<0>();
   }
+  finish_col_consts<EPI, NT>(a, cb, cs);
   f32x4 acc[8][NT];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){cb[j], cb[j], cb[j], cb[j]};
-  finish_col_consts<EPI, NT>(a, cs);
   __builtin_amdgcn_s_barrier();
   // STAGGER: the wm==1 waves run one barrier interval behind the wm==0 waves, so on every SIMD one wave is in its
   // MFMA interval while its partner is in its LDS-read / DMA-issue interval (two barriers per phase: R | M).
@@ -739,12 +816,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
   __builtin_amdgcn_s_barrier();
 
   while (true) {
+    finish_col_consts<EPI, NT>(a, cb, cs);
     f32x4 acc[8][NT];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){cb[j], cb[j], cb[j], cb[j]};
-    finish_col_consts<EPI, NT>(a, cs);
     STAMP(t0s);
     if (wm == 1) __builtin_amdgcn_s_barrier();               // stagger in (see the one-shot kernel)
 
@@ -847,6 +924,14 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
       variant = (cost(192) < cost(256)) ? 6 : 5;
     }
   }
+  constexpr bool kTrainEpi = (EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
+  if (kTrainEpi || ((EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_F32) && !a.bias)) {   // large-tile kernels only
+    if (kTrainEpi && ((a.N & 7) != 0 || a.K < 128)) return UCOD_EINVAL;
+    if (variant < 3) {
+      auto cost = [&](int bn) { return (double)cdiv((long)cdiv(a.M, 256) * cdiv(a.N, bn), 256) * (0.45 * 256 + 0.55 * bn); };
+      variant = (cost(192) < cost(256)) ? 6 : 5;
+    }
+  }
   if (variant >= 3 && variant <= 8 && (a.N & 3) != 0) return UCOD_EINVAL;
   if (variant >= 3 && variant <= 8) {
     const bool wide = (variant == 3 || variant == 5 || variant == 7);
@@ -882,12 +967,14 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
 
 }  // namespace ucod
 
-extern "C" int ucod_gemm_bf16(int epilogue, const void* A, const void* B, void* out, int M, int N, int K, const float* bias,
-                              const float* scale, const float* resid, const float* pos, int tokens_per_image, int variant,
-                              void* stream) {
+static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int M, int N, int K, const float* bias,
+                      const float* scale, const float* resid, const float* pos, int tokens_per_image, int variant,
+                      void* stream, const void* aux, void* out2) {
   using namespace ucod;
   if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0) return UCOD_EINVAL;
   GemmArgs a;
+  a.aux = aux;
+  a.out2 = out2;
   a.stamps = nullptr;
 #ifdef UCOD_GEMM_STAMPS
   a.stamps = (unsigned long long*)pos;   // diagnostic build: the (otherwise unused here) `pos` argument carries the stamp buffer
@@ -906,9 +993,13 @@ extern "C" int ucod_gemm_bf16(int epilogue, const void* A, const void* B, void* 
   a.tiles_m = cdiv(M, BM);
   a.tiles_n = cdiv(N, BN);
   hipStream_t s = (hipStream_t)stream;
-  UCOD_PROF(epilogue >= 0 && epilogue <= 5 ? epilogue : 5, s);
+  UCOD_PROF(epilogue >= 0 && epilogue <= 5 ? epilogue : (epilogue == UCOD_EPI_GELU_BWD_BF16 ? PROF_GEMM_EPI6 : PROF_GEMM_EPI7), s);
   switch (epilogue) {
-    case UCOD_EPI_BIAS_BF16: if (!bias) return UCOD_EINVAL; return launch<UCOD_EPI_BIAS_BF16>(a, variant, s);
+    case UCOD_EPI_BIAS_BF16:                                   // NULL bias (plain product) only in the large-tile kernels
+      if (!bias && (variant == 1 || variant == 2 || K < 128 || (N & 3))) return UCOD_EINVAL;
+      return launch<UCOD_EPI_BIAS_BF16>(a, variant, s);
+    case UCOD_EPI_GELU_BWD_BF16: if (!aux) return UCOD_EINVAL; return launch<UCOD_EPI_GELU_BWD_BF16>(a, variant, s);
+    case UCOD_EPI_BIAS_GELU_SAVE_BF16: if (!bias || !out2) return UCOD_EINVAL; return launch<UCOD_EPI_BIAS_GELU_SAVE_BF16>(a, variant, s);
     case UCOD_EPI_BIAS_GELU_BF16: if (!bias) return UCOD_EINVAL; return launch<UCOD_EPI_BIAS_GELU_BF16>(a, variant, s);
     case UCOD_EPI_BIAS_SCALE_RESID_F32:
       if (!bias || !scale || !resid) return UCOD_EINVAL;
@@ -919,7 +1010,21 @@ extern "C" int ucod_gemm_bf16(int epilogue, const void* A, const void* B, void* 
     case UCOD_EPI_KEY_NCHW_F32:
       if (!bias || tokens_per_image < 2) return UCOD_EINVAL;
       return launch<UCOD_EPI_KEY_NCHW_F32>(a, variant, s);
-    case UCOD_EPI_BIAS_F32: if (!bias) return UCOD_EINVAL; return launch<UCOD_EPI_BIAS_F32>(a, variant, s);
+    case UCOD_EPI_BIAS_F32:
+      if (!bias && (variant == 1 || variant == 2 || K < 128 || (N & 3))) return UCOD_EINVAL;
+      return launch<UCOD_EPI_BIAS_F32>(a, variant, s);
     default: return UCOD_EINVAL;
   }
+}
+
+extern "C" int ucod_gemm_bf16(int epilogue, const void* A, const void* B, void* out, int M, int N, int K, const float* bias,
+                              const float* scale, const float* resid, const float* pos, int tokens_per_image, int variant,
+                              void* stream) {
+  if (epilogue == UCOD_EPI_GELU_BWD_BF16 || epilogue == UCOD_EPI_BIAS_GELU_SAVE_BF16) return UCOD_EINVAL;   // need ucod_gemm_bf16_train
+  return gemm_entry(epilogue, A, B, out, M, N, K, bias, scale, resid, pos, tokens_per_image, variant, stream, nullptr, nullptr);
+}
+
+extern "C" int ucod_gemm_bf16_train(int epilogue, const void* A, const void* B, void* out, int M, int N, int K, const float* bias,
+                                    const void* aux_bf16, void* out2_bf16, int variant, void* stream) {
+  return gemm_entry(epilogue, A, B, out, M, N, K, bias, nullptr, nullptr, nullptr, 0, variant, stream, aux_bf16, out2_bf16);
 }

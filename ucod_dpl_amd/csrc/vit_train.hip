@@ -1,0 +1,420 @@
+// Backbone-backward mode (models/modules/full_model.py:47-72,79-126: LoRA r=2, alpha=4 on the query /
+// key / value projections of every layer, everything else frozen).  Row-wise kernels of the training pass; the GEMMs and
+// the attention kernels live in gemm_bf16.hip / attention.hip / attention_bwd.hip, the pass itself in vit_train_driver.hip.
+//
+// LoRA rides on the big GEMMs as 64 extra K columns ("aug" columns), so no GEMM kernel knows about it:
+//   forward   h_aug  [M, D+64]  = [ LN1(x) | u = LN1(x) A^T (3r values: q,k,v) | 0 ]        (ucod_layernorm_lora)
+//             Wqkv_aug [3D, D+64] = [ Wqkv | alpha/r * B on the block diagonal | 0 ]         (ucod_lora_pack)
+//             qkv = h_aug Wqkv_aug^T  ==  LN1(x) Wqkv^T + alpha/r * (LN1(x) A^T) B^T
+//   backward  dqkv_aug [M, 3D+64] = [ dqkv | t = alpha/r * dqkv B (3r values) | 0 ]          (ucod_lora_grad)
+//             WqkvT_aug [D, 3D+64] = [ Wqkv^T | A^T | 0 ]                                     (ucod_lora_pack)
+//             dLN1 = dqkv_aug WqkvT_aug^T  ==  dqkv Wqkv + t A
+//             dA = t^T LN1(x),  dB = alpha/r * dqkv^T u                                        (ucod_lora_grad)
+// Parameter layout of one layer in the flat LoRA arena (f32): [A_q (r x D) | B_q (D x r) | A_k | B_k | A_v | B_v].
+#include "common.h"
+#include "../../include/ucod_dpl.h"
+
+namespace ucod {
+
+constexpr int AUG = UCOD_LORA_AUG;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm forward + LoRA down-projection.  One wave per row, D = 128*NCH, row in registers (as layernorm_kernel).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_lora_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ lora,
+                                                      int r, bf16_raw* __restrict__ y, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float2* xr = reinterpret_cast<const float2*>(x + (size_t)row * D);
+  float2 v[NCH];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    v[i] = xr[lane + 64 * i];
+    s += v[i].x + v[i].y;
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean;
+    q += a * a + b * b;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  const float2* g2 = reinterpret_cast<const float2*>(gamma);
+  const float2* b2 = reinterpret_cast<const float2*>(beta);
+  bf16_raw* yr = y + (size_t)row * (D + AUG);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const float2 g = g2[lane + 64 * i], b = b2[lane + 64 * i];
+    v[i].x = (v[i].x - mean) * rstd * g.x + b.x;
+    v[i].y = (v[i].y - mean) * rstd * g.y + b.y;
+    reinterpret_cast<unsigned*>(yr)[lane + 64 * i] = pack_bf16x2(v[i].x, v[i].y);
+  }
+  // u[p*r + j] = <LN(x), A_p[j]>,  p in {q,k,v}: A_p at lora + p*2*r*D
+  float mine = 0.f;
+  for (int p = 0; p < 3; ++p)
+    for (int j = 0; j < r; ++j) {
+      const float2* a2 = reinterpret_cast<const float2*>(lora + (size_t)p * 2 * r * D + (size_t)j * D);
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const float2 a = a2[lane + 64 * i];
+        d += v[i].x * a.x + v[i].y * a.y;
+      }
+      d = wave_sum(d);
+      if (lane == p * r + j) mine = d;
+    }
+  yr[D + lane] = f32_to_bf16(lane < 3 * r ? mine : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm backward w.r.t. its input (gamma / beta are frozen), fused with the residual add and with the column scale +
+// bf16 cast the NEXT dgrad GEMM wants as its A operand:
+//   g = dy * gamma;  dx_ln = rstd * (g - mean(g) - xhat * mean(g * xhat));   dx = dres + dx_ln;   s = bf16(scale * dx)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                     const float* __restrict__ scale, float* __restrict__ dx,
+                                                     bf16_raw* __restrict__ sout, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float2* xr = reinterpret_cast<const float2*>(x + (size_t)row * D);
+  const float2* dyr = reinterpret_cast<const float2*>(dy + (size_t)row * D);
+  const float2* g2 = reinterpret_cast<const float2*>(gamma);
+  float2 v[NCH], g[NCH];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    v[i] = xr[lane + 64 * i];
+    const float2 d = dyr[lane + 64 * i], gm = g2[lane + 64 * i];
+    g[i] = make_float2(d.x * gm.x, d.y * gm.y);
+    s += v[i].x + v[i].y;
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    v[i].x -= mean;
+    v[i].y -= mean;
+    q += v[i].x * v[i].x + v[i].y * v[i].y;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    v[i].x *= rstd;
+    v[i].y *= rstd;
+    sg += g[i].x + g[i].y;
+    sgx += g[i].x * v[i].x + g[i].y * v[i].y;
+  }
+  const float mg = wave_sum(sg) / (float)D, mgx = wave_sum(sgx) / (float)D;
+  const float2* rr = dres ? reinterpret_cast<const float2*>(dres + (size_t)row * D) : nullptr;
+  const float2* sc2 = scale ? reinterpret_cast<const float2*>(scale) : nullptr;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    float o0 = rstd * (g[i].x - mg - v[i].x * mgx), o1 = rstd * (g[i].y - mg - v[i].y * mgx);
+    if (rr) {
+      const float2 r = rr[lane + 64 * i];
+      o0 += r.x;
+      o1 += r.y;
+    }
+    if (dx) reinterpret_cast<float2*>(dx + (size_t)row * D)[lane + 64 * i] = make_float2(o0, o1);
+    if (sout) {
+      float c0 = 1.f, c1 = 1.f;
+      if (sc2) {
+        const float2 c = sc2[lane + 64 * i];
+        c0 = c.x;
+        c1 = c.y;
+      }
+      reinterpret_cast<unsigned*>(sout + (size_t)row * D)[lane + 64 * i] = pack_bf16x2(o0 * c0, o1 * c1);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Cotangent of the key hook, [B, D, h*w] f32 (CLS dropped, NCHW) -> token-major rows of dqkv_aug: the k third gets the
+// transposed values (CLS row 0), the q and v thirds are zero (the last layer's q / v never reach the loss).
+// Block = (image, 32 tokens); 32x32 LDS transposes over the channel axis.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void key_grad_tokens_kernel(const float* __restrict__ dkey, bf16_raw* __restrict__ dqkv, int tok,
+                                                              int D) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.y, t0 = blockIdx.x * 32;
+  const int hw = tok - 1, ld = 3 * D + AUG;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+  bf16_raw* base = dqkv + (size_t)b * tok * ld;
+  // zero q, v (and aug) of these rows
+  for (int rr = 0; rr < 32; ++rr) {
+    const int t = t0 + rr;
+    if (t >= tok) break;
+    bf16_raw* rowp = base + (size_t)t * ld;
+    for (int c = threadIdx.x; c < D; c += 256) { rowp[c] = 0; rowp[2 * D + c] = 0; }
+    if (threadIdx.x < AUG) rowp[3 * D + threadIdx.x] = 0;
+  }
+  for (int c0 = 0; c0 < D; c0 += 32) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + ty + 8 * k, t = t0 + tx;                 // read: tokens contiguous
+      float v = 0.f;
+      if (t >= 1 && t < tok) v = dkey[((size_t)b * D + c) * hw + (t - 1)];
+      tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = t0 + ty + 8 * k, c = c0 + tx;                 // write: channels contiguous
+      if (t < tok) base[(size_t)t * ld + D + c] = f32_to_bf16(tile[tx][ty + 8 * k]);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LoRA pack: aug columns of Wqkv_aug [3D, D+64] and WqkvT_aug [D, 3D+64] from one layer's LoRA parameters.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict__ lora, int r, float scaling, bf16_raw* __restrict__ w_aug,
+                                                        bf16_raw* __restrict__ wt_aug, int D) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;                // one thread per (row, aug column) of either matrix
+  const int n_fwd = 3 * D * AUG;
+  if (idx < n_fwd) {
+    if (!w_aug) return;
+    const int n = idx / AUG, j = idx - n * AUG;                  // row n of Wqkv (which of q/k/v: p), aug column j
+    const int p = n / D, nn = n - p * D;
+    float v = 0.f;
+    if (j >= p * r && j < (p + 1) * r) v = scaling * lora[(size_t)p * 2 * r * D + (size_t)r * D + (size_t)nn * r + (j - p * r)];   // B_p[nn][j']
+    w_aug[(size_t)n * (D + AUG) + D + j] = f32_to_bf16(v);
+    return;
+  }
+  const int k = idx - n_fwd;
+  if (k >= D * AUG || !wt_aug) return;
+  const int d = k / AUG, j = k - d * AUG;
+  float v = 0.f;
+  if (j < 3 * r) {
+    const int p = j / r, jj = j - p * r;
+    v = lora[(size_t)p * 2 * r * D + (size_t)jj * D + d];        // A_p[jj][d]
+  }
+  wt_aug[(size_t)d * (3 * D + AUG) + 3 * D + j] = f32_to_bf16(v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LoRA gradients of one layer, ranks [j0, j0+RW) of each of q, k, v in one pass over dqkv and LN1(x):
+//   t[m][p][j]  = scaling * sum_n dqkv[m][pD+n] * B_p[n][j]          -> aug columns of dqkv_aug (bf16)
+//   dA_p[j][d] += t[m][p][j] * h[m][d]
+//   dB_p[n][j] += scaling * dqkv[m][pD+n] * u[m][p][j]                (u = aug columns of h_aug)
+// One wave per row at a time, lane owns columns {2*lane, 2*lane+1} + 128*i of each D-wide slice; B from LDS; per-wave
+// register accumulators, combined per block through LDS and written as one partial per block (summed in a fixed order by
+// lora_grad_reduce_kernel: deterministic).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NCH, int RW>
+__global__ __launch_bounds__(256) void lora_grad_kernel(bf16_raw* __restrict__ dqkv, const bf16_raw* __restrict__ h,
+                                                        const float* __restrict__ lora, int r, int j0, float scaling,
+                                                        float* __restrict__ partial, int rows, int D) {
+  extern __shared__ float lds[];                                  // B window [3][D][RW], later the block reduction buffer
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ldq = 3 * D + AUG, ldh = D + AUG;
+  for (int i = threadIdx.x; i < 3 * D * RW; i += 256) {
+    const int p = i / (D * RW), rem = i - p * D * RW, n = rem / RW, j = rem - n * RW;
+    lds[i] = (j0 + j < r) ? lora[(size_t)p * 2 * r * D + (size_t)r * D + (size_t)n * r + j0 + j] : 0.f;
+  }
+  __syncthreads();
+  float accA[3][RW][NCH][2], accB[3][NCH][2][RW];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        accA[p][j][i][0] = accA[p][j][i][1] = 0.f;
+        accB[p][i][0][j] = accB[p][i][1][j] = 0.f;
+      }
+  const int nw = gridDim.x * 4;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += nw) {
+    const unsigned* dq = reinterpret_cast<const unsigned*>(dqkv + (size_t)row * ldq);
+    const unsigned* hr = reinterpret_cast<const unsigned*>(h + (size_t)row * ldh);
+    float hv[NCH][2];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const unsigned w = hr[lane + 64 * i];
+      hv[i][0] = __uint_as_float(w << 16);
+      hv[i][1] = __uint_as_float(w & 0xFFFF0000u);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      float dv[NCH][2], t[RW], u[RW];
+#pragma unroll
+      for (int j = 0; j < RW; ++j) {
+        t[j] = 0.f;
+        const int jj = j0 + j;
+        u[j] = jj < r ? bf16_to_f32(h[(size_t)row * ldh + D + p * r + jj]) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const unsigned w = dq[p * (D / 2) + lane + 64 * i];
+        dv[i][0] = __uint_as_float(w << 16);
+        dv[i][1] = __uint_as_float(w & 0xFFFF0000u);
+        const int n = 2 * (lane + 64 * i);
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+          t[j] += dv[i][0] * lds[(p * D + n) * RW + j] + dv[i][1] * lds[(p * D + n + 1) * RW + j];
+          accB[p][i][0][j] += dv[i][0] * u[j];
+          accB[p][i][1][j] += dv[i][1] * u[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RW; ++j) {
+        t[j] = bf16_to_f32(f32_to_bf16(scaling * wave_sum(t[j])));   // the dgrad GEMM sees the bf16 value: use it for dA too
+        if (lane == 0 && j0 + j < r) dqkv[(size_t)row * ldq + 3 * D + p * r + j0 + j] = f32_to_bf16(t[j]);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          accA[p][j][i][0] += t[j] * hv[i][0];
+          accA[p][j][i][1] += t[j] * hv[i][1];
+        }
+      }
+    }
+  }
+  // block combine: [3][RW][D] (dA window) then [3][D][RW] (dB window)
+  __syncthreads();
+  const int nA = 3 * RW * D, nB = 3 * D * RW;
+  float* out = partial + (size_t)blockIdx.x * (nA + nB);
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int j = 0; j < RW; ++j)
+#pragma unroll
+          for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int d = 2 * (lane + 64 * i) + e;
+              const int ia = (p * RW + j) * D + d, ib = nA + (p * D + d) * RW + j;
+              if (w == 0) {
+                lds[ia] = accA[p][j][i][e];
+                lds[ib] = scaling * accB[p][i][e][j];
+              } else {
+                lds[ia] += accA[p][j][i][e];
+                lds[ib] += scaling * accB[p][i][e][j];
+              }
+            }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < nA + nB; i += 256) out[i] = lds[i];
+}
+
+// grad layout = parameter layout of the layer: [A_q | B_q | A_k | B_k | A_v | B_v]; accumulate = add to existing content
+template <int RW>
+__global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __restrict__ partial, int nblk, int r, int j0, float* __restrict__ grad,
+                                                               int D, int accumulate) {
+  const int nA = 3 * RW * D, nB = 3 * D * RW;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nA + nB) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * (nA + nB) + i];
+  int p, j, d;
+  size_t dst;
+  if (i < nA) {
+    p = i / (RW * D);
+    j = (i - p * RW * D) / D;
+    d = i - p * RW * D - j * D;
+    if (j0 + j >= r) return;
+    dst = (size_t)p * 2 * r * D + (size_t)(j0 + j) * D + d;
+  } else {
+    const int k = i - nA;
+    p = k / (D * RW);
+    d = (k - p * D * RW) / RW;
+    j = k - p * D * RW - d * RW;
+    if (j0 + j >= r) return;
+    dst = (size_t)p * 2 * r * D + (size_t)r * D + (size_t)d * r + j0 + j;
+  }
+  grad[dst] = accumulate ? grad[dst] + s : s;
+}
+
+constexpr int LORA_GRAD_BLOCKS = 512;
+
+}  // namespace ucod
+
+using namespace ucod;
+
+extern "C" int ucod_layernorm_lora(const float* x, const float* gamma, const float* beta, const float* lora, int r, void* y_aug, int rows,
+                                   int D, float eps, void* stream) {
+  if (!x || !gamma || !beta || !lora || !y_aug || rows <= 0 || D <= 0 || (D % 128) != 0 || r < 1 || 3 * r > AUG) return UCOD_EINVAL;
+  UCOD_PROF(PROF_LN, stream);
+  dim3 grid(cdiv(rows, 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (D / 128) {
+#define C(n) case n: hipLaunchKernelGGL((ln_lora_kernel<n>), grid, block, 0, s, x, gamma, beta, lora, r, (bf16_raw*)y_aug, rows, D, eps); break;
+    C(1) C(2) C(3) C(4) C(5) C(6) C(8) C(10) C(12)
+#undef C
+    default: return UCOD_EINVAL;
+  }
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
+                                  void* s_bf16, int rows, int D, float eps, void* stream) {
+  if (!dy || !x || !gamma || (!dx && !s_bf16) || rows <= 0 || D <= 0 || (D % 128) != 0) return UCOD_EINVAL;
+  UCOD_PROF(PROF_LN_BWD, stream);
+  dim3 grid(cdiv(rows, 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (D / 128) {
+#define C(n) case n: hipLaunchKernelGGL((ln_bwd_kernel<n>), grid, block, 0, s, dy, x, gamma, dres, next_scale, dx, (bf16_raw*)s_bf16, rows, D, eps); break;
+    C(1) C(2) C(3) C(4) C(5) C(6) C(8) C(10) C(12)
+#undef C
+    default: return UCOD_EINVAL;
+  }
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_key_grad_tokens(const float* dkey, void* dqkv_aug, int B, int tok, int D, void* stream) {
+  if (!dkey || !dqkv_aug || B <= 0 || tok < 2 || D <= 0 || (D % 32) != 0) return UCOD_EINVAL;
+  UCOD_PROF(PROF_LORA, stream);
+  hipLaunchKernelGGL(key_grad_tokens_kernel, dim3(cdiv(tok, 32), B), dim3(256), 0, (hipStream_t)stream, dkey, (bf16_raw*)dqkv_aug, tok, D);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_lora_pack(const float* lora_layer, int r, float scaling, void* w_aug, void* wt_aug, int D, void* stream) {
+  if (!lora_layer || (!w_aug && !wt_aug) || r < 1 || 3 * r > AUG || D <= 0) return UCOD_EINVAL;
+  UCOD_PROF(PROF_LORA, stream);
+  const int n = 3 * D * AUG + D * AUG;
+  hipLaunchKernelGGL(lora_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, lora_layer, r, scaling, (bf16_raw*)w_aug,
+                     (bf16_raw*)wt_aug, D);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" size_t ucod_lora_grad_workspace_bytes(int D) { return (size_t)LORA_GRAD_BLOCKS * (size_t)(12 * D) * sizeof(float); }
+
+extern "C" int ucod_lora_grad(void* dqkv_aug, const void* h_aug, const float* lora_layer, int r, float scaling, float* grad_layer,
+                              int accumulate, void* workspace, size_t workspace_bytes, int rows, int D, void* stream) {
+  if (!dqkv_aug || !h_aug || !lora_layer || !grad_layer || !workspace || r < 1 || 3 * r > AUG || rows <= 0 || D <= 0 || (D % 128) != 0)
+    return UCOD_EINVAL;
+  if (workspace_bytes < ucod_lora_grad_workspace_bytes(D)) return UCOD_ENOMEM;
+  UCOD_PROF(PROF_LORA, stream);
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int RW = 2;                                           // ranks per pass (the reference's r = 2 is one pass)
+  const int nblk = rows < LORA_GRAD_BLOCKS * 4 ? cdiv(rows, 4) : LORA_GRAD_BLOCKS;
+  const size_t lds_bytes = (size_t)6 * D * RW * sizeof(float);      // B window (3*D*RW) <= block reduction buffer (6*D*RW)
+  for (int j0 = 0; j0 < r; j0 += RW) {
+    switch (D / 128) {
+#define C(n) case n: hipLaunchKernelGGL((lora_grad_kernel<n, RW>), dim3(nblk), dim3(256), lds_bytes, s, (bf16_raw*)dqkv_aug, (const bf16_raw*)h_aug, lora_layer, r, j0, scaling, (float*)workspace, rows, D); break;
+      C(1) C(2) C(3) C(4) C(5) C(6) C(8)
+#undef C
+      default: return UCOD_EINVAL;
+    }
+    UCOD_CHECK_LAUNCH();
+    hipLaunchKernelGGL((lora_grad_reduce_kernel<RW>), dim3(cdiv(6 * RW * D, 256)), dim3(256), 0, s, (const float*)workspace, nblk, r, j0,
+                       grad_layer, D, accumulate);
+    UCOD_CHECK_LAUNCH();
+  }
+  return UCOD_OK;
+}

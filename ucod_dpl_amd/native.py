@@ -12,7 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_native", "libucod_dpl.so")
 
 EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_SCALE_RESID_F32, EPI_PATCH_TOKENS_F32, EPI_KEY_NCHW_F32, EPI_BIAS_F32 = range(6)
+EPI_GELU_BWD_BF16, EPI_BIAS_GELU_SAVE_BF16 = 6, 7          # ucod_gemm_bf16_train only (backbone-backward mode)
 VIT_LAYER_STRIDE = 14
+VIT_TRAIN_STRIDE = 7
+LORA_AUG = 64
 
 vp, ci, cf, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -20,6 +23,10 @@ vp, ci, cf, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 class VitDesc(C.Structure):
     _fields_ = [(n, ci) for n in ("B", "C", "H", "W", "P", "D", "heads", "F", "L", "Kpad")] + [("eps", cf)] + \
                [(n, ci) for n in ("full_last_layer", "gemm_variant", "attn_variant")]
+
+
+class VitTrainDesc(C.Structure):
+    _fields_ = [("vit", VitDesc), ("lora_r", ci), ("lora_scaling", cf)]
 
 
 class DiscParams(C.Structure):
@@ -48,6 +55,18 @@ SIGNATURES = {
     "ucod_cast_f32_bf16": (ci, [vp, vp, sz, vp]),
     "ucod_vit_workspace_bytes": (sz, [C.POINTER(VitDesc)]),
     "ucod_vit_forward": (ci, [C.POINTER(VitDesc), C.POINTER(vp), vp, vp, vp, sz, vp]),
+    "ucod_vit_train_workspace_bytes": (sz, [C.POINTER(VitTrainDesc)]),
+    "ucod_vit_forward_train": (ci, [C.POINTER(VitTrainDesc), C.POINTER(vp), C.POINTER(vp), vp, vp, vp, sz, vp]),
+    "ucod_vit_backward": (ci, [C.POINTER(VitTrainDesc), C.POINTER(vp), C.POINTER(vp), vp, vp, sz, vp]),
+    "ucod_gemm_bf16_train": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, ci, vp]),
+    "ucod_layernorm_lora": (ci, [vp, vp, vp, vp, ci, vp, ci, ci, cf, vp]),
+    "ucod_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp]),
+    "ucod_attention_fwd_lse": (ci, [vp, vp, vp, ci, ci, ci, vp]),
+    "ucod_attention_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "ucod_key_grad_tokens": (ci, [vp, vp, ci, ci, ci, vp]),
+    "ucod_lora_pack": (ci, [vp, ci, cf, vp, vp, ci, vp]),
+    "ucod_lora_grad_workspace_bytes": (sz, [ci]),
+    "ucod_lora_grad": (ci, [vp, vp, vp, ci, cf, vp, ci, vp, sz, ci, ci, vp]),
     "ucod_bilinear_resize": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "ucod_bilinear_resize_adjoint": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "ucod_dba_project": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),

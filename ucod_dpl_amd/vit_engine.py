@@ -180,3 +180,128 @@ class ViTEngine:
         return key
 
     __call__ = forward
+
+
+_QKV = ("query", "key", "value")
+
+
+class ViTLoRAEngine(ViTEngine):
+    """Backbone-backward mode: the frozen ViT with peft-style LoRA on query / key / value of every
+    encoder layer, as models/modules/full_model.py:47-72 configures it (r=2, lora_alpha=4, bias='none', target
+    query/key/value; lora_A kaiming_uniform(a=sqrt 5), lora_B zeros).  ``forward_train`` saves activations,
+    ``backward`` turns the cotangent of the key map into LoRA gradients -- both entirely in the HIP library
+    (``ucod_vit_forward_train`` / ``ucod_vit_backward``).  LoRA dropout (0.05 in the reference config) is not applied.
+
+    Parameters live in ONE flat f32 arena ``self.lora`` [L, 6*r*D] (layer-major: A_q | B_q | A_k | B_k | A_v | B_v), gradients
+    in ``self.lora_grad`` with the same layout -- ready for a single flat all-reduce and the fused AdamW kernel."""
+
+    def __init__(self, state_dict, heads, r=2, lora_alpha=4, eps=1e-6, device="cuda", gemm_variant=0, generator=None):
+        super().__init__(state_dict, heads, eps=eps, device=device, full_last_layer=False, gemm_variant=gemm_variant, attn_variant=2)
+        if r < 1 or 3 * r > N.LORA_AUG:
+            raise ValueError(f"LoRA rank {r} unsupported (1 <= r <= {N.LORA_AUG // 3})")
+        self.r, self.scaling = int(r), float(lora_alpha) / float(r)
+        D, L, dev = self.D, self.L, self.device
+        self.lora = torch.zeros(L, 6 * r * D, dtype=torch.float32, device=dev)
+        bound = 1.0 / math.sqrt(D)                      # kaiming_uniform_(a=sqrt(5)) on [r, D]: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+        a = (torch.rand(L, 3, r * D, generator=generator) * 2 - 1) * bound
+        for p in range(3):
+            self.lora[:, p * 2 * r * D:p * 2 * r * D + r * D] = a[:, p].to(dev)
+        self.lora_grad = torch.zeros_like(self.lora)
+        A = N.LORA_AUG
+        self.train_layers = []
+        for l in self.layers:
+            qkv_w, proj_w, fc1_w, fc2_w = l[2], l[4], l[9], l[11]
+            w_aug = torch.zeros(3 * D, D + A, dtype=torch.bfloat16, device=dev)
+            w_aug[:, :D] = qkv_w
+            wt_aug = torch.zeros(D, 3 * D + A, dtype=torch.bfloat16, device=dev)
+            wt_aug[:, :3 * D] = qkv_w.t()
+            self.train_layers.append([w_aug, wt_aug, proj_w.t().contiguous(), fc1_w.t().contiguous(), fc2_w.t().contiguous()])
+        self._tws = None
+        self._saved_for = None
+        self.repack()
+
+    # ---- parameters -------------------------------------------------------------------------------------------------
+    def _slices(self, p):
+        rD = self.r * self.D
+        return slice(p * 2 * rD, p * 2 * rD + rD), slice(p * 2 * rD + rD, (p + 1) * 2 * rD)
+
+    def lora_state_dict(self, grads=False, prefix="encoder.layer."):
+        """peft-style names: encoder.layer.{i}.attention.attention.{query,key,value}.lora_{A,B}.weight"""
+        src = self.lora_grad if grads else self.lora
+        out = {}
+        for i in range(self.L):
+            for p, name in enumerate(_QKV):
+                sa, sb = self._slices(p)
+                base = f"{prefix}{i}.attention.attention.{name}."
+                out[base + "lora_A.weight"] = src[i, sa].reshape(self.r, self.D).clone()
+                out[base + "lora_B.weight"] = src[i, sb].reshape(self.D, self.r).clone()
+        return out
+
+    def load_lora_state_dict(self, sd, prefix="encoder.layer."):
+        for i in range(self.L):
+            for p, name in enumerate(_QKV):
+                sa, sb = self._slices(p)
+                base = f"{prefix}{i}.attention.attention.{name}."
+                self.lora[i, sa] = sd[base + "lora_A.weight"].to(self.device, torch.float32).reshape(-1)
+                self.lora[i, sb] = sd[base + "lora_B.weight"].to(self.device, torch.float32).reshape(-1)
+        self.repack()
+
+    def repack(self):
+        """Refresh the LoRA columns of the augmented weights (call after every parameter update)."""
+        lib = N.load()
+        for i, tl in enumerate(self.train_layers):
+            N.check(lib.ucod_lora_pack(N.ptr(self.lora[i]), self.r, self.scaling, N.ptr(tl[0]), N.ptr(tl[1]), self.D, N.stream()), "ucod_lora_pack")
+
+    # ---- passes -----------------------------------------------------------------------------------------------------
+    def _train_desc(self, B, H, W):
+        t = N.VitTrainDesc()
+        t.vit = self._desc(B, H, W)
+        t.lora_r, t.lora_scaling = self.r, self.scaling
+        return t
+
+    def _tables(self, gh, gw):
+        pos = self._pos(gh, gw)
+        ptrs = [self.patch_w, self.patch_b, self.cls, pos]
+        for l in self.layers:
+            ptrs += l
+        tptrs = []
+        for i, tl in enumerate(self.train_layers):
+            tptrs += tl + [self.lora[i], self.lora_grad[i]]
+        keep = ptrs + tptrs
+        return (C.c_void_p * len(ptrs))(*[t.data_ptr() for t in ptrs]), (C.c_void_p * len(tptrs))(*[t.data_ptr() for t in tptrs]), keep
+
+    def forward_train(self, img, out=None):
+        if not img.is_cuda:
+            raise RuntimeError("ViTLoRAEngine needs a CUDA(ROCm) tensor; there is no CPU path")
+        img = img.to(torch.float32).contiguous()
+        B, _, H, W = img.shape
+        gh, gw = H // self.P, W // self.P
+        lib = N.load()
+        t = self._train_desc(B, H, W)
+        need = lib.ucod_vit_train_workspace_bytes(C.byref(t))
+        if need == 0:
+            raise ValueError("unsupported ViT geometry")
+        if self._tws is None or self._tws.numel() < need:
+            self._tws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        T, TT, keep = self._tables(gh, gw)
+        key = out if out is not None else torch.empty(B, self.D, gh, gw, dtype=torch.float32, device=self.device)
+        N.check(lib.ucod_vit_forward_train(C.byref(t), T, TT, N.ptr(img), N.ptr(key), N.ptr(self._tws), self._tws.numel(), N.stream()),
+                "ucod_vit_forward_train")
+        self._saved_for = (B, H, W)
+        return key
+
+    def backward(self, dkey):
+        """dkey [B, D, H/P, W/P] -> self.lora_grad (overwritten), returned as the flat [L, 6*r*D] tensor."""
+        if self._saved_for is None:
+            raise RuntimeError("backward() without a preceding forward_train()")
+        B, H, W = self._saved_for
+        gh, gw = H // self.P, W // self.P
+        dkey = dkey.to(torch.float32).contiguous()
+        if tuple(dkey.shape) != (B, self.D, gh, gw):
+            raise ValueError(f"dkey shape {tuple(dkey.shape)} != {(B, self.D, gh, gw)}")
+        lib = N.load()
+        t = self._train_desc(B, H, W)
+        T, TT, keep = self._tables(gh, gw)
+        N.check(lib.ucod_vit_backward(C.byref(t), T, TT, N.ptr(dkey), N.ptr(self._tws), self._tws.numel(), N.stream()), "ucod_vit_backward")
+        self._saved_for = None
+        return self.lora_grad
