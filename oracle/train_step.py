@@ -85,9 +85,11 @@ def update_ema(state):
     return alpha
 
 
-def process_batch(state, features, pseudo_labels, orth="gram"):
+def process_batch(state, features, pseudo_labels, orth="gram", extra_leaves=None):
     """loop_UCOD_DPL.py:148-184.  features [B,C,h,w], pseudo_labels [B,1,ph,pw].
-    Returns dict(loss, dis_loss, extra, w, merged, fg, bg, teacher, grads, alpha, lr)."""
+    Returns dict(loss, dis_loss, extra, w, merged, fg, bg, teacher, grads, alpha, lr).
+    ``extra_leaves``: tensors upstream of ``features`` (backbone-backward mode, SURVEY.md 8a row B9: the LoRA matrices,
+    or ``features`` itself) whose gradients of the same loss are returned as ``extra_grads``."""
     c = state.cfg
     fs = c["feature_size"]
     feats = torch_bilinear(features, fs, fs)
@@ -104,7 +106,10 @@ def process_batch(state, features, pseudo_labels, orth="gram"):
         loss = loss - dis_loss
     loss = loss + bce_with_logits_mean(bg.permute(0, 2, 3, 1).reshape(-1, 1), 1 - merged.permute(0, 2, 3, 1).reshape(-1, 1))
     loss = loss + extra
-    grads = dict(zip(p.keys(), torch.autograd.grad(loss, list(p.values()), allow_unused=True)))
+    extra_leaves = list(extra_leaves or [])
+    allg = torch.autograd.grad(loss, list(p.values()) + extra_leaves, allow_unused=True)
+    grads = dict(zip(p.keys(), allg[:len(p)]))
+    extra_grads = [torch.zeros_like(t) if g is None else g for t, g in zip(extra_leaves, allg[len(p):])]
     lr_used = state.opt.lr
     with torch.no_grad():
         state.opt.step(state.dec, grads)
@@ -112,7 +117,7 @@ def process_batch(state, features, pseudo_labels, orth="gram"):
         alpha = update_ema(state)
     state.global_step += 1                               # :182 (the caller run_epoch adds one more, :143)
     return dict(loss=loss.detach(), dis_loss=dis_loss, extra=extra.detach(), w=w, merged=merged, fg=fg.detach(),
-                bg=bg.detach(), teacher=teacher, grads=grads, alpha=alpha, lr=lr_used, p_s=p_s, p_p=p_p)
+                bg=bg.detach(), teacher=teacher, grads=grads, alpha=alpha, lr=lr_used, p_s=p_s, p_p=p_p, extra_grads=extra_grads)
 
 
 def discriminator_batch(state, features, pseudo_labels):

@@ -306,3 +306,114 @@ def test_medium_model_lora_gradients_vs_oracle_autograd():
             assert float(got[k].abs().max()) == 0.0, k
         else:
             assert rel_l2(got[k], ref) < 5e-2, (k, rel_l2(got[k], ref))
+
+
+def test_full_model_backward_through_decoder_and_backbone():
+    """models/modules/full_model.py mirror: image -> LoRA backbone -> key hook (bilinear 68x68) -> DBA decoder -> loss, and
+    loss.backward() down to the LoRA matrices, against the CPU oracle (oracle ViT + oracle decoder + torch autograd)."""
+    from oracle import decoder as OD
+    from oracle.resize import torch_bilinear
+    from ucod_dpl_amd.engine.config import CfgNode
+    from ucod_dpl_amd.models.modules.full_model import full_model, load_lora
+    from ucod_dpl_amd.models.uscod import baseline
+    g = load_golden("g12_lora_backbone")
+    sd = sub(g, "sd.")
+    base = {k: v for k, v in sd.items() if ".lora_" not in k}
+    torch.manual_seed(0)
+    cfg = CfgNode(dict(model_cfg=dict(dim=128, feature_size=8, ema_weight=0.99, enable_ocm=False, freeze_lora=False), lora_cfg=dict(r=2, lora_alpha=4)))
+    dec = baseline(cfg.model_cfg).to(DEV)
+    bb = load_lora(cfg.lora_cfg, base, heads=2, device=DEV)
+    bb.engine.load_lora_state_dict(sd)
+    fm = full_model(cfg, bb, dec)
+    fm.hook_size = HS = 8              # the tiny model has a 5x5 grid: 5->68 is outside the adjoint kernel's tap budget (37->68 is the real case)
+    x = g["x"]
+    gen = torch.Generator().manual_seed(9)
+    r1, r2 = torch.randn(2, 1, HS, HS, generator=gen), torch.randn(2, 1, HS, HS, generator=gen)
+    fg, bgm, extra = fm(x.to(DEV))
+    loss = (fg * r1.to(DEV)).sum() + (bgm * r2.to(DEV)).sum() + 100.0 * extra
+    loss.backward()
+    got = fm.backbone.lora.grad
+    assert got is not None and got.shape == bb.engine.lora.shape
+    # oracle
+    names = [k for k in sd if ".lora_" in k]
+    leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
+    sd2 = dict(sd)
+    sd2.update(leaf)
+    _, key = OV.dinov2_forward(x, sd2, heads=2, full_last_layer=False, lora_scale=2.0)
+    key68 = torch_bilinear(key, HS, HS)
+    p = {k: v.detach().cpu() for k, v in dec.decoder.state_dict().items()}
+    ofg, obg, oextra = OD.rev_decoder_forward(key68, p, orth="gram")
+    oloss = (ofg * r1).sum() + (obg * r2).sum() + 100.0 * oextra
+    gref = torch.autograd.grad(oloss, [leaf[k] for k in names], allow_unused=True)
+    assert abs(loss.item() - oloss.item()) < 2e-2 * max(1.0, abs(oloss.item()))
+    eng_grads = {}
+    flat = got.detach()
+    rD = 2 * 128
+    for i in range(3):
+        for pi, nm in enumerate(("query", "key", "value")):
+            basek = f"encoder.layer.{i}.attention.attention.{nm}."
+            eng_grads[basek + "lora_A.weight"] = flat[i, pi * 2 * rD:pi * 2 * rD + rD].reshape(2, 128)
+            eng_grads[basek + "lora_B.weight"] = flat[i, pi * 2 * rD + rD:(pi + 1) * 2 * rD].reshape(128, 2)
+    for k, ref in zip(names, gref):
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert float(eng_grads[k].abs().max()) == 0.0, k
+        else:
+            assert rel_l2(eng_grads[k], ref) < 5e-2, (k, rel_l2(eng_grads[k], ref))
+    # EMA path: no grad, same call shape
+    t = fm(x.to(DEV), ema=True)
+    assert t.shape == (2, 1, HS, HS) and not t.requires_grad
+
+
+def test_fused_full_step_against_oracle():
+    """TrainLoop._process_batch_full (images -> LoRA backbone -> decoder/APM/discriminator step -> backbone backward ->
+    optimisers) vs the CPU oracle: oracle ViT(+LoRA) feeding oracle process_batch, autograd down to the LoRA matrices."""
+    from oracle import train_step as OT
+    from test_gpu_train_step import make_cfg
+    from ucod_dpl_amd.engine.runner import StandardRunner, TrainLoop
+    g = load_golden("g12_lora_backbone")
+    sd = sub(g, "sd.")
+    base = {k: v for k, v in sd.items() if ".lora_" not in k}
+    cfg = make_cfg(C=128, fs=8)
+    torch.manual_seed(3)
+    runner = StandardRunner(cfg)
+    loop = TrainLoop(runner.config, runner)
+    eng = ViTLoRAEngine(base, heads=2, r=2, lora_alpha=4, device=DEV)
+    eng.load_lora_state_dict(sd)
+    loop.attach_lora_backbone(eng)
+    dec0 = {k: v.detach().cpu().clone() for k, v in runner.model.decoder.state_dict().items()}
+    ema0 = {k: v.detach().cpu().clone() for k, v in runner.model.decoder_ema.state_dict().items()}
+    disc0 = {k: v.detach().cpu().clone() for k, v in runner.discriminator.state_dict().items()}
+    lora0 = eng.lora.detach().cpu().clone()
+    gen = torch.Generator().manual_seed(11)
+    x = g["x"]
+    pl = (torch.rand(2, 1, 16, 16, generator=gen) > 0.5).float()
+    loss = loop._process_batch_full(x, pl)
+    # ---- oracle
+    CFG = dict(feature_size=8, ema_weight=0.99, lr0=6e-4, dis_lr0=1e-3, step_lr_size=2, step_lr_gamma=0.95, dis_step_lr_size=2,
+               dis_step_lr_gamma=0.95, max_epoch=25, start_finetune=-5)
+    st = OT.TrainState(dec0, ema0, disc0, CFG)
+    names = [k for k in sd if ".lora_" in k]
+    leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
+    sd2 = dict(sd)
+    sd2.update(leaf)
+    _, key = OV.dinov2_forward(x, sd2, heads=2, full_last_layer=False, lora_scale=2.0)
+    out = OT.process_batch(st, key, pl, orth="gram", extra_leaves=[leaf[k] for k in names])
+    assert abs(loss.item() - out["loss"].item()) < 2e-2 * max(1.0, abs(out["loss"].item())), (loss.item(), out["loss"].item())
+    got = eng.lora_state_dict(grads=True)
+    checked = 0
+    for k, ref in zip(names, out["extra_grads"]):
+        if float(ref.abs().max()) == 0.0:
+            assert float(got[k].abs().max()) == 0.0, k
+        else:
+            assert rel_l2(got[k], ref) < 8e-2, (k, rel_l2(got[k], ref))
+            checked += 1
+    assert checked == 14                                                # 3 layers x 3 x 2 minus the last layer's query/value
+    # the LoRA parameters moved (AdamW), the teacher's copy followed by EMA (alpha = 0 on the first step: copy of the student)
+    assert float((eng.lora.cpu() - lora0).abs().max()) > 0
+    assert maxdiff(loop.lora_engine_ema.lora.cpu(), eng.lora.cpu()) < 1e-7
+    # decoder parameters after the step vs the oracle's optimiser
+    sd_after = {k: v.cpu() for k, v in runner.model.decoder.state_dict().items()}
+    for k, v in st.dec.items():
+        if k == "learnable_embedding":
+            continue
+        assert maxdiff(sd_after[k], v) < 2e-3 * max(1e-3, v.abs().max().item()) + 1.5e-3, (k, maxdiff(sd_after[k], v))

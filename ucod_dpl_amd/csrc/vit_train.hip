@@ -207,116 +207,135 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict_
 //   t[m][p][j]  = scaling * sum_n dqkv[m][pD+n] * B_p[n][j]          -> aug columns of dqkv_aug (bf16)
 //   dA_p[j][d] += t[m][p][j] * h[m][d]
 //   dB_p[n][j] += scaling * dqkv[m][pD+n] * u[m][p][j]                (u = aug columns of h_aug)
-// One wave per row at a time, lane owns columns {2*lane, 2*lane+1} + 128*i of each D-wide slice; B from LDS; per-wave
-// register accumulators, combined per block through LDS and written as one partial per block (summed in a fixed order by
-// lora_grad_reduce_kernel: deterministic).
+// Block = 6 waves = 2 row streams x 3 projections: wave (p, s) walks rows s, s+2*gridDim, ... and touches only the p-th
+// third of dqkv, so its state is 2*RW*NCH*2 accumulators + the lane's B values (~110 VGPRs: 4 waves per SIMD, where the
+// first version -- one wave for all three thirds, 332 VGPRs, one wave per SIMD -- sat on the load latency of every row).
+// The next row's loads are issued before the current row's arithmetic.  Lane owns columns {2*lane, 2*lane+1} + 128*i of
+// its D-wide slice.  Per-block partials, summed in a fixed order by lora_grad_reduce_kernel (deterministic).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NCH, int RW>
-__global__ __launch_bounds__(256) void lora_grad_kernel(bf16_raw* __restrict__ dqkv, const bf16_raw* __restrict__ h,
+__global__ __launch_bounds__(384) void lora_grad_kernel(bf16_raw* __restrict__ dqkv, const bf16_raw* __restrict__ h,
                                                         const float* __restrict__ lora, int r, int j0, float scaling,
                                                         float* __restrict__ partial, int rows, int D) {
-  extern __shared__ float lds[];                                  // B window [3][D][RW], later the block reduction buffer
+  extern __shared__ float lds[];                                  // block reduction buffer [3][RW][D] | [3][D][RW]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = wave % 3, strm = wave / 3;
   const int ldq = 3 * D + AUG, ldh = D + AUG;
-  for (int i = threadIdx.x; i < 3 * D * RW; i += 256) {
-    const int p = i / (D * RW), rem = i - p * D * RW, n = rem / RW, j = rem - n * RW;
-    lds[i] = (j0 + j < r) ? lora[(size_t)p * 2 * r * D + (size_t)r * D + (size_t)n * r + j0 + j] : 0.f;
-  }
-  __syncthreads();
-  float accA[3][RW][NCH][2], accB[3][NCH][2][RW];
+  // this lane's B_p[n][j0 + j] (n = its 2*NCH columns)
+  float bw[NCH][2][RW];
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
+  for (int i = 0; i < NCH; ++i)
 #pragma unroll
-    for (int j = 0; j < RW; ++j)
+    for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        accA[p][j][i][0] = accA[p][j][i][1] = 0.f;
-        accB[p][i][0][j] = accB[p][i][1][j] = 0.f;
+      for (int j = 0; j < RW; ++j) {
+        const int n = 2 * (lane + 64 * i) + e;
+        bw[i][e][j] = (j0 + j < r) ? lora[(size_t)p * 2 * r * D + (size_t)r * D + (size_t)n * r + j0 + j] : 0.f;
       }
-  const int nw = gridDim.x * 4;
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += nw) {
-    const unsigned* dq = reinterpret_cast<const unsigned*>(dqkv + (size_t)row * ldq);
-    const unsigned* hr = reinterpret_cast<const unsigned*>(h + (size_t)row * ldh);
-    float hv[NCH][2];
+  float accA[RW][NCH][2], accB[NCH][2][RW];
+#pragma unroll
+  for (int j = 0; j < RW; ++j)
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const unsigned w = hr[lane + 64 * i];
-      hv[i][0] = __uint_as_float(w << 16);
-      hv[i][1] = __uint_as_float(w & 0xFFFF0000u);
+      accA[j][i][0] = accA[j][i][1] = 0.f;
+      accB[i][0][j] = accB[i][1][j] = 0.f;
     }
+  const int step = gridDim.x * 2;
+  int row = blockIdx.x * 2 + strm;
+  unsigned dw[NCH], hw_[NCH], uw = 0;
+  auto issue = [&](int rw) {
+    const unsigned* dq = reinterpret_cast<const unsigned*>(dqkv + (size_t)rw * ldq) + p * (D / 2);
+    const unsigned* hr = reinterpret_cast<const unsigned*>(h + (size_t)rw * ldh);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      float dv[NCH][2], t[RW], u[RW];
+    for (int i = 0; i < NCH; ++i) {
+      dw[i] = dq[lane + 64 * i];
+      hw_[i] = hr[lane + 64 * i];
+    }
+    // u[p][j0 .. j0+RW): bf16 pair read as one dword when aligned, else two halves (wave-uniform address: broadcast)
+    const bf16_raw* up = h + (size_t)rw * ldh + D + p * r + j0;
+    const unsigned lo = up[0], hi = (RW > 1 && j0 + 1 < r) ? up[1] : 0u;
+    uw = lo | (hi << 16);
+  };
+  if (row < rows) issue(row);
+  while (row < rows) {
+    float dv[NCH][2], hv[NCH][2], u[RW], t[RW];
 #pragma unroll
-      for (int j = 0; j < RW; ++j) {
-        t[j] = 0.f;
-        const int jj = j0 + j;
-        u[j] = jj < r ? bf16_to_f32(h[(size_t)row * ldh + D + p * r + jj]) : 0.f;
-      }
+    for (int i = 0; i < NCH; ++i) {
+      dv[i][0] = __uint_as_float(dw[i] << 16);
+      dv[i][1] = __uint_as_float(dw[i] & 0xFFFF0000u);
+      hv[i][0] = __uint_as_float(hw_[i] << 16);
+      hv[i][1] = __uint_as_float(hw_[i] & 0xFFFF0000u);
+    }
+    u[0] = __uint_as_float(uw << 16);
+    if (RW > 1) u[1] = __uint_as_float(uw & 0xFFFF0000u);
+    const int cur = row;
+    row += step;
+    if (row < rows) issue(row);                                    // next row in flight under this row's arithmetic
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+      float s = 0.f;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const unsigned w = dq[p * (D / 2) + lane + 64 * i];
-        dv[i][0] = __uint_as_float(w << 16);
-        dv[i][1] = __uint_as_float(w & 0xFFFF0000u);
-        const int n = 2 * (lane + 64 * i);
-#pragma unroll
-        for (int j = 0; j < RW; ++j) {
-          t[j] += dv[i][0] * lds[(p * D + n) * RW + j] + dv[i][1] * lds[(p * D + n + 1) * RW + j];
-          accB[p][i][0][j] += dv[i][0] * u[j];
-          accB[p][i][1][j] += dv[i][1] * u[j];
-        }
+        s += dv[i][0] * bw[i][0][j] + dv[i][1] * bw[i][1][j];
+        accB[i][0][j] += dv[i][0] * u[j];
+        accB[i][1][j] += dv[i][1] * u[j];
       }
+      t[j] = bf16_to_f32(f32_to_bf16(scaling * wave_sum(s)));      // the dgrad GEMM sees the bf16 value: use it for dA too
+      if (lane == 0 && j0 + j < r) dqkv[(size_t)cur * ldq + 3 * D + p * r + j0 + j] = f32_to_bf16(t[j]);
 #pragma unroll
-      for (int j = 0; j < RW; ++j) {
-        t[j] = bf16_to_f32(f32_to_bf16(scaling * wave_sum(t[j])));   // the dgrad GEMM sees the bf16 value: use it for dA too
-        if (lane == 0 && j0 + j < r) dqkv[(size_t)row * ldq + 3 * D + p * r + j0 + j] = f32_to_bf16(t[j]);
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-          accA[p][j][i][0] += t[j] * hv[i][0];
-          accA[p][j][i][1] += t[j] * hv[i][1];
-        }
+      for (int i = 0; i < NCH; ++i) {
+        accA[j][i][0] += t[j] * hv[i][0];
+        accA[j][i][1] += t[j] * hv[i][1];
       }
     }
   }
-  // block combine: [3][RW][D] (dA window) then [3][D][RW] (dB window)
-  __syncthreads();
+  // block combine: [3][RW][D] (dA window) then [3][D][RW] (dB window); stream 0 writes, stream 1 adds
   const int nA = 3 * RW * D, nB = 3 * D * RW;
   float* out = partial + (size_t)blockIdx.x * (nA + nB);
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
+  for (int s2 = 0; s2 < 2; ++s2) {
+    if (strm == s2) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int j = 0; j < RW; ++j)
 #pragma unroll
-        for (int j = 0; j < RW; ++j)
+        for (int i = 0; i < NCH; ++i)
 #pragma unroll
-          for (int i = 0; i < NCH; ++i)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              const int d = 2 * (lane + 64 * i) + e;
-              const int ia = (p * RW + j) * D + d, ib = nA + (p * D + d) * RW + j;
-              if (w == 0) {
-                lds[ia] = accA[p][j][i][e];
-                lds[ib] = scaling * accB[p][i][e][j];
-              } else {
-                lds[ia] += accA[p][j][i][e];
-                lds[ib] += scaling * accB[p][i][e][j];
-              }
+          for (int e = 0; e < 2; ++e) {
+            const int d = 2 * (lane + 64 * i) + e;
+            const int ia = (p * RW + j) * D + d, ib = nA + (p * D + d) * RW + j;
+            if (s2 == 0) {
+              lds[ia] = accA[j][i][e];
+              lds[ib] = scaling * accB[i][e][j];
+            } else {
+              lds[ia] += accA[j][i][e];
+              lds[ib] += scaling * accB[i][e][j];
             }
+          }
     }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < nA + nB; i += 256) out[i] = lds[i];
+  for (int i = threadIdx.x; i < nA + nB; i += 384) out[i] = lds[i];
 }
 
 // grad layout = parameter layout of the layer: [A_q | B_q | A_k | B_k | A_v | B_v]; accumulate = add to existing content
 template <int RW>
 __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __restrict__ partial, int nblk, int r, int j0, float* __restrict__ grad,
                                                                int D, int accumulate) {
+  // 32 elements x 8 slices of the block list per workgroup (a single thread walking all 512 partials was latency-bound)
+  __shared__ float red[8][33];
   const int nA = 3 * RW * D, nB = 3 * D * RW;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nA + nB) return;
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + e;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * (nA + nB) + i];
+  if (i < nA + nB) {
+#pragma unroll 4
+    for (int b = sl; b < nblk; b += 8) s += partial[(size_t)b * (nA + nB) + i];
+  }
+  red[sl][e] = s;
+  __syncthreads();
+  if (sl != 0 || i >= nA + nB) return;
+  s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += red[k][e];
   int p, j, d;
   size_t dst;
   if (i < nA) {
@@ -402,17 +421,17 @@ extern "C" int ucod_lora_grad(void* dqkv_aug, const void* h_aug, const float* lo
   UCOD_PROF(PROF_LORA, stream);
   hipStream_t s = (hipStream_t)stream;
   constexpr int RW = 2;                                           // ranks per pass (the reference's r = 2 is one pass)
-  const int nblk = rows < LORA_GRAD_BLOCKS * 4 ? cdiv(rows, 4) : LORA_GRAD_BLOCKS;
+  const int nblk = rows < LORA_GRAD_BLOCKS * 2 ? cdiv(rows, 2) : LORA_GRAD_BLOCKS;
   const size_t lds_bytes = (size_t)6 * D * RW * sizeof(float);      // B window (3*D*RW) <= block reduction buffer (6*D*RW)
   for (int j0 = 0; j0 < r; j0 += RW) {
     switch (D / 128) {
-#define C(n) case n: hipLaunchKernelGGL((lora_grad_kernel<n, RW>), dim3(nblk), dim3(256), lds_bytes, s, (bf16_raw*)dqkv_aug, (const bf16_raw*)h_aug, lora_layer, r, j0, scaling, (float*)workspace, rows, D); break;
+#define C(n) case n: hipLaunchKernelGGL((lora_grad_kernel<n, RW>), dim3(nblk), dim3(384), lds_bytes, s, (bf16_raw*)dqkv_aug, (const bf16_raw*)h_aug, lora_layer, r, j0, scaling, (float*)workspace, rows, D); break;
       C(1) C(2) C(3) C(4) C(5) C(6) C(8)
 #undef C
       default: return UCOD_EINVAL;
     }
     UCOD_CHECK_LAUNCH();
-    hipLaunchKernelGGL((lora_grad_reduce_kernel<RW>), dim3(cdiv(6 * RW * D, 256)), dim3(256), 0, s, (const float*)workspace, nblk, r, j0,
+    hipLaunchKernelGGL((lora_grad_reduce_kernel<RW>), dim3(cdiv(6 * RW * D, 32)), dim3(256), 0, s, (const float*)workspace, nblk, r, j0,
                        grad_layer, D, accumulate);
     UCOD_CHECK_LAUNCH();
   }

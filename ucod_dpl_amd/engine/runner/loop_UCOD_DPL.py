@@ -231,6 +231,86 @@ class TrainLoop(BaseLoop):
             r.logger.log("iter{}:loss:{:.4f}".format(self.global_step - 1, loss.item()))
         return loss
 
+    # ------------------------------------------------------------------ backbone-backward mode
+    def attach_lora_backbone(self, engine, lr=None):
+        """Switch the loop to the end-to-end mode models/modules/full_model.py describes: the student's features come from a
+        LoRA backbone that is trained with the decoder, the teacher's from its EMA copy (full_model.py:84,108-111).
+        ``engine`` is a ``ViTLoRAEngine``; the EMA engine shares its frozen weights.  LoRA matrices get their own fused
+        AdamW (same hyper-parameters as the decoder's: the reference ships no loop for this mode) with the EMA update of
+        the teacher's copy folded into the same launch."""
+        r = self.runner
+        self.lora_engine = engine
+        self.lora_engine_ema = engine.clone_for_ema()
+        n = engine.lora.numel()
+        mk = lambda: torch.zeros(n, dtype=torch.float32, device=engine.lora.device)  # noqa: E731
+        self.lora_optimizer = FusedAdamW(engine.lora.view(-1), engine.lora_grad.view(-1), mk(), mk(),
+                                         lr if lr is not None else r.optimizer.param_groups[0]["initial_lr"])
+        self.lora_lr_scheduler = StepLR(self.lora_optimizer, self.cfg.train_cfg.step_lr_size, self.cfg.train_cfg.step_lr_gamma)
+        parallel.broadcast_state([engine.lora, self.lora_engine_ema.lora])
+
+    def _process_batch_full(self, images, pseudo_labels):
+        """One optimiser step from IMAGES: LoRA backbone forward (student, saved activations) + EMA backbone forward (teacher)
+        -> key hooks -> the same DBA / APM / discriminator step as ``_process_batch`` -> decoder backward -> gradient w.r.t.
+        the student's key map -> backbone backward -> all-reduce of both flat gradient buffers -> both optimisers."""
+        r = self.runner
+        A = r.arena
+        world = r.world_size
+        dev = A.device
+        fs = self.cfg.model_cfg.feature_size
+        eng, eng_t = self.lora_engine, self.lora_engine_ema
+        images = images.to(dev, torch.float32)
+        pseudo_labels = pseudo_labels.to(dev, torch.float32)
+        B = images.shape[0]
+        feat_s = eng.forward_train(images)                                   # [B,C,h,w]; activations kept for backward
+        feat_t = eng_t.forward_train(images)
+        fh, fw = feat_s.shape[-2:]
+        pl = ops.bilinear_resize(pseudo_labels, fs, fs)
+        emb_s, W_s, b_s, hw_s, hb_s = A.slices(A.p)
+        emb_t, W_t, b_t, hw_t, hb_t = A.slices(A.ema)
+        native_grid = (fh, fw) != (fs, fs)
+        d_s = ops.dba_project(feat_s, W_s, b_s)                              # 1x1 conv on the native grid, resize after (commute)
+        d_t = ops.dba_project(feat_t, W_t, b_t)
+        if native_grid:
+            d_s = ops.bilinear_resize(d_s.view(B, 128, fh, fw), fs, fs).view(B, 128, fs * fs)
+            d_t = ops.bilinear_resize(d_t.view(B, 128, fh, fw), fs, fs).view(B, 128, fs * fs)
+        norm_s = ops.dba_colnorm(d_s, 0, emb_s)
+        norm_t = ops.dba_colnorm(d_t, 0, emb_t)
+        fg, bg, sdiag = ops.dba_heads(d_s, 0, emb_s, norm_s, hw_s, hb_s, want_bg=True, want_sdiag=True)
+        teacher, _, _ = ops.dba_heads(d_t, 0, emb_t, norm_t, hw_t, hb_t, want_bg=False)
+        extra, gram = ops.orth_gram(d_s, 0, emb_s, norm_s, sdiag)
+        disc_t = r.discriminator.tensor_table()
+        p_s, _ = ops.disc_fwd(ops.binarize(fg, logits=True).view(B, 1, fs, fs), disc_t, update_running=True, saved=r.disc_saved(B, fs))
+        r.discriminator._bump_num_batches()
+        p_p, _ = ops.disc_fwd(ops.binarize(pl, logits=False), disc_t, update_running=True, saved=r.disc_saved(B, fs))
+        r.discriminator._bump_num_batches()
+        epoch_frac = self._cur_epoch / (self._max_epoch + self._start_finetune)
+        w, merged, gfg, gbg, losses = ops.apm_bce(pl.view(B, -1), teacher, fg, bg, p_s, p_p, epoch_frac, gscale=1.0 / world)
+        g_emb, g_W, g_b, g_hw, g_hb = A.slices(A.g)
+        gd, _, _, _ = ops.dba_bwd(d_s, 0, emb_s, norm_s, hw_s, gram, gfg, gbg, 1.0 / world, g_head_w=g_hw, g_head_b=g_hb, g_dec_bias=g_b)
+        if native_grid:
+            gd = ops.bilinear_resize_adjoint(gd.view(B, 128, fs, fs), fh, fw).view(B, 128, fh * fw)
+        ops.dba_wgrad(gd, feat_s, gW=g_W)
+        # cotangent of the key hook: the 1x1 conv transposed (same exact-f32 MFMA kernel), then the backbone backward
+        if getattr(self, "_zero_c", None) is None or self._zero_c.numel() != A.C:
+            self._zero_c = torch.zeros(A.C, device=dev)
+        dfeat = ops.dba_project(gd.view(B, 128, fh, fw), W_s.t().contiguous(), self._zero_c).view(B, A.C, fh, fw)
+        eng.backward(dfeat)
+        parallel.allreduce_prescaled_(A.g)                    # decoder: 128C+386 floats; LoRA: 6*r*D*L floats -- two flat buffers
+        parallel.allreduce_prescaled_(eng.lora_grad.view(-1))
+        alpha = min(1 - 1 / (self.global_step + 1), self.ema_alpha)
+        r.optimizer.step(ema=A.ema, alpha=alpha)
+        r.lr_scheduler.step()
+        self.lora_optimizer.step(ema=eng_t.lora.view(-1), alpha=alpha)
+        self.lora_lr_scheduler.step()
+        eng.repack()
+        eng_t.repack()
+        self.global_step += 1
+        loss = losses[0] + losses[1] + extra[0]
+        if not self.finetune:
+            loss = loss - losses[2]
+        self.last = dict(loss=loss, dis_loss=losses[2], extra=extra[0], w=w, merged=merged, fg=fg, bg=bg, teacher=teacher, p_s=p_s, p_p=p_p)
+        return loss
+
     def merge_pseudo_label(self, pseudo_labels, p_teachers, p_students, features=None):
         """Stand-alone APM fusion with the reference's signature (:257-272) -> (merged [B,1,H,W], dis_loss)."""
         r = self.runner

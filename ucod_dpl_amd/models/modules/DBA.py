@@ -42,13 +42,11 @@ class _DBAFunction(torch.autograd.Function):
             extra, gram = torch.zeros((), device=x.device), None
         ctx.save_for_backward(x, d, norm, gram, emb_f, hw)
         ctx.want_extra = want_extra
+        ctx.W_t = W.detach().reshape(2 * EMB, C).t().contiguous() if ctx.needs_input_grad[0] else None
         return fg.view(B, 1, H, Wd), bg.view(B, 1, H, Wd), extra
 
     @staticmethod
     def backward(ctx, gfg, gbg, gextra):
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError("gradient w.r.t. the input features is not built (frozen backbone; LoRA mode of "
-                                      "models/modules/full_model.py is out of scope, see DESIGN.md)")
         x, d, norm, gram, emb_f, hw = ctx.saved_tensors
         B, C, H, Wd = x.shape
         dev = x.device
@@ -61,7 +59,13 @@ class _DBAFunction(torch.autograd.Function):
             ge = float(gextra) if gextra is not None else 0.0      # one host sync; the fused TrainLoop path has none
         gd, ghw, ghb, gdb = ops.dba_bwd(d, 0, emb_f, norm, hw, gram, gfg, gbg, ge)
         gW = ops.dba_wgrad(gd, x)
-        return (None, gW.view(2 * EMB, C, 1, 1), gdb, torch.zeros(2, EMB, device=dev), ghw[0].reshape(1, EMB, 1, 1), ghb[0:1].clone(),
+        gx = None
+        if ctx.needs_input_grad[0]:
+            # backbone-backward mode (models/modules/full_model.py:108-126): the 1x1 conv transposed, dX[b] = W^T gd[b],
+            # on the same exact-f32 MFMA kernel as the forward projection (input channels = the 128 decoder channels)
+            Wt = ctx.W_t
+            gx = ops.dba_project(gd.view(B, 2 * EMB, H, Wd), Wt, torch.zeros(C, device=dev)).view(B, C, H, Wd)
+        return (gx, gW.view(2 * EMB, C, 1, 1), gdb, torch.zeros(2, EMB, device=dev), ghw[0].reshape(1, EMB, 1, 1), ghb[0:1].clone(),
                 ghw[1].reshape(1, EMB, 1, 1), ghb[1:2].clone(), None)
 
 

@@ -94,6 +94,23 @@ def bilinear_resize_adjoint(gout, ih, iw):
     return gin
 
 
+class _BilinearResizeFn(torch.autograd.Function):
+    """F.interpolate(mode='bilinear', align_corners=False) with its exact transpose as the backward (both HIP kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        ctx.in_hw = tuple(x.shape[-2:])
+        return bilinear_resize(x, oh, ow)
+
+    @staticmethod
+    def backward(ctx, g):
+        return bilinear_resize_adjoint(g.contiguous(), *ctx.in_hw), None, None
+
+
+def bilinear_resize_autograd(x, oh, ow):
+    return _BilinearResizeFn.apply(x, oh, ow)
+
+
 def dba_project(x, W, bias):
     """x [B,C,H,W] f32, W [Nout,C], bias [Nout] -> d [B,Nout,HW]."""
     B, Cc, H, Wd = x.shape

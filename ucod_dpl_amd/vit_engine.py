@@ -305,3 +305,36 @@ class ViTLoRAEngine(ViTEngine):
         N.check(lib.ucod_vit_backward(C.byref(t), T, TT, N.ptr(dkey), N.ptr(self._tws), self._tws.numel(), N.stream()), "ucod_vit_backward")
         self._saved_for = None
         return self.lora_grad
+
+    # ---- torch.autograd / nn.Module integration ----------------------------------------------------------------------
+    def clone_for_ema(self):
+        """A second engine over the SAME frozen weight tensors with its own LoRA arena (models/modules/full_model.py:84:
+        ``backbone_ema = copy.deepcopy(backbone)``; only the LoRA matrices can ever differ, so only they are duplicated)."""
+        other = object.__new__(ViTLoRAEngine)
+        other.__dict__.update(self.__dict__)
+        other.lora = self.lora.clone()
+        other.lora_grad = torch.zeros_like(self.lora)
+        other.train_layers = [[tl[0].clone(), tl[1].clone()] + tl[2:] for tl in self.train_layers]
+        other._tws, other._saved_for = None, None
+        other._pos_cache = dict(self._pos_cache)
+        other.repack()
+        return other
+
+    def apply(self, img, lora_param):
+        """Differentiable call: key = f(img; lora_param).  ``lora_param`` must be a tensor sharing storage with ``self.lora``
+        (see ``LoRABackbone``); its ``.grad`` receives ``self.lora_grad`` on backward."""
+        return _LoRABackboneFn.apply(img, lora_param, self)
+
+
+class _LoRABackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, lora_param, engine):
+        if lora_param.data_ptr() != engine.lora.data_ptr():
+            raise RuntimeError("lora_param must alias engine.lora")
+        ctx.engine = engine
+        return engine.forward_train(img)
+
+    @staticmethod
+    def backward(ctx, dkey):
+        g = ctx.engine.backward(dkey.contiguous())
+        return None, g.clone(), None
