@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--cpu-images", type=int, default=2)
     ap.add_argument("--gemm-variant", type=int, default=0)
     ap.add_argument("--attn-variant", type=int, default=2)
+    ap.add_argument("--lora-steps", type=int, default=4, help="steps of the separate backbone-backward (LoRA) measurement; 0 = skip")
     return ap.parse_args()
 
 
@@ -98,6 +99,7 @@ def main():
     images = torch.randn(B, 3, a.image, a.image, generator=g).to(dev)
     pl = (torch.rand(B, 1, 16, 16, generator=g) > 0.7).float().to(dev)
     gh = a.image // P
+    kpad = bb.engine.Kpad
     key = torch.empty(B, D, gh, gh, dtype=torch.float32, device=dev)
 
     def step():
@@ -130,6 +132,44 @@ def main():
         torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
         dt = tdt.item()
     final_loss = float(loss.item())
+
+    # Optional mode of SURVEY.md 8a row B9, reported SEPARATELY (never part of `value`): images -> LoRA backbone (student,
+    # activations saved) + EMA backbone (teacher) -> the same decoder/APM/discriminator step -> backbone backward -> all-reduce
+    # of decoder and LoRA gradients -> both fused optimisers.
+    lora_mode = None
+    if a.lora_steps > 0:
+        from ucod_dpl_amd.vit_engine import ViTLoRAEngine
+        from ucod_dpl_amd.data.utils.feature_extractor import random_state_dict
+        del bb
+        torch.cuda.empty_cache()
+        eng = ViTLoRAEngine(random_state_dict(a.arch, 0, a.image), heads, r=2, lora_alpha=4, device=dev, gemm_variant=a.gemm_variant,
+                            generator=torch.Generator().manual_seed(7))
+        loop.attach_lora_backbone(eng)
+        for _ in range(2):
+            loop._process_batch_full(images, pl)
+            loop.global_step += 1
+        barrier()
+        lib.ucod_prof_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(a.lora_steps):
+            l2 = loop._process_batch_full(images, pl)
+            loop.global_step += 1
+        barrier()
+        dt2 = time.perf_counter() - t0
+        lib.ucod_prof_enable(0)
+        tot2 = (C.c_double * ncls)()
+        cnt2 = (C.c_longlong * ncls)()
+        lib.ucod_prof_collect(tot2, cnt2)
+        if world > 1:
+            tdt = torch.tensor([dt2], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
+            dt2 = tdt.item()
+        top = sorted(((lib.ucod_prof_class_name(i).decode(), tot2[i] / a.lora_steps) for i in range(ncls) if cnt2[i]), key=lambda r: -r[1])[:6]
+        lora_mode = {"value": round(world * B * a.lora_steps / dt2, 2), "unit": "images/s", "ms_per_step": round(dt2 / a.lora_steps * 1e3, 3),
+                     "steps": a.lora_steps, "final_loss": round(float(l2.item()), 6),
+                     "what": "LoRA r=2 on q/k/v of all layers: student fwd (saved activations) + EMA-teacher fwd + decoder step + backbone "
+                             "backward (dgrad only) + LoRA/decoder all-reduce + 2 fused AdamW/EMA",
+                     "top_kernels_ms_per_step": {n: round(t, 3) for n, t in top}}
     if rank != 0:
         return
 
@@ -143,7 +183,7 @@ def main():
         name = lib.ucod_prof_class_name(i).decode()
         avg_us = tot[i] / cnt[i] * 1e3
         k = {"launches_per_step": cnt[i] / a.steps, "avg_us": round(avg_us, 2), "ms_per_step": round(tot[i] / a.steps, 4)}
-        fl = algorithmic_work(name, B, tok, D, F, heads, bb.engine.Kpad, D, HW)
+        fl = algorithmic_work(name, B, tok, D, F, heads, kpad, D, HW)
         if name == "gemm_bf16_proj_fc2_scale_resid":
             n_layers = L if a.full_last_layer else L - 1
             per_step = n_layers * (2.0 * B * tok * D * D + 2.0 * B * tok * D * F)
@@ -182,6 +222,7 @@ def main():
                    "backbone_last_layer": "full (as reference)" if a.full_last_layer else "key-minimal (identical key output; 279.6 of 303.1 GFLOP/img)",
                    "random_init_weights": True},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "final_loss": round(final_loss, 6),
+        "backbone_backward_mode": lora_mode,
     }
     print(json.dumps(out))
 
