@@ -219,6 +219,67 @@ def test_vit_key_against_reference_golden(name, heads, fn, full, av):
     assert maxdiff(key, ref) < 0.1 * ref.abs().max().item()
 
 
+def _dino_v1_state_dict(D, L, P, img, seed):
+    """In-repo DINO VisionTransformer layout (models/backbones/dino.py), seeded trunc-normal-ish weights."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g) * 0.02  # noqa: E731
+    n = (img // P) ** 2
+    sd = {"cls_token": rn(1, 1, D), "pos_embed": rn(1, n + 1, D), "patch_embed.proj.weight": rn(D, 3, P, P), "patch_embed.proj.bias": rn(D)}
+    for i in range(L):
+        p = f"blocks.{i}."
+        sd[p + "norm1.weight"], sd[p + "norm1.bias"] = 1 + rn(D), rn(D)
+        sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"] = rn(3 * D, D), rn(3 * D)
+        sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"] = rn(D, D), rn(D)
+        sd[p + "norm2.weight"], sd[p + "norm2.bias"] = 1 + rn(D), rn(D)
+        sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = rn(4 * D, D), rn(4 * D)
+        sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = rn(D, 4 * D), rn(D)
+    sd["norm.weight"], sd["norm.bias"] = torch.ones(D), torch.zeros(D)
+    return sd
+
+
+def test_config_c1_dinov1_vits8_224_batch2():
+    """BASELINE.json configs[0]: DINOv1 ViT-S/8 (D=384, 6 heads, 12 layers, patch 8), 224x224, batch 2 -- full depth, real
+    geometry (785 tokens), HIP engine vs the f32 CPU oracle of models/backbones/dino.py; then the DBA decoder on that key map."""
+    from ucod_dpl_amd.vit_engine import ViTEngine
+    sd = _dino_v1_state_dict(384, 12, 8, 224, seed=5)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(6))
+    _, ref = OV.dinov1_forward(x, sd, heads=6, patch=8, eps=1e-6, full_last_layer=False)
+    eng = ViTEngine(sd, heads=6, eps=1e-6, device=DEV, attn_variant=2)
+    key = eng(x.to(DEV))
+    assert key.shape == (2, 384, 28, 28)
+    assert rel_l2(key.cpu(), ref) < 2e-2, rel_l2(key.cpu(), ref)
+    gen = torch.Generator().manual_seed(7)
+    p = OD.init_params(384, gen)
+    fg_ref, bg_ref, _ = OD.rev_decoder_forward(ref, p, orth="gram")
+    emb = p["learnable_embedding"].reshape(128).to(DEV)
+    hw = torch.cat((p["conv_out_fg.weight"].reshape(64), p["conv_out_bg.weight"].reshape(64))).to(DEV)
+    hb = torch.cat((p["conv_out_fg.bias"], p["conv_out_bg.bias"])).to(DEV)
+    d = ops.dba_project(key, p["decoupling.weight"].reshape(128, 384).to(DEV), p["decoupling.bias"].to(DEV))
+    norm = ops.dba_colnorm(d, 0, emb)
+    fg, bg, _ = ops.dba_heads(d, 0, emb, norm, hw, hb, want_bg=True)
+    # logits inherit the bf16 backbone's error (key rel-L2 ~4e-3): compare at that level, and exactly-f32 on the oracle's own key
+    assert rel_l2(fg.cpu().reshape(-1), fg_ref.reshape(-1)) < 3e-2
+    d2 = ops.dba_project(ref.contiguous().to(DEV), p["decoupling.weight"].reshape(128, 384).to(DEV), p["decoupling.bias"].to(DEV))
+    n2 = ops.dba_colnorm(d2, 0, emb)
+    fg2, bg2, _ = ops.dba_heads(d2, 0, emb, n2, hw, hb, want_bg=True)
+    assert maxdiff(fg2.cpu().reshape(-1), fg_ref.reshape(-1)) < 1e-3 and maxdiff(bg2.cpu().reshape(-1), bg_ref.reshape(-1)) < 1e-3
+
+
+def test_config_c4_dinov2_vitl14_518():
+    """BASELINE.json configs[3] backbone: DINOv2 ViT-L/14 (D=1024, 16 heads, 24 layers) at 518x518 (1370 tokens), one image,
+    full depth: HIP engine vs the f32 CPU oracle (HF Dinov2 restatement)."""
+    from ucod_dpl_amd.vit_engine import ViTEngine
+    from ucod_dpl_amd.data.utils.feature_extractor import random_state_dict
+    sd = random_state_dict("dinov2_vitl14", seed=11, image_size=518)
+    x = torch.randn(1, 3, 518, 518, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        _, ref = OV.dinov2_forward(x, sd, heads=16, patch=14, eps=1e-6, full_last_layer=False)
+    eng = ViTEngine(sd, heads=16, eps=1e-6, device=DEV, attn_variant=2)
+    key = eng(x.to(DEV))
+    assert key.shape == (1, 1024, 37, 37)
+    assert rel_l2(key.cpu(), ref) < 3e-2, rel_l2(key.cpu(), ref)
+
+
 # ----------------------------------------------------------------------------------------- decoder (exact f32)
 def test_bilinear_matches_aten_semantics():
     g = torch.Generator().manual_seed(1)

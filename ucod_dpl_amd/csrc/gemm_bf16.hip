@@ -374,10 +374,6 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][
       for (int j = 0; j < NT; ++j) {
         f32x4 v = acc[pass * 2 + i][j];
         if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) v = v * cs[j];
-        if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) {
-          const f32x2 g0 = gelu_erf2((f32x2){v[0], v[1]}), g1 = gelu_erf2((f32x2){v[2], v[3]});
-          v = (f32x4){g0[0], g0[1], g1[0], g1[1]};
-        }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
           *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * (WCOLS * 4) + (j * 16 + (lane & 15)) * 4) = v[rg];
@@ -446,7 +442,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-    } else if ((a.N & 7) == 0) {                                  // 16-byte stores need 8-column alignment of every row
+    } else {                                                      // bf16 out: 16-byte stores (launch() guarantees N % 8 == 0)
       constexpr bool GBWD = (EPI == UCOD_EPI_GELU_BWD_BF16), SAVE = (EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
       constexpr int CH = WCOLS / 8, ITS = PR * CH / 64;
       static_assert((PR * CH) % 64 == 0, "whole wave instructions");
@@ -454,21 +450,17 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][
       const void* second = GBWD ? a.aux : (SAVE ? (const void*)a.out2 : (const void*)a.out);
       const auto rs_2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(second)) + base, 0,
                                                           (GBWD || SAVE) ? records : 0u, 0x00020000);
-      unsigned off[ITS];
-      int lrow[ITS], lchk[ITS];
-#pragma unroll
-      for (int it = 0; it < ITS; ++it) {
-        const int idx = it * 64 + lane;
-        lrow[it] = idx / CH;
-        lchk[it] = idx - lrow[it] * CH;
-        const int n = n_first + lchk[it] * 8;
-        off[it] = n < a.N ? (unsigned)lrow[it] * row_bytes + (unsigned)n * 2u : OOB;
-      }
-      auto at = [&](int it, int pass) { return off[it] == OOB ? OOB : off[it] + (unsigned)pass * pass_bytes; };
+      // (row, chunk) of wave instruction `it`: recomputed where needed -- index arrays cost registers the persistent kernel lacks
+      auto lrow = [&](int it) { return (it * 64 + lane) / CH; };
+      auto lchk = [&](int it) { return (it * 64 + lane) - lrow(it) * CH; };
+      auto at = [&](int it, int pass) {
+        const int n = n_first + lchk(it) * 8;
+        return n < a.N ? (unsigned)(pass * PR + lrow(it)) * row_bytes + (unsigned)n * 2u : OOB;
+      };
       u32x4 pre[2][ITS];
       if constexpr (GBWD) {
 #pragma unroll
-        for (int it = 0; it < ITS; ++it) pre[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_2, off[it], 0, 0);
+        for (int it = 0; it < ITS; ++it) pre[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_2, at(it, 0), 0, 0);
       }
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
@@ -482,15 +474,17 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
-          f32x4 v0 = *reinterpret_cast<const f32x4*>(wbase + lrow[it] * (WCOLS * 4) + lchk[it] * 32);
-          f32x4 v1 = *reinterpret_cast<const f32x4*>(wbase + lrow[it] * (WCOLS * 4) + lchk[it] * 32 + 16);
-          if constexpr (SAVE) {                                   // pre-activation out first, GELU in the row-major layout
+          f32x4 v0 = *reinterpret_cast<const f32x4*>(wbase + lrow(it) * (WCOLS * 4) + lchk(it) * 32);
+          f32x4 v1 = *reinterpret_cast<const f32x4*>(wbase + lrow(it) * (WCOLS * 4) + lchk(it) * 32 + 16);
+          if constexpr (SAVE) {                                   // pre-activation out first
             u32x4 w;
             w[0] = pack_bf16x2(v0[0], v0[1]);
             w[1] = pack_bf16x2(v0[2], v0[3]);
             w[2] = pack_bf16x2(v1[0], v1[1]);
             w[3] = pack_bf16x2(v1[2], v1[3]);
             __builtin_amdgcn_raw_buffer_store_b128(w, rs_2, at(it, pass), 0, 0);
+          }
+          if constexpr (SAVE || EPI == UCOD_EPI_BIAS_GELU_BF16) {  // GELU in the row-major layout (fewer live registers than in the C layout)
             const f32x2 g0 = gelu_erf2((f32x2){v0[0], v0[1]}), g1 = gelu_erf2((f32x2){v0[2], v0[3]});
             const f32x2 g2 = gelu_erf2((f32x2){v1[0], v1[1]}), g3 = gelu_erf2((f32x2){v1[2], v1[3]});
             v0 = (f32x4){g0[0], g0[1], g1[0], g1[1]};
@@ -512,25 +506,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][
           w[2] = pack_bf16x2(v1[0], v1[1]);
           w[3] = pack_bf16x2(v1[2], v1[3]);
           __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, at(it, pass), 0, 0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-    } else if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) {
-      constexpr int CH = WCOLS / 4, ITS = PR * CH / 64;
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        stage(pass);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < ITS; ++it) {
-          const int idx = it * 64 + lane, row = idx / CH, c = idx - row * CH;
-          const int n = n_first + c * 4;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + row * (WCOLS * 4) + c * 16);
-          u32x2 w;
-          w[0] = pack_bf16x2(v[0], v[1]);
-          w[1] = pack_bf16x2(v[2], v[3]);
-          const unsigned o = n < a.N ? (unsigned)(pass * PR + row) * row_bytes + (unsigned)n * 2u : OOB;
-          __builtin_amdgcn_raw_buffer_store_b64(w, rs_out, o, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);                      // keep chunks in order: hoisting every ds_read/cvt of a pass spills in the persistent kernel
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
@@ -914,7 +890,7 @@ template <int EPI>
 static int launch(GemmArgs a, int variant, hipStream_t s) {
   if (variant == 0) {
     variant = 2;
-    if (a.M >= 2048 && a.K >= 128 && (a.N & 3) == 0) {
+    if (a.M >= 2048 && a.K >= 128 && (a.N & 3) == 0 && (!(EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) || (a.N & 7) == 0)) {
       // Makespan model on 256 CUs (one large-tile workgroup per CU), fitted to tools/gemm_bench.py on MI355X:
       // a tile costs a fixed part (A-panel DMA, prologue, epilogue set-up) plus a part proportional to its width.
       auto cost = [&](int bn) {
@@ -922,6 +898,9 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
         return rounds * (0.45 * 256 + 0.55 * bn);
       };
       variant = (cost(192) < cost(256)) ? 6 : 5;
+      // several rounds of tiles per CU: the persistent form hides every tile's first-K-tile latency under the previous epilogue
+      // (QKV 158 -> 152 us; neutral elsewhere)
+      if ((long)cdiv(a.M, 256) * cdiv(a.N, variant == 6 ? 192 : 256) >= 512) variant += 2;
     }
   }
   constexpr bool kTrainEpi = (EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
@@ -932,7 +911,8 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
       variant = (cost(192) < cost(256)) ? 6 : 5;
     }
   }
-  if (variant >= 3 && variant <= 8 && (a.N & 3) != 0) return UCOD_EINVAL;
+  constexpr bool kBf16Out = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || kTrainEpi);
+  if (variant >= 3 && variant <= 8 && ((a.N & 3) != 0 || (kBf16Out && (a.N & 7) != 0))) return UCOD_EINVAL;   // 16-byte row stores
   if (variant >= 3 && variant <= 8) {
     const bool wide = (variant == 3 || variant == 5 || variant == 7);
     a.tiles_m = cdiv(a.M, 256);
