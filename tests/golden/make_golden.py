@@ -492,7 +492,24 @@ def g12():
     save("g12_decoder_dx", **out)
 
 
+# ----------------------------------------------------------------------------- G13: feature-cache on-disk format (row N1)
+def g13():
+    """A three-item features cache written by the reference's OWN MultiCacheManager / MetaListPickleIO
+    (data/datasets/cache_manager.py, engine/utils/fileio/backend/ioctl/pickleio.py) -> tests/golden/cache_ref/."""
+    import shutil
+    from data.datasets.cache_manager import MultiCacheManager
+    root = os.path.join(OUT, "cache_ref")
+    shutil.rmtree(root, ignore_errors=True)
+    log = SimpleNamespace(log=lambda *a, **k: None)
+    m = MultiCacheManager(root, "dinov2", "train", "COD10K", logger=log)
+    g = torch.Generator().manual_seed(13)
+    feats = [torch.randn(4, 3, 3, generator=g) for _ in range(3)]
+    m.get_features_cache().dump_list(feats)
+    m.get_pseudo_label_cache().dump_list([(f[:1] > 0).float() for f in feats])
+    save("g13_cache_items", **{f"f{i}": f for i, f in enumerate(feats)})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g12", "g13"]
     for w in which:
         globals()[w]()

@@ -473,3 +473,21 @@ def test_adamw_ema_matches_torch_optimizer():
         ops.adamw_ema(p, grad.to(DEV), m, v, ema, 2e-4, step, ema_alpha=alpha)
         assert maxdiff(p.cpu(), ref_p.data) < 1e-6
         assert maxdiff(ema.cpu(), ema_ref) < 1e-6
+
+
+def test_feature_cache_pass_with_the_hip_backbone(tmp_path):
+    """Row N1: batched cache-building pass through the HIP backbone, reference on-disk format, read back == direct forward."""
+    from ucod_dpl_amd.data.datasets import MultiCacheManager, build_feature_cache
+    from ucod_dpl_amd.data.utils.feature_extractor import backbone
+    gd = load_golden("g8_dinov2_native")
+    bb = backbone.from_state_dict(sub(gd, "sd."), heads=2, device=DEV)
+    gen = torch.Generator().manual_seed(3)
+    imgs = [torch.randn(3, 70, 70, generator=gen) for _ in range(5)]
+    fc = MultiCacheManager(str(tmp_path), "dinov2", "val", "T").get_features_cache()
+    assert build_feature_cache(imgs, bb, fc, batch_size=2, device=DEV) == 5
+    for i, im in enumerate(imgs):
+        _, key = bb(im.unsqueeze(0).to(DEV))
+        got = fc.read_file(i)
+        assert got.device.type == "cpu" and got.dtype == torch.float32 and got.shape == (128, 5, 5)
+        # batch composition changes nothing: every kernel is row / image independent
+        assert torch.equal(got, key[0].cpu())
