@@ -12,43 +12,55 @@ template <int NCH, bool OUT_F32>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ y, int rows,
                                                         int D, float eps) {
+  // R rows per wave, all their loads issued before the first reduction: twice the bytes in flight per wave (the kernel is
+  // pure HBM streaming; one row per wave left the memory pipe waiting on the two shuffle reductions of every row)
+  constexpr int R = 2;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float2* xr = reinterpret_cast<const float2*>(x + (size_t)row * D);
-  float2 v[NCH];
-  float s = 0.f;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
+  float2 v[R][NCH];
+  float s[R];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    v[i] = xr[lane + 64 * i];
-    s += v[i].x + v[i].y;
-  }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const int row = (row0 + r) < rows ? (row0 + r) : rows - 1;
+    const float2* xr = reinterpret_cast<const float2*>(x + (size_t)row * D);
+    s[r] = 0.f;
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const float a = v[i].x - mean, b = v[i].y - mean;
-    q += a * a + b * b;
+    for (int i = 0; i < NCH; ++i) v[r][i] = xr[lane + 64 * i];
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
   const float2* g2 = reinterpret_cast<const float2*>(gamma);
   const float2* b2 = reinterpret_cast<const float2*>(beta);
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const float2 g = g2[lane + 64 * i], b = b2[lane + 64 * i];
-    const float o0 = (v[i].x - mean) * rstd * g.x + b.x;
-    const float o1 = (v[i].y - mean) * rstd * g.y + b.y;
-    if constexpr (OUT_F32) {
-      reinterpret_cast<float2*>(reinterpret_cast<float*>(y) + (size_t)row * D)[lane + 64 * i] = make_float2(o0, o1);
-    } else {
-      reinterpret_cast<unsigned*>(reinterpret_cast<bf16_raw*>(y) + (size_t)row * D)[lane + 64 * i] = pack_bf16x2(o0, o1);
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) s[r] += v[r][i].x + v[r][i].y;
+    const float mean = wave_sum(s[r]) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const float a = v[r][i].x - mean, b = v[r][i].y - mean;
+      q += a * a + b * b;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    const int row = row0 + r;
+    if (row >= rows) break;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const float2 g = g2[lane + 64 * i], b = b2[lane + 64 * i];
+      const float o0 = (v[r][i].x - mean) * rstd * g.x + b.x;
+      const float o1 = (v[r][i].y - mean) * rstd * g.y + b.y;
+      if constexpr (OUT_F32) {
+        reinterpret_cast<float2*>(reinterpret_cast<float*>(y) + (size_t)row * D)[lane + 64 * i] = make_float2(o0, o1);
+      } else {
+        reinterpret_cast<unsigned*>(reinterpret_cast<bf16_raw*>(y) + (size_t)row * D)[lane + 64 * i] = pack_bf16x2(o0, o1);
+      }
     }
   }
 }
 
 template <bool OUT_F32>
 static int launch_ln(const float* x, const float* g, const float* b, void* y, int rows, int D, float eps, hipStream_t s) {
-  dim3 grid(cdiv(rows, 4)), block(256);
+  dim3 grid(cdiv(rows, 8)), block(256);
   switch (D / 128) {
 #define LN_CASE(n) \
   case n: hipLaunchKernelGGL((layernorm_kernel<n, OUT_F32>), grid, block, 0, s, x, g, b, y, rows, D, eps); break;
