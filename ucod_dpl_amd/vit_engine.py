@@ -114,6 +114,7 @@ class ViTEngine:
         self.eps = float(eps)
         self.full_last_layer = bool(full_last_layer)
         self.gemm_variant, self.attn_variant = gemm_variant, attn_variant
+        self.streams = 1                                           # image-parallel sub-batches on side streams (see forward)
         K = self.C * self.P * self.P
         self.Kpad = (K + 63) // 64 * 64
         dev = self.device
@@ -156,28 +157,68 @@ class ViTEngine:
         d.gemm_variant, d.attn_variant = self.gemm_variant, self.attn_variant
         return d
 
-    def forward(self, img, out=None):
+    def forward(self, img, out=None, _async=False):
         if not img.is_cuda:
             raise RuntimeError("ViTEngine needs a CUDA(ROCm) tensor; there is no CPU path")
         img = img.to(torch.float32).contiguous()
         B, Cc, H, W = img.shape
         gh, gw = H // self.P, W // self.P
         lib = N.load()
-        d = self._desc(B, H, W)
-        need = lib.ucod_vit_workspace_bytes(C.byref(d))
-        if need == 0:
-            raise ValueError("unsupported ViT geometry")
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         pos = self._pos(gh, gw)
         ptrs = [self.patch_w, self.patch_b, self.cls, pos]
         for l in self.layers:
             ptrs += l
         table = (C.c_void_p * len(ptrs))(*[t.data_ptr() for t in ptrs])
         key = out if out is not None else torch.empty(B, self.D, gh, gw, dtype=torch.float32, device=self.device)
-        N.check(lib.ucod_vit_forward(C.byref(d), table, N.ptr(img), N.ptr(key), N.ptr(self._ws), self._ws.numel(), N.stream()),
-                "ucod_vit_forward")
+        ns = max(1, min(int(getattr(self, "streams", 1)), B))
+        if ns == 1 and not _async:
+            d = self._desc(B, H, W)
+            need = lib.ucod_vit_workspace_bytes(C.byref(d))
+            if need == 0:
+                raise ValueError("unsupported ViT geometry")
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            N.check(lib.ucod_vit_forward(C.byref(d), table, N.ptr(img), N.ptr(key), N.ptr(self._ws), self._ws.numel(), N.stream()),
+                    "ucod_vit_forward")
+            return key
+        # Image-parallel sub-batches on independent HIP streams: every kernel of the pass is per-image, so the halves are
+        # independent and the tail of one stream's GEMM (a partial last round of 256-row tiles leaves most CUs idle) is filled by
+        # the other stream's next kernel.  Results are identical to the single-stream pass (same kernels, same per-image math).
+        if getattr(self, "_side", None) is None or len(self._side) != ns:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(ns)]
+            self._side_ws = [None] * ns
+        cur = torch.cuda.current_stream(self.device)
+        start = torch.cuda.Event()
+        start.record(cur)
+        bounds = [B * i // ns for i in range(ns + 1)]
+        events = []
+        for i in range(ns):
+            b0, b1 = bounds[i], bounds[i + 1]
+            d = self._desc(b1 - b0, H, W)
+            need = lib.ucod_vit_workspace_bytes(C.byref(d))
+            if need == 0:
+                raise ValueError("unsupported ViT geometry")
+            if self._side_ws[i] is None or self._side_ws[i].numel() < need:
+                self._side_ws[i] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            st = self._side[i]
+            st.wait_event(start)
+            with torch.cuda.stream(st):
+                N.check(lib.ucod_vit_forward(C.byref(d), table, N.ptr(img[b0:b1]), N.ptr(key[b0:b1]), N.ptr(self._side_ws[i]),
+                                             self._side_ws[i].numel(), N.stream()), "ucod_vit_forward")
+                done = torch.cuda.Event()
+                done.record(st)
+            events.append(done)
+        if _async:
+            return key, events
+        for done in events:
+            cur.wait_event(done)
         return key
+
+    def forward_async(self, img, out=None):
+        """Enqueue the pass on the side streams WITHOUT making the current stream wait: returns (key, events); the consumer
+        calls ``torch.cuda.current_stream().wait_event(e)`` for each event before reading ``key``.  The side streams start
+        after everything already enqueued on the current stream (so a ring of key buffers is safe to reuse)."""
+        return self.forward(img, out=out, _async=True)
 
     __call__ = forward
 
