@@ -116,3 +116,53 @@ def test_generic_autograd_path_matches_fused_path():
         ref = g["grad." + n]
         assert maxdiff(p.grad.cpu(), ref) < 2e-3 * max(ref.abs().max().item(), 1e-6), n
     assert all(p.grad is None for p in m.decoder_ema.parameters())
+
+
+def test_pipelined_image_training_equals_serial_order():
+    """TrainLoop.run_images (backbone of batch k+1 on side streams under the decoder step of batch k, two image-parallel halves)
+    against the serial schedule.  The backbone has no atomics: its key maps must be BIT-identical under every schedule.  The decoder
+    step's weight gradient uses f32 atomics (split-K), so a serial run is only reproducible to rounding from step 1 on: the first
+    loss must be identical, later ones within 1e-5, the same bar a serial-vs-serial repeat meets."""
+    from ucod_dpl_amd.vit_engine import ViTEngine
+    from ucod_dpl_amd.engine.runner import FeaturePipeline
+    gd = load_golden("g8_dinov2_native")
+    base = sub(gd, "sd.")
+    gen = torch.Generator().manual_seed(17)
+    batches = [((torch.rand(4, 1, 16, 16, generator=gen) > 0.6).float(), torch.randn(4, 3, 70, 70, generator=gen)) for _ in range(4)]
+
+    def make():
+        torch.manual_seed(5)
+        runner = StandardRunner(make_cfg(C=128, fs=8))
+        return runner, TrainLoop(runner.config, runner)
+
+    r1, l1 = make()
+    eng1 = ViTEngine(base, heads=2, device=r1.device, attn_variant=2)
+    serial, keys = [], []
+    for pl, img in batches:
+        key = eng1(img.to(r1.device))
+        keys.append(key.clone())
+        serial.append(l1._process_batch((pl, key)).clone())
+        l1.global_step += 1
+    # (a) backbone under the other schedules: bit-identical
+    eng2 = ViTEngine(base, heads=2, device=r1.device, attn_variant=2)
+    for ns in (2, 3):
+        eng2.streams = ns
+        for (pl, img), k in zip(batches, keys):
+            assert torch.equal(eng2(img.to(r1.device)), k), ns
+    eng2.streams = 2
+    pipe = FeaturePipeline(eng2)
+    for pl, img in batches:
+        pipe.submit(img.to(r1.device))
+    for k in keys[:2]:                                          # ring depth 2: the last two submissions own the buffers
+        pipe.next_features()
+    for k in keys[2:]:
+        assert torch.equal(pipe.next_features(), k)
+    # (b) the whole loop
+    r2, l2 = make()
+    eng3 = ViTEngine(base, heads=2, device=r2.device, attn_variant=2)
+    piped = [x.clone() for x in l2.run_images(batches, eng3, streams=2)]
+    assert len(piped) == 4
+    assert torch.equal(serial[0], piped[0])
+    for a, b in zip(serial, piped):
+        assert abs(a.item() - b.item()) < 1e-5 * max(1.0, abs(a.item())), (a.item(), b.item())
+    assert maxdiff(r1.arena.p.cpu(), r2.arena.p.cpu()) < 1e-5

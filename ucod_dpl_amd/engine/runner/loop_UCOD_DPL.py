@@ -231,6 +231,32 @@ class TrainLoop(BaseLoop):
             r.logger.log("iter{}:loss:{:.4f}".format(self.global_step - 1, loss.item()))
         return loss
 
+    # ------------------------------------------------------------------ training straight from images (no feature cache)
+    def run_images(self, batches, feature_extractor, streams=2):
+        """Drive ``_process_batch`` from an iterable of ``(pseudo_labels, images)`` batches: the frozen backbone pass of batch k+1
+        runs on side HIP streams while the decoder step of batch k runs on the current stream (engine/runner/pipeline.py).
+        ``feature_extractor``: the ``backbone`` wrapper or a ``ViTEngine``.  Yields the loss tensor of every step, in order;
+        numerically identical to calling ``feature_extractor`` then ``_process_batch`` serially."""
+        from .pipeline import FeaturePipeline
+        engine = getattr(feature_extractor, "engine", feature_extractor)
+        engine.streams = streams
+        pipe = FeaturePipeline(engine)
+        it = iter(batches)
+        try:
+            cur = next(it)
+        except StopIteration:
+            return
+        pipe.submit(cur[1].to(engine.device))
+        while cur is not None:
+            nxt = next(it, None)
+            key = pipe.next_features()
+            if nxt is not None:
+                pipe.submit(nxt[1].to(engine.device))
+            loss = self._process_batch((cur[0], key))
+            self.global_step += 1                             # run_epoch's increment (loop_UCOD_DPL.py:143)
+            yield loss
+            cur = nxt
+
     # ------------------------------------------------------------------ backbone-backward mode (SURVEY.md 8a row B9)
     def attach_lora_backbone(self, engine, lr=None):
         """Switch the loop to the end-to-end mode models/modules/full_model.py describes: the student's features come from a
@@ -261,8 +287,19 @@ class TrainLoop(BaseLoop):
         images = images.to(dev, torch.float32)
         pseudo_labels = pseudo_labels.to(dev, torch.float32)
         B = images.shape[0]
+        # the teacher's pass has no consumer until the decoder step: run it on a side stream, concurrently with the student's
+        if getattr(self, "_teacher_stream", None) is None:
+            self._teacher_stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        ev0 = torch.cuda.Event()
+        ev0.record(cur)
+        self._teacher_stream.wait_event(ev0)
+        with torch.cuda.stream(self._teacher_stream):
+            feat_t = eng_t.forward_train(images)
+            ev1 = torch.cuda.Event()
+            ev1.record(self._teacher_stream)
         feat_s = eng.forward_train(images)                                   # [B,C,h,w]; activations kept for backward
-        feat_t = eng_t.forward_train(images)
+        cur.wait_event(ev1)
         fh, fw = feat_s.shape[-2:]
         pl = ops.bilinear_resize(pseudo_labels, fs, fs)
         emb_s, W_s, b_s, hw_s, hb_s = A.slices(A.p)
