@@ -547,8 +547,11 @@ __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 }
 
-template <int EPI, int NT, bool STAGGER>
+template <int EPI, int NT, bool STAGGER, int NPH = 4>
 __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
+  // NPH phases of 128/NPH rows per K-tile and wave group.  NPH = 2 halves the number of barrier intervals per MFMA (two
+  // 32-MFMA intervals instead of four 16-MFMA ones per K-tile and group) at the price of 16 more fragment registers.
+  constexpr int IT = 8 / NPH;                                     // 16-row i-tiles per phase
   using Cfg = BigCfg<NT>;
   __shared__ __attribute__((aligned(16))) char smem[2 * Cfg::BUF];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -639,11 +642,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
     const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
     bf16x8 fb[NT][2];
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph) {
-      if (ph == 0 && more1) stageA(t + 1, 0);
-      if (ph == 1 && more1) stageA(t + 1, 1);
-      if (ph == 2 && more2) stageB(t + 2, 0, B_SPLIT);
-      if (ph == 3 && more2) stageB(t + 2, B_SPLIT, Cfg::NB);
+    for (int ph = 0; ph < NPH; ++ph) {
+      if constexpr (NPH == 4) {
+        if (ph == 0 && more1) stageA(t + 1, 0);
+        if (ph == 1 && more1) stageA(t + 1, 1);
+        if (ph == 2 && more2) stageB(t + 2, 0, B_SPLIT);
+        if (ph == 3 && more2) stageB(t + 2, B_SPLIT, Cfg::NB);
+      } else {
+        if (ph == 0 && more1) { stageA(t + 1, 0); stageA(t + 1, 1); }
+        if (ph == 1 && more2) stageB(t + 2, 0, Cfg::NB);
+      }
       if (ph == 0) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -653,17 +661,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
             fb[j][ks] = *reinterpret_cast<const bf16x8*>(bufB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
           }
       }
-      bf16x8 fa[2][2];
+      bf16x8 fa[IT][2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < IT; ++i)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const int r = ph * 32 + i * 16 + (lane & 15);
+          const int r = ph * (128 / NPH) + i * 16 + (lane & 15);
           fa[i][ks] = *reinterpret_cast<const bf16x8*>(bufA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
         }
       if constexpr (STAGGER) {
         // RAW: every wave retires its tile-(t+1) DMAs BEFORE the barrier that precedes the leading group's first read
-        if (ph == 3) {
+        if (ph == NPH - 1) {
           if (more2) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -674,13 +682,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < IT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[ph * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[ph * 2 + i][j], 0, 0, 0);
+            acc[ph * IT + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[ph * IT + i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       if constexpr (!STAGGER) {
-        if (ph == 3) {
+        if (ph == NPH - 1) {
           if (more2) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
         }
       }
@@ -897,10 +905,9 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
         const double rounds = (double)cdiv((long)cdiv(a.M, 256) * cdiv(a.N, bn), 256);
         return rounds * (0.45 * 256 + 0.55 * bn);
       };
-      variant = (cost(192) < cost(256)) ? 6 : 5;
-      // several rounds of tiles per CU: the persistent form hides every tile's first-K-tile latency under the previous epilogue
-      // (QKV 158 -> 152 us; neutral elsewhere)
-      if ((long)cdiv(a.M, 256) * cdiv(a.N, variant == 6 ? 192 : 256) >= 512) variant += 2;
+      // two 32-MFMA barrier intervals per K-tile (variants 9/10) beat four 16-MFMA ones (5/6) by 2-4 % and the persistent
+      // form (7/8) by 1-5 % on every backbone shape (tools/gemm_bench.py)
+      variant = (cost(192) < cost(256)) ? 10 : 9;
     }
   }
   constexpr bool kTrainEpi = (EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
@@ -908,13 +915,13 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
     if (kTrainEpi && ((a.N & 7) != 0 || a.K < 128)) return UCOD_EINVAL;
     if (variant < 3) {
       auto cost = [&](int bn) { return (double)cdiv((long)cdiv(a.M, 256) * cdiv(a.N, bn), 256) * (0.45 * 256 + 0.55 * bn); };
-      variant = (cost(192) < cost(256)) ? 6 : 5;
+      variant = (cost(192) < cost(256)) ? 10 : 9;
     }
   }
   constexpr bool kBf16Out = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || kTrainEpi);
-  if (variant >= 3 && variant <= 8 && ((a.N & 3) != 0 || (kBf16Out && (a.N & 7) != 0))) return UCOD_EINVAL;   // 16-byte row stores
-  if (variant >= 3 && variant <= 8) {
-    const bool wide = (variant == 3 || variant == 5 || variant == 7);
+  if (variant >= 3 && variant <= 10 && ((a.N & 3) != 0 || (kBf16Out && (a.N & 7) != 0))) return UCOD_EINVAL;   // 16-byte row stores
+  if (variant >= 3 && variant <= 10) {
+    const bool wide = (variant == 3 || variant == 5 || variant == 7 || variant == 9);
     a.tiles_m = cdiv(a.M, 256);
     a.tiles_n = cdiv(a.N, wide ? 256 : 192);
     dim3 grid(a.tiles_m * a.tiles_n), block(512);
@@ -923,6 +930,8 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
       case 4: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3, false>), grid, block, 0, s, a); break;
       case 5: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4, true>), grid, block, 0, s, a); break;
       case 6: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3, true>), grid, block, 0, s, a); break;
+      case 9: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4, true, 2>), grid, block, 0, s, a); break;
+      case 10: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3, true, 2>), grid, block, 0, s, a); break;
       default: {                                             // 7, 8: persistent, one workgroup per CU
         static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
         const int ntiles = a.tiles_m * a.tiles_n;
