@@ -1,1 +1,1 @@
-from .cache_manager import MetaListPickleIO, CacheManager, MultiCacheManager, build_feature_cache  # noqa: F401
+from .feature_cache import MetaListPickleIO, CacheManager, MultiCacheManager, build_feature_cache  # noqa: F401

@@ -1,5 +1,8 @@
-"""Student + EMA-teacher container -- host-side mirror of models/uscod.py::baseline (:9-22):
-``baseline(cfg)(batched_inputs, ema=False)`` -> ``(fg, bg, extra_loss)``, or ``fg`` under no_grad when ``ema``."""
+"""Student + EMA-teacher container: the ``baseline`` of models/uscod.py (reference :9-22) on the HIP decoder.
+
+Call shape kept: ``baseline(cfg)(features, ema=False) -> (fg, bg, extra_loss)`` for the student, and with ``ema=True`` the
+teacher's ``fg`` logits, computed without an autograd graph.  Attribute names ``decoder`` / ``decoder_ema`` are what the
+shipped ``weights/UCOD_DPL_*.safetensors`` key on."""
 import torch
 from torch import nn
 
@@ -12,11 +15,13 @@ class baseline(nn.Module):
     def __init__(self, cfg):
         super().__init__()
         self.cfg = cfg
-        self.decoder = RevDecoder(cfg)
-        self.decoder_ema = RevDecoder(cfg, ema=True)
+        branches = {"decoder": RevDecoder(cfg), "decoder_ema": RevDecoder(cfg, ema=True)}
+        for name, module in branches.items():
+            self.add_module(name, module)
+
+    def branch(self, ema: bool):
+        return self.decoder_ema if ema else self.decoder
 
     def forward(self, batched_inputs, ema: bool = False):
-        if ema:
-            with torch.no_grad():
-                return self.decoder_ema(batched_inputs)
-        return self.decoder(batched_inputs)
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not ema):
+            return self.branch(ema)(batched_inputs)
