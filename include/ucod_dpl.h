@@ -280,6 +280,22 @@ int ucod_ccl8_host(const uint8_t* mask_host, int H, int W, int32_t* labels_host)
  * 'L' mask at loop_UCOD_DPL.py:350).  Bit-identical to Pillow. */
 int ucod_pil_resize_u8_host(const uint8_t* src_host, int h, int w, uint8_t* dst_host, int oh, int ow, int filter);
 
+/* GPU Look-Twice tail.
+ * ucod_ccl8_components: 8-connected components of a DEVICE uint8 [H,W] mask (non-zero = foreground) -> a DEVICE table of
+ * `*count` rows {root, area, xmin, xmax, ymin, ymax} (int32; at most `capacity` rows are written, *count may exceed it),
+ * in arbitrary order.  root = linear index of the component's first pixel in raster order, so sorting rows by root yields
+ * cv2.connectedComponents' label order (labels 1..n) -- loop_UCOD_DPL.py:366-384 needs only area and bounding box per label. */
+size_t ucod_ccl8_workspace_bytes(int H, int W);
+int ucod_ccl8_components(const uint8_t* mask_dev, int H, int W, int32_t* table_dev, int capacity, int32_t* count_dev, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* For each box i (HOST int32 [nbox,4] = x,y,w,h in canvas pixels, pasted in order): Pillow-BICUBIC resize of the DEVICE
+ * uint8 mask i ([nbox, sh, sw]) to (w,h) and paste into the DEVICE uint8 canvas [CH,CW], clipped to the canvas
+ * (Image.resize + Image.paste, loop_UCOD_DPL.py:346-352).  Bit-identical to Pillow.  w,h <= 0 is rejected like PIL does. */
+size_t ucod_paste_workspace_bytes(int nbox, int max_w, int max_h, int sh, int sw);
+int ucod_paste_resized_u8(const uint8_t* masks_dev, int nbox, int sh, int sw, const int32_t* boxes_host, uint8_t* canvas_dev, int CH, int CW,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* Batched crop + Pillow-BILINEAR resize + ToTensor + ImageNet Normalize on the GPU
  * (PIL crop + torchvision Resize/ToTensor/Normalize, loop_UCOD_DPL.py:282-286,341-342).
  * img u8 [H,W,3] (HWC, device); boxes_host int32 [nbox,4] = (x,y,w,h) in source pixels (regions outside the image read

@@ -81,6 +81,104 @@ def test_look_twice_end_to_end_matches_oracle_composition():
             return model(key)[0].cpu()
 
     ref = OLT.look_twice(img, bboxes, old.clone(), (518, 518), encode)
-    got = loop.look_twice(img, bboxes, old.clone())
+    got = loop.look_twice(img, bboxes, old.clone()).cpu()
     assert torch.equal(got, ref)
     assert (got != old).any()                                   # something was actually refined
+
+
+# ------------------------------------------------------------------------------------------------ GPU tail (row N2)
+def _box_str(bx):
+    return "none" if bx is None else ";".join(",".join(str(v) for v in b) for b in bx)
+
+
+@pytest.mark.parametrize("expand_type", ["dynamic", "const"])
+def test_gpu_ccl_boxes_reproduce_the_reference_tables(expand_type):
+    """G7: the 240 masks whose box lists were produced by the REFERENCE's process_preds tail -- device CCL + host arithmetic
+    must give the same strings (including the ValueError / ZeroDivisionError cases)."""
+    from conftest import load_golden
+    g = load_golden("g7_look_twice_int")
+    loop, _, _ = make_loop(img_size=(64, 64))
+    loop.cfg.val_cfg.expand_type = expand_type
+    for m, ref in zip(g["masks"].numpy(), g[expand_type]):
+        mask = torch.from_numpy((m * 255).astype(np.uint8)).cuda()
+        try:
+            got = _box_str(loop.boxes_from_mask_gpu(mask))
+        except ValueError:
+            got = "ValueError"
+        except ZeroDivisionError:
+            got = "ZeroDivisionError"
+        assert got == str(ref)
+
+
+def test_gpu_ccl_equals_host_ccl_on_full_size_masks():
+    """518x518 random blob / noise / snake masks: component table from the device == the host C++ labelling (cv2 order)."""
+    loop, _, _ = make_loop()
+    rng = np.random.default_rng(5)
+    H = W = 518
+    yy, xx = np.mgrid[0:H, 0:W]
+    masks = []
+    m = np.zeros((H, W), np.uint8)
+    for _ in range(40):
+        cy, cx, r = rng.integers(0, H), rng.integers(0, W), rng.integers(2, 40)
+        m[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] = 255
+    masks.append(m)
+    masks.append(((rng.random((H, W)) > 0.55) * 255).astype(np.uint8))            # percolation-like noise: thousands of components
+    s = np.zeros((H, W), np.uint8)                                                # one long serpentine component + diagonal touches
+    for r in range(0, H, 4):
+        s[r, :] = 255
+        s[r + 1:r + 4, (W - 1) if (r // 4) % 2 == 0 else 0] = 255
+    masks.append(s)
+    d = np.zeros((H, W), np.uint8)
+    d[np.arange(H), np.arange(W)] = 255                                           # pure diagonal: 8- but not 4-connected
+    d[np.arange(0, H, 2), (W - 1 - np.arange(0, W, 2))] = 255
+    masks.append(d)
+    masks.append(np.zeros((H, W), np.uint8))
+    masks.append(np.full((H, W), 255, np.uint8))
+    for m in masks:
+        n, labels = LT.connected_components(m)
+        ref = []
+        for k in range(1, n):
+            ys, xs = np.nonzero(labels == k)
+            ref.append((len(ys), int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)))
+        got = loop.components_gpu(torch.from_numpy(m).cuda())
+        assert got == ref
+
+
+def test_gpu_paste_is_bit_identical_to_the_pillow_path():
+    loop, _, _ = make_loop()
+    rng = np.random.default_rng(9)
+    masks = (rng.random((7, 37, 37)) > 0.5).astype(np.uint8) * 255
+    masks[3] = 255
+    boxes = [[100, 50, 300, 200], [0, 0, 518, 518], [400, 380, 200, 180], [-30, -20, 90, 70], [10, 10, 37, 37], [250, 100, 5, 400], [300, 300, 1, 1]]
+    canvas0 = (rng.random((518, 518)) > 0.5).astype(np.uint8) * 255
+    ref = canvas0.copy()
+    for b, m in zip(boxes, masks):
+        bx, by, bw, bh = b
+        rs = LT.pil_resize_u8(m, bw, bh, bicubic=True)
+        x0, y0, x1, y1 = max(bx, 0), max(by, 0), min(bx + bw, 518), min(by + bh, 518)
+        if x1 > x0 and y1 > y0:
+            ref[y0:y1, x0:x1] = rs[y0 - by:y1 - by, x0 - bx:x1 - bx]
+    canvas = torch.from_numpy(canvas0.copy()).cuda()
+    loop.paste_gpu(torch.from_numpy(masks).cuda(), boxes, canvas)
+    assert np.array_equal(canvas.cpu().numpy(), ref)
+    with pytest.raises(ValueError):
+        loop.paste_gpu(torch.from_numpy(masks[:1]).cuda(), [[5, 5, 0, 10]], canvas)
+
+
+def test_look_twice_gpu_tail_equals_host_tail():
+    """The whole refinement with the device tail vs the host tail (itself bit-exact vs the reference tables / Pillow)."""
+    loop, _, _ = make_loop()
+    img = synthetic_image(seed=4)
+    g = torch.Generator().manual_seed(21)
+    logits = torch.full((1, 1, 68, 68), -3.0)
+    for _ in range(3):
+        cy, cx = (int(v) for v in torch.randint(10, 58, (2,), generator=g))
+        logits[0, 0, cy - 3:cy + 4, cx - 4:cx + 5] = 3.0
+    out = {}
+    for tail in (True, False):
+        loop.gpu_tail = tail
+        preds_up, boxes = loop.process_preds(logits)
+        assert boxes is not None and len(boxes) >= 1
+        out[tail] = (boxes, loop.look_twice(img, boxes, preds_up).cpu())
+    assert out[True][0] == out[False][0]
+    assert torch.equal(out[True][1], out[False][1])

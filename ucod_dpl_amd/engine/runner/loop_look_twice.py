@@ -86,6 +86,7 @@ class ValLoop_Look_Twice(BaseLoop):
         self.feature_extractor = feature_extractor
         self.device = runner.device
         self._ws = None
+        self.gpu_tail = True                                                     # device CCL + device resize/paste (row N2)
 
     # ------------------------------------------------------------------ integer box logic (bit-exact)
     @staticmethod
@@ -98,9 +99,16 @@ class ValLoop_Look_Twice(BaseLoop):
     @staticmethod
     def expand_bbox(mask, bbox, img_width, img_height, expand_type="const", scale=1.3):
         x, y, w, h = bbox
+        inside = mask[y:y + h, x:x + w].sum() if expand_type == "dynamic" else 0
+        return ValLoop_Look_Twice._expand(inside, mask.shape[-2] * mask.shape[-1], bbox, img_width, img_height, expand_type, scale)
+
+    @staticmethod
+    def _expand(fg_in_box, mask_pixels, bbox, img_width, img_height, expand_type="const", scale=1.3):
+        """expand_bbox with the only two things it reads from the mask passed as numbers (:386-417)."""
+        x, y, w, h = bbox
         if expand_type == "dynamic":
-            fr = mask[y:y + h, x:x + w].sum() / (h * w)
-            br = (h * y) / (mask.shape[-2] * mask.shape[-1])
+            fr = np.float64(fg_in_box) / (h * w)
+            br = (h * y) / mask_pixels
             scale = math.sqrt(1 - br / fr + 1)
         new_w = w * scale
         new_h = h * scale
@@ -130,13 +138,68 @@ class ValLoop_Look_Twice(BaseLoop):
             return sorted(bboxes, key=lambda b: -1 * b[2] * b[3])
         return None
 
+    def components_gpu(self, mask_u8_dev):
+        """Device CCL -> host list of (area, x, y, w, h) per component in cv2's label order (raster order of the first pixel)."""
+        Hh, Ww = mask_u8_dev.shape
+        lib = N.load()
+        need = lib.ucod_ccl8_workspace_bytes(Hh, Ww)
+        if getattr(self, "_ccl_ws", None) is None or self._ccl_ws.numel() < need:
+            self._ccl_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        cap = 4096
+        while True:
+            table = torch.empty(cap, 6, dtype=torch.int32, device=self.device)
+            count = torch.zeros(1, dtype=torch.int32, device=self.device)
+            N.check(lib.ucod_ccl8_components(N.ptr(mask_u8_dev), Hh, Ww, N.ptr(table), cap, N.ptr(count), N.ptr(self._ccl_ws), self._ccl_ws.numel(),
+                                             N.stream()), "ucod_ccl8_components")
+            n = int(count.item())
+            if n <= cap:
+                break
+            cap = n
+        rows = table[:n].cpu().numpy()
+        rows = rows[np.argsort(rows[:, 0], kind="stable")]
+        return [(int(r[1]), int(r[2]), int(r[4]), int(r[3] - r[2] + 1), int(r[5] - r[4] + 1)) for r in rows]
+
+    def boxes_from_mask_gpu(self, mask_u8_dev):
+        """Integer tail of process_preds (:366-384) from a DEVICE 0/255 uint8 [h,w] mask; same result as ``boxes_from_mask``."""
+        h, w = self.img_size
+        comps = self.components_gpu(mask_u8_dev.contiguous())
+        p = [np.int64(c[0]) / (h * w) for c in comps]
+        if len(p) == 0:
+            return [list(DEFAULT_BOX)]
+        if max(p) < self.cfg.val_cfg.look_twice_th:
+            bboxes = []
+            npix = int(mask_u8_dev.shape[-2]) * int(mask_u8_dev.shape[-1])
+            for (area, x, y, bw, bh), pi in zip(comps, p):
+                if pi > 0.01:
+                    # the reference hands expand_bbox the one-component mask: its sum inside the component's own box IS the area
+                    bboxes.append(self._expand(np.uint64(area), npix, (x, y, bw, bh), h, w, expand_type=self.cfg.val_cfg.expand_type))
+            return sorted(bboxes, key=lambda b: -1 * b[2] * b[3])
+        return None
+
     def process_preds(self, preds, label_tensor=None):
         """:354-384.  preds [1,1,fs,fs] logits -> (preds_up float [1,h,w] on the GPU, boxes | None)."""
         h, w = self.img_size
         up = ops.binarize(ops.bilinear_resize(preds.to(self.device, torch.float32), h, w), logits=True)     # one resize + threshold
         preds_up = up.reshape(-1, h, w)[:1]
+        if getattr(self, "gpu_tail", True):
+            return preds_up, self.boxes_from_mask_gpu((preds_up[0] * 255).to(torch.uint8))
         mask = (preds_up[0].cpu().numpy() * 255).astype(np.uint8)
         return preds_up, self.boxes_from_mask(mask)
+
+    def paste_gpu(self, masks_u8_dev, bboxes, canvas_u8_dev):
+        """Pillow-BICUBIC resize of mask i to box i + paste, in order, on the device (:346-352)."""
+        nb, sh, sw = masks_u8_dev.shape
+        boxes = np.ascontiguousarray(np.asarray(bboxes, np.int32).reshape(nb, 4))
+        if (boxes[:, 2:] <= 0).any():
+            raise ValueError("height and width must be > 0")                  # what PIL's resize raises
+        lib = N.load()
+        need = lib.ucod_paste_workspace_bytes(nb, int(boxes[:, 2].max()), int(boxes[:, 3].max()), sh, sw)
+        if getattr(self, "_paste_ws", None) is None or self._paste_ws.numel() < need:
+            self._paste_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        CH, CW = canvas_u8_dev.shape
+        N.check(lib.ucod_paste_resized_u8(N.ptr(masks_u8_dev), nb, sh, sw, boxes.ctypes.data, N.ptr(canvas_u8_dev), CH, CW, N.ptr(self._paste_ws),
+                                          self._paste_ws.numel(), N.stream()), "ucod_paste_resized_u8")
+        return canvas_u8_dev
 
     # ------------------------------------------------------------------ crop / re-encode / paste (:326-352)
     def crop_batch(self, img_u8, boxes_xywh):
@@ -156,7 +219,8 @@ class ValLoop_Look_Twice(BaseLoop):
         return out
 
     def look_twice(self, path, bboxes, old_mask):
-        """path: image file or uint8 [H,W,3] array.  old_mask float [1,h,w] in {0,1}.  Returns ToTensor(new_mask) [1,h,w] (CPU)."""
+        """path: image file or uint8 [H,W,3] array.  old_mask float [1,h,w] in {0,1}.  Returns ToTensor(new_mask) [1,h,w]
+        (on the device with ``gpu_tail``, on the CPU with the host tail)."""
         ih, iw = self.img_size
         if isinstance(path, (str, os.PathLike)):
             from PIL import Image
@@ -165,13 +229,20 @@ class ValLoop_Look_Twice(BaseLoop):
         else:
             img = np.asarray(path)
         H, W = img.shape[:2]
-        canvas = (old_mask.squeeze(0).cpu().numpy() * 255).astype(np.uint8)
         src_boxes = [self.resize_bbox(b, iw, ih, W, H) for b in bboxes]          # img.size = (W, H) (:335)
         crops = self.crop_batch(img, src_boxes)
         _, key = self.feature_extractor(crops)                                   # [nbox,C,37,37], all boxes in one pass
         with torch.no_grad():
             preds = self.runner.model(key)[0]                                    # decoder at the native grid, no 68x68 resize
-        pred01 = ops.binarize(preds.contiguous(), logits=True).reshape(len(bboxes), preds.shape[-2], preds.shape[-1]).cpu().numpy()
+        pred01_dev = ops.binarize(preds.contiguous(), logits=True).reshape(len(bboxes), preds.shape[-2], preds.shape[-1])
+        if getattr(self, "gpu_tail", True):
+            canvas_dev = (old_mask.squeeze(0).to(self.device) * 255).to(torch.uint8).contiguous()
+            self.paste_gpu((pred01_dev * 255).to(torch.uint8).contiguous(), bboxes, canvas_dev)
+            # ToTensor's x/255 as a true IEEE division: torch turns `tensor / python_scalar` on the GPU into a multiplication by
+            # the reciprocal, and 255 * (1/255.f) != 1.0f
+            return torch.div(canvas_dev.to(torch.float32), torch.full((), 255.0, device=self.device)).unsqueeze(0)
+        canvas = (old_mask.squeeze(0).cpu().numpy() * 255).astype(np.uint8)
+        pred01 = pred01_dev.cpu().numpy()
         for b, m in zip(bboxes, pred01):
             bx, by, bw, bh = b
             if bw <= 0 or bh <= 0:
