@@ -9,8 +9,10 @@ from ucod_dpl_amd.data.utils.feature_extractor import random_state_dict
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+streams = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 lib = N.load()
 eng = ViTLoRAEngine(random_state_dict("dinov2_vitb14", seed=0), heads=12, device="cuda")
+eng.train_streams = streams
 x = torch.randn(B, 3, 518, 518, device="cuda")
 dkey = torch.randn(B, 768, 37, 37, device="cuda")
 for _ in range(2):
@@ -24,7 +26,10 @@ for _ in range(steps):
     eng.forward_train(x); eng.backward(dkey)
 torch.cuda.synchronize(); t2 = time.time()
 fwd = (t1 - t0) / steps * 1e3; both = (t2 - t1) / steps * 1e3
-print(f"B={B}: forward_train {fwd:.2f} ms, forward+backward {both:.2f} ms  ({B / both * 1e3:.1f} img/s), workspace {eng._tws.numel() / 2**30:.2f} GiB")
+print(f"B={B}: forward_train {fwd:.2f} ms, forward+backward {both:.2f} ms  ({B / both * 1e3:.1f} img/s), workspace {sum(w.numel() for w in eng._tside_ws if w is not None) / 2**30:.2f} GiB in {len(eng._tside)} stream(s)")
+eng.train_streams = 1          # exclusive per-kernel durations
+eng.forward_train(x); eng.backward(dkey)
+torch.cuda.synchronize()
 lib.ucod_prof_enable(1)
 eng.forward_train(x); eng.backward(dkey)
 torch.cuda.synchronize()

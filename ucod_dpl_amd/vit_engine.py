@@ -257,7 +257,7 @@ class ViTLoRAEngine(ViTEngine):
             wt_aug = torch.zeros(D, 3 * D + A, dtype=torch.bfloat16, device=dev)
             wt_aug[:, :3 * D] = qkv_w.t()
             self.train_layers.append([w_aug, wt_aug, proj_w.t().contiguous(), fc1_w.t().contiguous(), fc2_w.t().contiguous()])
-        self._tws = None
+        self._tside = None
         self._saved_for = None
         self.repack()
 
@@ -300,16 +300,41 @@ class ViTLoRAEngine(ViTEngine):
         t.lora_r, t.lora_scaling = self.r, self.scaling
         return t
 
-    def _tables(self, gh, gw):
+    def _tables(self, gh, gw, grad=None):
         pos = self._pos(gh, gw)
         ptrs = [self.patch_w, self.patch_b, self.cls, pos]
         for l in self.layers:
             ptrs += l
+        grad = self.lora_grad if grad is None else grad
         tptrs = []
         for i, tl in enumerate(self.train_layers):
-            tptrs += tl + [self.lora[i], self.lora_grad[i]]
+            tptrs += tl + [self.lora[i], grad[i]]
         keep = ptrs + tptrs
         return (C.c_void_p * len(ptrs))(*[t.data_ptr() for t in ptrs]), (C.c_void_p * len(tptrs))(*[t.data_ptr() for t in tptrs]), keep
+
+    def _chunks(self, B):
+        """Image-parallel sub-batches (``self.train_streams``, default 2): as in ViTEngine.forward, every kernel of both passes is
+        per image except the LoRA-gradient reduction over rows, which is done per chunk into its own buffer and summed at the end."""
+        ns = max(1, min(int(getattr(self, "train_streams", 2)), B))
+        if getattr(self, "_tside", None) is None or len(self._tside) != ns:
+            self._tside = [torch.cuda.Stream(device=self.device) for _ in range(ns)]
+            self._tside_ws = [None] * ns
+            self._tside_grad = [torch.zeros_like(self.lora) for _ in range(ns)]
+        return [(B * i // ns, B * (i + 1) // ns) for i in range(ns)]
+
+    def _fan_out(self, fn):
+        """Run fn(i, b0, b1) for every chunk on its side stream, between two events on the current stream."""
+        cur = torch.cuda.current_stream(self.device)
+        start = torch.cuda.Event()
+        start.record(cur)
+        for i, (b0, b1) in enumerate(self._bounds):
+            st = self._tside[i]
+            st.wait_event(start)
+            with torch.cuda.stream(st):
+                fn(i, b0, b1)
+                done = torch.cuda.Event()
+                done.record(st)
+            cur.wait_event(done)
 
     def forward_train(self, img, out=None):
         if not img.is_cuda:
@@ -318,16 +343,21 @@ class ViTLoRAEngine(ViTEngine):
         B, _, H, W = img.shape
         gh, gw = H // self.P, W // self.P
         lib = N.load()
-        t = self._train_desc(B, H, W)
-        need = lib.ucod_vit_train_workspace_bytes(C.byref(t))
-        if need == 0:
-            raise ValueError("unsupported ViT geometry")
-        if self._tws is None or self._tws.numel() < need:
-            self._tws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        T, TT, keep = self._tables(gh, gw)
         key = out if out is not None else torch.empty(B, self.D, gh, gw, dtype=torch.float32, device=self.device)
-        N.check(lib.ucod_vit_forward_train(C.byref(t), T, TT, N.ptr(img), N.ptr(key), N.ptr(self._tws), self._tws.numel(), N.stream()),
-                "ucod_vit_forward_train")
+        self._bounds = self._chunks(B)
+
+        def run(i, b0, b1):
+            t = self._train_desc(b1 - b0, H, W)
+            need = lib.ucod_vit_train_workspace_bytes(C.byref(t))
+            if need == 0:
+                raise ValueError("unsupported ViT geometry")
+            if self._tside_ws[i] is None or self._tside_ws[i].numel() < need:
+                self._tside_ws[i] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            T, TT, keep = self._tables(gh, gw, self._tside_grad[i])
+            N.check(lib.ucod_vit_forward_train(C.byref(t), T, TT, N.ptr(img[b0:b1]), N.ptr(key[b0:b1]), N.ptr(self._tside_ws[i]),
+                                               self._tside_ws[i].numel(), N.stream()), "ucod_vit_forward_train")
+
+        self._fan_out(run)
         self._saved_for = (B, H, W)
         return key
 
@@ -341,9 +371,15 @@ class ViTLoRAEngine(ViTEngine):
         if tuple(dkey.shape) != (B, self.D, gh, gw):
             raise ValueError(f"dkey shape {tuple(dkey.shape)} != {(B, self.D, gh, gw)}")
         lib = N.load()
-        t = self._train_desc(B, H, W)
-        T, TT, keep = self._tables(gh, gw)
-        N.check(lib.ucod_vit_backward(C.byref(t), T, TT, N.ptr(dkey), N.ptr(self._tws), self._tws.numel(), N.stream()), "ucod_vit_backward")
+
+        def run(i, b0, b1):
+            t = self._train_desc(b1 - b0, H, W)
+            T, TT, keep = self._tables(gh, gw, self._tside_grad[i])
+            N.check(lib.ucod_vit_backward(C.byref(t), T, TT, N.ptr(dkey[b0:b1]), N.ptr(self._tside_ws[i]), self._tside_ws[i].numel(), N.stream()),
+                    "ucod_vit_backward")
+
+        self._fan_out(run)
+        torch.sum(torch.stack(self._tside_grad[:len(self._bounds)]), dim=0, out=self.lora_grad) if len(self._bounds) > 1 else self.lora_grad.copy_(self._tside_grad[0])
         self._saved_for = None
         return self.lora_grad
 
@@ -356,7 +392,7 @@ class ViTLoRAEngine(ViTEngine):
         other.lora = self.lora.clone()
         other.lora_grad = torch.zeros_like(self.lora)
         other.train_layers = [[tl[0].clone(), tl[1].clone()] + tl[2:] for tl in self.train_layers]
-        other._tws, other._saved_for = None, None
+        other._tside, other._saved_for = None, None
         other._pos_cache = dict(self._pos_cache)
         other.repack()
         return other
