@@ -128,9 +128,11 @@ def test_attention(variant, B, tok, heads):
     assert rel_l2(out, ref) < 1e-2
 
 
+@pytest.mark.parametrize("variant", [2, 3])
 @pytest.mark.parametrize("B,tok,heads", [(1, 26, 2), (2, 64, 1), (1, 200, 3), (2, 1370, 2), (1, 1, 1)])
-def test_attention_prescaled_q_kernel(B, tok, heads):
-    """VALU-lean kernel: Q carries head_dim^-0.5*log2(e) already (scale=0 in the ABI)."""
+def test_attention_prescaled_q_kernel(B, tok, heads, variant):
+    """VALU-lean kernel: Q carries head_dim^-0.5*log2(e) already (scale=0 in the ABI).  variant 2 stages K/V by LDS-DMA,
+    variant 3 through registers; both must agree bit for bit (same arithmetic, different data path)."""
     g = torch.Generator().manual_seed(tok * 3 + heads)
     D = heads * 64
     qkv = torch.randn(B * tok, 3 * D, generator=g) * 1.5
@@ -139,9 +141,11 @@ def test_attention_prescaled_q_kernel(B, tok, heads):
     q, k, v = (qkv.float()[:, i * D:(i + 1) * D].reshape(B, tok, heads, 64).transpose(1, 2) for i in range(3))
     p = torch.softmax(torch.matmul(q, k.transpose(2, 3)) * math.log(2.0), dim=-1)
     ref = torch.matmul(p, v).transpose(1, 2).reshape(B * tok, D)
-    out = ops.attention(qkv.to(DEV), B, tok, heads, scale=0.0, variant=2).float().cpu()
+    qd = qkv.to(DEV)
+    out = ops.attention(qd, B, tok, heads, scale=0.0, variant=variant).float().cpu()
     assert maxdiff(out, ref) < 3e-2, maxdiff(out, ref)
     assert rel_l2(out, ref) < 1e-2
+    assert torch.equal(out, ops.attention(qd, B, tok, heads, scale=0.0, variant=5 - variant).float().cpu())
 
 
 def test_attention_prescaled_deferred_max_branches():

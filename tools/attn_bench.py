@@ -14,8 +14,8 @@ qkv_pre = qkv_f.to(torch.bfloat16)          # Q pre-scaled, as the QKV epilogue 
 fl = 4.0 * B * heads * tok * tok * 64
 for r in range(3):
     for v in variants:
-        sc = 0.0 if v == 2 else 0.125
-        x = qkv_pre if v == 2 else qkv
+        sc = 0.0 if v >= 2 else 0.125
+        x = qkv_pre if v >= 2 else qkv
         ops.attention(x, B, tok, heads, scale=sc, variant=v); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -224,6 +224,7 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 
 constexpr float DEFER_THR = 8.0f;
 
+template <bool DMA>
 __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N,
                                                               int heads, int npairs, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (KV_BYTES + KV_BYTES)];
@@ -282,6 +283,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __r
     }
   };
 
+  // DMA form: K/V tiles go HBM -> LDS by 16-byte LDS-DMA (no staging registers, no ds_write, no VALU): a wave instruction fills
+  // 8 rows (64 lanes x 16 B, lane-linear in LDS), so the bank swizzle is applied to the SOURCE chunk each lane fetches (both
+  // swizzles are XORs, hence their own inverses).  Wave w stages rows 8w..8w+7 and 32+8w..32+8w+7 of K and of V.
+  auto stage = [&](int t, int buf) {
+    char* kb = smem + buf * (2 * KV_BYTES);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = i * 32 + wave * 8 + (lane >> 3), slot = lane & 7;
+      int kr = t * KT + row;
+      kr = kr < N ? kr : N - 1;
+      const bf16_raw* g = base + (size_t)kr * ld;
+      const bf16_raw* gk = g + D + swz_k(row, slot) * 8;
+      const bf16_raw* gv = g + 2 * D + swz_v(row, slot) * 8;
+      char* dst = kb + (i * 32 + wave * 8) * 128;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gk, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gv, (__attribute__((address_space(3))) void*)(dst + KV_BYTES), 16, 0,
+                                       0);
+    }
+  };
+
   // loop-invariant LDS byte offsets of this lane's fragments (relative to the tile buffer)
   int koff[2][4], voff[2][2][2];
 #pragma unroll
@@ -303,12 +324,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __r
         voff[kt][ks][dt] = KV_BYTES + key * 128 + swz_v(key, dst >> 3) * 16 + (dst & 7) * 2;   // key+8 keeps the swizzle: +1024
       }
 
-  gload(0);
-  lwrite(0);
+  if constexpr (DMA) {
+    stage(0, 0);
+  } else {
+    gload(0);
+    lwrite(0);
+  }
   for (int t = 0; t < nt; ++t) {
-    __syncthreads();
+    __syncthreads();                                     // (DMA form: its vmcnt(0) retires this wave's DMAs of tile t before the barrier)
     const bool more = (t + 1 < nt);
-    if (more) gload(t + 1);
+    if constexpr (DMA) {
+      if (more) stage(t + 1, (t + 1) & 1);               // the other buffer: every wave is past its reads of tile t-1
+    } else {
+      if (more) gload(t + 1);
+    }
     const char* kb = smem + (t & 1) * (2 * KV_BYTES);
 
     // S' = K Q^T - m_run  (accumulator initialised with the row constant)
@@ -381,7 +410,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __r
         }
       }
     }
-    if (more) lwrite((t + 1) & 1);
+    if constexpr (!DMA) {
+      if (more) lwrite((t + 1) & 1);
+    }
   }
 
   const float inv = 1.0f / osum[0];
@@ -587,7 +618,10 @@ extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, in
   if (scale == 0.f) {   // Q pre-scaled by head_dim^-0.5 * log2(e): the VALU-lean kernel
     const int npairs = B * heads, nq = cdiv(tok, QT);
     dim3 grid1(cdiv(npairs, 8) * 8 * nq);
-    hipLaunchKernelGGL(attn_fwd_v2_kernel, grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
+    if (variant == 3)
+      hipLaunchKernelGGL((attn_fwd_v2_kernel<false>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
+    else
+      hipLaunchKernelGGL((attn_fwd_v2_kernel<true>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
     UCOD_CHECK_LAUNCH();
     return UCOD_OK;
   }
@@ -616,7 +650,7 @@ extern "C" int ucod_attention_fwd_lse(const void* qkv, void* out, float* lse, in
   if (!qkv || !out || !lse || B <= 0 || tok <= 0 || heads <= 0) return UCOD_EINVAL;
   UCOD_PROF(PROF_ATTN, stream);
   const int npairs = B * heads, nq = cdiv(tok, QT);
-  hipLaunchKernelGGL(attn_fwd_v2_kernel, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok,
+  hipLaunchKernelGGL((attn_fwd_v2_kernel<true>), dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok,
                      heads, npairs, lse);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
