@@ -99,3 +99,24 @@ def test_refiner_small_kernels_exact_f32():
     l2_d = l2.cuda()
     N.check(lib.ucod_gated_ensemble(N.ptr(l1u), N.ptr(l2_d), N.ptr(P["f0w"]), N.ptr(P["f0b"]), N.ptr(P["f2w"]), P["f2b"], N.ptr(o), N.ptr(w), N.ptr(wsb), 2, 21, 21, N.stream()), "ge")
     assert maxdiff(w.cpu(), ref_w) < 2e-5 and maxdiff(o.cpu(), ref_out) < 2e-5
+
+
+def test_sparse_refiner_no_window_selected():
+    """Edge case of ASR.py:41-51: confident predictions everywhere -> no window passes the entropy threshold.  The reference then
+    feeds an empty batch through CSF; h_preds is all zeros and the output is the gated ensemble of preds with zeros.  HIP mirror vs
+    the CPU oracle (pinned by G9 on the non-empty cases)."""
+    from oracle import refiner as OR
+    torch.manual_seed(RI.SEED)
+    m = RI.perturb_(SparseRefiner.from_config(CfgNode(dict(window_size=3, threshold=0.0015)))).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    l, h, preds = RI.make_inputs(False)
+    preds = torch.full_like(preds, 15.0)
+    preds[1] = -15.0
+    ref_out, ref_opt = OR.sparse_refiner_forward(l, h, preds, sd)
+    assert int(ref_opt["mask"].sum()) == 0
+    m = m.cuda()
+    with torch.no_grad():
+        out, ex, opt = m(l.cuda(), h.cuda(), preds.cuda())
+    assert int(opt["mask"].sum()) == 0 and opt["coords_list"].shape[0] == 0
+    assert float(opt["h_preds"].abs().max()) == 0.0
+    assert maxdiff(out.cpu(), ref_out) < 1e-4 * max(1.0, ref_out.abs().max().item())
