@@ -898,7 +898,10 @@ template <int EPI>
 static int launch(GemmArgs a, int variant, hipStream_t s) {
   if (variant == 0) {
     variant = 2;
-    if (a.M >= 2048 && a.K >= 128 && (a.N & 3) == 0 && (!(EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) || (a.N & 7) == 0)) {
+    // large tiles when either dimension is long enough to fill the chip with 256-row tiles (the key hook has M = channels = 768
+    // but N = all tokens: 3 x 172 tiles)
+    const bool big_enough = a.M >= 2048 || (a.M >= 512 && (long)a.M * a.N >= (1L << 24));
+    if (big_enough && a.K >= 128 && (a.N & 3) == 0 && (!(EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) || (a.N & 7) == 0)) {
       // Makespan model on 256 CUs (one large-tile workgroup per CU), fitted to tools/gemm_bench.py on MI355X:
       // a tile costs a fixed part (A-panel DMA, prologue, epilogue set-up) plus a part proportional to its width.
       auto cost = [&](int bn) {
