@@ -58,9 +58,70 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// float4 form for D % 256 == 0 (ViT-B 768, ViT-L 1024): half the load / store instructions of the float2 form at equal bytes.
+template <int NV, bool OUT_F32>
+__global__ __launch_bounds__(256) void layernorm4_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, void* __restrict__ y, int rows,
+                                                         int D, float eps) {
+  constexpr int R = 2;
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
+  float4 v[R][NV];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = (row0 + r) < rows ? (row0 + r) : rows - 1;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[r][i] = xr[lane + 64 * i];
+  }
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float a = v[r][i].x - mean, b = v[r][i].y - mean, c = v[r][i].z - mean, d = v[r][i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    const int row = row0 + r;
+    if (row >= rows) break;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float4 g = g4[lane + 64 * i], b = b4[lane + 64 * i];
+      const float o0 = (v[r][i].x - mean) * rstd * g.x + b.x, o1 = (v[r][i].y - mean) * rstd * g.y + b.y;
+      const float o2 = (v[r][i].z - mean) * rstd * g.z + b.z, o3 = (v[r][i].w - mean) * rstd * g.w + b.w;
+      if constexpr (OUT_F32) {
+        reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + (size_t)row * D)[lane + 64 * i] = make_float4(o0, o1, o2, o3);
+      } else {
+        u32x2 w;
+        w[0] = pack_bf16x2(o0, o1);
+        w[1] = pack_bf16x2(o2, o3);
+        reinterpret_cast<u32x2*>(reinterpret_cast<bf16_raw*>(y) + (size_t)row * D)[lane + 64 * i] = w;
+      }
+    }
+  }
+}
+
 template <bool OUT_F32>
 static int launch_ln(const float* x, const float* g, const float* b, void* y, int rows, int D, float eps, hipStream_t s) {
   dim3 grid(cdiv(rows, 8)), block(256);
+  if ((D % 256) == 0 && D / 256 <= 6) {
+    switch (D / 256) {
+#define LN4_CASE(n) \
+  case n: hipLaunchKernelGGL((layernorm4_kernel<n, OUT_F32>), grid, block, 0, s, x, g, b, y, rows, D, eps); break;
+      LN4_CASE(1) LN4_CASE(2) LN4_CASE(3) LN4_CASE(4) LN4_CASE(5) LN4_CASE(6)
+#undef LN4_CASE
+    }
+    UCOD_CHECK_LAUNCH();
+    return UCOD_OK;
+  }
   switch (D / 128) {
 #define LN_CASE(n) \
   case n: hipLaunchKernelGGL((layernorm_kernel<n, OUT_F32>), grid, block, 0, s, x, g, b, y, rows, D, eps); break;
