@@ -7,9 +7,10 @@
 //     running max / sum and the O rescale are lane-local (one cross-half exchange with lane^32);
 //   * the S^T accumulator registers are converted to bf16 in place and fed as the B operand of
 //     O^T += V^T P^T (accumulator-as-operand: no LDS round trip for P);
-//   * K and V tiles (64 keys) are staged through LDS once per workgroup with register prefetch of the
-//     next tile (issue-early / write-late), double buffered, one barrier per tile; K is XOR-swizzled for
-//     conflict-free ds_read_b128, V is consumed through ds_read_b64_tr_b16 (hardware transpose).
+//   * K and V tiles (64 keys) are staged through LDS once per workgroup, double buffered, one barrier per tile:
+//     attn_fwd_kernel and variant 3 of the v2 kernel through registers (issue-early / write-late), the default v2 kernel
+//     by LDS-DMA with the swizzle applied to the source chunk; K is XOR-swizzled for conflict-free ds_read_b128, V is
+//     consumed through ds_read_b64_tr_b16 (hardware transpose).
 //   * N (=1370 tokens) is not a tile multiple: out-of-range keys are clamped on load and masked to -inf.
 #include "common.h"
 #include "../../include/ucod_dpl.h"

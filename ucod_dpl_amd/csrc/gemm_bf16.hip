@@ -1,4 +1,4 @@
-// bf16 MFMA GEMM with fused epilogues for the ViT backbone (SURVEY.md 8a rows B1,B4,B5,B7,B8).
+// bf16 MFMA GEMM with fused epilogues for the ViT backbone (SURVEY.md 8a rows B1,B4,B5,B7,B8; training epilogues: row B9).
 //
 //   C[m][n] = sum_k A[m][k] * B[n][k]        A:[M,K]  B:[N,K]  both row-major, K contiguous (bf16)
 //
@@ -6,11 +6,15 @@
 // swapped (A = W_key, B = tokens), the last layer's key projection written straight into the
 // [B,C,h,w] map the reference's hook produces (data/utils/feature_extractor.py:46-47,55-58).
 //
-// gfx950 design: 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 tiles of
-// v_mfma_f32_16x16x32_bf16.  Operand tiles are staged HBM->LDS with 16-byte LDS-DMA
-// (global_load_lds_dwordx4; the LDS image is lane-linear, so the bank swizzle is applied to the
-// per-lane SOURCE address and again on the ds_read_b128 side), double buffered, one barrier per
-// K-tile.  The workgroup->tile map is XCD-aware (bijective remap: blocks b and b+8 share an XCD/L2).
+// Three kernels (variant numbers of ucod_gemm_bf16 in brackets):
+//   * gemm_bf16_kernel       [1,2]    128x128x64 tile, 4 waves (2x2), 2 workgroups per CU: small shapes.
+//   * gemm_bf16_big_kernel   [3-6,9,10] 256 x 256|192 x 64 tile, 8 waves (2x4), ONE workgroup per CU; LDS-DMA operands that stay in
+//                                     flight across raw s_barriers, staggered wave groups, 4 or 2 barrier phases per K-tile; what
+//                                     `auto` picks for every large shape (9/10).  Section comment below.
+//   * gemm_bf16_pers_kernel  [7,8]    persistent form of the large tile (next tile's first K-tile under the epilogue).
+// All share the XCD-aware tile order (blocks b and b+8 share an XCD/L2) and, for the hot epilogues, `big_epilogue`: bias as the
+// accumulator's initial value, column scale in the MFMA layout, drain through wave-private LDS into 16-byte buffer stores with no
+// load between two stores, f32 residual / saved pre-activation double-buffered across passes.
 #include <cstdlib>
 #include "common.h"
 #include "../../include/ucod_dpl.h"
