@@ -497,3 +497,23 @@ def test_feature_cache_pass_with_the_hip_backbone(tmp_path):
         assert got.device.type == "cpu" and got.dtype == torch.float32 and got.shape == (128, 5, 5)
         # batch composition changes nothing: every kernel is row / image independent
         assert torch.equal(got, key[0].cpu())
+
+
+def test_backbone_full_size_properties():
+    """BASELINE.json configs[1] at full size (DINOv2 ViT-B/14, 518x518, batch 32) -- too big for the CPU oracle, so size-independent
+    properties: (1) images are independent: permuting the batch permutes the key maps BIT for bit; (2) the image-parallel two-stream
+    pass equals the single-stream pass bit for bit; (3) a single image run alone agrees with its slot in the batch to bf16 rounding
+    (its GEMMs take a different tile path); (4) finite, non-degenerate output."""
+    from ucod_dpl_amd.data.utils.feature_extractor import backbone
+    bb = backbone.random_init("dinov2_vitb14", seed=0, image_size=518, device=DEV, attn_variant=2)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(32, 3, 518, 518, generator=g).to(DEV)
+    k0 = bb.engine(x).clone()
+    assert k0.shape == (32, 768, 37, 37) and bool(torch.isfinite(k0).all()) and float(k0.std()) > 1e-3
+    perm = torch.randperm(32, generator=g).to(DEV)
+    assert torch.equal(bb.engine(x[perm].contiguous()), k0[perm])
+    bb.engine.streams = 2
+    assert torch.equal(bb.engine(x), k0)
+    bb.engine.streams = 1
+    k1 = bb.engine(x[5:6].contiguous())
+    assert rel_l2(k1[0], k0[5]) < 1e-2
