@@ -281,6 +281,21 @@ int ucod_ccl8_host(const uint8_t* mask_host, int H, int W, int32_t* labels_host)
  * 'L' mask at loop_UCOD_DPL.py:350).  Bit-identical to Pillow. */
 int ucod_pil_resize_u8_host(const uint8_t* src_host, int h, int w, uint8_t* dst_host, int oh, int ow, int filter);
 
+/* Pseudo-label generator (generate_pseudo_label.py:71-94, data/utils/found_bkg_mask.py:4-86).
+ * ucod_vit_last_ln1_offset: byte offset, inside the workspace of ucod_vit_forward (full_last_layer == 0), of the last layer's
+ * LayerNorm-1 output bf16 [B*tok, D]; valid until the next pass on that workspace.
+ * ucod_cls_qk: q_cls, k_cls f32 [B,D] = that layer's query / key projection of token 0 (qkv_w bf16 [3D,D], qkv_b f32 [3D]).
+ * ucod_cls_attention: att f32 [B,heads,hw] = outputs.attentions[-1][:, :, 0, 1:] -- softmax of the CLS query over CLS + all
+ * patch keys, patch columns only -- with the patch keys taken from key_map f32 [B, D, hw] (the backbone's NCHW output).
+ * ucod_bkg_seg: found_bkg_mask.py:31-86 with up_size = grid: bkg_mask, sim_map f32 [B,hw] (sim_map already multiplied by
+ * 1 - bkg_mask and normalised by the batch-wide maximum, :81-82), cos_row f32 [B,hw], seed int32 [B], beta f32 [B,heads];
+ * scratch4 = 4 bytes of device scratch. */
+size_t ucod_vit_last_ln1_offset(const ucod_vit_desc* d);
+int ucod_cls_qk(const void* h_ln1_bf16, const void* qkv_w_bf16, const float* qkv_b, float* q_cls, float* k_cls, int B, int tok, int D, void* stream);
+int ucod_cls_attention(const float* q_cls, const float* k_cls, const float* key_map, float* att, int B, int heads, int hw, float scale, void* stream);
+int ucod_bkg_seg(const float* att, const float* key_map, float th_bkg, float epsilon, int apply_weights, float* bkg_mask, float* sim_map,
+                 float* cos_row, int* seed, float* beta, void* scratch4, int B, int heads, int hw, void* stream);
+
 /* GPU Look-Twice tail.
  * ucod_ccl8_components: 8-connected components of a DEVICE uint8 [H,W] mask (non-zero = foreground) -> a DEVICE table of
  * `*count` rows {root, area, xmin, xmax, ymin, ymax} (int32; at most `capacity` rows are written, *count may exceed it),

@@ -84,6 +84,7 @@ def dinov2_forward(img, sd, heads, patch=14, eps=1e-6, n_layers=None, full_last_
         k = _lora_linear(h, sd, a + "key", lora_scale)
         if i == L - 1:
             key = k
+            dinov2_forward.last_ln1 = h                 # LN1 output of the last layer (CLS-attention row of the pseudo-label generator)
             if not full_last_layer:
                 break
         q = _lora_linear(h, sd, a + "query", lora_scale)

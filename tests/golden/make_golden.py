@@ -63,7 +63,21 @@ def boundingRect(m):
     return int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)
 
 
-mod("cv2", connectedComponents=connectedComponents, boundingRect=boundingRect)
+def connectedComponentsWithStats(img, connectivity=8):
+    """(n, labels, stats[n,5] = LEFT, TOP, WIDTH, HEIGHT, AREA, centroids) like OpenCV, labels in raster order of first pixel."""
+    n, lab = connectedComponents(img, connectivity)
+    stats = np.zeros((n, 5), np.int32)
+    cent = np.zeros((n, 2))
+    for k in range(n):
+        ys, xs = np.nonzero(lab == k)
+        if len(ys):
+            stats[k] = (xs.min(), ys.min(), xs.max() - xs.min() + 1, ys.max() - ys.min() + 1, len(ys))
+            cent[k] = (xs.mean(), ys.mean())
+    return n, lab, stats, cent
+
+
+mod("cv2", connectedComponents=connectedComponents, boundingRect=boundingRect, connectedComponentsWithStats=connectedComponentsWithStats,
+    CC_STAT_LEFT=0, CC_STAT_TOP=1, CC_STAT_WIDTH=2, CC_STAT_HEIGHT=3, CC_STAT_AREA=4)
 
 
 class _T:
@@ -509,7 +523,54 @@ def g13():
     save("g13_cache_items", **{f"f{i}": f for i, f in enumerate(feats)})
 
 
+# ----------------------------------------------------------------------------- G14: pseudo-label generator (row N3)
+def g14():
+    """data/utils/found_bkg_mask.py::compute_img_bkg_seg and generate_pseudo_label.py::refine_post_process -- the REAL reference
+    functions -- on the last-layer attentions / key hook of a seeded HF Dinov2Model (eager attention, output_attentions)."""
+    from data.utils.found_bkg_mask import compute_img_bkg_seg
+    mod("tqdm", tqdm=lambda x, **k: x)
+    spec = importlib.util.spec_from_file_location("ref_gpl", REF + "/generate_pseudo_label.py")
+    gpl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gpl)
+    torch.manual_seed(14)
+    cfg = Dinov2Config(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, image_size=112, patch_size=14, mlp_ratio=4,
+                       layerscale_value=1.0)
+    cfg._attn_implementation = "eager"
+    m = Dinov2Model(cfg).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+            if "position_embeddings" in n or "cls_token" in n:
+                p.mul_(0.05)
+    keys = {}
+    m.encoder.layer[-1].attention.attention.key.register_forward_hook(lambda mod_, i, o: keys.__setitem__("k", o.detach()))
+    x = torch.randn(3, 3, 112, 112)
+    x[1] = x[1] * 0.2 + torch.linspace(-2, 2, 112).view(1, 1, 112)          # a smoother image: different sparsity pattern
+    with torch.no_grad():
+        out = m(x, output_attentions=True)
+    attn = out.attentions[-1]
+    key = keys["k"]
+    nh = attn.shape[1]
+    d = dict(x=x, attn_cls=attn[:, :, 0, :].clone(), key=key)
+    d.update({"sd." + n: v for n, v in m.state_dict().items()})
+    for th in (0.6, 0.3):
+        for aw in (True, False):
+            mask, sim = compute_img_bkg_seg(attentions=attn, feats=key, featmap_dims=(8, 8), th_bkg=th, dim=key.shape[-1] // nh, apply_weights=aw)
+            tag = f"th{int(th * 10)}_w{int(aw)}"
+            d["mask." + tag], d["sim." + tag] = mask, sim
+    # refine_post_process on binary masks with small islands / holes of every kind
+    g = torch.Generator().manual_seed(15)
+    masks = (torch.rand(24, 1, 16, 16, generator=g) > 0.82).float()
+    masks[8:16] = 1 - masks[8:16]
+    masks[16:] = (torch.rand(8, 1, 16, 16, generator=g) > 0.5).float()
+    d["pp_in"] = masks
+    d["pp_out"] = torch.stack([gpl.refine_post_process(mk.clone()) for mk in masks])
+    d["pp_out_a9"] = torch.stack([gpl.refine_post_process(mk.clone(), area_threshold=9) for mk in masks])
+    save("g14_pseudo_label", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g12", "g13", "g14"]
     for w in which:
         globals()[w]()

@@ -70,3 +70,20 @@ def test_build_feature_cache_batches_and_streams(tmp_path):
     assert idx == {str(i): f"data_{i}.pkl" for i in range(6)}
     with pytest.raises(RuntimeError):
         build_feature_cache(imgs, fe, fc, batch_size=2, device="cpu")
+
+
+def test_pseudo_label_post_process_and_cache(tmp_path):
+    """Row N3 host side (runs without a GPU: the connected components come from the library's host entry): the package's
+    refine_post_process vs the reference's (G14), and the pseudo_label_cache directory it feeds."""
+    from ucod_dpl_amd.generate_pseudo_label import refine_post_process
+    g = load_golden("g14_pseudo_label")
+    outs = []
+    for key, a in (("pp_out", 4), ("pp_out_a9", 9)):
+        for mk, ref in zip(g["pp_in"], g[key]):
+            out = refine_post_process(mk.clone(), area_threshold=a)
+            assert torch.equal(out, ref)
+            outs.append(out)
+    pc = MultiCacheManager(str(tmp_path), "dinov2", "train", "TR-CAMO+TR-COD10K").get_pseudo_label_cache()
+    pc.dump_list(outs[:5])
+    assert pc.mode == "r" and pc.length() == 5 and torch.equal(pc.read_file(3), outs[3])
+    assert (tmp_path / "pseudo_label_cache" / "TR-CAMO+TR-COD10K" / "index.json").exists()

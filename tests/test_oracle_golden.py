@@ -210,3 +210,25 @@ def test_g12_decoder_input_gradient():
     out = OD.rev_decoder_backward(g["x"].double(), p, g["r1"].double(), g["r2"].double(), 1000.0, with_dx=True)
     ref = g["dx"].double()
     assert maxdiff(out["dx"], ref) < 2e-4 * ref.abs().max().item()
+
+
+def test_g14_pseudo_label_generator():
+    """Row N3: oracle restatement of compute_img_bkg_seg / refine_post_process vs the reference functions (G14)."""
+    from oracle import pseudo_label as OPL
+    g = load_golden("g14_pseudo_label")
+    att, key = g["attn_cls"], g["key"]
+    for th in (0.6, 0.3):
+        for aw in (True, False):
+            tag = f"th{int(th * 10)}_w{int(aw)}"
+            mask, sim, row = OPL.bkg_seg(att, key, (8, 8), th, dim=64, apply_weights=aw)
+            safe = (row - th).abs() > 1e-5                          # one-row dot product vs the reference's full bmm: last-bit ties aside
+            assert torch.equal(mask[safe], g["mask." + tag][safe])
+            assert maxdiff(sim[safe], g["sim." + tag][safe]) < 1e-5
+    # the CLS attention row itself, from the oracle ViT's last-layer LN1 output
+    sd = sub(g, "sd.")
+    _, kmap = OV.dinov2_forward(g["x"], sd, heads=2, full_last_layer=False)
+    a_cls = OPL.cls_attention(OV.dinov2_forward.last_ln1, sd, layer=1, heads=2)
+    assert maxdiff(a_cls, att) < 2e-6
+    for pp_key, a in (("pp_out", 4), ("pp_out_a9", 9)):
+        for mk, ref in zip(g["pp_in"], g[pp_key]):
+            assert torch.equal(OPL.refine_post_process(mk.clone(), area_threshold=a), ref)

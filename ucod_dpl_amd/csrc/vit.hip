@@ -47,6 +47,7 @@ bool valid(const ucod_vit_desc* d) {
   } while (0)
 
 extern "C" size_t ucod_vit_workspace_bytes(const ucod_vit_desc* d) { return valid(d) ? make_plan(d).total : 0; }
+extern "C" size_t ucod_vit_last_ln1_offset(const ucod_vit_desc* d) { return valid(d) ? make_plan(d).off_h : (size_t)-1; }
 
 extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, const float* img, float* key_out, void* workspace,
                                 size_t workspace_bytes, void* stream) {

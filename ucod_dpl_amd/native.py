@@ -85,6 +85,10 @@ SIGNATURES = {
     "ucod_binarize": (ci, [vp, vp, sz, ci, vp]),
     "ucod_ccl8_host": (ci, [vp, ci, ci, vp]),
     "ucod_pil_resize_u8_host": (ci, [vp, ci, ci, vp, ci, ci, ci]),
+    "ucod_vit_last_ln1_offset": (sz, [C.POINTER(VitDesc)]),
+    "ucod_cls_qk": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, vp]),
+    "ucod_cls_attention": (ci, [vp, vp, vp, vp, ci, ci, ci, cf, vp]),
+    "ucod_bkg_seg": (ci, [vp, vp, cf, cf, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     "ucod_ccl8_workspace_bytes": (sz, [ci, ci]),
     "ucod_ccl8_components": (ci, [vp, ci, ci, vp, ci, vp, vp, sz, vp]),
     "ucod_paste_workspace_bytes": (sz, [ci, ci, ci, ci, ci]),

@@ -214,6 +214,31 @@ class ViTEngine:
             cur.wait_event(done)
         return key
 
+    def forward_with_cls_attention(self, img):
+        """(key [B,D,h,w], att [B,heads,h*w]): the key map plus ``outputs.attentions[-1][:, :, 0, 1:]`` of the HF model -- the CLS
+        query's softmax row of the LAST layer, which is all the pseudo-label generator reads from the attentions
+        (data/utils/found_bkg_mask.py:23; generate_pseudo_label.py:78-89).  Single-stream pass: the CLS projections are taken
+        from the LayerNorm-1 output the pass leaves in its workspace."""
+        if self.full_last_layer:
+            raise RuntimeError("forward_with_cls_attention needs the key-minimal pass (full_last_layer=False)")
+        ns, self.streams = self.streams, 1
+        try:
+            key = self.forward(img)
+        finally:
+            self.streams = ns
+        B, _, H, W = img.shape
+        lib = N.load()
+        d = self._desc(B, H, W)
+        off = lib.ucod_vit_last_ln1_offset(C.byref(d))
+        tok = key.shape[-2] * key.shape[-1] + 1
+        last = self.layers[-1]
+        q = torch.empty(B, self.D, dtype=torch.float32, device=self.device)
+        k = torch.empty(B, self.D, dtype=torch.float32, device=self.device)
+        N.check(lib.ucod_cls_qk(self._ws.data_ptr() + off, N.ptr(last[2]), N.ptr(last[3]), N.ptr(q), N.ptr(k), B, tok, self.D, N.stream()), "ucod_cls_qk")
+        att = torch.empty(B, self.heads, tok - 1, dtype=torch.float32, device=self.device)
+        N.check(lib.ucod_cls_attention(N.ptr(q), N.ptr(k), N.ptr(key), N.ptr(att), B, self.heads, tok - 1, 0.125, N.stream()), "ucod_cls_attention")
+        return key, att
+
     def forward_async(self, img, out=None):
         """Enqueue the pass on the side streams WITHOUT making the current stream wait: returns (key, events); the consumer
         calls ``torch.cuda.current_stream().wait_event(e)`` for each event before reading ``key``.  The side streams start
