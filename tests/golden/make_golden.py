@@ -570,7 +570,57 @@ def g14():
     save("g14_pseudo_label", **d)
 
 
+# ----------------------------------------------------------------------------- G15: CORAL validation loop pieces (row N4)
+def g15():
+    """engine/runner/loop_CORAL.py::LocalRefineValidationLoop -- the REAL class (constructed without its progress-bar __init__) on
+    the real `baseline` and `SparseRefiner`: feature preparation (both require_m_patches settings), crop decision, refiner call,
+    centre padding and prediction post-processing.  Inputs come from tests/golden/refiner_init.coral_inputs (seeded)."""
+    for name in ("matplotlib", "matplotlib.pyplot", "matplotlib.patches", "torchvision.transforms.functional"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                mod(name)
+    sys.modules["torchvision"].transforms.functional = sys.modules["torchvision.transforms.functional"]
+    import engine.runner.loop_CORAL as LC
+    from models.UDLR import SparseRefiner
+    sys.path.insert(0, OUT)
+    import refiner_init as RI
+    torch.manual_seed(RI.SEED)
+    refiner = RI.perturb_(SparseRefiner.from_config(CfgNode(dict(window_size=3, threshold=0.0015, dim=768)))).eval()
+    torch.manual_seed(151)
+    model = baseline(model_cfg(768, 68)).eval()
+    out = {"dec." + k: v for k, v in model.state_dict().items()}
+    for req_m in (False, True):
+        loop = object.__new__(LC.LocalRefineValidationLoop)
+        loop.cfg = CfgNode(dict(model_cfg=dict(window_length=6), dataset_cfg=dict(valset_cfg=dict(require_m_patches=req_m, DATASET="X"))))
+        loop._runner = SimpleNamespace(model=model, refiner=refiner)
+        loop.window_length = 6
+        l, m, h = RI.coral_inputs()
+        with torch.no_grad():
+            fd = loop._prepare_validation_features(l, m, h)
+            crop = loop._should_crop_center(fd["preds"])
+            outputs, _, opt = refiner(fd["l_features"], fd["h_features"], fd["preds"])
+            padded = loop._center_pad(outputs)
+            up = loop.process_preds(outputs, (50, 70))
+            up_pad = loop.process_preds(padded, (50, 70))
+        t = f"m{int(req_m)}."
+        out.update({t + "l_features": fd["l_features"], t + "h_features": fd["h_features"], t + "preds": fd["preds"], t + "crop": np.int64(bool(crop)),
+                    t + "outputs": outputs, t + "padded": padded, t + "up": up, t + "up_pad": up_pad})
+    # _should_crop_center on both sides of its 0.001 threshold, and process_preds on already-probabilities
+    loop = object.__new__(LC.LocalRefineValidationLoop)
+    z = torch.full((1, 1, 40, 40), -1.0)
+    z[0, 0, 0, 0] = 1.0
+    out["crop_sparse"] = np.int64(bool(loop._should_crop_center(z)))
+    z[0, 0, 0, :2] = 1.0
+    out["crop_dense"] = np.int64(bool(loop._should_crop_center(z)))
+    pr = torch.rand(1, 1, 9, 9, generator=torch.Generator().manual_seed(3))
+    out["probs_in"] = pr
+    out["probs_up"] = loop.process_preds(pr, (20, 31))
+    save("g15_coral_loop", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g12", "g13", "g14", "g15"]
     for w in which:
         globals()[w]()

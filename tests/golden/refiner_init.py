@@ -30,3 +30,14 @@ def make_inputs(partial):
         preds[0, :, :4, :] = 14.0
         preds[1, :, :, 2:] = -14.0
     return l, h, preds
+
+
+def coral_inputs():
+    """Seeded inputs of the CORAL validation-loop vectors (G15): l [1,768,5,5], m [1,4,768,36,36] (the 2x2 overlapping crops of a
+    54x54 map, lr_dataset.py:155-166), h [1,9,768,5,5]."""
+    g = torch.Generator().manual_seed(150)
+    l = torch.randn(1, 768, 5, 5, generator=g)
+    full = torch.randn(1, 768, 54, 54, generator=g) * 0.7
+    m = torch.stack([full[:, :, i * 18:i * 18 + 36, j * 18:j * 18 + 36] for i in range(2) for j in range(2)], dim=1)
+    h = torch.randn(1, 9, 768, 5, 5, generator=g)
+    return l, m, h

@@ -120,3 +120,75 @@ def test_sparse_refiner_no_window_selected():
     assert int(opt["mask"].sum()) == 0 and opt["coords_list"].shape[0] == 0
     assert float(opt["h_preds"].abs().max()) == 0.0
     assert maxdiff(out.cpu(), ref_out) < 1e-4 * max(1.0, ref_out.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------ CORAL validation loop (row N4)
+def _coral_loop(req_m):
+    import types
+    from ucod_dpl_amd.engine.runner import LocalRefineValidationLoop
+    from ucod_dpl_amd.models.uscod import baseline
+    g = load_golden("g15_coral_loop")
+    dev = torch.device("cuda", 0)
+    model = baseline(CfgNode(dict(dim=768, feature_size=68, ema_weight=0.99, dis_use_features=False))).to(dev).eval()
+    model.load_state_dict({k[4:]: v.to(dev) for k, v in g.items() if k.startswith("dec.")}, strict=True)
+    torch.manual_seed(RI.SEED)
+    refiner = RI.perturb_(SparseRefiner.from_config(CfgNode(dict(window_size=3, threshold=0.0015)))).eval().to(dev)
+    logs = []
+    runner = types.SimpleNamespace(device=dev, model=model, refiner=refiner, world_size=1, rank=0, val_dataloader=[],
+                                   logger=types.SimpleNamespace(log_table=logs.append, log=logs.append))
+    cfg = CfgNode(dict(train_cfg=dict(dist_train=False), model_cfg=dict(window_length=6), dataset_cfg=dict(valset_cfg=dict(require_m_patches=req_m, DATASET="X"))))
+    return LocalRefineValidationLoop(cfg, runner), g, runner, logs
+
+
+@pytest.mark.parametrize("req_m", [False, True])
+def test_coral_validation_loop_matches_reference(req_m):
+    """The reference's LocalRefineValidationLoop methods run on the real baseline / SparseRefiner (G15) vs the HIP-backed mirror."""
+    loop, g, runner, _ = _coral_loop(req_m)
+    t = f"m{int(req_m)}."
+    l, m, h = RI.coral_inputs()
+    fd = loop._prepare_validation_features(l, m, h)
+    assert maxdiff(fd["l_features"].cpu(), g[t + "l_features"]) < 1e-5 and maxdiff(fd["h_features"].cpu(), g[t + "h_features"]) < 1e-5
+    assert maxdiff(fd["preds"].cpu(), g[t + "preds"]) < 2e-4                       # exact-f32 decoder
+    assert int(loop._should_crop_center(fd["preds"])) == int(g[t + "crop"])
+    with torch.no_grad():
+        out, _, _ = runner.refiner(fd["l_features"], fd["h_features"], fd["preds"])
+    assert rel_l2(out, g[t + "outputs"]) < 2e-2                                    # bf16 projections inside the refiner
+    assert torch.equal(loop._center_pad(g[t + "outputs"].cuda()).cpu(), g[t + "padded"])
+    for src, ref in ((t + "outputs", t + "up"), (t + "padded", t + "up_pad")):
+        up = loop.process_preds(g[src].cuda(), (50, 70)).cpu()
+        assert float((up != g[ref]).float().mean()) < 2e-3                         # thresholded bilinear: last-bit ties only
+    assert torch.equal(loop.process_preds(g["probs_in"].cuda(), (20, 31)).cpu(), g["probs_up"])
+
+
+def test_coral_loop_run_and_window_features():
+    """run(): batches in the reference's dict layout -> MAE; WindowFeatures: one resize, nine windows by slicing, one batched pass."""
+    import types
+    import numpy as np
+    from ucod_dpl_amd.engine.runner import WindowFeatures, loop_look_twice as LT
+    from ucod_dpl_amd.data.utils.feature_extractor import backbone, random_state_dict, ARCHS
+    loop, g, runner, logs = _coral_loop(False)
+    l, m, h = RI.coral_inputs()
+    label = (torch.rand(1, 1, 50, 70, generator=torch.Generator().manual_seed(2)) > 0.5).float()
+    batch = dict(pseudo_label=None, label_tensor=label, features=l, img_path=["x"], m_inputs=m, h_inputs=h, index=[0])
+    runner.val_dataloader = [batch, batch]
+    res = loop.run()
+    up = loop._process_validation_batch(batch, LT.MAEStatistics())
+    assert abs(res["MAE"] - float((up.cpu() - label[0]).abs().mean())) < 1e-6 and logs
+    # window features on a tiny backbone: windows are exact slices of ONE Pillow-bilinear resize of the whole image
+    ARCHS["wf_vit"] = (128, 2, 2, 14, 56, True)
+    dev = torch.device("cuda", 0)
+    bb = backbone.from_state_dict(random_state_dict("wf_vit", seed=1, image_size=56), heads=2, device=dev)
+    lt_runner = types.SimpleNamespace(device=dev, model=None, world_size=1, rank=0, val_dataloader=[], logger=None)
+    lt_cfg = CfgNode(dict(train_cfg=dict(dist_train=False), model_cfg=dict(feature_size=68), val_cfg=dict(look_twice=True, look_twice_th=0.15, expand_type="dynamic"),
+                          dataset_cfg=dict(valset_cfg=dict(image_size=(56, 56)))))
+    lt = LT.ValLoop_Look_Twice(lt_cfg, lt_runner, feature_extractor=bb)
+    wf = WindowFeatures(bb, lt, window_size=3, grid=(56, 56), extractor_size=(84, 84), image_size=(56, 56))
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 255, (90, 120, 3), dtype=np.uint8)
+    lfe, hin, _ = wf.get_features(img, require_m_patches=False, crop_center=True)
+    assert hin.shape == (1, 9, 128, 4, 4) and lfe.shape == (1, 128, 4, 4)
+    from oracle import look_twice as OLT
+    crop = wf.crop_center(img)
+    big = OLT.crop_resize_normalize(crop, [0, 0, crop.shape[1], crop.shape[0]], (168, 168))
+    _, ref_key = bb(big[:, 56:112, 112:168].unsqueeze(0).cuda())                   # window (row 1, col 2) = index 5
+    assert torch.equal(hin[0, 5], ref_key[0])

@@ -232,3 +232,36 @@ def test_g14_pseudo_label_generator():
     for pp_key, a in (("pp_out", 4), ("pp_out_a9", 9)):
         for mk, ref in zip(g["pp_in"], g[pp_key]):
             assert torch.equal(OPL.refine_post_process(mk.clone(), area_threshold=a), ref)
+
+
+def test_g15_coral_validation_loop_pieces():
+    """Row N4: oracle restatement vs the reference's LocalRefineValidationLoop methods (G15)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import refiner_init as RI
+    from oracle import coral_loop as OC, refiner as OR
+    from ucod_dpl_amd.models.UDLR import SparseRefiner
+    from ucod_dpl_amd.engine.config import CfgNode
+    g = load_golden("g15_coral_loop")
+    dec = sub(g, "dec.decoder.")
+    torch.manual_seed(RI.SEED)
+    m = RI.perturb_(SparseRefiner.from_config(CfgNode(dict(window_size=3, threshold=0.0015)))).eval()
+    rsd = {k: v.detach() for k, v in m.state_dict().items()}
+    l, mm, h = RI.coral_inputs()
+    for req in (False, True):
+        t = f"m{int(req)}."
+        fd = OC.prepare_validation_features(l, mm, h, dec, 6, req)
+        assert maxdiff(fd["l_features"], g[t + "l_features"]) < 1e-6 and maxdiff(fd["h_features"], g[t + "h_features"]) < 1e-6
+        assert maxdiff(fd["preds"], g[t + "preds"]) < 5e-5
+        assert int(OC.should_crop_center(fd["preds"])) == int(g[t + "crop"])
+        out, _ = OR.sparse_refiner_forward(fd["l_features"], fd["h_features"], fd["preds"], rsd)
+        assert maxdiff(out, g[t + "outputs"]) < 5e-4
+        assert torch.equal(OC.center_pad(g[t + "outputs"]), g[t + "padded"])
+        assert torch.equal(OC.process_preds(g[t + "outputs"], (50, 70)), g[t + "up"])
+        assert torch.equal(OC.process_preds(g[t + "padded"], (50, 70)), g[t + "up_pad"])
+    z = torch.full((1, 1, 40, 40), -1.0)
+    z[0, 0, 0, 0] = 1.0
+    assert int(OC.should_crop_center(z)) == int(g["crop_sparse"])
+    z[0, 0, 0, :2] = 1.0
+    assert int(OC.should_crop_center(z)) == int(g["crop_dense"])
+    assert torch.equal(OC.process_preds(g["probs_in"], (20, 31)), g["probs_up"])
