@@ -300,12 +300,14 @@ class TrainLoop(BaseLoop):
         ev0 = torch.cuda.Event()
         ev0.record(cur)
         self._teacher_stream.wait_event(ev0)
+        images.record_stream(self._teacher_stream)
         with torch.cuda.stream(self._teacher_stream):
             feat_t = eng_t.forward_train(images)
             ev1 = torch.cuda.Event()
             ev1.record(self._teacher_stream)
         feat_s = eng.forward_train(images)                                   # [B,C,h,w]; activations kept for backward
         cur.wait_event(ev1)
+        feat_t.record_stream(cur)                                            # allocated on the teacher's stream, consumed on this one
         fh, fw = feat_s.shape[-2:]
         pl = ops.bilinear_resize(pseudo_labels, fs, fs)
         emb_s, W_s, b_s, hw_s, hb_s = A.slices(A.p)

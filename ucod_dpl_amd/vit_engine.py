@@ -202,6 +202,8 @@ class ViTEngine:
                 self._side_ws[i] = torch.empty(need, dtype=torch.uint8, device=self.device)
             st = self._side[i]
             st.wait_event(start)
+            img.record_stream(st)                                  # allocated on the caller's stream, consumed on this one: keep the
+            key.record_stream(st)                                  # caching allocator from recycling them before this stream is done
             with torch.cuda.stream(st):
                 N.check(lib.ucod_vit_forward(C.byref(d), table, N.ptr(img[b0:b1]), N.ptr(key[b0:b1]), N.ptr(self._side_ws[i]),
                                              self._side_ws[i].numel(), N.stream()), "ucod_vit_forward")
@@ -347,14 +349,17 @@ class ViTLoRAEngine(ViTEngine):
             self._tside_grad = [torch.zeros_like(self.lora) for _ in range(ns)]
         return [(B * i // ns, B * (i + 1) // ns) for i in range(ns)]
 
-    def _fan_out(self, fn):
-        """Run fn(i, b0, b1) for every chunk on its side stream, between two events on the current stream."""
+    def _fan_out(self, fn, tensors=()):
+        """Run fn(i, b0, b1) for every chunk on its side stream, between two events on the current stream.  ``tensors``: caller-stream
+        tensors the side streams touch (recorded on them so the caching allocator does not recycle their memory early)."""
         cur = torch.cuda.current_stream(self.device)
         start = torch.cuda.Event()
         start.record(cur)
         for i, (b0, b1) in enumerate(self._bounds):
             st = self._tside[i]
             st.wait_event(start)
+            for t in tensors:
+                t.record_stream(st)
             with torch.cuda.stream(st):
                 fn(i, b0, b1)
                 done = torch.cuda.Event()
@@ -382,7 +387,7 @@ class ViTLoRAEngine(ViTEngine):
             N.check(lib.ucod_vit_forward_train(C.byref(t), T, TT, N.ptr(img[b0:b1]), N.ptr(key[b0:b1]), N.ptr(self._tside_ws[i]),
                                                self._tside_ws[i].numel(), N.stream()), "ucod_vit_forward_train")
 
-        self._fan_out(run)
+        self._fan_out(run, (img, key))
         self._saved_for = (B, H, W)
         return key
 
@@ -403,7 +408,7 @@ class ViTLoRAEngine(ViTEngine):
             N.check(lib.ucod_vit_backward(C.byref(t), T, TT, N.ptr(dkey[b0:b1]), N.ptr(self._tside_ws[i]), self._tside_ws[i].numel(), N.stream()),
                     "ucod_vit_backward")
 
-        self._fan_out(run)
+        self._fan_out(run, (dkey,))
         torch.sum(torch.stack(self._tside_grad[:len(self._bounds)]), dim=0, out=self.lora_grad) if len(self._bounds) > 1 else self.lora_grad.copy_(self._tside_grad[0])
         self._saved_for = None
         return self.lora_grad
