@@ -174,7 +174,7 @@ def main():
         del bb
         torch.cuda.empty_cache()
         eng = ViTLoRAEngine(random_state_dict(a.arch, 0, a.image), heads, r=2, lora_alpha=4, device=dev, gemm_variant=a.gemm_variant,
-                            generator=torch.Generator().manual_seed(7))
+                            generator=torch.Generator().manual_seed(7), lora_dropout=0.05, seed=1234 + rank)
         loop.attach_lora_backbone(eng)
         for _ in range(2):
             loop._process_batch_full(images, pl)
@@ -198,7 +198,7 @@ def main():
         top = sorted(((lib.ucod_prof_class_name(i).decode(), tot2[i] / a.lora_steps) for i in range(ncls) if cnt2[i]), key=lambda r: -r[1])[:6]
         lora_mode = {"value": round(world * B * a.lora_steps / dt2, 2), "unit": "images/s", "ms_per_step": round(dt2 / a.lora_steps * 1e3, 3),
                      "steps": a.lora_steps, "final_loss": round(float(l2.item()), 6),
-                     "what": "LoRA r=2 on q/k/v of all layers: student fwd (saved activations) + EMA-teacher fwd + decoder step + backbone "
+                     "what": "LoRA r=2, alpha=4, dropout 0.05 on q/k/v of all layers: student fwd (saved activations) + EMA-teacher fwd + decoder step + backbone "
                              "backward (dgrad only) + LoRA/decoder all-reduce + 2 fused AdamW/EMA",
                      "top_kernels_ms_per_step": {n: round(t, 3) for n, t in top}}
     if rank != 0:

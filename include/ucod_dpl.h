@@ -104,15 +104,32 @@ int ucod_cast_f32_bf16(const float* src, void* dst_bf16, size_t n, void* stream)
 int ucod_gemm_bf16_train(int epilogue, const void* A, const void* B, void* out, int M, int N, int K, const float* bias,
                          const void* aux_bf16, void* out2_bf16, int variant, void* stream);
 
-/* y_aug bf16 [rows, D+64] = [ LayerNorm(x) | LayerNorm(x) A_q^T, A_k^T, A_v^T (3r values) | 0 ] */
+/* LoRA dropout (LoraConfig.lora_dropout, full_model.py:50: nn.Dropout on the input of every lora_A, an independent mask per target
+ * module).  Counter-based: element (row, col) of projection p (0 q, 1 k, 2 v) in `layer` is dropped iff
+ *   h = seed_lo ^ (idx * 0x9E3779B1);  h ^= seed_hi + (3*layer + p) * 0x85EBCA77;  h ^= h >> 16;  h *= 0x7FEB352D;  h ^= h >> 15;
+ *   h *= 0x846CA68B;  h ^= h >> 16;      (32-bit wrap-around arithmetic, idx = row * D + col)
+ * is below p * 2^32; kept elements are scaled by 1 / (1 - p).  Forward and backward regenerate the mask; nothing is stored.
+ * Pass NULL (or p == 0) for no dropout. */
+typedef struct {
+  float p;
+  unsigned long long seed;   /* change it every step */
+  int layer;
+} ucod_lora_dropout;
+
+/* y_aug bf16 [rows, D+64] = [ LayerNorm(x) | dropout_q(LN(x)) A_q^T, dropout_k(LN(x)) A_k^T, dropout_v(LN(x)) A_v^T (3r values) | 0 ] */
 int ucod_layernorm_lora(const float* x, const float* gamma, const float* beta, const float* lora_layer, int r, void* y_aug_bf16,
-                        int rows, int D, float eps, void* stream);
+                        int rows, int D, float eps, const ucod_lora_dropout* dropout, void* stream);
 
 /* LayerNorm backward w.r.t. its input (frozen gamma/beta), fused with the residual add and the next GEMM's A operand:
  * dx f32 [rows,D] = dres (nullable) + dLN(dy; x, gamma);  s bf16 [rows,D] = next_scale (nullable: ones) * dx.
  * dx may alias dres or dy; either output may be NULL. */
 int ucod_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
                        void* s_bf16, int rows, int D, float eps, void* stream);
+/* The same with the dropout-masked LoRA branch added to dy first:  dy += sum_p mask_p/(1-p) * (t_p A_p),  t = aug columns of
+ * dqkv_aug [rows, 3D+64].  Used for LayerNorm-1 when dropout is on (the A^T columns of WqkvT_aug are then zero, ucod_lora_pack). */
+int ucod_layernorm_bwd_lora(const float* dy, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
+                            void* s_bf16, int rows, int D, float eps, const void* dqkv_aug_bf16, const float* lora_layer, int r,
+                            const ucod_lora_dropout* dropout, void* stream);
 
 /* Attention forward that also returns the base-2 log-sum-exp of the scaled scores, lse f32 [B, heads, tok]
  * (Q must carry head_dim^-0.5 * log2(e), as for ucod_attention_fwd with scale == 0). */
@@ -129,14 +146,16 @@ int ucod_attention_bwd(const void* qkv_bf16, const void* out_bf16, const void* d
 int ucod_key_grad_tokens(const float* dkey, void* dqkv_aug_bf16, int B, int tok, int D, void* stream);
 
 /* Fill the aug columns of Wqkv_aug bf16 [3D, D+64] (alpha/r * B_q|B_k|B_v on the block diagonal) and of WqkvT_aug bf16
- * [D, 3D+64] (A_q^T|A_k^T|A_v^T) from one layer's LoRA parameters.  Either matrix may be NULL. */
-int ucod_lora_pack(const float* lora_layer, int r, float scaling, void* w_aug_bf16, void* wt_aug_bf16, int D, void* stream);
+ * [D, 3D+64] (A_q^T|A_k^T|A_v^T; zeros when zero_a_columns != 0, the dropout case) from one layer's LoRA parameters.  Either
+ * matrix may be NULL. */
+int ucod_lora_pack(const float* lora_layer, int r, float scaling, void* w_aug_bf16, void* wt_aug_bf16, int D, int zero_a_columns,
+                   void* stream);
 
 /* One layer's LoRA gradients from dqkv_aug [rows, 3D+64] and h_aug [rows, D+64]; also writes t = alpha/r * dqkv B into the
  * aug columns of dqkv_aug (consumed by the dgrad GEMM).  grad_layer has the parameter layout; accumulate != 0 adds. */
 size_t ucod_lora_grad_workspace_bytes(int D);
 int ucod_lora_grad(void* dqkv_aug_bf16, const void* h_aug_bf16, const float* lora_layer, int r, float scaling, float* grad_layer,
-                   int accumulate, void* workspace, size_t workspace_bytes, int rows, int D, void* stream);
+                   int accumulate, void* workspace, size_t workspace_bytes, int rows, int D, const ucod_lora_dropout* dropout, void* stream);
 
 /* Whole frozen backbone forward up to the last layer's key projection: one call enqueues every kernel.
  * Pointer table (HOST array of DEVICE pointers; "w" entries are bf16 [out,in], the rest f32):
@@ -170,12 +189,14 @@ int ucod_vit_forward(const ucod_vit_desc* d, const void* const* table_host, cons
  *   +5 LoRA parameters f32 [6*r*D]   +6 LoRA gradients f32 [6*r*D] (overwritten by ucod_vit_backward)
  * forward_train saves its activations in `workspace`; backward must be given the same, untouched workspace.
  * dkey f32 [B, D, H/P, W/P] = cotangent of key_out.  gemm_variant of the embedded desc applies; attention is the
- * pre-scaled kernel.  Dropout of the reference's LoraConfig (0.05) is not applied (documented deviation). */
+ * pre-scaled kernel.  With lora_dropout > 0 the aug A^T columns of qkv_wT_aug must have been packed as zeros (ucod_lora_pack). */
 #define UCOD_VIT_TRAIN_STRIDE 7
 typedef struct {
   ucod_vit_desc vit;
-  int lora_r;           /* models/modules/full_model.py:48: r = 2 */
-  float lora_scaling;   /* lora_alpha / r = 4 / 2 */
+  int lora_r;                    /* models/modules/full_model.py:48: r = 2 */
+  float lora_scaling;            /* lora_alpha / r = 4 / 2 */
+  float lora_dropout;            /* full_model.py:50: 0.05 in the reference config; 0 = off (eval mode) */
+  unsigned long long seed;       /* dropout seed of THIS step: forward_train and backward must be given the same value */
 } ucod_vit_train_desc;
 size_t ucod_vit_train_workspace_bytes(const ucod_vit_train_desc* t);
 int ucod_vit_forward_train(const ucod_vit_train_desc* t, const void* const* table_host, const void* const* train_table_host,

@@ -57,18 +57,38 @@ def dinov2_pos_embed(pos, n_h, n_w):
     return torch.cat((pos[:, :1], pp.permute(0, 2, 3, 1).reshape(1, n_h * n_w, -1)), 1)
 
 
-def _lora_linear(h, sd, name, lora_scale):
+def lora_dropout_mask(seed, layer, proj, rows, D, p):
+    """The counter-based LoRA-dropout mask of include/ucod_dpl.h (ucod_lora_dropout), restated with numpy uint32 arithmetic:
+    [rows, D] float tensor of 0 or 1/(1-p)."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        idx = np.arange(rows * D, dtype=np.uint64).astype(np.uint32)
+        h = np.uint32(seed & 0xFFFFFFFF) ^ (idx * np.uint32(0x9E3779B1))
+        h = h ^ (np.uint32((seed >> 32) & 0xFFFFFFFF) + np.uint32(3 * layer + proj) * np.uint32(0x85EBCA77))
+        h = h ^ (h >> np.uint32(16))
+        h = h * np.uint32(0x7FEB352D)
+        h = h ^ (h >> np.uint32(15))
+        h = h * np.uint32(0x846CA68B)
+        h = h ^ (h >> np.uint32(16))
+    thresh = min(int(np.float32(p).astype(np.float64) * 4294967296.0), 0xFFFFFFFF)
+    keep = h >= np.uint32(thresh)
+    inv = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return torch.from_numpy(np.where(keep, inv, np.float32(0.0)).astype(np.float32).reshape(rows, D))
+
+
+def _lora_linear(h, sd, name, lora_scale, mask=None):
     """nn.Linear, plus -- when the state dict carries ``<name>.lora_A.weight`` [r,D] / ``<name>.lora_B.weight`` [D,r] -- the
     peft LoRA branch the reference wraps query/key/value in (models/modules/full_model.py:47-72: r=2, lora_alpha=4,
     bias='none'; peft is not installed here, its published forward is ``base(x) + lora_B(lora_A(dropout(x))) * alpha/r``;
     dropout is the identity in this restatement -- SURVEY.md 8a row B9)."""
     y = h @ sd[name + ".weight"].t() + sd[name + ".bias"]
     if name + ".lora_A.weight" in sd:
-        y = y + (h @ sd[name + ".lora_A.weight"].t()) @ sd[name + ".lora_B.weight"].t() * lora_scale
+        hd = h if mask is None else h * mask.reshape(h.shape)       # nn.Dropout on lora_A's input (train mode)
+        y = y + (hd @ sd[name + ".lora_A.weight"].t()) @ sd[name + ".lora_B.weight"].t() * lora_scale
     return y
 
 
-def dinov2_forward(img, sd, heads, patch=14, eps=1e-6, n_layers=None, full_last_layer=True, lora_scale=2.0):
+def dinov2_forward(img, sd, heads, patch=14, eps=1e-6, n_layers=None, full_last_layer=True, lora_scale=2.0, lora_masks=None):
     """Returns (last_hidden_state [B,N,D] after the final LayerNorm, key [B,D,h,w])."""
     B, _, H, W = img.shape
     pre = "embeddings."
@@ -81,14 +101,15 @@ def dinov2_forward(img, sd, heads, patch=14, eps=1e-6, n_layers=None, full_last_
         p = f"encoder.layer.{i}."
         h = layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
         a = p + "attention.attention."
-        k = _lora_linear(h, sd, a + "key", lora_scale)
+        lm = (lambda nm: None) if lora_masks is None else (lambda nm: lora_masks.get((i, nm)))
+        k = _lora_linear(h, sd, a + "key", lora_scale, lm("key"))
         if i == L - 1:
             key = k
             dinov2_forward.last_ln1 = h                 # LN1 output of the last layer (CLS-attention row of the pseudo-label generator)
             if not full_last_layer:
                 break
-        q = _lora_linear(h, sd, a + "query", lora_scale)
-        v = _lora_linear(h, sd, a + "value", lora_scale)
+        q = _lora_linear(h, sd, a + "query", lora_scale, lm("query"))
+        v = _lora_linear(h, sd, a + "value", lora_scale, lm("value"))
         o = attention(q, k, v, heads)
         o = o @ sd[p + "attention.output.dense.weight"].t() + sd[p + "attention.output.dense.bias"]
         x = o * sd[p + "layer_scale1.lambda1"] + x
@@ -145,7 +166,7 @@ def dinov1_forward(img, sd, heads, patch=8, eps=1e-6, full_last_layer=True):
     return last, key_map
 
 
-def dinov2_lora_grads(img, sd, heads, dkey, patch=14, eps=1e-6, lora_scale=2.0):
+def dinov2_lora_grads(img, sd, heads, dkey, patch=14, eps=1e-6, lora_scale=2.0, lora_masks=None):
     """Backbone-backward mode: gradients of <key map, dkey> w.r.t. every LoRA matrix in ``sd``, by
     autograd over the restated forward.  ``dkey`` [B,D,h,w] is the cotangent arriving at the key hook
     (models/modules/full_model.py:95-106).  Returns (key [B,D,h,w], {param name: grad})."""
@@ -153,6 +174,6 @@ def dinov2_lora_grads(img, sd, heads, dkey, patch=14, eps=1e-6, lora_scale=2.0):
     leaf = {k: sd[k].detach().clone().requires_grad_(True) for k in names}
     sd2 = dict(sd)
     sd2.update(leaf)
-    _, key = dinov2_forward(img, sd2, heads, patch=patch, eps=eps, full_last_layer=False, lora_scale=lora_scale)
+    _, key = dinov2_forward(img, sd2, heads, patch=patch, eps=eps, full_last_layer=False, lora_scale=lora_scale, lora_masks=lora_masks)
     grads = torch.autograd.grad((key * dkey).sum(), [leaf[k] for k in names], allow_unused=True)
     return key.detach(), {k: (torch.zeros_like(leaf[k]) if g is None else g) for k, g in zip(names, grads)}

@@ -55,7 +55,7 @@ def test_layernorm_lora(M, D, r):
     flat, mats = lora_arena(r, D, g)
     out = torch.full((M, D + AUG), 7.0, dtype=torch.bfloat16, device=DEV)
     xs, gs, bs, fs = x.to(DEV), gam.to(DEV), bet.to(DEV), flat.to(DEV)
-    N.check(N.load().ucod_layernorm_lora(N.ptr(xs), N.ptr(gs), N.ptr(bs), N.ptr(fs), r, N.ptr(out), M, D, 1e-6, N.stream()), "ln_lora")
+    N.check(N.load().ucod_layernorm_lora(N.ptr(xs), N.ptr(gs), N.ptr(bs), N.ptr(fs), r, N.ptr(out), M, D, 1e-6, None, N.stream()), "ln_lora")
     out = out.float().cpu()
     h = OV.layer_norm(x.double(), gam.double(), bet.double(), 1e-6)
     assert maxdiff(out[:, :D], h) < 2e-2 * max(1.0, h.abs().max().item())
@@ -100,7 +100,7 @@ def test_key_grad_tokens_and_lora_pack():
     w = torch.zeros(3 * D, D + AUG, dtype=torch.bfloat16, device=DEV)
     wt = torch.zeros(D, 3 * D + AUG, dtype=torch.bfloat16, device=DEV)
     fs = flat.to(DEV)
-    N.check(N.load().ucod_lora_pack(N.ptr(fs), r, 2.0, N.ptr(w), N.ptr(wt), D, N.stream()), "lora_pack")
+    N.check(N.load().ucod_lora_pack(N.ptr(fs), r, 2.0, N.ptr(w), N.ptr(wt), D, 0, N.stream()), "lora_pack")
     w, wt = w.float().cpu(), wt.float().cpu()
     for p, (A, Bm) in enumerate(mats):
         blk = w[p * D:(p + 1) * D, D:]
@@ -130,7 +130,7 @@ def test_lora_grad(M, D, r):
     ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
     grad = torch.full((6 * r * D,), 9.0, device=DEV)
     ds, hs, fs = d_aug.to(DEV), h_aug.to(DEV), flat.to(DEV)
-    N.check(lib.ucod_lora_grad(N.ptr(ds), N.ptr(hs), N.ptr(fs), r, scaling, N.ptr(grad), 0, N.ptr(ws), wsb, M, D, N.stream()), "lora_grad")
+    N.check(lib.ucod_lora_grad(N.ptr(ds), N.ptr(hs), N.ptr(fs), r, scaling, N.ptr(grad), 0, N.ptr(ws), wsb, M, D, None, N.stream()), "lora_grad")
     grad, t_out = grad.cpu(), ds.float().cpu()[:, 3 * D:]
     off = 0
     for p, (A, Bm) in enumerate(mats):
@@ -320,7 +320,7 @@ def test_full_model_backward_through_decoder_and_backbone():
     sd = sub(g, "sd.")
     base = {k: v for k, v in sd.items() if ".lora_" not in k}
     torch.manual_seed(0)
-    cfg = CfgNode(dict(model_cfg=dict(dim=128, feature_size=8, ema_weight=0.99, enable_ocm=False, freeze_lora=False), lora_cfg=dict(r=2, lora_alpha=4)))
+    cfg = CfgNode(dict(model_cfg=dict(dim=128, feature_size=8, ema_weight=0.99, enable_ocm=False, freeze_lora=False), lora_cfg=dict(r=2, lora_alpha=4, lora_dropout=0.0)))
     dec = baseline(cfg.model_cfg).to(DEV)
     bb = load_lora(cfg.lora_cfg, base, heads=2, device=DEV)
     bb.engine.load_lora_state_dict(sd)
@@ -417,3 +417,49 @@ def test_fused_full_step_against_oracle():
         if k == "learnable_embedding":
             continue
         assert maxdiff(sd_after[k], v) < 2e-3 * max(1e-3, v.abs().max().item()) + 1.5e-3, (k, maxdiff(sd_after[k], v))
+
+
+def test_lora_dropout_masks_and_gradients():
+    """LoRA dropout (LoraConfig.lora_dropout): counter-based masks regenerated by every kernel.  (1) the forward's masked
+    down-projection against numpy masks from the documented hash; (2) whole forward/backward with p = 0.3 against the oracle given
+    the SAME masks; (3) keep rate; (4) eval() switches it off and reproduces the no-dropout key map."""
+    g = load_golden("g12_lora_backbone")
+    sd = sub(g, "sd.")
+    base = {k: v for k, v in sd.items() if ".lora_" not in k}
+    p_drop, seed = 0.3, 1234
+    eng = ViTLoRAEngine(base, heads=2, r=2, lora_alpha=4, device=DEV, lora_dropout=p_drop, seed=seed)
+    eng.train_streams = 1
+    eng.load_lora_state_dict(sd)
+    x, dkey = g["x"], g["dkey"]
+    key = eng.forward_train(x.to(DEV))
+    step_seed = eng._step_seed
+    rows, D = 2 * 26, 128
+    masks = {(i, nm): OV.lora_dropout_mask(step_seed, i, pi, rows, D, p_drop) for i in range(3) for pi, nm in enumerate(("query", "key", "value"))}
+    m0 = masks[(0, "query")]
+    assert abs(float((m0 > 0).float().mean()) - (1 - p_drop)) < 0.03 and abs(float(m0.max()) - 1 / (1 - p_drop)) < 1e-6
+    assert not torch.equal(masks[(0, "query")], masks[(0, "key")]) and not torch.equal(masks[(0, "query")], masks[(1, "query")])
+    key_ref, gref = OV.dinov2_lora_grads(x, sd, heads=2, dkey=dkey, lora_scale=2.0, lora_masks=masks)
+    assert maxdiff(key.cpu(), key_ref) < 3e-2 * max(1.0, key_ref.abs().max().item())
+    eng.backward(dkey.to(DEV))
+    got = eng.lora_state_dict(grads=True)
+    for k, ref in gref.items():
+        if float(ref.abs().max()) == 0.0:
+            assert float(got[k].abs().max()) == 0.0, k
+        else:
+            assert rel_l2(got[k], ref) < 5e-2, (k, rel_l2(got[k], ref))
+    # the dropped branch really changes the answer: without masks the oracle disagrees
+    _, g_nomask = OV.dinov2_lora_grads(x, sd, heads=2, dkey=dkey, lora_scale=2.0)
+    k0 = "encoder.layer.0.attention.attention.query.lora_A.weight"
+    assert rel_l2(got[k0], g_nomask[k0]) > 0.1
+    # a new step draws new masks; eval() turns dropout off
+    key2 = eng.forward_train(x.to(DEV))
+    assert eng._step_seed != step_seed and not torch.equal(key2, key)
+    eng.eval()
+    k_eval = eng.forward_train(x.to(DEV))
+    ref_eng = ViTLoRAEngine(base, heads=2, r=2, lora_alpha=4, device=DEV)
+    ref_eng.train_streams = 1
+    ref_eng.load_lora_state_dict(sd)
+    assert torch.equal(k_eval, ref_eng.forward_train(x.to(DEV)))
+    eng.backward(dkey.to(DEV))
+    ref_eng.backward(dkey.to(DEV))
+    assert torch.equal(eng.lora_grad, ref_eng.lora_grad)

@@ -11,6 +11,8 @@
 //             dLN1 = dqkv_aug WqkvT_aug^T  ==  dqkv Wqkv + t A
 //             dA = t^T LN1(x),  dB = alpha/r * dqkv^T u                                        (ucod_lora_grad)
 // Parameter layout of one layer in the flat LoRA arena (f32): [A_q (r x D) | B_q (D x r) | A_k | B_k | A_v | B_v].
+// With LoRA dropout on, u is computed from the dropped LN1(x) (one mask per projection), dA from the same dropped input, and the
+// t A term of dLN1 is added -- masked -- by the LayerNorm-1 backward instead of the dgrad GEMM (A^T columns packed as zeros).
 #include "common.h"
 #include "../../include/ucod_dpl.h"
 
@@ -18,13 +20,47 @@ namespace ucod {
 
 constexpr int AUG = UCOD_LORA_AUG;
 
+// LoRA dropout (LoraConfig.lora_dropout of models/modules/full_model.py:50,63: nn.Dropout on the input of every lora_A, one
+// independent mask per target module).  Counter-based: the keep decision of element (row, col) of projection p in layer l is a
+// pure function of (seed, 3*l + p, row*D + col), so forward and backward regenerate the same mask and nothing is stored.
+struct Drop {
+  unsigned seed_lo, seed_hi, thresh;     // drop iff hash < thresh  (thresh = p * 2^32)
+  int key0;                              // 3 * layer
+  float inv_keep;                        // 1 / (1 - p); 0 thresh = dropout off
+};
+__host__ __device__ __forceinline__ unsigned drop_hash(unsigned seed_lo, unsigned seed_hi, unsigned key, unsigned idx) {
+  unsigned h = seed_lo ^ (idx * 0x9E3779B1u);
+  h ^= seed_hi + key * 0x85EBCA77u;
+  h ^= h >> 16;
+  h *= 0x7FEB352Du;
+  h ^= h >> 15;
+  h *= 0x846CA68Bu;
+  h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ float drop_scale(const Drop& d, int p, unsigned idx) {
+  return drop_hash(d.seed_lo, d.seed_hi, (unsigned)(d.key0 + p), idx) < d.thresh ? 0.f : d.inv_keep;
+}
+static Drop make_drop(const ucod_lora_dropout* dd) {
+  Drop d{0u, 0u, 0u, 0, 1.f};
+  if (dd && dd->p > 0.f) {
+    d.seed_lo = (unsigned)(dd->seed & 0xFFFFFFFFull);
+    d.seed_hi = (unsigned)(dd->seed >> 32);
+    const double t = (double)dd->p * 4294967296.0;
+    d.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+    d.key0 = 3 * dd->layer;
+    d.inv_keep = 1.0f / (1.0f - dd->p);
+  }
+  return d;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // LayerNorm forward + LoRA down-projection.  One wave per row, D = 128*NCH, row in registers (as layernorm_kernel).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_lora_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ lora,
-                                                      int r, bf16_raw* __restrict__ y, int rows, int D, float eps) {
+                                                      int r, bf16_raw* __restrict__ y, int rows, int D, float eps, Drop drop) {
   // the 3r LoRA A rows live in LDS for the whole block (they were re-read from L2 for every row: 92 us against 33 us for the plain
   // LayerNorm); each wave walks rows block-stride, two rows in flight (as layernorm_kernel)
   extern __shared__ float a_lds[];                               // [3r][D]
@@ -69,18 +105,31 @@ __global__ __launch_bounds__(256) void ln_lora_kernel(const float* __restrict__ 
         v[q][i].y = (v[q][i].y - mean) * rstd * g.y + b.y;
         reinterpret_cast<unsigned*>(yr)[lane + 64 * i] = pack_bf16x2(v[q][i].x, v[q][i].y);
       }
-      // u[j] = <LN(x), A[j]>, j = p*r + rank
+      // u[j] = <dropout_p(LN(x)), A[j]>, j = p*r + rank
       float mine = 0.f;
-      for (int j = 0; j < 3 * r; ++j) {
-        const float2* a2 = reinterpret_cast<const float2*>(a_lds + (size_t)j * D);
-        float d = 0.f;
+      for (int p = 0; p < 3; ++p) {
+        float2 vm[NCH];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-          const float2 a = a2[lane + 64 * i];
-          d += v[q][i].x * a.x + v[q][i].y * a.y;
+          vm[i] = v[q][i];
+          if (drop.thresh) {
+            const unsigned idx = (unsigned)row * (unsigned)D + 2u * (unsigned)(lane + 64 * i);
+            vm[i].x *= drop_scale(drop, p, idx);
+            vm[i].y *= drop_scale(drop, p, idx + 1u);
+          }
         }
-        d = wave_sum(d);
-        if (lane == j) mine = d;
+        for (int jr = 0; jr < r; ++jr) {
+          const int j = p * r + jr;
+          const float2* a2 = reinterpret_cast<const float2*>(a_lds + (size_t)j * D);
+          float d = 0.f;
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) {
+            const float2 a = a2[lane + 64 * i];
+            d += vm[i].x * a.x + vm[i].y * a.y;
+          }
+          d = wave_sum(d);
+          if (lane == j) mine = d;
+        }
       }
       yr[D + lane] = f32_to_bf16(lane < 3 * r ? mine : 0.f);
     }
@@ -92,11 +141,14 @@ __global__ __launch_bounds__(256) void ln_lora_kernel(const float* __restrict__ 
 // bf16 cast the NEXT dgrad GEMM wants as its A operand:
 //   g = dy * gamma;  dx_ln = rstd * (g - mean(g) - xhat * mean(g * xhat));   dx = dres + dx_ln;   s = bf16(scale * dx)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NCH>
+// LORA: dy additionally receives the dropout-masked LoRA branch  sum_p mask_p/keep * (t_p A_p)  (t = aug columns of dqkv_aug); with
+// dropout off that term rides on the dgrad GEMM instead (A^T columns of WqkvT_aug) and this kernel is launched with LORA = false.
+template <int NCH, bool LORA>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      const float* __restrict__ scale, float* __restrict__ dx,
-                                                     bf16_raw* __restrict__ sout, int rows, int D, float eps) {
+                                                     bf16_raw* __restrict__ sout, int rows, int D, float eps,
+                                                     const bf16_raw* __restrict__ tq, int ldt, const float* __restrict__ lora, int r, Drop drop) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -108,7 +160,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     v[i] = xr[lane + 64 * i];
-    const float2 d = dyr[lane + 64 * i], gm = g2[lane + 64 * i];
+    float2 d = dyr[lane + 64 * i];
+    if constexpr (LORA) {
+      const unsigned idx = (unsigned)row * (unsigned)D + 2u * (unsigned)(lane + 64 * i);
+      for (int p = 0; p < 3; ++p) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int jr = 0; jr < r; ++jr) {
+          const float t = bf16_to_f32(tq[(size_t)row * ldt + p * r + jr]);
+          const float2 av = reinterpret_cast<const float2*>(lora + (size_t)p * 2 * r * D + (size_t)jr * D)[lane + 64 * i];
+          a0 += t * av.x;
+          a1 += t * av.y;
+        }
+        d.x += a0 * drop_scale(drop, p, idx);
+        d.y += a1 * drop_scale(drop, p, idx + 1u);
+      }
+    }
+    const float2 gm = g2[lane + 64 * i];
     g[i] = make_float2(d.x * gm.x, d.y * gm.y);
     s += v[i].x + v[i].y;
   }
@@ -195,7 +262,7 @@ __global__ __launch_bounds__(256) void key_grad_tokens_kernel(const float* __res
 // LoRA pack: aug columns of Wqkv_aug [3D, D+64] and WqkvT_aug [D, 3D+64] from one layer's LoRA parameters.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict__ lora, int r, float scaling, bf16_raw* __restrict__ w_aug,
-                                                        bf16_raw* __restrict__ wt_aug, int D) {
+                                                        bf16_raw* __restrict__ wt_aug, int D, int zero_at) {
   const int idx = blockIdx.x * 256 + threadIdx.x;                // one thread per (row, aug column) of either matrix
   const int n_fwd = 3 * D * AUG;
   if (idx < n_fwd) {
@@ -211,7 +278,7 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict_
   if (k >= D * AUG || !wt_aug) return;
   const int d = k / AUG, j = k - d * AUG;
   float v = 0.f;
-  if (j < 3 * r) {
+  if (j < 3 * r && !zero_at) {                                   // zero_at: dropout on -- the (masked) A term is added by ln_bwd instead
     const int p = j / r, jj = j - p * r;
     v = lora[(size_t)p * 2 * r * D + (size_t)jj * D + d];        // A_p[jj][d]
   }
@@ -232,7 +299,7 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict_
 template <int NCH, int RW>
 __global__ __launch_bounds__(384) void lora_grad_kernel(bf16_raw* __restrict__ dqkv, const bf16_raw* __restrict__ h,
                                                         const float* __restrict__ lora, int r, int j0, float scaling,
-                                                        float* __restrict__ partial, int rows, int D) {
+                                                        float* __restrict__ partial, int rows, int D, Drop drop) {
   extern __shared__ float lds[];                                  // block reduction buffer [3][RW][D] | [3][D][RW]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = wave % 3, strm = wave / 3;
@@ -285,6 +352,14 @@ __global__ __launch_bounds__(384) void lora_grad_kernel(bf16_raw* __restrict__ d
     u[0] = __uint_as_float(uw << 16);
     if (RW > 1) u[1] = __uint_as_float(uw & 0xFFFF0000u);
     const int cur = row;
+    if (drop.thresh) {                                               // dA sees the SAME dropped input the forward's lora_A saw
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const unsigned idx = (unsigned)cur * (unsigned)D + 2u * (unsigned)(lane + 64 * i);
+        hv[i][0] *= drop_scale(drop, p, idx);
+        hv[i][1] *= drop_scale(drop, p, idx + 1u);
+      }
+    }
     row += step;
     if (row < rows) issue(row);                                    // next row in flight under this row's arithmetic
 #pragma unroll
@@ -378,15 +453,35 @@ constexpr int LORA_GRAD_BLOCKS = 512;
 using namespace ucod;
 
 extern "C" int ucod_layernorm_lora(const float* x, const float* gamma, const float* beta, const float* lora, int r, void* y_aug, int rows,
-                                   int D, float eps, void* stream) {
+                                   int D, float eps, const ucod_lora_dropout* dropout, void* stream) {
   if (!x || !gamma || !beta || !lora || !y_aug || rows <= 0 || D <= 0 || (D % 128) != 0 || r < 1 || 3 * r > AUG) return UCOD_EINVAL;
+  if (dropout && (dropout->p < 0.f || dropout->p >= 1.f)) return UCOD_EINVAL;
   UCOD_PROF(PROF_LN, stream);
+  const Drop drop = make_drop(dropout);
   const int nblk = cdiv(rows, 8) < 2048 ? cdiv(rows, 8) : 2048;   // block-stride over rows: the A rows are staged once per block
   dim3 grid(nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)3 * r * D * sizeof(float);
   switch (D / 128) {
-#define C(n) case n: hipLaunchKernelGGL((ln_lora_kernel<n>), grid, block, lds, s, x, gamma, beta, lora, r, (bf16_raw*)y_aug, rows, D, eps); break;
+#define C(n) case n: hipLaunchKernelGGL((ln_lora_kernel<n>), grid, block, lds, s, x, gamma, beta, lora, r, (bf16_raw*)y_aug, rows, D, eps, drop); break;
+    C(1) C(2) C(3) C(4) C(5) C(6) C(8) C(10) C(12)
+#undef C
+    default: return UCOD_EINVAL;
+  }
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+static int launch_ln_bwd(const float* dy, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx, void* s_bf16,
+                         int rows, int D, float eps, const bf16_raw* tq, int ldt, const float* lora, int r, const Drop& drop, hipStream_t s) {
+  dim3 grid(cdiv(rows, 4)), block(256);
+  const bool lo = tq != nullptr;
+  switch (D / 128) {
+#define C(n)                                                                                                                                   \
+  case n:                                                                                                                                      \
+    if (lo) hipLaunchKernelGGL((ln_bwd_kernel<n, true>), grid, block, 0, s, dy, x, gamma, dres, next_scale, dx, (bf16_raw*)s_bf16, rows, D, eps, tq, ldt, lora, r, drop); \
+    else hipLaunchKernelGGL((ln_bwd_kernel<n, false>), grid, block, 0, s, dy, x, gamma, dres, next_scale, dx, (bf16_raw*)s_bf16, rows, D, eps, tq, ldt, lora, r, drop); \
+    break;
     C(1) C(2) C(3) C(4) C(5) C(6) C(8) C(10) C(12)
 #undef C
     default: return UCOD_EINVAL;
@@ -399,16 +494,18 @@ extern "C" int ucod_layernorm_bwd(const float* dy, const float* x, const float* 
                                   void* s_bf16, int rows, int D, float eps, void* stream) {
   if (!dy || !x || !gamma || (!dx && !s_bf16) || rows <= 0 || D <= 0 || (D % 128) != 0) return UCOD_EINVAL;
   UCOD_PROF(PROF_LN_BWD, stream);
-  dim3 grid(cdiv(rows, 4)), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  switch (D / 128) {
-#define C(n) case n: hipLaunchKernelGGL((ln_bwd_kernel<n>), grid, block, 0, s, dy, x, gamma, dres, next_scale, dx, (bf16_raw*)s_bf16, rows, D, eps); break;
-    C(1) C(2) C(3) C(4) C(5) C(6) C(8) C(10) C(12)
-#undef C
-    default: return UCOD_EINVAL;
-  }
-  UCOD_CHECK_LAUNCH();
-  return UCOD_OK;
+  return launch_ln_bwd(dy, x, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, nullptr, 0, nullptr, 0, make_drop(nullptr), (hipStream_t)stream);
+}
+
+extern "C" int ucod_layernorm_bwd_lora(const float* dy, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
+                                       void* s_bf16, int rows, int D, float eps, const void* dqkv_aug, const float* lora_layer, int r,
+                                       const ucod_lora_dropout* dropout, void* stream) {
+  if (!dy || !x || !gamma || (!dx && !s_bf16) || rows <= 0 || D <= 0 || (D % 128) != 0 || !dqkv_aug || !lora_layer || r < 1 || 3 * r > AUG ||
+      !dropout || dropout->p < 0.f || dropout->p >= 1.f)
+    return UCOD_EINVAL;
+  UCOD_PROF(PROF_LN_BWD, stream);
+  return launch_ln_bwd(dy, x, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, (const bf16_raw*)dqkv_aug + 3 * D, 3 * D + AUG, lora_layer, r,
+                       make_drop(dropout), (hipStream_t)stream);
 }
 
 extern "C" int ucod_key_grad_tokens(const float* dkey, void* dqkv_aug, int B, int tok, int D, void* stream) {
@@ -419,12 +516,12 @@ extern "C" int ucod_key_grad_tokens(const float* dkey, void* dqkv_aug, int B, in
   return UCOD_OK;
 }
 
-extern "C" int ucod_lora_pack(const float* lora_layer, int r, float scaling, void* w_aug, void* wt_aug, int D, void* stream) {
+extern "C" int ucod_lora_pack(const float* lora_layer, int r, float scaling, void* w_aug, void* wt_aug, int D, int zero_a_columns, void* stream) {
   if (!lora_layer || (!w_aug && !wt_aug) || r < 1 || 3 * r > AUG || D <= 0) return UCOD_EINVAL;
   UCOD_PROF(PROF_LORA, stream);
   const int n = 3 * D * AUG + D * AUG;
   hipLaunchKernelGGL(lora_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, lora_layer, r, scaling, (bf16_raw*)w_aug,
-                     (bf16_raw*)wt_aug, D);
+                     (bf16_raw*)wt_aug, D, zero_a_columns);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }
@@ -432,18 +529,21 @@ extern "C" int ucod_lora_pack(const float* lora_layer, int r, float scaling, voi
 extern "C" size_t ucod_lora_grad_workspace_bytes(int D) { return (size_t)LORA_GRAD_BLOCKS * (size_t)(12 * D) * sizeof(float); }
 
 extern "C" int ucod_lora_grad(void* dqkv_aug, const void* h_aug, const float* lora_layer, int r, float scaling, float* grad_layer,
-                              int accumulate, void* workspace, size_t workspace_bytes, int rows, int D, void* stream) {
+                              int accumulate, void* workspace, size_t workspace_bytes, int rows, int D, const ucod_lora_dropout* dropout,
+                              void* stream) {
   if (!dqkv_aug || !h_aug || !lora_layer || !grad_layer || !workspace || r < 1 || 3 * r > AUG || rows <= 0 || D <= 0 || (D % 128) != 0)
     return UCOD_EINVAL;
+  if (dropout && (dropout->p < 0.f || dropout->p >= 1.f)) return UCOD_EINVAL;
   if (workspace_bytes < ucod_lora_grad_workspace_bytes(D)) return UCOD_ENOMEM;
   UCOD_PROF(PROF_LORA, stream);
+  const Drop drop = make_drop(dropout);
   hipStream_t s = (hipStream_t)stream;
   constexpr int RW = 2;                                           // ranks per pass (the reference's r = 2 is one pass)
   const int nblk = rows < LORA_GRAD_BLOCKS * 2 ? cdiv(rows, 2) : LORA_GRAD_BLOCKS;
   const size_t lds_bytes = (size_t)6 * D * RW * sizeof(float);      // B window (3*D*RW) <= block reduction buffer (6*D*RW)
   for (int j0 = 0; j0 < r; j0 += RW) {
     switch (D / 128) {
-#define C(n) case n: hipLaunchKernelGGL((lora_grad_kernel<n, RW>), dim3(nblk), dim3(384), lds_bytes, s, (bf16_raw*)dqkv_aug, (const bf16_raw*)h_aug, lora_layer, r, j0, scaling, (float*)workspace, rows, D); break;
+#define C(n) case n: hipLaunchKernelGGL((lora_grad_kernel<n, RW>), dim3(nblk), dim3(384), lds_bytes, s, (bf16_raw*)dqkv_aug, (const bf16_raw*)h_aug, lora_layer, r, j0, scaling, (float*)workspace, rows, D, drop); break;
       C(1) C(2) C(3) C(4) C(5) C(6) C(8)
 #undef C
       default: return UCOD_EINVAL;

@@ -26,7 +26,7 @@ bool valid(const ucod_vit_train_desc* t) {
   const ucod_vit_desc* d = &t->vit;
   return d->B > 0 && d->C > 0 && d->P > 0 && d->H > 0 && d->W > 0 && d->H % d->P == 0 && d->W % d->P == 0 && d->D > 0 && d->heads > 0 &&
          d->D == d->heads * 64 && d->D % 128 == 0 && d->F % 128 == 0 && d->L >= 1 && d->Kpad % 64 == 0 && d->Kpad >= d->C * d->P * d->P &&
-         t->lora_r >= 1 && 3 * t->lora_r <= UCOD_LORA_AUG;
+         t->lora_r >= 1 && 3 * t->lora_r <= UCOD_LORA_AUG && t->lora_dropout >= 0.f && t->lora_dropout < 1.f;
 }
 
 TPlan make_plan(const ucod_vit_train_desc* t) {
@@ -103,7 +103,9 @@ extern "C" int ucod_vit_forward_train(const ucod_vit_train_desc* t, const void* 
     const bool last = (l == d->L - 1);
     float* x_in = (float*)(ws + p.x_in + p.s_x * l);
     void* h_aug = ws + p.h_aug + p.s_h * l;
-    RUN(ucod_layernorm_lora(x_in, (const float*)W[0], (const float*)W[1], (const float*)X[5], t->lora_r, h_aug, M, D, d->eps, stream));
+    const ucod_lora_dropout drop{t->lora_dropout, t->seed, l};
+    RUN(ucod_layernorm_lora(x_in, (const float*)W[0], (const float*)W[1], (const float*)X[5], t->lora_r, h_aug, M, D, d->eps,
+                            t->lora_dropout > 0.f ? &drop : nullptr, stream));
     if (last) {   // key hook: K rows of the augmented qkv weight; [B,D,h,w] out
       const char* wk = (const char*)X[0] + (size_t)D * KA * 2;
       RUN(ucod_gemm_bf16(UCOD_EPI_KEY_NCHW_F32, wk, h_aug, key_out, D, M, KA, (const float*)W[3] + D, nullptr, nullptr, nullptr, tok, gv, stream));
@@ -146,9 +148,21 @@ extern "C" int ucod_vit_backward(const ucod_vit_train_desc* t, const void* const
   auto qkv_side = [&](int l) -> int {   // dqkv_aug (k/q/v thirds filled) -> LoRA grads of layer l, dh = d LN1 output
     const void* const* X = TT + UCOD_VIT_TRAIN_STRIDE * l;
     const void* h_aug = ws + p.h_aug + p.s_h * l;
-    RUN(ucod_lora_grad(dqkv, h_aug, (const float*)X[5], r, t->lora_scaling, (float*)X[6], 0, lgw, lgw_bytes, M, D, stream));
+    const ucod_lora_dropout drop{t->lora_dropout, t->seed, l};
+    RUN(ucod_lora_grad(dqkv, h_aug, (const float*)X[5], r, t->lora_scaling, (float*)X[6], 0, lgw, lgw_bytes, M, D,
+                       t->lora_dropout > 0.f ? &drop : nullptr, stream));
     RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_F32, dqkv, X[1], dh, M, D, KQ, nullptr, nullptr, nullptr, nullptr, tok, gv, stream));
     return UCOD_OK;
+  };
+
+  // LayerNorm-1 backward of layer l: with dropout on, the masked LoRA branch t A is added here (it cannot ride on the dgrad GEMM)
+  auto ln1_bwd = [&](int l, const float* dy, const float* x, const float* gam, const float* dres, const float* next_scale) -> int {
+    if (t->lora_dropout > 0.f) {
+      const ucod_lora_dropout drop{t->lora_dropout, t->seed, l};
+      return ucod_layernorm_bwd_lora(dy, x, gam, dres, next_scale, dx, s, M, D, d->eps, dqkv, (const float*)(TT + UCOD_VIT_TRAIN_STRIDE * l)[5], r, &drop,
+                                     stream);
+    }
+    return ucod_layernorm_bwd(dy, x, gam, dres, next_scale, dx, s, M, D, d->eps, stream);
   };
 
   // last layer: only the key projection reaches the loss
@@ -159,7 +173,7 @@ extern "C" int ucod_vit_backward(const ucod_vit_train_desc* t, const void* const
   {
     const void* const* W = T + 4 + UCOD_VIT_LAYER_STRIDE * last;
     const void* const* Wp = T + 4 + UCOD_VIT_LAYER_STRIDE * (last - 1);
-    RUN(ucod_layernorm_bwd(dh, (const float*)(ws + p.x_in + p.s_x * last), (const float*)W[0], nullptr, (const float*)Wp[13], dx, s, M, D, d->eps, stream));
+    RUN(ln1_bwd(last, dh, (const float*)(ws + p.x_in + p.s_x * last), (const float*)W[0], nullptr, (const float*)Wp[13]));
   }
   for (int l = last - 1; l >= 0; --l) {
     const void* const* W = T + 4 + UCOD_VIT_LAYER_STRIDE * l;
@@ -180,7 +194,7 @@ extern "C" int ucod_vit_backward(const ucod_vit_train_desc* t, const void* const
     RUN(qkv_side(l));
     if (l > 0) {
       const void* const* Wp = T + 4 + UCOD_VIT_LAYER_STRIDE * (l - 1);
-      RUN(ucod_layernorm_bwd(dh, x_in, (const float*)W[0], dx, (const float*)Wp[13], dx, s, M, D, d->eps, stream));
+      RUN(ln1_bwd(l, dh, x_in, (const float*)W[0], dx, (const float*)Wp[13]));
     }
   }
   return UCOD_OK;

@@ -6,7 +6,8 @@ Same names and call shapes: ``load_lora(cfg, model)``, ``get_full_model(cfg, che
 ``load_state_dict`` (decoder only, :146-147).  What runs underneath is the HIP training engine (``ViTLoRAEngine``):
 LoRA r / lora_alpha / target modules as :47-72 (query, key, value; bias 'none'), the key hook of the last layer -> CLS
 dropped -> NCHW -> bilinear 68x68 (:95-106), student backbone differentiable w.r.t. its LoRA matrices, EMA backbone
-frozen.  ``enable_ocm`` is rejected: its module does not exist in the reference.  LoRA dropout is not applied.
+frozen.  ``enable_ocm`` is rejected: its module does not exist in the reference.  LoRA dropout (``lora_dropout``, 0.05 in the
+reference config) is applied in train mode with counter-based masks (it cannot reproduce torch's RNG stream).
 """
 import os
 
@@ -31,6 +32,10 @@ class LoRABackbone(nn.Module):
             return self.engine.apply(pixel_values, self.lora)
         return self.engine.forward_train(pixel_values)
 
+    def train(self, mode=True):
+        self.engine.train(mode)                                    # LoRA dropout follows the module's mode, like peft's nn.Dropout
+        return super().train(mode)
+
     def sync(self):
         """Re-derive the LoRA columns of the augmented GEMM weights after ``lora`` changed (optimiser step / EMA / load)."""
         self.engine.repack()
@@ -47,7 +52,8 @@ def load_lora(config, state_dict, heads, device="cuda", generator=None):
         raise NotImplementedError(f"target_modules {targets}: only query/key/value (the reference default) is built")
     if getattr(config, "bias", "none") != "none":
         raise NotImplementedError("LoRA bias modes other than 'none' are not built")
-    return LoRABackbone(ViTLoRAEngine(state_dict, heads, r=r, lora_alpha=alpha, device=device, generator=generator))
+    drop = float(getattr(config, "lora_dropout", 0.05))                      # :50
+    return LoRABackbone(ViTLoRAEngine(state_dict, heads, r=r, lora_alpha=alpha, device=device, generator=generator, lora_dropout=drop))
 
 
 class full_model(nn.Module):

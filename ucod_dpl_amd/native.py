@@ -26,7 +26,11 @@ class VitDesc(C.Structure):
 
 
 class VitTrainDesc(C.Structure):
-    _fields_ = [("vit", VitDesc), ("lora_r", ci), ("lora_scaling", cf)]
+    _fields_ = [("vit", VitDesc), ("lora_r", ci), ("lora_scaling", cf), ("lora_dropout", cf), ("seed", C.c_ulonglong)]
+
+
+class LoraDropout(C.Structure):
+    _fields_ = [("p", cf), ("seed", C.c_ulonglong), ("layer", ci)]
 
 
 class DiscParams(C.Structure):
@@ -59,14 +63,15 @@ SIGNATURES = {
     "ucod_vit_forward_train": (ci, [C.POINTER(VitTrainDesc), C.POINTER(vp), C.POINTER(vp), vp, vp, vp, sz, vp]),
     "ucod_vit_backward": (ci, [C.POINTER(VitTrainDesc), C.POINTER(vp), C.POINTER(vp), vp, vp, sz, vp]),
     "ucod_gemm_bf16_train": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, ci, vp]),
-    "ucod_layernorm_lora": (ci, [vp, vp, vp, vp, ci, vp, ci, ci, cf, vp]),
+    "ucod_layernorm_lora": (ci, [vp, vp, vp, vp, ci, vp, ci, ci, cf, C.POINTER(LoraDropout), vp]),
+    "ucod_layernorm_bwd_lora": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp, vp, ci, C.POINTER(LoraDropout), vp]),
     "ucod_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp]),
     "ucod_attention_fwd_lse": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "ucod_attention_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "ucod_key_grad_tokens": (ci, [vp, vp, ci, ci, ci, vp]),
-    "ucod_lora_pack": (ci, [vp, ci, cf, vp, vp, ci, vp]),
+    "ucod_lora_pack": (ci, [vp, ci, cf, vp, vp, ci, ci, vp]),
     "ucod_lora_grad_workspace_bytes": (sz, [ci]),
-    "ucod_lora_grad": (ci, [vp, vp, vp, ci, cf, vp, ci, vp, sz, ci, ci, vp]),
+    "ucod_lora_grad": (ci, [vp, vp, vp, ci, cf, vp, ci, vp, sz, ci, ci, C.POINTER(LoraDropout), vp]),
     "ucod_bilinear_resize": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "ucod_bilinear_resize_adjoint": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "ucod_dba_project": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),

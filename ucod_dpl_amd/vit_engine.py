@@ -263,8 +263,15 @@ class ViTLoRAEngine(ViTEngine):
     Parameters live in ONE flat f32 arena ``self.lora`` [L, 6*r*D] (layer-major: A_q | B_q | A_k | B_k | A_v | B_v), gradients
     in ``self.lora_grad`` with the same layout -- ready for a single flat all-reduce and the fused AdamW kernel."""
 
-    def __init__(self, state_dict, heads, r=2, lora_alpha=4, eps=1e-6, device="cuda", gemm_variant=0, generator=None):
+    def __init__(self, state_dict, heads, r=2, lora_alpha=4, eps=1e-6, device="cuda", gemm_variant=0, generator=None, lora_dropout=0.0,
+                 seed=0):
         super().__init__(state_dict, heads, eps=eps, device=device, full_last_layer=False, gemm_variant=gemm_variant, attn_variant=2)
+        if not 0.0 <= lora_dropout < 1.0:
+            raise ValueError("lora_dropout must be in [0, 1)")
+        # LoRA dropout (LoraConfig.lora_dropout, full_model.py:50): active while `self.training` is True; the mask of a step is a pure
+        # function of (seed, step), regenerated by the backward kernels.  `eval()` / `train()` switch it like nn.Module does.
+        self.lora_dropout, self.training = float(lora_dropout), True
+        self._seed, self._step, self._step_seed = int(seed), 0, 0
         if r < 1 or 3 * r > N.LORA_AUG:
             raise ValueError(f"LoRA rank {r} unsupported (1 <= r <= {N.LORA_AUG // 3})")
         self.r, self.scaling = int(r), float(lora_alpha) / float(r)
@@ -314,17 +321,31 @@ class ViTLoRAEngine(ViTEngine):
                 self.lora[i, sb] = sd[base + "lora_B.weight"].to(self.device, torch.float32).reshape(-1)
         self.repack()
 
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def _drop_p(self):
+        return self.lora_dropout if self.training else 0.0
+
     def repack(self):
-        """Refresh the LoRA columns of the augmented weights (call after every parameter update)."""
+        """Refresh the LoRA columns of the augmented weights (call after every parameter update).  With dropout active the A^T
+        columns of the dgrad weight are zero: the masked t A term is added by the LayerNorm-1 backward instead."""
         lib = N.load()
+        zero_a = int(self._drop_p() > 0.0)
         for i, tl in enumerate(self.train_layers):
-            N.check(lib.ucod_lora_pack(N.ptr(self.lora[i]), self.r, self.scaling, N.ptr(tl[0]), N.ptr(tl[1]), self.D, N.stream()), "ucod_lora_pack")
+            N.check(lib.ucod_lora_pack(N.ptr(self.lora[i]), self.r, self.scaling, N.ptr(tl[0]), N.ptr(tl[1]), self.D, zero_a, N.stream()), "ucod_lora_pack")
+        self._packed_zero_a = zero_a
 
     # ---- passes -----------------------------------------------------------------------------------------------------
     def _train_desc(self, B, H, W):
         t = N.VitTrainDesc()
         t.vit = self._desc(B, H, W)
         t.lora_r, t.lora_scaling = self.r, self.scaling
+        t.lora_dropout, t.seed = self._drop_p(), self._step_seed
         return t
 
     def _tables(self, gh, gw, grad=None):
@@ -347,6 +368,7 @@ class ViTLoRAEngine(ViTEngine):
             self._tside = [torch.cuda.Stream(device=self.device) for _ in range(ns)]
             self._tside_ws = [None] * ns
             self._tside_grad = [torch.zeros_like(self.lora) for _ in range(ns)]
+            self._chunk_seed = [0] * ns
         return [(B * i // ns, B * (i + 1) // ns) for i in range(ns)]
 
     def _fan_out(self, fn, tensors=()):
@@ -375,9 +397,15 @@ class ViTLoRAEngine(ViTEngine):
         lib = N.load()
         key = out if out is not None else torch.empty(B, self.D, gh, gw, dtype=torch.float32, device=self.device)
         self._bounds = self._chunks(B)
+        self._step += 1
+        self._step_seed = (self._seed * 0x9E3779B97F4A7C15 + self._step) & 0xFFFFFFFFFFFFFFFF     # fresh masks every step
+        if int(self._drop_p() > 0.0) != getattr(self, "_packed_zero_a", 0):
+            self.repack()                                           # train()/eval() changed which side carries the A term
 
         def run(i, b0, b1):
             t = self._train_desc(b1 - b0, H, W)
+            t.seed = (self._step_seed + 0x51ED270B * (i + 1) * int(b0 > 0)) & 0xFFFFFFFFFFFFFFFF   # (chunks index rows from 0: decorrelate them)
+            self._chunk_seed[i] = t.seed
             need = lib.ucod_vit_train_workspace_bytes(C.byref(t))
             if need == 0:
                 raise ValueError("unsupported ViT geometry")
@@ -404,6 +432,7 @@ class ViTLoRAEngine(ViTEngine):
 
         def run(i, b0, b1):
             t = self._train_desc(b1 - b0, H, W)
+            t.seed = self._chunk_seed[i]
             T, TT, keep = self._tables(gh, gw, self._tside_grad[i])
             N.check(lib.ucod_vit_backward(C.byref(t), T, TT, N.ptr(dkey[b0:b1]), N.ptr(self._tside_ws[i]), self._tside_ws[i].numel(), N.stream()),
                     "ucod_vit_backward")
