@@ -178,6 +178,24 @@ def main():
         tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
         dt = tdt.item()
+    # Discriminator phase (row A8, loop_UCOD_DPL.py:230-255), timed separately as SURVEY.md 8d asks: it runs one epoch in every
+    # `dis_intertrain` epochs on the cached features (no backbone pass), so its unit is feature batches, not images through the ViT.
+    for _ in range(3):
+        loop._discriminator_batch((pl, key))
+    barrier()
+    t2 = time.perf_counter()
+    for _ in range(a.steps):
+        dl = loop._discriminator_batch((pl, key))
+    barrier()
+    dt_dis = time.perf_counter() - t2
+    if world > 1:
+        tdt = torch.tensor([dt_dis], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
+        dt_dis = tdt.item()
+    dis_phase = {"value": round(world * B * a.steps / dt_dis, 1), "unit": "feature maps/s", "ms_per_step": round(dt_dis / a.steps * 1e3, 3),
+                 "loss": round(float(dl.item()), 6),
+                 "what": "discriminator step on resident key maps: student decoder fwd (no grad), 2 discriminator fwd + bwd, all-reduce, fused AdamW"}
+
     # Optional mode of SURVEY.md 8a row B9, reported SEPARATELY (never part of `value`): images -> LoRA backbone (student,
     # activations saved) + EMA backbone (teacher) -> the same decoder/APM/discriminator step -> backbone backward -> all-reduce
     # of decoder and LoRA gradients -> both fused optimisers.
@@ -272,7 +290,7 @@ def main():
                    "schedule": "serial, one stream" if a.no_pipeline else
                                f"backbone pass of step k+1 on {a.streams} side stream(s) overlapped with the decoder step of step k"},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "final_loss": round(final_loss, 6),
-        "backbone_backward_mode": lora_mode,
+        "backbone_backward_mode": lora_mode, "discriminator_phase": dis_phase,
     }
     print(json.dumps(out))
 

@@ -269,13 +269,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
-// weight gradient: one workgroup per (co, ci); gW[co][ci][tap] += sum_{b,oy,ox} gy[b,co,oy,ox] * act_in[b,ci,iy,ix]
+// weight gradient: workgroup = (co, ci) x image chunk; partial[chunk][co][ci][tap] = sum over the chunk's (b,oy,ox) of
+// gy[b,co,oy,ox] * act_in[b,ci,iy,ix], summed over chunks in a fixed order by conv3x3_wgrad_reduce_kernel (deterministic).
+// (One workgroup per (co, ci) over ALL images was the whole discriminator phase: the 1->32 first layer has only 32 such pairs,
+// 32 workgroups on a 256-CU chip each walking 148 k pixels: 0.98 ms per call.)
 template <int CIN, int COUT, int STRIDE, bool BN_IN>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ in_stats,
                                                             const float* __restrict__ in_g, const float* __restrict__ in_b,
-                                                            const float* __restrict__ gy, float* __restrict__ gw, int B, int IH, int OH) {
+                                                            const float* __restrict__ gy, float* __restrict__ partial, int B, int IH, int OH) {
   __shared__ float red[16];
   const int co = blockIdx.x / CIN, ci = blockIdx.x % CIN, tid = threadIdx.x;
+  const int b_lo = (int)((long)B * blockIdx.y / gridDim.y), b_hi = (int)((long)B * (blockIdx.y + 1) / gridDim.y);
   float sc = 1.f, sh = 0.f;
   if (BN_IN) {
     const float mean = in_stats[ci], rstd = in_stats[CIN + ci];
@@ -285,9 +289,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
   float acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-  const long total = (long)B * OH * OH;
+  const long total = (long)(b_hi - b_lo) * OH * OH;
   for (long idx = tid; idx < total; idx += 256) {
-    const int ox = (int)(idx % OH), oy = (int)((idx / OH) % OH), b = (int)(idx / ((long)OH * OH));
+    const int ox = (int)(idx % OH), oy = (int)((idx / OH) % OH), b = b_lo + (int)(idx / ((long)OH * OH));
     const float gv = gy[(((long)b * COUT + co) * OH + oy) * OH + ox];
     const float* ib = in + ((long)b * CIN + ci) * IH * IH;
 #pragma unroll
@@ -308,8 +312,16 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     const float s = block_sum(acc[t], red);
-    if (tid == 0) gw[((long)co * CIN + ci) * 9 + t] += s;
+    if (tid == 0) partial[((long)blockIdx.y * COUT * CIN + blockIdx.x) * 9 + t] = s;
   }
+}
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int n, int chunks) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += partial[(long)c * n + i];
+  gw[i] += s;
 }
 
 // input gradient of a conv block, fused with the LeakyReLU' of the block BELOW: thread = input pixel (b,iy,ix),
@@ -358,9 +370,12 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_kernel(const float* __restr
 
 }  // namespace ucod
 
+// weight-gradient partials: chunks x (co*ci) x 9, chunks = min(B, 2048 / pairs) -> at most 2048 x 9 floats per layer
+constexpr int WGRAD_MAX_PARTIAL = 2048 * 9 + 512 * 9;
+
 extern "C" size_t ucod_disc_bwd_workspace_bytes(int B, int fs) {
   const DiscDims d = disc_dims(B, fs);
-  return (d.n1 + d.n2 + d.n3 + 2 * (32 + 16 + 8)) * sizeof(float);
+  return (d.n1 + d.n2 + d.n3 + 2 * (32 + 16 + 8) + (size_t)WGRAD_MAX_PARTIAL) * sizeof(float);
 }
 
 extern "C" int ucod_disc_bwd(const float* mask, const ucod_disc_params* p, const void* saved, const float* gprob,
@@ -380,7 +395,9 @@ extern "C" int ucod_disc_bwd(const float* mask, const ucod_disc_params* p, const
   float* su1 = gh3 + d.n3;
   float* su2 = su1 + 64;
   float* su3 = su2 + 32;
+  float* wpart = su3 + 16;
   const int hw1 = d.s1 * d.s1, hw2 = d.s2 * d.s2, hw3 = d.s3 * d.s3;
+  auto chunks_for = [&](int pairs) { const int c = 2048 / pairs; return c < 1 ? 1 : (c > B ? B : c); };
   UCOD_PROF(PROF_DISC_BWD, s);
   if (!accumulate) {
     hipError_t e = hipSuccess;
@@ -394,17 +411,29 @@ extern "C" int ucod_disc_bwd(const float* mask, const ucod_disc_params* p, const
   // block 3
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(8), dim3(1024), 0, s, y3, gh3, 8, B, hw3, st3, su3, g->g3, g->b3);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, blocks(d.n3), dim3(256), 0, s, y3, gh3, 8, hw3, (long)d.n3, st3, p->g3, su3);
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<16, 8, 2, true>), dim3(8 * 16), dim3(256), 0, s, y2, st2, p->g2, p->b2, gh3, g->w3, B, d.s2, d.s3);
+  {
+    const int ch = chunks_for(8 * 16);
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<16, 8, 2, true>), dim3(8 * 16, ch), dim3(256), 0, s, y2, st2, p->g2, p->b2, gh3, wpart, B, d.s2, d.s3);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(cdiv(8 * 16 * 9, 256)), dim3(256), 0, s, wpart, g->w3, 8 * 16 * 9, ch);
+  }
   hipLaunchKernelGGL((conv3x3_dgrad_kernel<16, 8, 2>), dim3(cdiv((long)B * hw2, 256)), dim3(256), 0, s, gh3, p->w3, y2, st2, p->g2, p->b2, gh2, B, d.s2, d.s3);
   // block 2
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(16), dim3(1024), 0, s, y2, gh2, 16, B, hw2, st2, su2, g->g2, g->b2);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, blocks(d.n2), dim3(256), 0, s, y2, gh2, 16, hw2, (long)d.n2, st2, p->g2, su2);
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<32, 16, 2, true>), dim3(16 * 32), dim3(256), 0, s, y1, st1, p->g1, p->b1, gh2, g->w2, B, d.s1, d.s2);
+  {
+    const int ch = chunks_for(16 * 32);
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<32, 16, 2, true>), dim3(16 * 32, ch), dim3(256), 0, s, y1, st1, p->g1, p->b1, gh2, wpart, B, d.s1, d.s2);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(cdiv(16 * 32 * 9, 256)), dim3(256), 0, s, wpart, g->w2, 16 * 32 * 9, ch);
+  }
   hipLaunchKernelGGL((conv3x3_dgrad_kernel<32, 16, 2>), dim3(cdiv((long)B * hw1, 256)), dim3(256), 0, s, gh2, p->w2, y1, st1, p->g1, p->b1, gh1, B, d.s1, d.s2);
   // block 1
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(32), dim3(1024), 0, s, y1, gh1, 32, B, hw1, st1, su1, g->g1, g->b1);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, blocks(d.n1), dim3(256), 0, s, y1, gh1, 32, hw1, (long)d.n1, st1, p->g1, su1);
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 32, 1, false>), dim3(32), dim3(256), 0, s, mask, nullptr, nullptr, nullptr, gh1, g->w1, B, fs, d.s1);
+  {
+    const int ch = chunks_for(32);
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 32, 1, false>), dim3(32, ch), dim3(256), 0, s, mask, nullptr, nullptr, nullptr, gh1, wpart, B, fs, d.s1);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(cdiv(32 * 9, 256)), dim3(256), 0, s, wpart, g->w1, 32 * 9, ch);
+  }
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }
