@@ -71,9 +71,11 @@ int ucod_layernorm(const float* x, const float* gamma, const float* beta, void* 
 /* softmax(Q K^T * scale) V per (image, head), head_dim 64 (modeling_dinov2.py:153-179; dino.py:113-117).
  * qkv bf16 [B*tok, 3*heads*64] rows = [q | k | v], heads contiguous; out bf16 [B*tok, heads*64].
  * variant: 0 = V consumed through ds_read_b64_tr_b16, 1 = V transposed while staging.
- * scale == 0 selects the VALU-lean kernel (K/V staged by LDS-DMA, softmax denominator as f32 adds; variants 3 / 4: denominator
- * on the matrix pipe with K/V staged through registers / by LDS-DMA) and declares that Q already carries head_dim^-0.5 * log2(e)
- * (ucod_fill_qscale + the QKV epilogue scale do that inside ucod_vit_forward when attn_variant == 2). */
+ * scale == 0 selects the VALU-lean kernels and declares that Q already carries head_dim^-0.5 * log2(e) (ucod_fill_qscale + the
+ * QKV epilogue scale do that inside ucod_vit_forward when attn_variant == 2).  With scale == 0, variant 0 / 2 / 5 = K/V staged by
+ * buffer loads to LDS, compile-time LDS offsets, softmax denominator as packed f32 adds (the default); 6 = the same arithmetic
+ * with per-tile address computation (previous default); 3 / 4 = denominator on the matrix pipe with K/V staged through
+ * registers / by LDS-DMA. */
 int ucod_attention_fwd(const void* qkv_bf16, void* out_bf16, int B, int tok, int heads, float scale, int variant,
                        void* stream);
 

@@ -128,12 +128,12 @@ def test_attention(variant, B, tok, heads):
     assert rel_l2(out, ref) < 1e-2
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4])
-@pytest.mark.parametrize("B,tok,heads", [(1, 26, 2), (2, 64, 1), (1, 200, 3), (2, 1370, 2), (1, 1, 1)])
+@pytest.mark.parametrize("variant", [2, 3, 4, 6])
+@pytest.mark.parametrize("B,tok,heads", [(1, 26, 2), (2, 64, 1), (1, 200, 3), (2, 1370, 2), (1, 1, 1), (3, 129, 2)])
 def test_attention_prescaled_q_kernel(B, tok, heads, variant):
     """VALU-lean kernel: Q carries head_dim^-0.5*log2(e) already (scale=0 in the ABI).  Variants 3 (K/V through registers) and 4
-    (LDS-DMA) share their arithmetic and must agree bit for bit; variant 2 (default: LDS-DMA, denominator as f32 adds) differs
-    from them by the rounding of the denominator only."""
+    (LDS-DMA) share their arithmetic and must agree bit for bit; variants 2 (default: buffer DMA, compile-time LDS offsets) and 6
+    (its predecessor) keep the denominator as f32 adds and differ from them by its rounding only."""
     g = torch.Generator().manual_seed(tok * 3 + heads)
     D = heads * 64
     qkv = torch.randn(B * tok, 3 * D, generator=g) * 1.5
@@ -169,8 +169,9 @@ def test_attention_prescaled_deferred_max_branches():
         q, k, v = (x.float()[:, i * D:(i + 1) * D] for i in range(3))
         p = torch.softmax((q @ k.t()) * math.log(2.0), dim=-1)
         ref = p @ v
-        out = ops.attention(x.to(DEV), 1, tok, 1, scale=0.0, variant=2).float().cpu()
-        assert maxdiff(out, ref) < 3e-2, maxdiff(out, ref)
+        for variant in (2, 6):
+            out = ops.attention(x.to(DEV), 1, tok, 1, scale=0.0, variant=variant).float().cpu()
+            assert maxdiff(out, ref) < 3e-2, (variant, maxdiff(out, ref))
 
 
 @pytest.mark.parametrize("variant", [0, 1])

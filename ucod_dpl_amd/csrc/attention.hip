@@ -442,6 +442,192 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __r
 
 
 // =====================================================================================================
+// v5: the v2 kernel with its VALU issue stream trimmed (rocprofv3 PMC: v2 is VALU-issue-bound, 0.56 matrix-pipe busy; of
+// its ~190 VALU instructions per 64-key tile and wave about a third were address arithmetic, not softmax):
+//   * K/V tiles staged by BUFFER loads to LDS: the per-lane byte offset is loop-carried (one v_add per DMA and tile), rows
+//     past the last token fail the descriptor's range check and arrive as zeros -- no clamp, no 64-bit pointer math;
+//   * the tile loop is unrolled by two so the LDS buffer index is a compile-time constant: every ds_read address is one of
+//     six loop-invariant registers plus an immediate;
+//   * the wave index is made scalar (M0 of the DMA comes from SALU, not v_readfirstlane);
+//   * the cross-half max exchange is one v_permlane32_swap instead of an LDS bpermute + wait;
+//   * the denominator is accumulated pairwise (v_pk_add_f32).
+// Same arithmetic as v2 <DMA, VSUM> except for the order of the denominator's f32 adds.
+// =====================================================================================================
+template <int V> struct IntC { static constexpr int value = V; };
+
+__device__ __forceinline__ float xhalf_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // r[0]: lanes 0..31's value everywhere, r[1]: lanes 32..63's
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N, int heads,
+                                                              int npairs, float* __restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * KV_BYTES];       // [buffer][K | V]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h5 = lane >> 5, l31 = lane & 31;
+  const int nq = (N + QT - 1) / QT;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pair = (slot / nq) * 8 + xcd, qt = slot - (slot / nq) * nq;
+  if (pair >= npairs) return;
+  const int head = pair % heads, b = pair / heads;
+  const int D = heads * HD, ld = 3 * D;
+  const int q0 = qt * QT + wave * 32;
+  const bf16_raw* base = qkv + (size_t)b * N * ld + head * HD;
+
+  bf16x8 qf[4];
+  {
+    int qr = q0 + l31;
+    qr = qr < N ? qr : N - 1;
+    const bf16_raw* qp = base + (size_t)qr * ld + 8 * h5;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+
+  // this image's qkv rows as one buffer: byte offsets fit 32 bits, a key row >= N is out of range and reads as zero
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(qkv + (size_t)b * N * ld), 0, (unsigned)N * (unsigned)ld * 2u, 0x00020000);
+  unsigned sk[2], sv[2];                                 // loop-carried source offsets of this lane's four DMA chunks
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = i * 32 + wave * 8 + (lane >> 3), ch = lane & 7;
+    sk[i] = (unsigned)(row * ld + D + head * HD + swz_k(row, ch) * 8) * 2u;
+    sv[i] = (unsigned)(row * ld + 2 * D + head * HD + swz_v(row, ch) * 8) * 2u;
+  }
+  const unsigned tile_step = (unsigned)(KT * ld) * 2u;
+  auto stage = [&](auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      char* dst = smem + BUF * (2 * KV_BYTES) + (i * 32 + wave * 8) * 128;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, sk[i], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + KV_BYTES), 16, sv[i], 0, 0, 0);
+      sk[i] += tile_step;
+      sv[i] += tile_step;
+    }
+  };
+
+  // loop-invariant LDS byte offsets: K fragment chunk per 16-wide d step, V fragment per 32-wide d half
+  int koff[4], voff[2];
+#pragma unroll
+  for (int sd = 0; sd < 4; ++sd) koff[sd] = l31 * 128 + swz_k(l31, 2 * sd + h5) * 16;      // +4096 per 32 keys keeps the swizzle
+  {
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    const int key = 4 * h5 + (i16 >> 2);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int dst = dt * 32 + g1 * 16 + 4 * (i16 & 3);
+      voff[dt] = KV_BYTES + key * 128 + swz_v(key, dst >> 3) * 16 + (dst & 7) * 2;          // +8/16/32 keys keep the swizzle
+    }
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m_run = 0.f;
+  f32x2_t lsum = {0.f, 0.f};
+  const int nt = (N + KT - 1) / KT;
+
+  auto tile = [&](int t, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    __syncthreads();                                     // retires this wave's DMAs of tile t (vmcnt(0)) and everyone's reads of tile t-1
+    if (t + 1 < nt) stage(IntC<BUF ^ 1>{});
+    const char* kb = smem + BUF * (2 * KV_BYTES);
+
+    f32x16 s[2];
+    const float neg_m = -m_run;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kt][i] = neg_m;
+#pragma unroll
+      for (int sd = 0; sd < 4; ++sd) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + kt * 4096 + koff[sd]);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sd], s[kt], 0, 0, 0);
+      }
+    }
+    if (t == nt - 1 && (N & (KT - 1)) != 0) {
+      const int kbase = t * KT + 4 * h5;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + kt * 32 + (r & 3) + 8 * (r >> 2);
+          if (key >= N) s[kt][r] = -1e30f;
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      float mloc = fmaxf(fmaxf(s[kt][0], s[kt][1]), s[kt][2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) mloc = fmaxf(fmaxf(mloc, s[kt][r]), s[kt][r + 1]);
+      mloc = xhalf_max(fmaxf(mloc, s[kt][15]));
+      const bool first = (t == 0 && kt == 0);
+      if (first || __any(mloc > DEFER_THR)) {
+        const float delta = first ? mloc : fmaxf(mloc, 0.f);
+        const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+        m_run += delta;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          s[kt][i] -= delta;
+          if (kt == 0) s[1][i] -= delta;
+          o[0][i] *= alpha;
+          o[1][i] *= alpha;
+        }
+        lsum *= alpha;
+      }
+      bf16x8 pb[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 w;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const f32x2_t e = {__builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj + 1])};
+          lsum += e;
+          w[jj] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_t));
+        }
+        pb[ks] = __builtin_bit_cast(bf16x8, w);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const char* p0 = kb + (kt * 32 + ks * 16) * 128 + voff[dt];
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p0 + 8 * 128));
+          const bf16x8 vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[ks], o[dt], 0, 0, 0);
+        }
+    }
+  };
+
+  stage(IntC<0>{});
+  for (int t = 0; t < nt; t += 2) {
+    tile(t, IntC<0>{});
+    if (t + 1 < nt) tile(t + 1, IntC<1>{});
+  }
+
+  const float lane_sum = lsum[0] + lsum[1];
+  const float denom = lane_sum + __shfl_xor(lane_sum, 32, 64);
+  const float inv = 1.0f / denom;
+  const int q = q0 + l31;
+  if (q < N) {
+    if (lse && h5 == 0) lse[((size_t)b * heads + head) * N + q] = m_run + __builtin_amdgcn_logf(denom);
+    bf16_raw* op = out + ((size_t)b * N + q) * D + head * HD + 4 * h5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w;
+        w[0] = cvt_pk_bf16(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+        w[1] = cvt_pk_bf16(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
+      }
+  }
+}
+
+
+// =====================================================================================================
 // Cross-attention, head_dim 96 (CORAL refiner: nn.MultiheadAttention with 8 heads on C=768, models/modules/mlp.py:122,143).
 // Same structure as attn_fwd_v2_kernel (pre-scaled Q, accumulator initialised with -m, per-half deferred max, denominator on
 // the matrix pipe, V through ds_read_b64_tr_b16) with separate query / key-value sources and lengths.  LDS rows are padded
@@ -626,13 +812,15 @@ extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, in
     const int npairs = B * heads, nq = cdiv(tok, QT);
     dim3 grid1(cdiv(npairs, 8) * 8 * nq);
     // variant 3: K/V staged through registers, 4: LDS-DMA, both with the denominator on the matrix pipe (all-ones MFMA);
-    // default: LDS-DMA + denominator as f32 adds of the unrounded probabilities (4 % faster at 4 waves per SIMD)
+    // 6: LDS-DMA + denominator as f32 adds of the unrounded probabilities (4 % faster than 4 at 4 waves per SIMD)
     if (variant == 4)
       hipLaunchKernelGGL((attn_fwd_v2_kernel<true, false>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
     else if (variant == 3)
       hipLaunchKernelGGL((attn_fwd_v2_kernel<false>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
-    else
+    else if (variant == 6)
       hipLaunchKernelGGL((attn_fwd_v2_kernel<true, true>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
+    else                                                 // 0 / 2 / 5: the trimmed-issue kernel (buffer DMA, constant LDS offsets), 7-10 % faster than 6
+      hipLaunchKernelGGL(attn_fwd_v5_kernel, grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
     UCOD_CHECK_LAUNCH();
     return UCOD_OK;
   }
@@ -661,8 +849,8 @@ extern "C" int ucod_attention_fwd_lse(const void* qkv, void* out, float* lse, in
   if (!qkv || !out || !lse || B <= 0 || tok <= 0 || heads <= 0) return UCOD_EINVAL;
   UCOD_PROF(PROF_ATTN, stream);
   const int npairs = B * heads, nq = cdiv(tok, QT);
-  hipLaunchKernelGGL((attn_fwd_v2_kernel<true, true>), dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok,
-                     heads, npairs, lse);
+  hipLaunchKernelGGL(attn_fwd_v5_kernel, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs,
+                     lse);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }
