@@ -83,6 +83,50 @@ def test_gemm_bf16_large_tile_is_race_free_and_deterministic():
                 assert torch.equal(out, first), (variant, it)
 
 
+@pytest.mark.parametrize("variant,M,Nn,K", [(9, 21916, 768, 768), (9, 21916, 768, 3072), (10, 16401, 768, 3136), (9, 43840, 768, 192),
+                                            (0, 43840, 768, 3072), (5, 65600, 512, 64), (3, 22000, 768, 768)])
+def test_gemm_bf16_leftover_tiles_as_patches(variant, M, Nn, K):
+    """Shapes a few tiles past one or two rounds of 256 large tiles: the launch has rounds x 256 workgroups and the remaining tiles
+    are computed as 16 x 32 patches on the side (gemm_bf16.hip patch_phase).  Every output of every epilogue against an f32
+    product, the rows past M untouched, in-place residual, repeatable bits."""
+    g = torch.Generator().manual_seed(M + K)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = bf(torch.randn(Nn, K, generator=g) * 0.05).to(DEV)
+    b, sc = torch.randn(Nn, generator=g).to(DEV), (torch.rand(Nn, generator=g) + 0.5).to(DEV)
+    acc = A.float() @ W.float().t()
+    tol = 2e-2 * max(1.0, acc.abs().max().item())
+
+    def guarded(dtype, fill):
+        buf = torch.full((M + 64, Nn), fill, dtype=dtype, device=DEV)
+        return buf, buf[:M]
+
+    # LayerScale + residual, written in place over the residual (what the backbone does)
+    resid = torch.randn(M, Nn, generator=g).to(DEV)
+    buf, x = guarded(torch.float32, 7.0)
+    x.copy_(resid)
+    ops.gemm_bf16(N.EPI_BIAS_SCALE_RESID_F32, A, W, x, M, Nn, K, bias=b, scale=sc, resid=x, variant=variant)
+    assert maxdiff(x, resid + sc * (acc + b)) < 2e-3 * max(1.0, acc.abs().max().item())
+    assert torch.all(buf[M:] == 7.0)
+    first = x.clone()
+    for _ in range(4):
+        x.copy_(resid)
+        ops.gemm_bf16(N.EPI_BIAS_SCALE_RESID_F32, A, W, x, M, Nn, K, bias=b, scale=sc, resid=x, variant=variant)
+        assert torch.equal(x, first)
+    # bias (+ column scale) -> bf16, GELU -> bf16
+    buf, o = guarded(torch.bfloat16, 3.0)
+    ops.gemm_bf16(N.EPI_BIAS_BF16, A, W, o, M, Nn, K, bias=b, scale=sc, variant=variant)
+    assert maxdiff(o.float(), (acc + b) * sc) < tol and rel_l2(o.float(), (acc + b) * sc) < 4e-3
+    assert torch.all(buf[M:] == 3.0)
+    ops.gemm_bf16(N.EPI_BIAS_GELU_BF16, A, W, o, M, Nn, K, bias=b, variant=variant)
+    assert maxdiff(o.float(), torch.nn.functional.gelu(acc + b)) < tol
+    # plain product (NULL bias) -> f32
+    buf, o32 = guarded(torch.float32, -5.0)
+    plain = K >= 128                                            # the ABI takes a NULL bias from K = 128 up
+    ops.gemm_bf16(N.EPI_BIAS_F32, A, W, o32, M, Nn, K, bias=None if plain else b, variant=variant)
+    assert maxdiff(o32, acc if plain else acc + b) < 2e-3 * max(1.0, acc.abs().max().item())
+    assert torch.all(buf[M:] == -5.0)
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_gemm_bf16_epilogues(variant):
     g = torch.Generator().manual_seed(5)
@@ -500,21 +544,34 @@ def test_feature_cache_pass_with_the_hip_backbone(tmp_path):
         assert torch.equal(got, key[0].cpu())
 
 
-def test_backbone_full_size_properties():
+def test_backbone_full_size_properties(monkeypatch):
     """BASELINE.json configs[1] at full size (DINOv2 ViT-B/14, 518x518, batch 32) -- too big for the CPU oracle, so size-independent
-    properties: (1) images are independent: permuting the batch permutes the key maps BIT for bit; (2) the image-parallel two-stream
-    pass equals the single-stream pass bit for bit; (3) a single image run alone agrees with its slot in the batch to bf16 rounding
-    (its GEMMs take a different tile path); (4) finite, non-degenerate output."""
+    properties: (1) images are independent: permuting the batch permutes the key maps; (2) the image-parallel two-stream pass equals
+    the single-stream pass; (3) a single image run alone agrees with its slot in the batch to bf16 rounding (its GEMMs take a
+    different tile path); (4) finite, non-degenerate output.  (1) and (2) hold BIT for bit when every GEMM output goes through the
+    tile path (UCOD_GEMM_NO_PATCH=1); in the default mode the few tiles past the last whole round are summed over K in a different
+    order (gemm_bf16.hip patch_phase), so there they hold to f32-summation / bf16-rounding level."""
     from ucod_dpl_amd.data.utils.feature_extractor import backbone
     bb = backbone.random_init("dinov2_vitb14", seed=0, image_size=518, device=DEV, attn_variant=2)
     g = torch.Generator().manual_seed(77)
     x = torch.randn(32, 3, 518, 518, generator=g).to(DEV)
-    k0 = bb.engine(x).clone()
-    assert k0.shape == (32, 768, 37, 37) and bool(torch.isfinite(k0).all()) and float(k0.std()) > 1e-3
     perm = torch.randperm(32, generator=g).to(DEV)
-    assert torch.equal(bb.engine(x[perm].contiguous()), k0[perm])
-    bb.engine.streams = 2
-    assert torch.equal(bb.engine(x), k0)
-    bb.engine.streams = 1
+    xp = x[perm].contiguous()
+    for no_patch in ("1", "0"):
+        monkeypatch.setenv("UCOD_GEMM_NO_PATCH", no_patch)
+        bb.engine.streams = 1
+        k0 = bb.engine(x).clone()
+        assert k0.shape == (32, 768, 37, 37) and bool(torch.isfinite(k0).all()) and float(k0.std()) > 1e-3
+        kp = bb.engine(xp).clone()
+        bb.engine.streams = 2
+        k2 = bb.engine(x).clone()
+        bb.engine.streams = 1
+        if no_patch == "1":
+            assert torch.equal(kp, k0[perm]) and torch.equal(k2, k0)
+            exact = k0
+        else:
+            assert torch.equal(bb.engine(x), k0)                  # repeatable
+            for other, same in ((kp, k0[perm]), (k2, k0), (k0, exact)):
+                assert rel_l2(other, same) < 3e-3, rel_l2(other, same)
     k1 = bb.engine(x[5:6].contiguous())
     assert rel_l2(k1[0], k0[5]) < 1e-2

@@ -449,7 +449,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __r
 //   * the tile loop is unrolled by two so the LDS buffer index is a compile-time constant: every ds_read address is one of
 //     six loop-invariant registers plus an immediate;
 //   * the wave index is made scalar (M0 of the DMA comes from SALU, not v_readfirstlane);
-//   * the cross-half max exchange is one v_permlane32_swap instead of an LDS bpermute + wait;
+//   * the per-tile max is a v_maximum3_f32 chain over the lane's own 16 keys; the cross-half exchange (one v_permlane32_swap)
+//     happens only inside the rare rescale branch;
 //   * the denominator is accumulated pairwise (v_pk_add_f32).
 // Same arithmetic as v2 <DMA, VSUM> except for the order of the denominator's f32 adds.
 // =====================================================================================================
@@ -558,12 +559,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      float mloc = fmaxf(fmaxf(s[kt][0], s[kt][1]), s[kt][2]);
+      // v_maximum3_f32 (IEEE maximum: no operand canonicalisation), two scores per instruction.  The lane's 16 keys are enough
+      // for the wave-wide "does any score run away" test; the other half's keys are fetched only when the rescale fires.
+      float mloc = __builtin_elementwise_maximum(s[kt][0], s[kt][1]);
 #pragma unroll
-      for (int r = 3; r < 15; r += 2) mloc = fmaxf(fmaxf(mloc, s[kt][r]), s[kt][r + 1]);
-      mloc = xhalf_max(fmaxf(mloc, s[kt][15]));
+      for (int r = 2; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[kt][r]), s[kt][r + 1]);
       const bool first = (t == 0 && kt == 0);
       if (first || __any(mloc > DEFER_THR)) {
+        mloc = xhalf_max(mloc);
         const float delta = first ? mloc : fmaxf(mloc, 0.f);
         const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
         m_run += delta;

@@ -38,6 +38,8 @@ struct GemmArgs {
   int M, N, K;
   int tok;   // tokens per image incl. CLS (PATCH / KEY epilogues)
   int tiles_m, tiles_n;
+  int main_tiles;      // large-tile kernel, leftover-as-patches mode (see patch_phase): workgroups launched = whole tiles computed; 0 = off
+  int patches_per_wg;  // 16 x 32 patches of the remaining tiles each workgroup computes on the side
 };
 
 // 16-byte chunk swizzle inside a 128-byte (64 x bf16) tile row: conflict-free ds_read_b128 for the
@@ -518,6 +520,117 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][
   }
 }
 
+// ---- leftover tiles as patches ------------------------------------------------------------------------------------
+// One large-tile workgroup fills a CU, so a launch runs in rounds of n_cu tiles and the backbone's shapes all land just past
+// a whole number of rounds (32 x 1370 rows: 516 = 2 x 256 + 4 tiles for proj / fc2): the last 4 tiles ran alone on 4 CUs
+// while 252 idled -- 18 % of fc2, 11 % of proj (tools/gemm_tail_probe.py: M = 43520 vs 43840).  In this mode the launch has
+// exactly rounds x n_cu workgroups, and the outputs of the remaining L tiles are cut into 16 x 32 patches that the
+// workgroups compute on the side, one or two each, BEFORE their own tile: the patch's operand loads are in flight together
+// with the tile's first K-tile DMAs (a latency every workgroup pays anyway), the K range is dealt round-robin to the 8 waves
+// (v_mfma_f32_16x16x32_bf16 straight from global registers), partial sums meet in the LDS slot the main loop touches last.
+// Deterministic: a patch is summed by one workgroup in a fixed order.  Result bits differ from the tile path only by the
+// order of the f32 adds over K.
+template <int C> struct PatchC { static constexpr int value = C; };
+
+template <int EPI>
+constexpr bool kPatchPrefetch = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 ||
+                                 EPI == UCOD_EPI_BIAS_F32);
+
+template <int EPI, int BN_>
+__device__ __forceinline__ void patch_phase(const GemmArgs& a, char* scratch /* 16 KiB */, int orig, int wave, int lane) {
+  constexpr int PC = BN_ / 32, PPT = 16 * PC;                   // patches per leftover tile
+  constexpr int GROUP_M = 8;
+  const int total = a.tiles_m * a.tiles_n;
+  const int npatch = (total - a.main_tiles) * PPT;
+  const int K = a.K, steps = K >> 5;
+  const int l15 = lane & 15, q = lane >> 4;
+  for (int pi = 0; pi < a.patches_per_wg; ++pi) {
+    const int p = orig * a.patches_per_wg + pi;
+    if (p >= npatch) break;
+    const int wg = a.main_tiles + p / PPT, rem = p % PPT;
+    const int per_group = GROUP_M * a.tiles_n;
+    const int grp = wg / per_group, first_m = grp * GROUP_M;
+    const int gsz = (a.tiles_m - first_m) < GROUP_M ? (a.tiles_m - first_m) : GROUP_M;
+    const int in_grp = wg - grp * per_group;
+    const int r0 = (first_m + in_grp % gsz) * 256 + (rem / PC) * 16;
+    const int c0 = (in_grp / gsz) * BN_ + (rem % PC) * 32;
+    if (r0 >= a.M || c0 >= a.N) continue;                       // ragged last row / column tile: nothing there
+    // this thread's output of the patch (one of 16 x 32) and its epilogue operands, requested before the operand loads so that
+    // nothing is left to fetch once the partial sums meet
+    const int idx = wave * 64 + lane, om = r0 + (idx >> 5), on = c0 + (idx & 31);
+    const bool live = om < a.M && on < a.N;
+    const int cm = om < a.M ? om : a.M - 1, cn = on < a.N ? on : a.N - 1;
+    float e_bias = 0.f, e_scale = 1.f, e_resid = 0.f;
+    if constexpr (kPatchPrefetch<EPI>) {
+      if (a.bias) e_bias = a.bias[cn];
+      if constexpr (EPI == UCOD_EPI_BIAS_BF16) { if (a.scale) e_scale = a.scale[cn]; }
+      if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) {
+        e_scale = a.scale[cn];
+        e_resid = a.resid[(size_t)cm * a.N + cn];
+      }
+    }
+    int ar = r0 + l15, br0 = c0 + l15, br1 = c0 + 16 + l15;
+    ar = ar < a.M ? ar : a.M - 1;
+    br0 = br0 < a.N ? br0 : a.N - 1;
+    br1 = br1 < a.N ? br1 : a.N - 1;
+    const bf16_raw* pa = a.A + (size_t)ar * K + q * 8;
+    const bf16_raw* pb0 = a.B + (size_t)br0 * K + q * 8;
+    const bf16_raw* pb1 = a.B + (size_t)br1 * K + q * 8;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // this wave's k-steps: wave, wave + 8, ...; loaded in the largest chunks that fit (every load is a real one: the patch is
+    // bound by the 64 B/clk/CU of the vector-memory path, 48 rows x K x 2 bytes per patch)
+    auto chunk = [&](int s0, auto cnt) {
+      constexpr int C = decltype(cnt)::value;
+      bf16x8 fa[C], f0[C], f1[C];
+#pragma unroll
+      for (int i = 0; i < C; ++i) {
+        const int st = s0 + 8 * i;
+        fa[i] = *reinterpret_cast<const bf16x8*>(pa + st * 32);
+        f0[i] = *reinterpret_cast<const bf16x8*>(pb0 + st * 32);
+        f1[i] = *reinterpret_cast<const bf16x8*>(pb1 + st * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < C; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], f0[i], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], f1[i], acc1, 0, 0, 0);
+      }
+    };
+    {
+      int s0 = wave, left = (steps - wave + 7) >> 3;            // wave-uniform
+      for (; left >= 12; left -= 12, s0 += 96) chunk(s0, PatchC<12>{});
+      if (left >= 6) { chunk(s0, PatchC<6>{}); left -= 6; s0 += 48; }
+      if (left >= 3) { chunk(s0, PatchC<3>{}); left -= 3; s0 += 24; }
+      for (; left > 0; --left, s0 += 8) chunk(s0, PatchC<1>{});
+    }
+    // partial sums [wave][16 rows][32 cols]; C layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+    float* sc = reinterpret_cast<float*>(scratch) + wave * 512;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      sc[(4 * q + rg) * 32 + l15] = acc0[rg];
+      sc[(4 * q + rg) * 32 + 16 + l15] = acc1[rg];
+    }
+    __syncthreads();
+    {
+      const float* rd = reinterpret_cast<const float*>(scratch) + idx;
+      float v = rd[0];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) v += rd[w * 512];
+      if constexpr (kPatchPrefetch<EPI>) {
+        if (live) {
+          const size_t o = (size_t)om * a.N + on;
+          if constexpr (EPI == UCOD_EPI_BIAS_BF16) reinterpret_cast<bf16_raw*>(a.out)[o] = f32_to_bf16((v + e_bias) * e_scale);
+          else if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) reinterpret_cast<bf16_raw*>(a.out)[o] = f32_to_bf16(gelu_erf(v + e_bias));
+          else if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) reinterpret_cast<float*>(a.out)[o] = e_resid + e_scale * (v + e_bias);
+          else reinterpret_cast<float*>(a.out)[o] = v + e_bias;
+        }
+      } else {
+        epilogue_store<EPI>(a, om, on, v);
+      }
+    }
+    if (pi + 1 < a.patches_per_wg) __syncthreads();            // scratch is reused by the next patch
+  }
+}
+
 // =====================================================================================================
 // Large-tile kernel: 256 x (64*NT) x 64 block tile, 8 waves (2 in M x 4 in N), one workgroup per CU.
 //   * per wave 128 x 16*NT outputs; a K-tile is consumed in FOUR phases of 32 rows each (2 x NT tiles x 2 k-steps
@@ -562,7 +675,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
-  const int nwg = a.tiles_m * a.tiles_n;
+  const int nwg = a.main_tiles > 0 ? a.main_tiles : a.tiles_m * a.tiles_n;   // leftover-as-patches mode: the first main_tiles tiles of the order
   const int orig = blockIdx.x;
   const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
   const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
@@ -622,12 +735,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   stageA(0, 0);
   stageA(0, 1);
   stageB(0, 0, Cfg::NB);
-  if (nt > 1) {
-    stageB(1, 0, Cfg::NB);
-    wait_vmcnt<Cfg::NB>();
-  } else {
-    wait_vmcnt<0>();
+  if (nt > 1) stageB(1, 0, Cfg::NB);
+  if constexpr (EPI != UCOD_EPI_GELU_BWD_BF16 && EPI != UCOD_EPI_BIAS_GELU_SAVE_BF16) {
+    // scratch: the A0 slot of buffer 1, first written by the DMAs of K-tile 1 after the barrier below.  vmcnt retires in order,
+    // so the patch's stores (older than every later DMA) never disturb the counted waits of the main loop.
+    if (a.patches_per_wg > 0) patch_phase<EPI, Cfg::BN_>(a, smem + Cfg::BUF, orig, wave, lane);
   }
+  if (nt > 1) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
   finish_col_consts<EPI, NT>(a, cb, cs);
   f32x4 acc[8][NT];
 #pragma unroll
@@ -898,32 +1012,55 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
 }
 
 // variant: 0 auto | 1 128^2 register staging | 2 128^2 LDS-DMA | 3 256x256 | 4 256x192 | 5,6 = 3,4 with staggered wave groups
+// Large-tile launch plan for a tile width: whole rounds of n_cu tiles, and whether the tiles past the last whole round are few
+// enough to be computed as patches on the side (patch_phase) instead of as a nearly empty extra round.
+struct BigPlan {
+  int total, rounds, left, ppt;
+  bool patches;
+  double cost;        // makespan model, fitted to tools/gemm_bench.py on MI355X: a tile costs a fixed part (A-panel DMA, prologue,
+};                    // epilogue set-up) plus a part proportional to its width; a patch ~2 % of a tile per round
+static int device_cus() {
+  static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+  return n_cu;
+}
+static BigPlan big_plan(int M, int N, int K, int bn, bool patch_epi) {
+  // UCOD_GEMM_NO_PATCH=1 (read per call): every output through the tile path, whose f32 sum over K has one fixed order -- results
+  // are then bitwise independent of where a row sits in the batch; a patch sums K in 8 interleaved partials
+  const char* no_patch = getenv("UCOD_GEMM_NO_PATCH");
+  const bool off = no_patch && no_patch[0] != '0';
+  const char* mr = getenv("UCOD_GEMM_PATCH_ROUNDS");
+  const int max_rounds = mr ? atoi(mr) : 2;
+  const int n_cu = device_cus();
+  BigPlan p;
+  p.total = cdiv(M, 256) * cdiv(N, bn);
+  p.rounds = p.total / n_cu;
+  p.left = p.total - p.rounds * n_cu;
+  p.ppt = 16 * (bn / 32);
+  // more rounds dilute the tail below what a patch costs every workgroup (QKV / fc1: 6 and 8 rounds of ~25 us tiles)
+  p.patches = patch_epi && !off && p.rounds >= 1 && p.rounds <= max_rounds && p.left > 0 && (long)p.left * p.ppt <= 2L * p.rounds * n_cu && (K & 31) == 0;
+  const double tile = 0.45 * 256 + 0.55 * bn;
+  p.cost = p.patches ? p.rounds * tile * 1.03 : (double)cdiv(p.total, n_cu) * tile;
+  return p;
+}
+
 template <int EPI>
 static int launch(GemmArgs a, int variant, hipStream_t s) {
+  constexpr bool kTrainEpi = (EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
+  constexpr bool kPatchEpi = !kTrainEpi;
   if (variant == 0) {
     variant = 2;
     // large tiles when either dimension is long enough to fill the chip with 256-row tiles (the key hook has M = channels = 768
     // but N = all tokens: 3 x 172 tiles)
     const bool big_enough = a.M >= 2048 || (a.M >= 512 && (long)a.M * a.N >= (1L << 24));
     if (big_enough && a.K >= 128 && (a.N & 3) == 0 && (!(EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) || (a.N & 7) == 0)) {
-      // Makespan model on 256 CUs (one large-tile workgroup per CU), fitted to tools/gemm_bench.py on MI355X:
-      // a tile costs a fixed part (A-panel DMA, prologue, epilogue set-up) plus a part proportional to its width.
-      auto cost = [&](int bn) {
-        const double rounds = (double)cdiv((long)cdiv(a.M, 256) * cdiv(a.N, bn), 256);
-        return rounds * (0.45 * 256 + 0.55 * bn);
-      };
       // two 32-MFMA barrier intervals per K-tile (variants 9/10) beat four 16-MFMA ones (5/6) by 2-4 % and the persistent
-      // form (7/8) by 1-5 % on every backbone shape (tools/gemm_bench.py)
-      variant = (cost(192) < cost(256)) ? 10 : 9;
+      // form (7/8) by 1-5 % on every backbone shape (tools/gemm_bench.py); the width with the shorter modelled makespan
+      variant = (big_plan(a.M, a.N, a.K, 192, kPatchEpi).cost < big_plan(a.M, a.N, a.K, 256, kPatchEpi).cost) ? 10 : 9;
     }
   }
-  constexpr bool kTrainEpi = (EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
   if (kTrainEpi || ((EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_F32) && !a.bias)) {   // large-tile kernels only
     if (kTrainEpi && ((a.N & 7) != 0 || a.K < 128)) return UCOD_EINVAL;
-    if (variant < 3) {
-      auto cost = [&](int bn) { return (double)cdiv((long)cdiv(a.M, 256) * cdiv(a.N, bn), 256) * (0.45 * 256 + 0.55 * bn); };
-      variant = (cost(192) < cost(256)) ? 10 : 9;
-    }
+    if (variant < 3) variant = (big_plan(a.M, a.N, a.K, 192, kPatchEpi).cost < big_plan(a.M, a.N, a.K, 256, kPatchEpi).cost) ? 10 : 9;
   }
   constexpr bool kBf16Out = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || kTrainEpi);
   if (variant >= 3 && variant <= 10 && ((a.N & 3) != 0 || (kBf16Out && (a.N & 7) != 0))) return UCOD_EINVAL;   // 16-byte row stores
@@ -932,6 +1069,14 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
     a.tiles_m = cdiv(a.M, 256);
     a.tiles_n = cdiv(a.N, wide ? 256 : 192);
     dim3 grid(a.tiles_m * a.tiles_n), block(512);
+    if (variant != 7 && variant != 8) {
+      const BigPlan pl = big_plan(a.M, a.N, a.K, wide ? 256 : 192, kPatchEpi);
+      if (pl.patches) {                                        // leftover-as-patches: exactly rounds x n_cu workgroups
+        a.main_tiles = pl.rounds * device_cus();
+        a.patches_per_wg = cdiv((long)pl.left * pl.ppt, a.main_tiles);
+        grid.x = a.main_tiles;
+      }
+    }
     switch (variant) {
       case 3: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4, false>), grid, block, 0, s, a); break;
       case 4: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3, false>), grid, block, 0, s, a); break;
@@ -940,7 +1085,7 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
       case 9: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4, true, 2>), grid, block, 0, s, a); break;
       case 10: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3, true, 2>), grid, block, 0, s, a); break;
       default: {                                             // 7, 8: persistent, one workgroup per CU
-        static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+        const int n_cu = device_cus();
         const int ntiles = a.tiles_m * a.tiles_n;
         dim3 pgrid(ntiles < n_cu ? ntiles : n_cu);
 #ifdef UCOD_GEMM_STAMPS
@@ -988,6 +1133,8 @@ static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int
   a.tok = tokens_per_image;
   a.tiles_m = cdiv(M, BM);
   a.tiles_n = cdiv(N, BN);
+  a.main_tiles = 0;
+  a.patches_per_wg = 0;
   hipStream_t s = (hipStream_t)stream;
   UCOD_PROF(epilogue >= 0 && epilogue <= 5 ? epilogue : (epilogue == UCOD_EPI_GELU_BWD_BF16 ? PROF_GEMM_EPI6 : PROF_GEMM_EPI7), s);
   switch (epilogue) {
