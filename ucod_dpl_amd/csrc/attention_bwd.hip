@@ -12,7 +12,7 @@
 //                        writes delta for the second kernel;
 //   attn_bwd_dkv_kernel  a wave owns 32 KEYS (lane = key), walks the query tiles: S and dP (A operand = Q' / dO rows from
 //                        LDS, B operand = the wave's K / V fragments in registers), then dV^T += dO^T P and
-//                        dK^T += Q'^T dS with dO^T / Q'^T read through ds_read_b64_tr_b16; -L[q] and -delta[q] vary
+//                        dK^T += Q'^T dS with dO^T / Q'^T read through ds_read_b64_tr_b16; L[q] and delta[q] vary
 //                        along the accumulator ROWS here, so they are staged in LDS and loaded as the initial values.
 // Tiles that are needed both row-major (A operand of the score products) and transposed (A operand of the gradient
 // products) are staged twice, once per bank swizzle.
@@ -65,13 +65,25 @@ __device__ __forceinline__ Map decode(int N, int heads, int npairs) {
 
 }  // namespace
 
+// Staging (both kernels): 16-byte buffer loads straight to LDS, the bank swizzle applied to the SOURCE chunk a lane fetches; the
+// per-lane byte offsets are loop-carried (one v_add per DMA and tile) and a row past the last token fails the descriptor's range
+// check and arrives as zeros.  The tile loop is unrolled by two, so the LDS buffer index is a compile-time constant and every
+// ds_read address is a loop-invariant register plus an immediate.  (The first version staged through registers: 4 global loads
+// with 64-bit address arithmetic and 6-8 ds_write_b128 per thread and tile -- the LDS store path alone was 40 % of the kernel's
+// LDS cycles, on a kernel whose LDS and VALU/MFMA cycles per tile are about equal.)
+template <int V> struct IntC { static constexpr int value = V; };
+#define LDS_DMA16(rs, dst, voff, soff) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((rs), (__attribute__((address_space(3))) void*)(dst), 16, (voff), (soff), 0, 0)
+
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_raw* __restrict__ qkv, const bf16_raw* __restrict__ out,
                                                               const bf16_raw* __restrict__ dout, const float* __restrict__ lse,
                                                               float* __restrict__ delta, bf16_raw* __restrict__ dqkv, int ldd, int N,
                                                               int heads, int npairs, float qscale) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE];      // per stage: K (swz_k) | K (swz_v) | V (swz_k)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int STAGE = 3 * TILE;                                        // K (swz_k) | K (swz_v) | V (swz_k)
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h5 = lane >> 5, l31 = lane & 31;
   const Map mp = decode(N, heads, npairs);
   if (!mp.ok) return;
@@ -105,55 +117,46 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_raw* __r
   for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
 
   const int nt = (N + ST - 1) / ST;
-  u32x4 rk[2], rv[2];
-  auto gload = [&](int t) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(qkv + (size_t)mp.b * N * ld), 0, (unsigned)N * (unsigned)ld * 2u, 0x00020000);
+  unsigned sk1[2], sk2[2];                                               // K chunk under swz_k / swz_v; V = the swz_k offset + 2*D bytes (soffset)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = i * 32 + wave * 8 + (lane >> 3), ch = lane & 7;
+    sk1[i] = (unsigned)(row * ld + D + mp.head * HD + swz_k(row, ch) * 8) * 2u;
+    sk2[i] = (unsigned)(row * ld + D + mp.head * HD + swz_v(row, ch) * 8) * 2u;
+  }
+  const unsigned tile_step = (unsigned)(ST * ld) * 2u;
+  const int v_delta = D * 2;
+  auto stage = [&](auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
-      int kr = t * ST + row;
-      kr = kr < N ? kr : N - 1;
-      const bf16_raw* p = base + (size_t)kr * ld + ch * 8;
-      rk[i] = *reinterpret_cast<const u32x4*>(p + D);
-      rv[i] = *reinterpret_cast<const u32x4*>(p + 2 * D);
+      char* dst = smem + BUF * STAGE + (i * 32 + wave * 8) * 128;
+      LDS_DMA16(rs, dst, sk1[i], 0);
+      LDS_DMA16(rs, dst + TILE, sk2[i], 0);
+      LDS_DMA16(rs, dst + 2 * TILE, sk1[i], v_delta);
+      sk1[i] += tile_step;
+      sk2[i] += tile_step;
     }
   };
-  auto lwrite = [&](int buf) {
-    char* kb = smem + buf * (3 * TILE);
+  int roff[4], toff[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
-      *reinterpret_cast<u32x4*>(kb + row * 128 + swz_k(row, ch) * 16) = rk[i];
-      *reinterpret_cast<u32x4*>(kb + TILE + row * 128 + swz_v(row, ch) * 16) = rk[i];
-      *reinterpret_cast<u32x4*>(kb + 2 * TILE + row * 128 + swz_k(row, ch) * 16) = rv[i];
+  for (int sd = 0; sd < 4; ++sd) roff[sd] = l31 * 128 + swz_k(l31, 2 * sd + h5) * 16;       // +4096 per 32 rows keeps the swizzle
+  {
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    const int row = 4 * h5 + (i16 >> 2);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int dst = dt * 32 + g1 * 16 + 4 * (i16 & 3);
+      toff[dt] = row * 128 + swz_v(row, dst >> 3) * 16 + (dst & 7) * 2;                      // +8/16/32 rows keep the swizzle
     }
-  };
-  int roff[2][4], toff[2][2][2];
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-    for (int sd = 0; sd < 4; ++sd) {
-      const int row = kt * 32 + l31;
-      roff[kt][sd] = row * 128 + swz_k(row, 2 * sd + h5) * 16;
-    }
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const int i16 = lane & 15, g1 = (lane >> 4) & 1;
-        const int row = kt * 32 + ks * 16 + 4 * h5 + (i16 >> 2);
-        const int dst = dt * 32 + g1 * 16 + 4 * (i16 & 3);
-        toff[kt][ks][dt] = row * 128 + swz_v(row, dst >> 3) * 16 + (dst & 7) * 2;
-      }
+  }
 
-  gload(0);
-  lwrite(0);
-  for (int t = 0; t < nt; ++t) {
+  auto tile = [&](int t, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
     __syncthreads();
-    const bool more = (t + 1 < nt);
-    if (more) gload(t + 1);
-    const char* kb = smem + (t & 1) * (3 * TILE);
+    if (t + 1 < nt) stage(IntC<BUF ^ 1>{});
+    const char* kb = smem + BUF * STAGE;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       f32x16 s, dp;
@@ -161,16 +164,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_raw* __r
       for (int i = 0; i < 16; ++i) { s[i] = -L; dp[i] = -dl; }
 #pragma unroll
       for (int sd = 0; sd < 4; ++sd) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + roff[kt][sd]);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + kt * 4096 + roff[sd]);
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sd], s, 0, 0, 0);
-        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(kb + 2 * TILE + roff[kt][sd]);
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(kb + 2 * TILE + kt * 4096 + roff[sd]);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[sd], dp, 0, 0, 0);
       }
       const bool tail = (t == nt - 1) && (N & (ST - 1)) != 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float p = __builtin_amdgcn_exp2f(s[r]);
-        if (tail) {
+        if (tail) {                                                      // zero-filled K rows give P = exp2(-L), not 0
           const int key = t * ST + kt * 32 + 4 * h5 + (r & 3) + 8 * (r >> 2);
           if (key >= N) p = 0.f;
         }
@@ -180,10 +183,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_raw* __r
       for (int ks = 0; ks < 2; ++ks) {
         const bf16x8 dsb = pack_b(s, ks);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr(kb + TILE, toff[kt][ks][dt]), dsb, acc[dt], 0, 0, 0);
+        for (int dt = 0; dt < 2; ++dt)
+          acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr(kb + TILE + (kt * 32 + ks * 16) * 128, toff[dt]), dsb, acc[dt], 0, 0, 0);
       }
     }
-    if (more) lwrite((t + 1) & 1);
+  };
+  stage(IntC<0>{});
+  for (int t = 0; t < nt; t += 2) {
+    tile(t, IntC<0>{});
+    if (t + 1 < nt) tile(t + 1, IntC<1>{});
   }
   if (q < N) {
     bf16_raw* op = dqkv + ((size_t)mp.b * N + q) * ldd + mp.head * HD + 4 * h5;
@@ -200,31 +208,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_raw* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// L[q] and delta[q] vary along the accumulator ROWS here, so they come through LDS as raw copies (two 256-byte DMAs per tile) and
+// the signs are moved to where they are free: the wave's K and V fragments are negated once, so the accumulators hold
+// L - S and delta - dP; P = exp2(-(L - S)) is a source modifier of v_exp_f32, dS comes out negated and the final dK scale is
+// -ln 2.  Out-of-range query rows need no mask: their Q', dO, L and delta all read as zero, so P = 1 meets dO = 0 and dS = 0.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_raw* __restrict__ qkv, const bf16_raw* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                bf16_raw* __restrict__ dqkv, int ldd, int N, int heads, int npairs) {
-  // per stage: Q' (swz_k) | Q' (swz_v) | dO (swz_k) | dO (swz_v) | -L [64] | -delta [64]
+  // per stage: Q' (swz_k) | Q' (swz_v) | dO (swz_k) | dO (swz_v) | L [64] | delta [64]
   constexpr int STAGE = 4 * TILE + 2 * ST * 4;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h5 = lane >> 5, l31 = lane & 31;
   const Map mp = decode(N, heads, npairs);
   if (!mp.ok) return;
   const int D = heads * HD, ld = 3 * D;
   const int k0 = mp.blk * WT + wave * 32;
   const bf16_raw* base = qkv + (size_t)mp.b * N * ld + mp.head * HD;
-  const bf16_raw* dob = dout + (size_t)mp.b * N * D + mp.head * HD;
-  const float* lseb = lse + ((size_t)mp.b * heads + mp.head) * N;
-  const float* dlb = delta + ((size_t)mp.b * heads + mp.head) * N;
   const int key = k0 + l31, kc = key < N ? key : N - 1;
 
-  bf16x8 kf[4], vf[4];
+  bf16x8 kf[4], vf[4];                                                   // NEGATED K and V rows of this lane's key
   {
     const bf16_raw* kp = base + (size_t)kc * ld + D + 8 * h5;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
-      vf[s] = *reinterpret_cast<const bf16x8*>(kp + D + 16 * s);
+      u32x4_t kk = *reinterpret_cast<const u32x4_t*>(kp + 16 * s), vv = *reinterpret_cast<const u32x4_t*>(kp + D + 16 * s);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { kk[e] ^= 0x80008000u; vv[e] ^= 0x80008000u; }
+      kf[s] = __builtin_bit_cast(bf16x8, kk);
+      vf[s] = __builtin_bit_cast(bf16x8, vv);
     }
   }
   f32x16 dk[2], dv[2];
@@ -232,68 +245,62 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_raw* __
   for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
 
   const int nt = (N + ST - 1) / ST;
-  u32x4 rq[2], rd[2];
-  float rl = 0.f, rdl = 0.f;
-  auto gload = [&](int t) {
+  const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(qkv + (size_t)mp.b * N * ld), 0, (unsigned)N * (unsigned)ld * 2u, 0x00020000);
+  const auto rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(dout + (size_t)mp.b * N * D), 0, (unsigned)N * (unsigned)D * 2u, 0x00020000);
+  const size_t stat0 = ((size_t)mp.b * heads + mp.head) * N;
+  const auto rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((wave & 1) ? delta + stat0 : lse + stat0), 0, (unsigned)N * 4u, 0x00020000);
+  unsigned sq1[2], sq2[2], sd1[2], sd2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = i * 32 + wave * 8 + (lane >> 3), ch = lane & 7;
+    sq1[i] = (unsigned)(row * ld + mp.head * HD + swz_k(row, ch) * 8) * 2u;
+    sq2[i] = (unsigned)(row * ld + mp.head * HD + swz_v(row, ch) * 8) * 2u;
+    sd1[i] = (unsigned)(row * D + mp.head * HD + swz_k(row, ch) * 8) * 2u;
+    sd2[i] = (unsigned)(row * D + mp.head * HD + swz_v(row, ch) * 8) * 2u;
+  }
+  unsigned ss = (unsigned)lane * 4u;                                     // waves 0 / 1: the tile's 64 L / delta values
+  const unsigned q_step = (unsigned)(ST * ld) * 2u, d_step = (unsigned)(ST * D) * 2u;
+  auto stage = [&](auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
-      int qr = t * ST + row;
-      qr = qr < N ? qr : N - 1;
-      rq[i] = *reinterpret_cast<const u32x4*>(base + (size_t)qr * ld + ch * 8);
-      rd[i] = *reinterpret_cast<const u32x4*>(dob + (size_t)qr * D + ch * 8);
+      char* dst = smem + BUF * STAGE + (i * 32 + wave * 8) * 128;
+      LDS_DMA16(rs_q, dst, sq1[i], 0);
+      LDS_DMA16(rs_q, dst + TILE, sq2[i], 0);
+      LDS_DMA16(rs_d, dst + 2 * TILE, sd1[i], 0);
+      LDS_DMA16(rs_d, dst + 3 * TILE, sd2[i], 0);
+      sq1[i] += q_step;
+      sq2[i] += q_step;
+      sd1[i] += d_step;
+      sd2[i] += d_step;
     }
-    if (tid < ST) {
-      const int qr = t * ST + tid;
-      rl = qr < N ? -lseb[qr] : -1e30f;                              // out-of-range queries: P = exp2(-huge) = 0
-      rdl = qr < N ? -dlb[qr] : 0.f;
-    }
-  };
-  auto lwrite = [&](int buf) {
-    char* sb = smem + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
-      *reinterpret_cast<u32x4*>(sb + row * 128 + swz_k(row, ch) * 16) = rq[i];
-      *reinterpret_cast<u32x4*>(sb + TILE + row * 128 + swz_v(row, ch) * 16) = rq[i];
-      *reinterpret_cast<u32x4*>(sb + 2 * TILE + row * 128 + swz_k(row, ch) * 16) = rd[i];
-      *reinterpret_cast<u32x4*>(sb + 3 * TILE + row * 128 + swz_v(row, ch) * 16) = rd[i];
-    }
-    if (tid < ST) {
-      reinterpret_cast<float*>(sb + 4 * TILE)[tid] = rl;
-      reinterpret_cast<float*>(sb + 4 * TILE + ST * 4)[tid] = rdl;
+    if (wave < 2) {
+      char* dst = smem + BUF * STAGE + 4 * TILE + wave * (ST * 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (__attribute__((address_space(3))) void*)dst, 4, ss, 0, 0, 0);
+      ss += ST * 4;
     }
   };
-  int roff[2][4], toff[2][2][2];
+  int roff[4], toff[2];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
+  for (int sd = 0; sd < 4; ++sd) roff[sd] = l31 * 128 + swz_k(l31, 2 * sd + h5) * 16;
+  {
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    const int row = 4 * h5 + (i16 >> 2);
 #pragma unroll
-    for (int sd = 0; sd < 4; ++sd) {
-      const int row = qt * 32 + l31;
-      roff[qt][sd] = row * 128 + swz_k(row, 2 * sd + h5) * 16;
+    for (int dt = 0; dt < 2; ++dt) {
+      const int dst = dt * 32 + g1 * 16 + 4 * (i16 & 3);
+      toff[dt] = row * 128 + swz_v(row, dst >> 3) * 16 + (dst & 7) * 2;
     }
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const int i16 = lane & 15, g1 = (lane >> 4) & 1;
-        const int row = qt * 32 + ks * 16 + 4 * h5 + (i16 >> 2);
-        const int dst = dt * 32 + g1 * 16 + 4 * (i16 & 3);
-        toff[qt][ks][dt] = row * 128 + swz_v(row, dst >> 3) * 16 + (dst & 7) * 2;
-      }
+  }
 
-  gload(0);
-  lwrite(0);
-  for (int t = 0; t < nt; ++t) {
+  auto tile = [&](int t, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
     __syncthreads();
-    const bool more = (t + 1 < nt);
-    if (more) gload(t + 1);
-    const char* sb = smem + (t & 1) * STAGE;
+    if (t + 1 < nt) stage(IntC<BUF ^ 1>{});
+    const char* sb = smem + BUF * STAGE;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      // accumulator rows r <-> query qt*32 + 4*h5 + (r&3) + 8*(r>>2): initial values -L[q], -delta[q] (four float4 each)
+      // accumulator rows r <-> query qt*32 + 4*h5 + (r&3) + 8*(r>>2): initial values L[q], delta[q] (four float4 each)
       f32x16 s, dp;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -304,38 +311,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_raw* __
       }
 #pragma unroll
       for (int sd = 0; sd < 4; ++sd) {
-        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sb + roff[qt][sd]);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[sd], s, 0, 0, 0);
-        const bf16x8 da = *reinterpret_cast<const bf16x8*>(sb + 2 * TILE + roff[qt][sd]);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[sd], dp, 0, 0, 0);
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sb + qt * 4096 + roff[sd]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[sd], s, 0, 0, 0);                  // L - S
+        const bf16x8 da = *reinterpret_cast<const bf16x8*>(sb + 2 * TILE + qt * 4096 + roff[sd]);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[sd], dp, 0, 0, 0);                // delta - dP
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] = __builtin_amdgcn_exp2f(s[r]);                         // P
-        dp[r] = s[r] * dp[r];                                        // dS
+        s[r] = __builtin_amdgcn_exp2f(-s[r]);                        // P
+        dp[r] = s[r] * dp[r];                                        // -dS
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const bf16x8 pb = pack_b(s, ks), dsb = pack_b(dp, ks);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr(sb + 3 * TILE, toff[qt][ks][dt]), pb, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr(sb + TILE, toff[qt][ks][dt]), dsb, dk[dt], 0, 0, 0);
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr(sb + 3 * TILE + (qt * 32 + ks * 16) * 128, toff[dt]), pb, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr(sb + TILE + (qt * 32 + ks * 16) * 128, toff[dt]), dsb, dk[dt], 0, 0, 0);
         }
       }
     }
-    if (more) lwrite((t + 1) & 1);
+  };
+  stage(IntC<0>{});
+  for (int t = 0; t < nt; t += 2) {
+    tile(t, IntC<0>{});
+    if (t + 1 < nt) tile(t + 1, IntC<1>{});
   }
   if (key < N) {
     bf16_raw* op = dqkv + ((size_t)mp.b * N + key) * ldd + D + mp.head * HD + 4 * h5;
-    constexpr float LN2 = 0.69314718055994531f;
+    constexpr float NLN2 = -0.69314718055994531f;                        // dk holds -dS^T Q'
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         u32x2 w;
-        w[0] = pack_bf16x2(dk[dt][4 * g + 0] * LN2, dk[dt][4 * g + 1] * LN2);
-        w[1] = pack_bf16x2(dk[dt][4 * g + 2] * LN2, dk[dt][4 * g + 3] * LN2);
+        w[0] = pack_bf16x2(dk[dt][4 * g + 0] * NLN2, dk[dt][4 * g + 1] * NLN2);
+        w[1] = pack_bf16x2(dk[dt][4 * g + 2] * NLN2, dk[dt][4 * g + 3] * NLN2);
         *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
         w[0] = pack_bf16x2(dv[dt][4 * g + 0], dv[dt][4 * g + 1]);
         w[1] = pack_bf16x2(dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
@@ -343,6 +354,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_raw* __
       }
   }
 }
+#undef LDS_DMA16
 
 }  // namespace ucod
 
