@@ -338,6 +338,13 @@ def test_bilinear_matches_aten_semantics():
         x = torch.randn(3, 5, ih, ih, generator=g)
         out = ops.bilinear_resize(x.to(DEV), oh, oh).cpu()
         assert maxdiff(out, torch_bilinear(x, oh, oh)) < 1e-5
+    # on the step's geometries (68-wide outputs) the blend's rounding is pinned to ATen's CPU contraction: bit for bit, through
+    # both the element kernel (15 planes) and the LDS-staged one (90 planes)
+    for (ih, oh) in ((37, 68), (16, 68), (24, 68)):
+        for c in (5, 30):
+            x = torch.randn(3, c, ih, ih, generator=g)
+            aten = torch.nn.functional.interpolate(x, size=(oh, oh), mode="bilinear", align_corners=False)      # the library itself, on the CPU
+            assert torch.equal(ops.bilinear_resize(x.to(DEV), oh, oh).cpu(), aten), (ih, oh, c)
     pl = (torch.rand(8, 1, 16, 16, generator=g) > 0.7).float()          # binary labels: lambda==0.5 ties must not flip
     a = ops.bilinear_resize(pl.to(DEV), 68, 68).cpu()
     assert torch.equal(a > 0.5, torch_bilinear(pl, 68, 68) > 0.5)
@@ -354,6 +361,25 @@ def test_bilinear_adjoint_is_the_transpose():
         assert maxdiff(got, xr.grad) < 2e-5
         ux = ops.bilinear_resize(x.to(DEV), oh, oh).cpu()
         assert abs((ux * y).sum().item() - (x * got).sum().item()) < 1e-3          # <Ux, y> == <x, U^T y>
+
+
+@pytest.mark.parametrize("ih,oh,planes", [(37, 68, 256), (37, 68, 67), (24, 68, 96), (14, 28, 130), (5, 12, 64), (28, 56, 65)])
+def test_bilinear_lds_paths_match_the_elementwise_kernels(ih, oh, planes):
+    """From 64 planes up the resize and its adjoint run the LDS-staged kernels (elementwise.hip: bilinear_up4_kernel,
+    bilinear_adjoint_sep_kernel); below that the element-per-thread ones.  Same taps, same arithmetic: bit-identical results,
+    plane by plane, including a ragged last workgroup and source planes that are not 16-byte aligned."""
+    g = torch.Generator().manual_seed(ih * oh + planes)
+    x = torch.randn(planes, ih, ih, generator=g).to(DEV)
+    y = torch.randn(planes, oh, oh, generator=g).to(DEV)
+    up = ops.bilinear_resize(x, oh, oh)
+    ad = ops.bilinear_resize_adjoint(y, ih, ih)
+    assert maxdiff(up.cpu(), torch_bilinear(x.cpu().unsqueeze(0), oh, oh)[0]) < 1e-5
+    for lo in range(0, planes, 50):                              # 50 planes per call: the fallback kernels
+        hi = min(lo + 50, planes)
+        assert torch.equal(ops.bilinear_resize(x[lo:hi].contiguous(), oh, oh), up[lo:hi])
+        assert torch.equal(ops.bilinear_resize_adjoint(y[lo:hi].contiguous(), ih, ih), ad[lo:hi])
+    off = ops.bilinear_resize(x[1:], oh, oh)                      # a view that starts one (odd-sized) plane in: unaligned source
+    assert torch.equal(off, up[1:])
 
 
 @pytest.mark.parametrize("B,C,H,Nout", [(2, 384, 28, 128), (1, 768, 37, 256), (3, 768, 68, 256), (2, 128, 5, 128)])

@@ -1,6 +1,7 @@
 // Small streaming kernels of the decoder / APM path: bilinear resize (A1), APM fusion + both BCE losses + their
 // gradients in one pass (A5+A6), thresholding, fused AdamW + EMA over a flat parameter arena (A7).
 // These move < 2 MB per step (except the feature resize) and are launch-latency bound: each is one launch.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/ucod_dpl.h"
 
@@ -18,6 +19,18 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int
   l1 = s - (float)i0;
 }
 
+// The four-tap blend with its roundings pinned: per axis the product with the SECOND weight is rounded, the one with the first is
+// fused -- w0*a + w1*b = fma(a, w0, rn(b*w1)).  That is the contraction ATen's CPU kernel was built with: on the step's geometries
+// (37 -> 68 and 16 -> 68) this reproduces F.interpolate(mode="bilinear") bit for bit (tools/resize_rounding.py tries the nine
+// candidate patterns), which is what keeps thresholds taken downstream (binarize at 0.5, loop_UCOD_DPL.py:241,261) on the
+// reference's side of a tie.  Left to -ffp-contract, hipcc picked different patterns in the unrolled and the remainder loop.
+__device__ __forceinline__ float lerp2(float v00, float v01, float v10, float v11, float lx, float ly) {
+  const float wx = 1.f - lx, wy = 1.f - ly;
+  const float top = fmaf(v00, wx, v01 * lx);
+  const float bot = fmaf(v10, wx, v11 * lx);
+  return fmaf(top, wy, bot * ly);
+}
+
 __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, long planes, int ih,
                                                        int iw, int oh, int ow, float sh, float sw) {
   const long total = planes * oh * ow;
@@ -30,10 +43,49 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__
     src_index(y, sh, ih, y0, y1, ly);
     src_index(x, sw, iw, x0, x1, lx);
     const float* p = in + pl * ih * iw;
-    const float v00 = p[y0 * iw + x0], v01 = p[y0 * iw + x1], v10 = p[y1 * iw + x0], v11 = p[y1 * iw + x1];
-    const float top = v00 * (1.f - lx) + v01 * lx;
-    const float bot = v10 * (1.f - lx) + v11 * lx;
-    out[idx] = top * (1.f - ly) + bot * ly;
+    out[idx] = lerp2(p[y0 * iw + x0], p[y0 * iw + x1], p[y1 * iw + x0], p[y1 * iw + x1], lx, ly);
+  }
+}
+
+// Upsampling form used by the step (256-channel d: 37x37 -> 68x68, 196 MB): PB source planes are staged in LDS by 16-byte
+// loads, a thread owns one group of four output columns (its x taps are computed once) and walks (plane, row) pairs, one
+// 16-byte store per output group.  The element-per-thread kernel above spends its time in 64-bit index divisions and 4-byte
+// stores (store-issue bound at ~2 TB/s); same arithmetic here, so the two agree bit for bit.
+template <int PB>
+__global__ __launch_bounds__(256) void bilinear_up4_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int ih, int iw,
+                                                           int oh, int ow, float sh, float sw) {
+  extern __shared__ __attribute__((aligned(16))) float sp[];           // PB x ih x iw
+  const int tid = threadIdx.x;
+  const int plane0 = blockIdx.x * PB;
+  const int np = (planes - plane0) < PB ? (planes - plane0) : PB;
+  const int src_elems = np * ih * iw;
+  const float* src = in + (size_t)plane0 * ih * iw;
+  if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    for (int i = tid * 4; i + 3 < src_elems; i += 1024) *reinterpret_cast<f32x4*>(sp + i) = *reinterpret_cast<const f32x4*>(src + i);
+    for (int i = (src_elems & ~3) + tid; i < src_elems; i += 256) sp[i] = src[i];
+  } else {
+    for (int i = tid; i < src_elems; i += 256) sp[i] = src[i];
+  }
+  const int G = ow >> 2, S = 256 / G;                                  // column groups per row, row slots per pass
+  const int xg = tid % G, slot = tid / G;
+  int x0[4], x1[4];
+  float lx[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) src_index(4 * xg + e, sw, iw, x0[e], x1[e], lx[e]);
+  __syncthreads();
+  if (slot >= S) return;
+  for (int r = slot; r < np * oh; r += S) {
+    const int pl = r / oh, y = r - pl * oh;
+    int y0, y1;
+    float ly;
+    src_index(y, sh, ih, y0, y1, ly);
+    const float* p = sp + pl * ih * iw;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = lerp2(p[y0 * iw + x0[e]], p[y0 * iw + x1[e]], p[y1 * iw + x0[e]], p[y1 * iw + x1[e]], lx[e], ly);
+    }
+    *reinterpret_cast<f32x4*>(out + ((size_t)(plane0 + pl) * oh + y) * ow + 4 * xg) = o;
   }
 }
 
@@ -86,6 +138,70 @@ __global__ __launch_bounds__(256) void bilinear_adjoint_kernel(const float* __re
       }
     }
     gin[pl * ih * iw + p] = acc;
+  }
+}
+
+// Separable LDS form of the adjoint (what the step uses: gd 4096 planes 68x68 -> 37x37).  The element kernel above already sums
+// "x taps inside, y taps outside"; here the inner sums R[oy][ix] are formed ONCE per output row instead of once per (iy, tap):
+// a workgroup walks `ppw` planes; per plane it stages gout in LDS (16-byte loads), pass 1 reduces along x with the thread's own
+// column taps held in registers, pass 2 reduces along y with the row taps read from an LDS table.  Same products, same order:
+// bit-identical to the element kernel, without its ~20 global gathers per output (it was bound by the gather rate).
+__global__ __launch_bounds__(256) void bilinear_adjoint_sep_kernel(const float* __restrict__ gout, float* __restrict__ gin, int planes, int ih,
+                                                                   int iw, int oh, int ow, float sh, float sw, int ppw) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];           // G [oh*ow (padded to 4)] | R [oh*iw] | y taps
+  const int g_elems = (oh * ow + 3) & ~3;
+  float* G = sm;
+  float* R = G + g_elems;
+  int* yt_i = reinterpret_cast<int*>(R + oh * iw);                     // [ih][MAXT]
+  float* yt_w = reinterpret_cast<float*>(yt_i + ih * MAXT);             // [ih][MAXT]
+  int* yt_n = reinterpret_cast<int*>(yt_w + ih * MAXT);                 // [ih]
+  const int tid = threadIdx.x;
+  const int S = 256 / iw, ix = tid % iw, slot = tid / iw;
+  const bool active = slot < S;
+  int xi[MAXT];
+  float xw[MAXT];
+  const int nx = adjoint_taps(ix, sw, iw, ow, xi, xw);
+  for (int a = tid; a < ih; a += 256) {
+    int idx[MAXT];
+    float w[MAXT];
+    const int n = adjoint_taps(a, sh, ih, oh, idx, w);
+    yt_n[a] = n;
+#pragma unroll
+    for (int e = 0; e < MAXT; ++e) { yt_i[a * MAXT + e] = e < n ? idx[e] : 0; yt_w[a * MAXT + e] = e < n ? w[e] : 0.f; }
+  }
+  const int n_in = oh * ow, hw = ih * iw;
+  const int pl_end = (blockIdx.x + 1) * ppw < planes ? (blockIdx.x + 1) * ppw : planes;
+  for (int pl = blockIdx.x * ppw; pl < pl_end; ++pl) {
+    const float* src = gout + (size_t)pl * n_in;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+      for (int i = tid * 4; i + 3 < n_in; i += 1024) *reinterpret_cast<f32x4*>(G + i) = *reinterpret_cast<const f32x4*>(src + i);
+      for (int i = (n_in & ~3) + tid; i < n_in; i += 256) G[i] = src[i];
+    } else {
+      for (int i = tid; i < n_in; i += 256) G[i] = src[i];
+    }
+    __syncthreads();                                                   // G (and, first time, the y table) ready; R free: everyone is past pass 2
+    if (active) {
+      for (int oy = slot; oy < oh; oy += S) {
+        const float* grow = G + oy * ow;
+        float row = 0.f;
+#pragma unroll
+        for (int b2 = 0; b2 < MAXT; ++b2)
+          if (b2 < nx) row = fmaf(xw[b2], grow[xi[b2]], row);
+        R[oy * iw + ix] = row;
+      }
+    }
+    __syncthreads();                                                   // R ready; G free for the next plane
+    if (active) {
+      float* dst = gin + (size_t)pl * hw;
+      for (int iy = slot; iy < ih; iy += S) {
+        const int ny = yt_n[iy];
+        float acc = 0.f;
+#pragma unroll
+        for (int a2 = 0; a2 < MAXT; ++a2)
+          if (a2 < ny) acc = fmaf(yt_w[iy * MAXT + a2], R[yt_i[iy * MAXT + a2] * iw + ix], acc);
+        dst[iy * iw + ix] = acc;
+      }
+    }
   }
 }
 
@@ -167,7 +283,13 @@ extern "C" int ucod_bilinear_resize(const float* in, float* out, int planes, int
   const size_t total = (size_t)planes * oh * ow;
   const float sh = (float)ih / (float)oh, sw = (float)iw / (float)ow;   // area_pixel_compute_scale<float>
   UCOD_PROF(PROF_BILINEAR, stream);
-  hipLaunchKernelGGL(bilinear_kernel, dim3(nblocks(total, 16384)), dim3(256), 0, (hipStream_t)stream, in, out, (long)planes, ih, iw, oh, ow, sh, sw);
+  constexpr int PB = 4;
+  const size_t lds = (size_t)PB * ih * iw * sizeof(float);
+  if (!getenv("UCOD_RESIZE_ELEMENTWISE") && (ow & 3) == 0 && ow >= 4 && ow <= 1024 && lds <= 48 * 1024 && planes >= 64 && oh * ow >= ih * iw) {
+    hipLaunchKernelGGL(bilinear_up4_kernel<PB>, dim3(cdiv(planes, PB)), dim3(256), lds, (hipStream_t)stream, in, out, planes, ih, iw, oh, ow, sh, sw);
+  } else {
+    hipLaunchKernelGGL(bilinear_kernel, dim3(nblocks(total, 16384)), dim3(256), 0, (hipStream_t)stream, in, out, (long)planes, ih, iw, oh, ow, sh, sw);
+  }
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }
@@ -179,8 +301,16 @@ extern "C" int ucod_bilinear_resize_adjoint(const float* gout, float* gin, int p
   UCOD_PROF(PROF_BILINEAR, stream);
   (void)total;
   if (ceilf(2.f / fminf(sh, sw)) + 1.f > (float)MAXT) return UCOD_EINVAL;   // more than MAXT taps per axis (upsampling beyond ~3.5x)
-  const int py = planes < 1024 ? planes : 1024;
-  hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(cdiv((long)ih * iw, 256), py), dim3(256), 0, (hipStream_t)stream, gout, gin, (long)planes, ih, iw, oh, ow, sh, sw);
+  const size_t lds = ((((size_t)oh * ow + 3) & ~(size_t)3) + (size_t)oh * iw + (size_t)ih * (2 * MAXT + 1)) * sizeof(float);
+  if (!getenv("UCOD_RESIZE_ELEMENTWISE") && lds <= 60 * 1024 && planes >= 64 && iw <= 128) {
+    // planes per workgroup: amortises the tap set-up, but a workgroup's planes are strictly sequential (load, barrier, pass 1, barrier,
+    // pass 2) and the latencies are hidden by the other 4 workgroups on the CU -- 4096 planes: 4 per workgroup 40 us, 8: 72 us, 1: 50 us
+    const int ppw = planes >= 2048 ? 4 : (planes >= 512 ? 2 : 1);
+    hipLaunchKernelGGL(bilinear_adjoint_sep_kernel, dim3(cdiv(planes, ppw)), dim3(256), lds, (hipStream_t)stream, gout, gin, planes, ih, iw, oh, ow, sh, sw, ppw);
+  } else {
+    const int py = planes < 1024 ? planes : 1024;
+    hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(cdiv((long)ih * iw, 256), py), dim3(256), 0, (hipStream_t)stream, gout, gin, (long)planes, ih, iw, oh, ow, sh, sw);
+  }
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }
