@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--image", type=int, default=518)
     ap.add_argument("--full-last-layer", action="store_true", help="also run the reference's dead tail of the last layer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--cpu-images", type=int, default=4)
     ap.add_argument("--gemm-variant", type=int, default=0)
     ap.add_argument("--attn-variant", type=int, default=2)
     ap.add_argument("--streams", type=int, default=2, help="image-parallel sub-batches of the backbone pass on independent HIP streams")
