@@ -15,6 +15,15 @@
  *   - return value: 0 on success, UCOD_EINVAL (-1) for rejected arguments, otherwise a hipError_t;
  *   - "bf16" buffers are raw uint16 bfloat16; "f32" are IEEE float.
  *   - tensors are dense row-major; [B,C,H,W] is NCHW exactly as the reference holds them.
+ *
+ * Environment switches read by the library (diagnostics; defaults are the fast paths):
+ *   UCOD_GEMM_NO_PATCH=1       ucod_gemm_bf16*: every output through the tile path.  By default a launch that ends a few tiles past
+ *                              one or two whole rounds of CUs computes those tiles as 16x32 patches on the side, which sums K in a
+ *                              different order: results stay deterministic but a row's low f32 bits then depend on where the row
+ *                              sits in the batch.  Set this for bitwise batch-position independence (read at every call).
+ *   UCOD_GEMM_PATCH_ROUNDS=n   largest number of whole rounds for which the patch mode is used (default 2).
+ *   UCOD_RESIZE_ELEMENTWISE=1  ucod_bilinear_resize / _adjoint: the element-per-thread kernels also for >= 64 planes (the LDS-staged
+ *                              kernels produce the same bits; this is for timing comparisons).
  */
 #ifndef UCOD_DPL_H
 #define UCOD_DPL_H
