@@ -386,6 +386,19 @@ size_t ucod_gated_ensemble_workspace_bytes(int B, int h, int w);
 int ucod_gated_ensemble(const float* l1_up, const float* l2, const float* fuser0_w, const float* fuser0_b, const float* fuser2_w,
                         float fuser2_b, float* out, float* weight_out, void* workspace, int B, int h, int w, void* stream);
 
+/* ------------------------------------------------------------------ COD measures (row N4: engine/utils/metrics/metric.py::statistics)
+ * pred, gt f32 [B,H,W] (any range: the measures min-max normalise the prediction and threshold the normalised ground truth at 0.5,
+ * _prepare_data :125-133).  out f64 [B][UCOD_COD_RECORD], per image:
+ *   [0] MAE  [1] ACC  [2] IoU  [3] S-measure  [4] weighted F  [5] adaptive E  [6] adaptive F  [7] ground-truth foreground pixels,
+ *   [8..263] E-measure over the 256 thresholds, [264..519] F-measure curve (beta^2 = 0.3), [520..775] precision, [776..1031] recall
+ * -- exactly what one statistics.step() appends to its seven measure objects; get_result() is means over images of these.
+ * float64 arithmetic throughout, fixed reduction trees (deterministic); agreement with the reference's numpy is to summation order.
+ * A constant prediction follows the reference's integer branch (pred.astype(int)); constants outside [0, 2) are not supported. */
+#define UCOD_COD_RECORD 1032
+size_t ucod_cod_metrics_workspace_bytes(int B, int H, int W);
+int ucod_cod_metrics(const float* pred, const float* gt, int B, int H, int W, double* out, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -620,7 +620,60 @@ def g15():
     save("g15_coral_loop", **out)
 
 
+# ----------------------------------------------------------------------------- G16: COD metrics (row N4, `statistics`)
+def g16():
+    """engine/utils/metrics/metric.py::statistics -- the REAL class (cv2, which it imports for its file-based helper only, is stubbed)
+    on seeded prediction / ground-truth pairs: soft and binary predictions, blobs, empty and full ground truths, constant
+    predictions, odd sizes.  Stored per case: every per-image quantity the measures append, and the final get_result() of the set."""
+    if "cv2" not in sys.modules:
+        mod("cv2")
+    import engine.utils.metrics.metric as M
+    g = torch.Generator().manual_seed(16)
+
+    def blob(h, w, n):
+        yy, xx = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+        m = torch.zeros(h, w)
+        for _ in range(n):
+            cy, cx = torch.rand(1, generator=g).item() * h, torch.rand(1, generator=g).item() * w
+            ry, rx = 2 + torch.rand(1, generator=g).item() * h / 3, 2 + torch.rand(1, generator=g).item() * w / 3
+            m = torch.maximum(m, (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1).float())
+        return m
+
+    cases = []
+    for (h, w) in ((23, 31), (40, 40), (17, 52), (64, 48)):
+        gt = blob(h, w, 2)
+        soft = (gt * 0.6 + torch.rand(h, w, generator=g) * 0.5).clamp(0, 1)                    # soft prediction correlated with gt
+        cases.append((gt, soft))
+        cases.append((gt, (soft > 0.55).float()))                                               # binary prediction (what the loops pass)
+        cases.append((gt * 255.0, torch.rand(h, w, generator=g) * 3.0 - 1.0))                   # 0/255 gt, unnormalised prediction
+    cases.append((torch.zeros(20, 20), torch.rand(20, 20, generator=g)))                         # empty ground truth
+    cases.append((torch.ones(20, 20), torch.rand(20, 20, generator=g)))                          # full ground truth
+    cases.append((blob(20, 26, 1), torch.full((20, 26), 0.7)))                                   # constant prediction (astype(int) branch)
+    cases.append((blob(20, 26, 1), torch.ones(20, 26)))
+    cases.append(((torch.rand(30, 30, generator=g) > 0.9).float(), torch.rand(30, 30, generator=g)))   # scattered gt: many EDT ties
+    cases.append(((torch.rand(15, 33, generator=g) > 0.5).float(), (torch.rand(15, 33, generator=g) > 0.5).float()))
+    out = {"n": np.int64(len(cases))}
+    st = M.statistics()
+    for i, (gt, pred) in enumerate(cases):
+        out[f"gt{i}"], out[f"pred{i}"] = gt, pred
+        st.step(gt.unsqueeze(0).unsqueeze(0), pred.unsqueeze(0).unsqueeze(0))
+        out[f"mae{i}"] = np.float64(st.MAE.maes[-1])
+        out[f"acc{i}"] = np.float64(st.ACC.accs[-1])
+        out[f"iou{i}"] = np.float64(st.MIOU.ious[-1])
+        out[f"sm{i}"] = np.float64(st.SM.sms[-1])
+        out[f"wfm{i}"] = np.float64(st.WFM.weighted_fms[-1])
+        out[f"adp_em{i}"] = np.float64(st.EM.adaptive_ems[-1])
+        out[f"em_curve{i}"] = np.asarray(st.EM.changeable_ems[-1], np.float64)
+        out[f"adp_fm{i}"] = np.float64(st.FM.adaptive_fms[-1])
+        out[f"fm_curve{i}"] = np.asarray(st.FM.changeable_fms[-1], np.float64)
+        out[f"p_curve{i}"] = np.asarray(st.FM.precisions[-1], np.float64)
+        out[f"r_curve{i}"] = np.asarray(st.FM.recalls[-1], np.float64)
+    for k, v in st.get_result().items():
+        out["final." + k] = np.float64(v)
+    save("g16_cod_metrics", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g12", "g13", "g14", "g15", "g16"]
     for w in which:
         globals()[w]()

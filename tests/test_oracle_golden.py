@@ -265,3 +265,20 @@ def test_g15_coral_validation_loop_pieces():
     z[0, 0, 0, :2] = 1.0
     assert int(OC.should_crop_center(z)) == int(g["crop_dense"])
     assert torch.equal(OC.process_preds(g["probs_in"], (20, 31)), g["probs_up"])
+
+
+def test_g16_cod_metrics_oracle_matches_the_reference_class():
+    """oracle/cod_metrics.py against engine/utils/metrics/metric.py::statistics (golden G16): every per-image quantity and the
+    aggregated get_result(), to float64 rounding."""
+    import numpy as np
+    from oracle import cod_metrics as OM
+    g = load_golden("g16_cod_metrics")
+    per = []
+    for i in range(int(g["n"])):
+        m = OM.image_measures(g[f"pred{i}"].numpy(), g[f"gt{i}"].numpy())
+        per.append(m)
+        for k in ("mae", "acc", "iou", "sm", "wfm", "adp_em", "adp_fm", "em_curve", "fm_curve", "p_curve", "r_curve"):
+            assert float(np.max(np.abs(np.asarray(m[k]) - g[f"{k}{i}"].numpy()))) < 1e-12, (i, k)
+    agg = OM.aggregate(per)
+    for k, v in agg.items():
+        assert abs(v - float(g["final." + k])) < 1e-12, k

@@ -5,8 +5,8 @@ Same method names and semantics: ``concate_preds`` (:61-95), ``_prepare_validati
 (:248-259), ``_center_pad`` (:168-203), ``crop_center`` (:276-311), ``process_preds`` (:313-341), ``_process_validation_batch``
 (:130-166), ``run`` (:97-128).  Every resize is the HIP bilinear kernel (ATen semantics), the first-stage logits come from the HIP
 decoder, the refinement from the HIP refiner; predictions are not written to disk (``_save_prediction_image`` is I/O, out of
-scope) and the statistic is MAE (``MAEStatistics``; the other COD measures of engine/utils/metrics are host-side numpy in the
-reference and are not rebuilt).  ``WindowFeatures`` is the data side (data/datasets/lr_dataset.py:82-166): the 3x3 window key
+scope); the statistics are the nine COD measures of engine/utils/metrics/metric.py::statistics, computed on the device
+(``engine/utils/metrics``, csrc/cod_metrics.hip).  ``WindowFeatures`` is the data side (data/datasets/lr_dataset.py:82-166): the 3x3 window key
 features and the 2x2 overlapping crops of the 54x54 key map, with every backbone call of an image batched into one pass.
 """
 import numpy as np
@@ -14,7 +14,8 @@ import torch
 
 from ... import ops
 from .loop_UCOD_DPL import BaseLoop
-from .loop_look_twice import MAEStatistics
+from .loop_look_twice import MAEStatistics  # noqa: F401  (re-exported)
+from ..utils.metrics import statistics
 
 
 class WindowFeatures:
@@ -135,11 +136,11 @@ class LocalRefineValidationLoop(BaseLoop):
             if crop:
                 outputs = self._center_pad(outputs)
             preds_up = self.process_preds(outputs, tuple(label_tensor.shape[2:]))
-            statistics_val.step(label_tensor, preds_up)
+            statistics_val.step(label_tensor.to(preds_up.device) if isinstance(statistics_val, statistics) else label_tensor, preds_up)
         return preds_up
 
     def run(self):
-        stats = MAEStatistics()
+        stats = statistics()                                  # the nine COD measures on the device (engine/utils/metrics/metric.py:19-74)
         self.runner.refiner.eval()
         for batch in self.runner.val_dataloader:
             self._process_validation_batch(batch, stats)

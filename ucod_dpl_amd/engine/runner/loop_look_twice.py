@@ -20,6 +20,7 @@ import torch
 
 from ... import native as N, ops
 from .loop_UCOD_DPL import BaseLoop
+from ..utils.metrics import statistics
 
 DEFAULT_BOX = [129, 129, 259, 259]
 
@@ -51,7 +52,8 @@ def pil_resize_u8(src, out_w, out_h, bicubic=True):
 
 
 class MAEStatistics:
-    """The MAE part of engine/utils/metrics/metric.py::statistics (_prepare_data :125-133, MAEmeasure :187-207)."""
+    """The MAE part of engine/utils/metrics/metric.py::statistics (_prepare_data :125-133, MAEmeasure :187-207) on host arrays --
+    kept for callers that hold numpy data; the validation loops use the full device-side ``statistics``."""
 
     def __init__(self):
         self.maes = []
@@ -255,7 +257,7 @@ class ValLoop_Look_Twice(BaseLoop):
 
     # ------------------------------------------------------------------ :297-324
     def run(self):
-        stats = MAEStatistics()
+        stats = statistics()                                                       # all nine COD measures, on the device (:299)
         self.runner.model.eval()
         fs = self.cfg.model_cfg.feature_size
         world = self.runner.world_size
@@ -272,7 +274,7 @@ class ValLoop_Look_Twice(BaseLoop):
             if bboxes is not None and self.cfg.val_cfg.look_twice:
                 preds_up = self.look_twice(img_path[0], bboxes, preds_up).to(self.device)
             out = ops.bilinear_resize(preds_up.reshape(1, 1, *preds_up.shape[-2:]).to(self.device), label_tensor.shape[-2], label_tensor.shape[-1])
-            stats.step(label_tensor, (out.reshape(1, *out.shape[-2:]) > 0.5))
+            stats.step(label_tensor.to(self.device), (out.reshape(1, *out.shape[-2:]) > 0.5))
         result = stats.get_result()
         self.runner.logger.log_table({k: [round(v, 4)] for k, v in result.items()})
         return result

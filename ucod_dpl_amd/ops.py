@@ -236,3 +236,18 @@ def disc_bwd(mask, tensors, saved, gprob, grads=None, accumulate=False):
     check(lib.ucod_disc_bwd(ptr(_f32(mask)), C.byref(ps), ptr(saved), ptr(_f32(gprob)), C.byref(gs), int(accumulate), ptr(ws), B, fs,
                             stream()), "ucod_disc_bwd")
     return grads
+
+
+# ----------------------------------------------------------------------------- COD measures (row N4)
+def cod_metrics(pred, gt):
+    """pred, gt f32 [B,H,W] -> f64 [B, COD_RECORD] per-image measures (layout in include/ucod_dpl.h)."""
+    pred, gt = _f32(pred).contiguous(), _f32(gt).contiguous()
+    B, H, W = pred.shape
+    if gt.shape != pred.shape:
+        raise ValueError(f"prediction {tuple(pred.shape)} and ground truth {tuple(gt.shape)} differ")
+    lib = N.load()
+    nbytes = lib.ucod_cod_metrics_workspace_bytes(B, H, W)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pred.device)
+    out = torch.empty(B, N.COD_RECORD, dtype=torch.float64, device=pred.device)
+    check(lib.ucod_cod_metrics(ptr(pred), ptr(gt), B, H, W, ptr(out), ptr(ws), nbytes, stream()), "ucod_cod_metrics")
+    return out
