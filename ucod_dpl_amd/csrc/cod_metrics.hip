@@ -7,7 +7,7 @@
 // registers (float64 throughout, like the reference) and reduced by a fixed tree, so results are deterministic and agree with the
 // reference to summation-order rounding (tests: 1e-9).
 //
-// Passes (one 1024-thread workgroup per image unless noted; images are validation-sized, the work is tiny next to the backbone):
+// Passes (1024-thread workgroups over up to 64 pixel chunks per image, chunk partials combined in chunk order):
 //   1  min / max of prediction and ground truth (the min-max normalisation of _prepare_data :125-133);
 //   2  sums over pixels of everything that needs only p and g: MAE, ACC, IoU, the object-similarity moments, the centroid, and the
 //      two 256-bin histograms of uint8(p * 255) inside / outside the ground truth (integer LDS atomics);
@@ -28,7 +28,7 @@ constexpr double EPS = 2.220446049250313e-16;            // np.spacing(1)
 constexpr int NS2 = 12, NS3 = 18;                        // doubles reduced by pass 2 / pass 3
 
 struct Norm {                                            // _prepare_data: how to turn the raw inputs into p (float64) and g (bool)
-  double pmin, pscale;                                   // pscale = 1 / (pmax - pmin) as a DIVISOR is not used: the reference divides
+  double pmin, pden;                                     // p = (v - pmin) / pden, a true division as in the reference (not a reciprocal multiply)
   double gmin, gden;
   bool p_const, g_const;
 };
@@ -36,14 +36,14 @@ struct Norm {                                            // _prepare_data: how t
 __device__ __forceinline__ Norm load_norm(const float* mm) {
   Norm n;
   n.pmin = (double)mm[0];
-  n.pscale = (double)mm[1] - (double)mm[0];
+  n.pden = (double)mm[1] - (double)mm[0];
   n.gmin = (double)mm[2];
   n.gden = (double)mm[3] - (double)mm[2];
   n.p_const = mm[1] == mm[0];
   n.g_const = mm[3] == mm[2];
   return n;
 }
-__device__ __forceinline__ double norm_p(const Norm& n, float v) { return n.p_const ? trunc((double)v) : ((double)v - n.pmin) / n.pscale; }
+__device__ __forceinline__ double norm_p(const Norm& n, float v) { return n.p_const ? trunc((double)v) : ((double)v - n.pmin) / n.pden; }
 __device__ __forceinline__ bool norm_g(const Norm& n, float v) { return (n.g_const ? (double)v : ((double)v - n.gmin) / n.gden) > 0.5; }
 
 // fixed-tree block reduction of K doubles per thread (blockDim.x = 1024): lane tree, then wave 0 over the 16 wave partials
@@ -91,18 +91,37 @@ __global__ __launch_bounds__(1024) void cod_minmax_kernel(const float* __restric
   }
 }
 
+// The per-pixel passes run on gridDim.x chunks per image (chunk c owns pixels [c*per, (c+1)*per)): each workgroup reduces its chunk
+// with the fixed tree and writes one partial; cod_combine_kernel then adds the chunk partials in chunk order.  Deterministic, and a
+// 1024 x 1024 map uses 64 CUs instead of one.
+__device__ __forceinline__ void chunk_range(int n, int& lo, int& hi) {
+  const int per = (n + gridDim.x - 1) / gridDim.x;
+  lo = blockIdx.x * per;
+  hi = lo + per < n ? lo + per : n;
+}
+
+__global__ void cod_combine_kernel(const double* __restrict__ part, int chunks, int K, double* __restrict__ out) {
+  const int b = blockIdx.x, k = threadIdx.x;
+  if (k >= K) return;
+  double x = 0.0;
+  for (int c = 0; c < chunks; ++c) x += part[((size_t)b * chunks + c) * K + k];
+  out[(size_t)b * K + k] = x;
+}
+
 __global__ __launch_bounds__(1024) void cod_pass2_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int H, int W,
                                                          const float* __restrict__ mm, double* __restrict__ S2, unsigned* __restrict__ hist) {
   __shared__ double red[16 * NS2];
   __shared__ unsigned h[512];
-  const int n = H * W, b = blockIdx.x;
+  const int n = H * W, b = blockIdx.y;
+  int lo, hi;
+  chunk_range(n, lo, hi);
   const Norm nm = load_norm(mm + b * 4);
   for (int i = threadIdx.x; i < 512; i += blockDim.x) h[i] = 0;
   __syncthreads();
   double s[NS2];
 #pragma unroll
   for (int k = 0; k < NS2; ++k) s[k] = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const double p = norm_p(nm, pred[(size_t)b * n + i]);
     const bool g = norm_g(nm, gt[(size_t)b * n + i]);
     const double gf = g ? 1.0 : 0.0;
@@ -116,8 +135,9 @@ __global__ __launch_bounds__(1024) void cod_pass2_kernel(const float* __restrict
     else { const double q = 1.0 - p; s[8] += q; s[9] += q * q; }
     atomicAdd(&h[(g ? 0 : 256) + (int)(unsigned char)(p * 255.0)], 1u);
   }
-  block_reduce<NS2>(s, red, S2 + (size_t)b * NS2);
-  for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[(size_t)b * 512 + i] = h[i];
+  block_reduce<NS2>(s, red, S2 + ((size_t)b * gridDim.x + blockIdx.x) * NS2);
+  for (int i = threadIdx.x; i < 512; i += blockDim.x)
+    if (h[i]) atomicAdd(&hist[(size_t)b * 512 + i], h[i]);             // integer adds: order does not matter
 }
 
 // centroid of the ground truth (:259-268): np.round is round-half-even; an empty mask takes the image centre
@@ -129,7 +149,9 @@ __device__ __forceinline__ void centroid(const double* S2, int H, int W, int& cx
 __global__ __launch_bounds__(1024) void cod_pass3_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int H, int W,
                                                          const float* __restrict__ mm, const double* __restrict__ S2, double* __restrict__ S3) {
   __shared__ double red[16 * NS3];
-  const int n = H * W, b = blockIdx.x;
+  const int n = H * W, b = blockIdx.y;
+  int lo, hi;
+  chunk_range(n, lo, hi);
   const Norm nm = load_norm(mm + b * 4);
   const double* s2 = S2 + (size_t)b * NS2;
   const double thr = fmin(2.0 * (s2[1] / (double)n), 1.0);            // _get_adaptive_threshold (:135-136)
@@ -138,7 +160,7 @@ __global__ __launch_bounds__(1024) void cod_pass3_kernel(const float* __restrict
   double s[NS3];
 #pragma unroll
   for (int k = 0; k < NS3; ++k) s[k] = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const double p = norm_p(nm, pred[(size_t)b * n + i]);
     const bool g = norm_g(nm, gt[(size_t)b * n + i]);
     if (p >= thr) s[g ? 0 : 1] += 1.0;
@@ -149,7 +171,7 @@ __global__ __launch_bounds__(1024) void cod_pass3_kernel(const float* __restrict
     for (int qq = 0; qq < 4; ++qq)
       if (q == qq) { s[2 + 4 * qq] += p; s[3 + 4 * qq] += p * p; s[4 + 4 * qq] += gf; s[5 + 4 * qq] += p * gf; }
   }
-  block_reduce<NS3>(s, red, S3 + (size_t)b * NS3);
+  block_reduce<NS3>(s, red, S3 + ((size_t)b * gridDim.x + blockIdx.x) * NS3);
 }
 
 // ---- weighted F-measure -------------------------------------------------------------------------------------------------
@@ -204,13 +226,15 @@ struct Gauss7 { double k[49]; };
 __global__ __launch_bounds__(1024) void cod_wfm_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int H, int W, const float* __restrict__ mm,
                                                        const double* __restrict__ dist, const double* __restrict__ Et, Gauss7 gk, double* __restrict__ T) {
   __shared__ double red[16 * 2];
-  const int n = H * W, b = blockIdx.x;
+  const int n = H * W, b = blockIdx.y;
+  int lo, hi;
+  chunk_range(n, lo, hi);
   const Norm nm = load_norm(mm + b * 4);
   const double* et = Et + (size_t)b * n;
   const double* ds = dist + (size_t)b * n;
   const double c = log(0.5) / 5.0;
   double s[2] = {0.0, 0.0};
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const int y = i / W, x = i - y * W;
     double ea = 0.0;
     for (int dy = 0; dy < 7; ++dy) {
@@ -228,7 +252,7 @@ __global__ __launch_bounds__(1024) void cod_wfm_kernel(const float* __restrict__
     const double w = g ? 1.0 : 2.0 - exp(c * ds[i]);
     s[g ? 0 : 1] += m * w;
   }
-  block_reduce<2>(s, red, T + (size_t)b * 2);
+  block_reduce<2>(s, red, T + ((size_t)b * gridDim.x + blockIdx.x) * 2);
 }
 
 // ---- pass 5: curves and scalar formulas ------------------------------------------------------------------------------------
@@ -335,7 +359,10 @@ __global__ __launch_bounds__(256) void cod_finalize_kernel(int H, int W, const d
   o[7] = n_fg;
 }
 
-struct Layout { size_t mm, s2, s3, hist, t, lc, rc, dist, et, total; };
+constexpr int MAX_CHUNKS = 64;
+static int chunks_for(int n) { const int c = cdiv(n, 8192); return c < 1 ? 1 : (c > MAX_CHUNKS ? MAX_CHUNKS : c); }
+
+struct Layout { size_t mm, s2, s3, hist, t, part, lc, rc, dist, et, total; };
 static Layout layout(int B, int H, int W) {
   Layout l;
   size_t off = 0;
@@ -346,6 +373,7 @@ static Layout layout(int B, int H, int W) {
   l.s3 = take((size_t)B * NS3 * sizeof(double));
   l.hist = take((size_t)B * 512 * sizeof(unsigned));
   l.t = take((size_t)B * 2 * sizeof(double));
+  l.part = take((size_t)B * MAX_CHUNKS * NS3 * sizeof(double));      // chunk partials of the pass in flight (NS3 is the widest)
   l.lc = take((size_t)B * n * sizeof(int));
   l.rc = take((size_t)B * n * sizeof(int));
   l.dist = take((size_t)B * n * sizeof(double));
@@ -402,12 +430,18 @@ extern "C" int ucod_cod_metrics(const float* pred, const float* gt, int B, int H
   hipStream_t s = (hipStream_t)stream;
   const int n = H * W;
   static const Gauss7 gk = gauss7();
+  double* part = (double*)(ws + l.part);
+  const int ch = chunks_for(n);
   hipLaunchKernelGGL(cod_minmax_kernel, dim3(B), dim3(1024), 0, s, pred, gt, n, mm);
-  hipLaunchKernelGGL(cod_pass2_kernel, dim3(B), dim3(1024), 0, s, pred, gt, H, W, mm, S2, hist);
-  hipLaunchKernelGGL(cod_pass3_kernel, dim3(B), dim3(1024), 0, s, pred, gt, H, W, mm, S2, S3);
+  if (hipMemsetAsync(hist, 0, (size_t)B * 512 * sizeof(unsigned), s) != hipSuccess) return UCOD_EINVAL;
+  hipLaunchKernelGGL(cod_pass2_kernel, dim3(ch, B), dim3(1024), 0, s, pred, gt, H, W, mm, part, hist);
+  hipLaunchKernelGGL(cod_combine_kernel, dim3(B), dim3(32), 0, s, part, ch, NS2, S2);
+  hipLaunchKernelGGL(cod_pass3_kernel, dim3(ch, B), dim3(1024), 0, s, pred, gt, H, W, mm, S2, part);
+  hipLaunchKernelGGL(cod_combine_kernel, dim3(B), dim3(32), 0, s, part, ch, NS3, S3);
   hipLaunchKernelGGL(cod_rowscan_kernel, dim3(cdiv(H, 64), B), dim3(64), 0, s, gt, H, W, mm, Lc, Rc);
   hipLaunchKernelGGL(cod_edt_kernel, dim3(cdiv(n, 256), B), dim3(256), 0, s, pred, gt, H, W, mm, Lc, Rc, dist, Et);
-  hipLaunchKernelGGL(cod_wfm_kernel, dim3(B), dim3(1024), 0, s, pred, gt, H, W, mm, dist, Et, gk, T);
+  hipLaunchKernelGGL(cod_wfm_kernel, dim3(ch, B), dim3(1024), 0, s, pred, gt, H, W, mm, dist, Et, gk, part);
+  hipLaunchKernelGGL(cod_combine_kernel, dim3(B), dim3(32), 0, s, part, ch, 2, T);
   hipLaunchKernelGGL(cod_finalize_kernel, dim3(B), dim3(256), 0, s, H, W, S2, S3, hist, T, out);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
