@@ -299,6 +299,7 @@ def cpu_baseline(a, D, heads, L, P):
     """The CPU oracle (a parity-pinned restatement of the reference: HF Dinov2 forward + TrainLoop._process_batch with the
     reference's naive [B,HW,HW] orthogonality loss) timed on this box's host cores, on a bounded sample."""
     from oracle import vit as OV, train_step as OT, decoder as OD, discriminator as ODISC
+    from oracle.resize import torch_bilinear
     from ucod_dpl_amd.data.utils.feature_extractor import random_state_dict
     n = a.cpu_images
     torch.manual_seed(0)
@@ -313,10 +314,34 @@ def cpu_baseline(a, D, heads, L, P):
     with torch.no_grad():
         _, key = OV.dinov2_forward(img, sd, heads=heads, patch=P, eps=1e-6, full_last_layer=True)
     t1 = time.perf_counter()
+    with torch.no_grad():
+        fg_ref, _, _ = OD.rev_decoder_forward(torch_bilinear(key, 68, 68), dec, orth="gram")
     OT.process_batch(st, key, pl, orth="naive")
     t2 = time.perf_counter()
-    return {"value": round(n / (t2 - t0), 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} images: oracle Dinov2 fwd f32 ({t1 - t0:.1f}s) + oracle _process_batch with the reference's naive orth loss ({t2 - t1:.1f}s)"}
+    out = {"value": round(n / (t2 - t0), 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n} images: oracle Dinov2 fwd f32 ({t1 - t0:.1f}s) + oracle _process_batch with the reference's naive orth loss ({t2 - t1:.1f}s)"}
+    # Parity of the bf16 device path at FULL size against the f32 oracle on the same images and weights (report max-abs,
+    # relative L2 and the fraction of mask pixels that land on the other side of the 0.5 threshold).  The oracle is the checker here.
+    try:
+        from ucod_dpl_amd import ops
+        from ucod_dpl_amd.vit_engine import ViTEngine
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        eng = ViTEngine(sd, heads=heads, eps=1e-6, device=dev, attn_variant=a.attn_variant)
+        key_dev = eng(img.to(dev))
+        d = ops.bilinear_resize(ops.dba_project(key_dev, dec["decoupling.weight"].reshape(128, D).to(dev), dec["decoupling.bias"].to(dev)).view(n, 128, *key_dev.shape[-2:]), 68, 68).view(n, 128, 68 * 68)
+        emb = dec["learnable_embedding"].reshape(128).to(dev)
+        hw = torch.cat((dec["conv_out_fg.weight"].reshape(64), dec["conv_out_bg.weight"].reshape(64))).to(dev)
+        hb = torch.cat((dec["conv_out_fg.bias"], dec["conv_out_bg.bias"])).to(dev)
+        fg_dev, _, _ = ops.dba_heads(d, 0, emb, ops.dba_colnorm(d, 0, emb), hw, hb, want_bg=False)
+        kd, fd = key_dev.cpu(), fg_dev.view(n, 1, 68, 68).cpu()
+        out["parity_full_size"] = {
+            "what": f"{n} images at {a.image}x{a.image}, {a.arch}: bf16 device backbone + f32 device decoder vs the f32 oracle (same random-init weights)",
+            "key_rel_l2": round(float((kd - key).norm() / key.norm()), 6), "key_max_abs": round(float((kd - key).abs().max()), 5),
+            "logit_max_abs": round(float((fd - fg_ref).abs().max()), 6), "logit_rel_l2": round(float((fd - fg_ref).norm() / fg_ref.norm()), 6),
+            "mask_flipped_fraction": round(float(((fd > 0) != (fg_ref > 0)).float().mean()), 6)}
+    except Exception as e:                                      # the measurement must not take the bench line down
+        out["parity_full_size"] = {"error": repr(e)}
+    return out
 
 
 if __name__ == "__main__":
