@@ -1038,8 +1038,16 @@ static BigPlan big_plan(int M, int N, int K, int bn, bool patch_epi) {
   p.ppt = 16 * (bn / 32);
   // more rounds dilute the tail below what a patch costs every workgroup (QKV / fc1: 6 and 8 rounds of ~25 us tiles)
   p.patches = patch_epi && !off && p.rounds >= 1 && p.rounds <= max_rounds && p.left > 0 && (long)p.left * p.ppt <= 2L * p.rounds * n_cu && (K & 31) == 0;
+  // Makespan in tile units.  A last, partly filled round is cheaper than a full one (its tiles run on an otherwise idle chip: measured
+  // 0.42 of a round at 1.6 % fill, fc2 2 rounds 183 us -> 2.016 rounds 221 us): 0.4 + 0.6 * fill.  A patch costs every workgroup ~8 % of
+  // its tile (3.4 us of 41 at K = 768, 7.4 of 91 at K = 3072).  With these two numbers the model reproduces the measured choices: patches
+  // for ViT-B proj / fc2 (553 vs 617 units = the measured 198 vs 221 us), plain 256-wide tiles for ViT-L's N = 1024 (1.34 rounds).
   const double tile = 0.45 * 256 + 0.55 * bn;
-  p.cost = p.patches ? p.rounds * tile * 1.03 : (double)cdiv(p.total, n_cu) * tile;
+  const double fill = (double)p.left / n_cu;
+  const double plain = (p.rounds + (p.left ? 0.4 + 0.6 * fill : 0.0)) * tile;
+  const double patched = p.rounds * tile * 1.08;
+  if (p.patches && patched >= plain) p.patches = false;
+  p.cost = p.patches ? patched : plain;
   return p;
 }
 
