@@ -1029,14 +1029,14 @@ static BigPlan big_plan(int M, int N, int K, int bn, bool patch_epi) {
   const char* no_patch = getenv("UCOD_GEMM_NO_PATCH");
   const bool off = no_patch && no_patch[0] != '0';
   const char* mr = getenv("UCOD_GEMM_PATCH_ROUNDS");
-  const int max_rounds = mr ? atoi(mr) : 2;
+  const int max_rounds = mr ? atoi(mr) : 4;             // beyond ~5 rounds the model below never prefers patches anyway
   const int n_cu = device_cus();
   BigPlan p;
   p.total = cdiv(M, 256) * cdiv(N, bn);
   p.rounds = p.total / n_cu;
   p.left = p.total - p.rounds * n_cu;
   p.ppt = 16 * (bn / 32);
-  // more rounds dilute the tail below what a patch costs every workgroup (QKV / fc1: 6 and 8 rounds of ~25 us tiles)
+  // (more rounds dilute the tail below what a patch costs every workgroup -- QKV / fc1 of ViT-B: 6 and 8 rounds -- the cost model decides)
   p.patches = patch_epi && !off && p.rounds >= 1 && p.rounds <= max_rounds && p.left > 0 && (long)p.left * p.ppt <= 2L * p.rounds * n_cu && (K & 31) == 0;
   // Makespan in tile units.  A last, partly filled round is cheaper than a full one (its tiles run on an otherwise idle chip: measured
   // 0.42 of a round at 1.6 % fill, fc2 2 rounds 183 us -> 2.016 rounds 221 us): 0.4 + 0.6 * fill.  A patch costs every workgroup ~8 % of
