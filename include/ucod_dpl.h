@@ -21,7 +21,7 @@
  *                              one or two whole rounds of CUs computes those tiles as 16x32 patches on the side, which sums K in a
  *                              different order: results stay deterministic but a row's low f32 bits then depend on where the row
  *                              sits in the batch.  Set this for bitwise batch-position independence (read at every call).
- *   UCOD_GEMM_PATCH_ROUNDS=n   largest number of whole rounds for which the patch mode is considered (default 4).
+ *   UCOD_GEMM_PATCH_ROUNDS=n   largest number of whole rounds for which the patch mode is considered (default 2).
  *   UCOD_RESIZE_ELEMENTWISE=1  ucod_bilinear_resize / _adjoint: the element-per-thread kernels also for >= 64 planes (the LDS-staged
  *                              kernels produce the same bits; this is for timing comparisons).
  */
