@@ -274,7 +274,7 @@ def main():
                                "frac": round(kernels["layernorm"]["gbs"] / HBM_PEAK_GBS, 4)}
 
     cpu = None
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:                  # rank 0 at N = 1 only (the contract); the N > 1 lines carry null
         cpu = cpu_baseline(a, D, heads, L, P)
 
     ips = world * B * a.steps / dt
