@@ -433,7 +433,7 @@ extern "C" int ucod_cod_metrics(const float* pred, const float* gt, int B, int H
   double* part = (double*)(ws + l.part);
   const int ch = chunks_for(n);
   hipLaunchKernelGGL(cod_minmax_kernel, dim3(B), dim3(1024), 0, s, pred, gt, n, mm);
-  if (hipMemsetAsync(hist, 0, (size_t)B * 512 * sizeof(unsigned), s) != hipSuccess) return UCOD_EINVAL;
+  if (const hipError_t e = hipMemsetAsync(hist, 0, (size_t)B * 512 * sizeof(unsigned), s); e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(cod_pass2_kernel, dim3(ch, B), dim3(1024), 0, s, pred, gt, H, W, mm, part, hist);
   hipLaunchKernelGGL(cod_combine_kernel, dim3(B), dim3(32), 0, s, part, ch, NS2, S2);
   hipLaunchKernelGGL(cod_pass3_kernel, dim3(ch, B), dim3(1024), 0, s, pred, gt, H, W, mm, S2, part);
