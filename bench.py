@@ -17,7 +17,11 @@ import os
 import sys
 import time
 
-import torch
+# HIP runtime knob, set before the runtime initialises: kernel arguments are written straight to device memory instead of being
+# fetched from host memory at dispatch.  The step is ~130 launches; measured +1.2 % (2890 -> 2925 images/s, same box, alternating runs).
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
