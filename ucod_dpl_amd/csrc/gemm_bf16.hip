@@ -138,8 +138,17 @@ template <int EPI>
 __device__ __forceinline__ void epilogue_store4(const GemmArgs& a, int m, int n, f32x4 v) {
   if (m >= a.M || n >= a.N) return;
   if constexpr (EPI == UCOD_EPI_KEY_NCHW_F32) {
+    // four consecutive tokens of one image, none of them CLS: one dword-aligned 16-byte store into [B, C, tok-1] (row starts are
+    // only 4-byte aligned there: tok-1 is odd); groups that touch a CLS token or straddle two images go token by token
+    const int b = n / a.tok, t = n - b * a.tok;
+    if (t >= 1 && t + 3 < a.tok && n + 3 < a.N) {
+      typedef f32x4 f32x4_u __attribute__((aligned(4)));
+      const float bm = a.bias[m];
+      *reinterpret_cast<f32x4_u*>(reinterpret_cast<float*>(a.out) + ((size_t)b * a.M + m) * (a.tok - 1) + (t - 1)) = v + (f32x4){bm, bm, bm, bm};
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) epilogue_store<EPI>(a, m, n + e, v[e]);
+      for (int e = 0; e < 4; ++e) epilogue_store<EPI>(a, m, n + e, v[e]);
+    }
   } else {
     const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
     if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) {
