@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Timings of the "next" rows of SURVEY.md 8f on one MI355X: N1 feature-cache pass, N2 device Look-Twice tail, N3 pseudo-label
+generator (N4's COD measures: tools/cod_bench.py).  Synthetic inputs of the real sizes; results are printed, not asserted."""
+import os, shutil, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from ucod_dpl_amd import native as N
+from ucod_dpl_amd.data.utils.feature_extractor import backbone
+from ucod_dpl_amd.data.datasets import MultiCacheManager, build_feature_cache
+from ucod_dpl_amd.generate_pseudo_label import PseudoLabelGenerator
+
+dev = "cuda"
+def sync_time(fn, n=5):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
+
+# ---- N1: the cache-building pass (base_dataset.py:124-145): backbone over images, items streamed to features_cache/.../data_i.pkl
+bb = backbone.random_init("dinov2_vitb14", seed=0, image_size=518, device=dev, attn_variant=2)
+imgs = [torch.randn(3, 518, 518) for _ in range(128)]
+x = torch.stack(imgs[:32]).to(dev)
+tb = sync_time(lambda: bb(x), 3)                                      # also the warm-up of the pass
+t0 = time.perf_counter(); k = bb(x)[1].to("cpu"); torch.cuda.synchronize(); td2h = time.perf_counter() - t0
+tmp = tempfile.mkdtemp(prefix="ucod_cache_")
+try:
+    mc = MultiCacheManager(tmp, "dinov2_vitb14", "train", "SYNTH")
+    t0 = time.perf_counter(); n = build_feature_cache(imgs, bb, mc.get_features_cache(), batch_size=32, device=dev); t1 = time.perf_counter() - t0
+    size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(tmp) for f in fs)
+    print(f"N1 feature cache: {n} images at 518x518 in {t1:.2f} s = {n / t1:.0f} img/s end to end, {size / 1e6:.0f} MB of per-item pickles written "
+          f"({size / 1e6 / t1:.0f} MB/s: host-side stacking, D2H and file I/O bound -- one 32-image batch: pass {tb * 1e3:.1f} ms, pass + copy of the "
+          f"134 MB key maps to the host {td2h * 1e3:.0f} ms); the batched backbone pass alone {32 / tb:.0f} img/s (the reference runs it one image per call)")
+finally:
+    shutil.rmtree(tmp, ignore_errors=True)
+
+# ---- N3: pseudo-label generator (generate_pseudo_label.py:30-94) at its 224x224 / 16x16 geometry
+bb224 = backbone.random_init("dinov2_vitb14", seed=0, image_size=224, device=dev, attn_variant=2)
+gen = PseudoLabelGenerator(bb224)
+x224 = torch.randn(32, 3, 224, 224, device=dev)
+tr = sync_time(lambda: gen.raw_masks(x224), 5)
+t0 = time.perf_counter(); masks = gen.generate_masks(x224); tg = time.perf_counter() - t0
+print(f"N3 pseudo labels: backbone + CLS attention row + seed similarity + threshold for 32 images at 224x224: {tr * 1e3:.2f} ms ({32 / tr:.0f} img/s) on the device; "
+      f"with the host small-component post-process {tg * 1e3:.1f} ms per batch")
+
+# ---- N2: device connected components + bounding boxes, and bicubic resize + paste
+lib = N.load()
+H = W = 518
+yy, xx = np.mgrid[0:H, 0:W]
+mask = np.zeros((H, W), np.uint8)
+rng = np.random.default_rng(0)
+for _ in range(6):
+    cy, cx, ry, rx = rng.uniform(0, H), rng.uniform(0, W), rng.uniform(10, 80), rng.uniform(10, 80)
+    mask[((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1] = 255
+md = torch.from_numpy(mask).to(dev)
+ws = torch.empty(lib.ucod_ccl8_workspace_bytes(H, W), dtype=torch.uint8, device=dev)
+table = torch.empty(4096, 6, dtype=torch.int32, device=dev); count = torch.zeros(1, dtype=torch.int32, device=dev)
+def ccl():
+    count.zero_()
+    N.check(lib.ucod_ccl8_components(N.ptr(md), H, W, N.ptr(table), 4096, N.ptr(count), N.ptr(ws), ws.numel(), N.stream()), "ccl")
+tc = sync_time(ccl, 20)
+print(f"N2 connected components + boxes of a 518x518 mask ({int(count.item())} components): {tc * 1e6:.0f} us on the device")
