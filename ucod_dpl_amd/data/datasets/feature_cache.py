@@ -15,6 +15,7 @@ pass (base_dataset.py:124-145) with the backbone fed ``batch_size`` images per l
 import json
 import os
 import pickle
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 import torch
@@ -65,7 +66,8 @@ class IndexedPickleDir:
         with open(self.dir / self.names[str(key)], "rb") as fh:
             return pickle.load(fh)
 
-    def store(self, key, obj, named=None):
+    def reserve(self, key, named=None):
+        """Enter ``key`` into the index (in call order) and return the file name its pickle will get."""
         if self.readable:
             raise AssertionError("Not working on write mode!")
         if named:                                                    # pickleio.py:126-128: <name>_<running count>.pkl
@@ -76,8 +78,15 @@ class IndexedPickleDir:
             fname = f"{self.stem}_{key}.pkl"
         self.names[key] = fname
         self.dir.mkdir(parents=True, exist_ok=True)
+        return fname
+
+    def write(self, fname, obj):
+        """The file half of ``store``: safe to run on a worker thread (one file per call, nothing shared)."""
         with open(self.dir / fname, "wb") as fh:
             pickle.dump(obj, fh)
+
+    def store(self, key, obj, named=None):
+        self.write(self.reserve(key, named), obj)
 
     def commit(self):
         """Write index.json (plain json.dump: integer keys become the strings the readers look up)."""
@@ -186,7 +195,7 @@ class MultiCacheManager:
 
 
 # ------------------------------------------------------------------------------------------- the cache-building pass
-def build_feature_cache(images, feature_extractor, features_cache, batch_size=32, device="cuda"):
+def build_feature_cache(images, feature_extractor, features_cache, batch_size=32, device="cuda", writers=8):
     """Run ``feature_extractor`` (``backbone``-like: ``(img) -> (outputs, key [B,C,h,w])``) over ``images`` -- an iterable of
     ``[3,H,W]`` f32 tensors, already transformed as base_dataset.py:133 does -- in batches, and write the features cache in
     the reference's format.  Items are streamed to disk as they are produced (the reference first collects the whole list
@@ -196,6 +205,11 @@ def build_feature_cache(images, feature_extractor, features_cache, batch_size=32
         raise RuntimeError(f"cache at {store.dir} already exists and is valid; remove it to rebuild")
     written = 0
     pending = []
+    # The format is one pickle per image (4.2 MB at ViT-B/14, 518x518): pickling and file writes, not the device, set the pace of this
+    # pass (3 k images/s of backbone against ~60 images/s of serial pickle.dump).  Index entries are made in order on this thread; the
+    # files themselves are written by a small pool while the next batch is on the device.
+    pool = ThreadPoolExecutor(max_workers=writers) if writers > 0 else None
+    jobs = []
 
     def flush():
         nonlocal written
@@ -204,17 +218,27 @@ def build_feature_cache(images, feature_extractor, features_cache, batch_size=32
         _, key = feature_extractor(torch.stack(pending).to(device))
         key = key.to("cpu")                                       # base_dataset.py:138: features.squeeze(0).to('cpu')
         for row in key:
-            store.store(written, row.clone())
+            fname = store.reserve(written)
+            if pool is None:
+                store.write(fname, row.clone())
+            else:
+                jobs.append(pool.submit(store.write, fname, row.clone()))
             written += 1
         pending.clear()
 
-    for img in images:
-        if pending and tuple(img.shape) != tuple(pending[0].shape):
-            flush()                                               # ragged sizes: one launch per shape
-        pending.append(img)
-        if len(pending) == batch_size:
-            flush()
-    flush()
+    try:
+        for img in images:
+            if pending and tuple(img.shape) != tuple(pending[0].shape):
+                flush()                                           # ragged sizes: one launch per shape
+            pending.append(img)
+            if len(pending) == batch_size:
+                flush()
+        flush()
+        for j in jobs:
+            j.result()                                            # surface a failed write before the index is committed
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
     store.commit()
     features_cache.io.reload_path()
     return written
