@@ -144,6 +144,22 @@ def test_gpu_ccl_equals_host_ccl_on_full_size_masks():
         assert got == ref
 
 
+@pytest.mark.parametrize("H,W", [(1, 1), (1, 70), (70, 1), (3, 64), (65, 129), (37, 200), (130, 63)])
+def test_gpu_ccl_run_logic_on_odd_sizes(H, W):
+    """The device labelling works on horizontal runs found 64 columns at a time: widths around the 64-column step, single rows and
+    columns, and noise at densities from isolated pixels to almost full, against the host labelling (cv2 order)."""
+    loop, _, _ = make_loop()
+    rng = np.random.default_rng(H * 1000 + W)
+    for density in (0.05, 0.3, 0.5, 0.7, 0.95):
+        m = ((rng.random((H, W)) < density) * 255).astype(np.uint8)
+        n, labels = LT.connected_components(m)
+        ref = []
+        for k in range(1, n):
+            ys, xs = np.nonzero(labels == k)
+            ref.append((len(ys), int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)))
+        assert loop.components_gpu(torch.from_numpy(m).cuda()) == ref, (H, W, density)
+
+
 def test_gpu_paste_is_bit_identical_to_the_pillow_path():
     loop, _, _ = make_loop()
     rng = np.random.default_rng(9)

@@ -38,32 +38,65 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
   }
 }
 
-__global__ __launch_bounds__(256) void ccl_init_kernel(const unsigned char* __restrict__ mask, int* __restrict__ parent, int n) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) parent[i] = mask[i] ? i : -1;
+// Run-based labelling.  A pixel-per-thread union-find (every foreground pixel unions with its four scanned neighbours, every pixel adds
+// itself to its component's statistics) costs 0.6 ms on a 518 x 518 blob mask: long find chains across solid regions and ~10^5 atomics
+// on one statistics row.  Horizontal runs remove both: a row scan points every foreground pixel at the first pixel of its run, only
+// run starts are ever union-find roots, one union is issued per pair of 8-adjacent runs, and one set of atomics per run.
+// (a) one wave per row, 64 columns per step: latest run start at or before x = running max of (start ? x : -1).
+__global__ __launch_bounds__(256) void ccl_runs_kernel(const unsigned char* __restrict__ mask, int* __restrict__ parent, int H, int W) {
+  const int lane = threadIdx.x & 63, y = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (y >= H) return;
+  const unsigned char* row = mask + (size_t)y * W;
+  int carry = -1;                                         // latest run start seen in earlier chunks of this row
+  bool prev_fg = false;                                   // column x0 - 1
+  for (int x0 = 0; x0 < W; x0 += 64) {
+    const int x = x0 + lane;
+    const bool fg = x < W && row[x] != 0;
+    const int left = __shfl_up((int)fg, 1, 64);
+    const bool before = lane == 0 ? prev_fg : (left != 0);
+    int v = (fg && !before) ? x : -1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(v, o, 64);
+      if (lane >= o) v = v > u ? v : u;
+    }
+    v = v > carry ? v : carry;
+    if (x < W) parent[(size_t)y * W + x] = fg ? y * W + v : -1;
+    carry = __shfl(v, 63, 64);
+    prev_fg = __shfl((int)fg, 63, 64) != 0;
+  }
 }
 
+// (b) one union per pair of 8-adjacent runs of rows y-1 and y: at the first column where they overlap (where either run starts), or
+//     through the diagonal when they only touch corner to corner
 __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned char* __restrict__ mask, int* __restrict__ parent, int H, int W) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= H * W || !mask[i]) return;
   const int y = i / W, x = i - y * W;
-  if (x > 0 && mask[i - 1]) uf_union(parent, i, i - 1);
-  if (y > 0) {
-    if (mask[i - W]) uf_union(parent, i, i - W);
-    if (x > 0 && mask[i - W - 1]) uf_union(parent, i, i - W - 1);
-    if (x + 1 < W && mask[i - W + 1]) uf_union(parent, i, i - W + 1);
+  if (y == 0) return;
+  const bool left = x > 0 && mask[i - 1], right = x + 1 < W && mask[i + 1];
+  const bool up = mask[i - W] != 0, upl = x > 0 && mask[i - W - 1], upr = x + 1 < W && mask[i - W + 1];
+  if (up) {
+    if (!left || !upl) uf_union(parent, i, i - W);
+  } else {
+    if (upl && !left) uf_union(parent, i, i - W - 1);
+    if (upr && !right) uf_union(parent, i, i - W + 1);
   }
 }
 
-// stats[root] = {area, xmin, xmax, ymin, ymax}; labels (optional) = root index or -1
-__global__ __launch_bounds__(256) void ccl_stats_kernel(int* __restrict__ parent, int* __restrict__ stats, int H, int W) {
+// stats[root] = {area, xmin, xmax, ymin, ymax}: the LAST pixel of every run adds the whole run
+__global__ __launch_bounds__(256) void ccl_stats_kernel(const unsigned char* __restrict__ mask, int* __restrict__ parent, int* __restrict__ stats, int H,
+                                                        int W) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= H * W || parent[i] < 0) return;
-  const int r = uf_find(parent, i);
+  if (i >= H * W || !mask[i]) return;
   const int y = i / W, x = i - y * W;
+  if (x + 1 < W && mask[i + 1]) return;                   // not the end of its run
+  const bool is_start = x == 0 || !mask[i - 1];
+  const int start = is_start ? i : parent[i];             // non-start pixels keep pointing at their run start for ever
+  const int r = uf_find(parent, start);
   int* s = stats + (size_t)r * 5;
-  atomicAdd(&s[0], 1);
-  atomicMin(&s[1], x);
+  atomicAdd(&s[0], i - start + 1);
+  atomicMin(&s[1], start - y * W);
   atomicMax(&s[2], x);
   atomicMin(&s[3], y);
   atomicMax(&s[4], y);
@@ -180,10 +213,10 @@ extern "C" int ucod_ccl8_components(const uint8_t* mask, int H, int W, int32_t* 
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(cdiv(n, 256)), block(256);
   { const hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s); if (e != hipSuccess) return (int)e; }
-  hipLaunchKernelGGL(ccl_init_kernel, grid, block, 0, s, mask, parent, n);
+  hipLaunchKernelGGL(ccl_runs_kernel, dim3(cdiv(H, 4)), block, 0, s, mask, parent, H, W);
   hipLaunchKernelGGL(ccl_merge_kernel, grid, block, 0, s, mask, parent, H, W);
   hipLaunchKernelGGL(ccl_stats_init_kernel, grid, block, 0, s, parent, stats, n, W, H);
-  hipLaunchKernelGGL(ccl_stats_kernel, grid, block, 0, s, parent, stats, H, W);
+  hipLaunchKernelGGL(ccl_stats_kernel, grid, block, 0, s, mask, parent, stats, H, W);
   hipLaunchKernelGGL(ccl_compact_kernel, grid, block, 0, s, parent, stats, n, count, table, capacity);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
