@@ -59,3 +59,29 @@ def ccl():
     N.check(lib.ucod_ccl8_components(N.ptr(md), H, W, N.ptr(table), 4096, N.ptr(count), N.ptr(ws), ws.numel(), N.stream()), "ccl")
 tc = sync_time(ccl, 20)
 print(f"N2 connected components + boxes of a 518x518 mask ({int(count.item())} components): {tc * 1e6:.0f} us on the device")
+
+# ---- R1-R4 / N4: one CORAL validation step (features -> first-stage logits -> SparseRefiner -> thresholded full-size mask -> nine COD measures)
+import types
+from ucod_dpl_amd.engine.config import CfgNode
+from ucod_dpl_amd.engine.runner import LocalRefineValidationLoop
+from ucod_dpl_amd.models.uscod import baseline
+from ucod_dpl_amd.models.UDLR import SparseRefiner
+from ucod_dpl_amd.engine.utils.metrics import statistics
+torch.manual_seed(0)
+model = baseline(CfgNode(dict(dim=768, feature_size=68, ema_weight=0.99, dis_use_features=False))).to(dev).eval()
+refiner = SparseRefiner.from_config(CfgNode(dict(window_size=3, threshold=0.0015))).eval().to(dev)
+runner = types.SimpleNamespace(device=torch.device(dev, 0), model=model, refiner=refiner, world_size=1, rank=0, val_dataloader=[],
+                               logger=types.SimpleNamespace(log_table=lambda *a: None, log=lambda *a: None))
+for req_m in (False, True):
+    cfg = CfgNode(dict(train_cfg=dict(dist_train=False), model_cfg=dict(window_length=6), dataset_cfg=dict(valset_cfg=dict(require_m_patches=req_m, DATASET="X"))))
+    loop = LocalRefineValidationLoop(cfg, runner)
+    g = torch.Generator().manual_seed(150)
+    l = torch.randn(1, 768, 37, 37, generator=g).to(dev)
+    full = torch.randn(1, 768, 54, 54, generator=g) * 0.7
+    m = torch.stack([full[:, :, i * 18:i * 18 + 36, j * 18:j * 18 + 36] for i in range(2) for j in range(2)], dim=1).to(dev)
+    h = torch.randn(1, 9, 768, 37, 37, generator=g).to(dev)
+    label = (torch.rand(1, 1, 480, 640, generator=g) > 0.5).float().to(dev)
+    batch = dict(pseudo_label=None, label_tensor=label, features=l, img_path=["x"], m_inputs=m, h_inputs=h, index=[0])
+    st = statistics()
+    t = sync_time(lambda: loop._process_validation_batch(batch, st), 10)
+    print(f"N4 one CORAL validation step (require_m_patches={req_m}): first-stage decoder + SparseRefiner + 480x640 mask + nine COD measures: {t * 1e3:.2f} ms per image")
