@@ -85,3 +85,22 @@ for req_m in (False, True):
     st = statistics()
     t = sync_time(lambda: loop._process_validation_batch(batch, st), 10)
     print(f"N4 one CORAL validation step (require_m_patches={req_m}): first-stage decoder + SparseRefiner + 480x640 mask + nine COD measures: {t * 1e3:.2f} ms per image")
+
+# ---- L1-L3 (BASELINE C4's validation side): Look-Twice on one image with the fallback centre box, real backbones
+from ucod_dpl_amd.engine.runner import loop_look_twice as LT
+rng = np.random.default_rng(0)
+img_u8 = rng.integers(0, 256, (427, 640, 3), dtype=np.uint8)
+for arch in ("dinov2_vitb14", "dinov2_vitl14"):
+    bbx = backbone.random_init(arch, seed=0, image_size=518, device=dev, attn_variant=2)
+    Dx = bbx.engine.D if hasattr(bbx.engine, "D") else (768 if arch.endswith("b14") else 1024)
+    torch.manual_seed(5)
+    mdl = baseline(CfgNode(dict(dim=Dx, feature_size=68, ema_weight=0.99, dis_use_features=False))).to(dev).eval()
+    rn = types.SimpleNamespace(device=torch.device(dev, 0), model=mdl, world_size=1, rank=0, val_dataloader=[], logger=None)
+    cfg = CfgNode(dict(train_cfg=dict(dist_train=False), model_cfg=dict(feature_size=68), val_cfg=dict(look_twice=True, look_twice_th=0.15, expand_type="dynamic"),
+                       dataset_cfg=dict(valset_cfg=dict(image_size=(518, 518)))))
+    lt = LT.ValLoop_Look_Twice(cfg, rn, feature_extractor=bbx)
+    old = torch.zeros(1, 518, 518)
+    for nbox in (1, 4):
+        boxes = [list(LT.DEFAULT_BOX)] * nbox
+        t = sync_time(lambda: lt.look_twice(img_u8, boxes, old), 10)
+        print(f"L3 look_twice, {arch}, {nbox} box(es) of a 427x640 image (crop + Pillow-exact resize + backbone + decoder at 37x37 + bicubic paste): {t * 1e3:.2f} ms")
