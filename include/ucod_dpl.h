@@ -65,7 +65,8 @@ enum {
 };
 /* variant: 0 = auto, 1 = 128x128 register staging, 2 = 128x128 LDS-DMA, 3/4 = 256x256 / 256x192 large tile,
  * 5/6 = 3/4 with staggered wave groups, 7/8 = persistent forms of 5/6, 9/10 = 5/6 with two (instead of four) barrier
- * phases per K-tile (what auto picks for large shapes).  Large-tile variants need N % 4 == 0 (N % 8 == 0 for bf16 output).
+ * phases per K-tile (what auto picks for large shapes), 12 = 64x64 tile with LDS-DMA (what auto picks when there are fewer
+ * 128x128 tiles than CUs: batch-1 passes).  Large-tile variants need N % 4 == 0 (N % 8 == 0 for bf16 output).
  * K % 64 == 0.  For UCOD_EPI_BIAS_BF16 a non-NULL `scale` [N] multiplies
  * (C + bias) per column before the bf16 rounding (used to fold the softmax scale into Q). */
 int ucod_gemm_bf16(int epilogue, const void* A_bf16, const void* B_bf16, void* out, int M, int N, int K,

@@ -39,7 +39,7 @@ def test_library_is_native_and_device_is_gfx950():
 
 
 # ----------------------------------------------------------------------------------------- bf16 GEMM
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12])
 @pytest.mark.parametrize("M,Nn,K", [(128, 128, 64), (200, 256, 128), (1370 * 2, 384, 768), (333, 128, 3072), (2500, 768, 128), (4111, 2304, 768)])
 def test_gemm_bf16_bias(variant, M, Nn, K):
     g = torch.Generator().manual_seed(M + Nn + K)
@@ -52,7 +52,7 @@ def test_gemm_bf16_bias(variant, M, Nn, K):
     assert maxdiff(out, ref) < 2e-2 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12])
 def test_gemm_bf16_asymmetric_identity(variant):
     """A = I with an asymmetric B catches a transposed C write (guide: always A=I-check with asymmetric B)."""
     M = Nn = K = 128
@@ -127,7 +127,7 @@ def test_gemm_bf16_leftover_tiles_as_patches(variant, M, Nn, K):
     assert torch.all(buf[M:] == -5.0)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12])
 def test_gemm_bf16_epilogues(variant):
     g = torch.Generator().manual_seed(5)
     M, Nn, K = 300, 256, 192

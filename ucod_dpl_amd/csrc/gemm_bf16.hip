@@ -22,7 +22,7 @@
 namespace ucod {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+
 
 struct GemmArgs {
   unsigned long long* stamps;   // diagnostic builds only (UCOD_GEMM_STAMPS): per-workgroup segment cycle sums, never read by kernels
@@ -46,12 +46,12 @@ struct GemmArgs {
 // 16x16x32 fragment pattern (rows l&15, chunk l>>4) under the 64-bank / 16-lane-group rule.
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-template <bool GLDS>
+template <bool GLDS, int NI = 4>
 __device__ __forceinline__ void stage_tile(const bf16_raw* __restrict__ G, int rows_total, int row0, int K, int k0,
-                                           char* lds_tile, int wave, int lane, u32x4 (&regs)[4]) {
-  // 128 rows x 8 chunks; wave-instruction i covers rows (i*4+wave)*8 .. +7, lane -> (row l>>3, phys chunk l&7)
+                                           char* lds_tile, int wave, int lane, u32x4 (&regs)[NI]) {
+  // 32*NI rows x 8 chunks; wave-instruction i covers rows (i*4+wave)*8 .. +7, lane -> (row l>>3, phys chunk l&7)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int r = (i * 4 + wave) * 8 + (lane >> 3);
     const int c = swz(r, lane & 7);
     int gr = row0 + r;
@@ -67,9 +67,10 @@ __device__ __forceinline__ void stage_tile(const bf16_raw* __restrict__ G, int r
   }
 }
 
-__device__ __forceinline__ void write_tile(char* lds_tile, int wave, int lane, const u32x4 (&regs)[4]) {
+template <int NI = 4>
+__device__ __forceinline__ void write_tile(char* lds_tile, int wave, int lane, const u32x4 (&regs)[NI]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NI; ++i) {
     *reinterpret_cast<u32x4*>(lds_tile + (i * 4 + wave) * 1024 + lane * 16) = regs[i];
   }
 }
@@ -236,9 +237,12 @@ __device__ __forceinline__ void drain_rows(const GemmArgs& a, const char* wbase,
   }
 }
 
-template <int EPI, bool GLDS>
+// T = 128: the 128 x 128 tile (each wave 64 x 64).  T = 64: a 64 x 64 tile (each wave 32 x 32) for launches whose 128-tiles would
+// leave most CUs idle -- a batch-1 backbone pass (Look-Twice, validation) has 66 tiles of proj / fc2 on 256 CUs.
+template <int EPI, bool GLDS, int T = 128>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [stage][A|B]
+  constexpr int TB = T * BK * 2, NI = T / 32, FI = T / 32;            // bytes per operand per stage; DMA instructions per wave; 16-row fragments per wave
+  __shared__ __attribute__((aligned(16))) char smem[4 * TB];          // [stage][A|B]; reused as the epilogue staging (4 waves x (T/2)^2 f32 = 4 * TB / 4 bytes... <= 4 * TB)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -249,55 +253,55 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
   const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
   const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
   const int tm = wg / a.tiles_n, tn = wg - tm * a.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * T, n0 = tn * T;
 
-  f32x4 acc[4][4];
+  f32x4 acc[FI][FI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nt = a.K / BK;
-  u32x4 ra[4], rb[4];
-  stage_tile<GLDS>(a.A, a.M, m0, a.K, 0, smem, wave, lane, ra);
-  stage_tile<GLDS>(a.B, a.N, n0, a.K, 0, smem + TILE_BYTES, wave, lane, rb);
+  u32x4 ra[NI], rb[NI];
+  stage_tile<GLDS, NI>(a.A, a.M, m0, a.K, 0, smem, wave, lane, ra);
+  stage_tile<GLDS, NI>(a.B, a.N, n0, a.K, 0, smem + TB, wave, lane, rb);
   if constexpr (!GLDS) {
-    write_tile(smem, wave, lane, ra);
-    write_tile(smem + TILE_BYTES, wave, lane, rb);
+    write_tile<NI>(smem, wave, lane, ra);
+    write_tile<NI>(smem + TB, wave, lane, rb);
   }
 
   for (int t = 0; t < nt; ++t) {
     __syncthreads();  // tile t visible (the fence drains the LDS-DMA); everyone is done with the other stage
-    char* curA = smem + (t & 1) * 2 * TILE_BYTES;
-    char* curB = curA + TILE_BYTES;
-    char* nxtA = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+    char* curA = smem + (t & 1) * 2 * TB;
+    char* curB = curA + TB;
+    char* nxtA = smem + ((t + 1) & 1) * 2 * TB;
     const bool more = (t + 1 < nt);
     if (more) {
-      stage_tile<GLDS>(a.A, a.M, m0, a.K, (t + 1) * BK, nxtA, wave, lane, ra);
-      stage_tile<GLDS>(a.B, a.N, n0, a.K, (t + 1) * BK, nxtA + TILE_BYTES, wave, lane, rb);
+      stage_tile<GLDS, NI>(a.A, a.M, m0, a.K, (t + 1) * BK, nxtA, wave, lane, ra);
+      stage_tile<GLDS, NI>(a.B, a.N, n0, a.K, (t + 1) * BK, nxtA + TB, wave, lane, rb);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[4], fb[4];
+      bf16x8 fa[FI], fb[FI];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = wr * 64 + i * 16 + (lane & 15);
+      for (int i = 0; i < FI; ++i) {
+        const int r = wr * (T / 2) + i * 16 + (lane & 15);
         fa[i] = *reinterpret_cast<const bf16x8*>(curA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = wc * 64 + j * 16 + (lane & 15);
+      for (int j = 0; j < FI; ++j) {
+        const int r = wc * (T / 2) + j * 16 + (lane & 15);
         fb[j] = *reinterpret_cast<const bf16x8*>(curB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     if constexpr (!GLDS) {
       if (more) {
-        write_tile(nxtA, wave, lane, ra);
-        write_tile(nxtA + TILE_BYTES, wave, lane, rb);
+        write_tile<NI>(nxtA, wave, lane, ra);
+        write_tile<NI>(nxtA + TB, wave, lane, rb);
       }
     }
   }
@@ -305,24 +309,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
   // C/D map of v_mfma_f32_16x16x32: col = lane&15, row = (lane>>4)*4 + reg.  Drain through LDS (see drain_rows).
   __syncthreads();
   if ((a.N & 3) == 0) {
-    char* wbase = smem + wave * (64 * 64 * 4);
+    constexpr int WT = T / 2;                                      // the wave's square sub-tile
+    char* wbase = smem + wave * (WT * WT * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < FI; ++j)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
-          *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * 256 + (j * 16 + (lane & 15)) * 4) = acc[i][j][rg];
+          *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * (WT * 4) + (j * 16 + (lane & 15)) * 4) = acc[i][j][rg];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    drain_rows<EPI, 64, 64>(a, wbase, m0 + wr * 64, n0 + wc * 64, lane);
+    drain_rows<EPI, WT, WT>(a, wbase, m0 + wr * WT, n0 + wc * WT, lane);
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < FI; ++j)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
-          epilogue_store<EPI>(a, m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + rg, n0 + wc * 64 + j * 16 + (lane & 15), acc[i][j][rg]);
+          epilogue_store<EPI>(a, m0 + wr * (T / 2) + i * 16 + (lane >> 4) * 4 + rg, n0 + wc * (T / 2) + j * 16 + (lane & 15), acc[i][j][rg]);
   }
 }
 
@@ -1064,6 +1069,7 @@ template <int EPI>
 static int launch(GemmArgs a, int variant, hipStream_t s) {
   constexpr bool kTrainEpi = (EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
   constexpr bool kPatchEpi = !kTrainEpi;
+  const bool auto_small = variant == 0;                       // only `auto` may pick the 64 x 64 tile by itself
   if (variant == 0) {
     variant = 2;
     // large tiles when either dimension is long enough to fill the chip with 256-row tiles (the key hook has M = channels = 768
@@ -1113,11 +1119,21 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
       }
     }
   } else {
-    dim3 grid(a.tiles_m * a.tiles_n), block(256);
-    if (variant == 1)
-      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, false>), grid, block, 0, s, a);
-    else
-      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, true>), grid, block, 0, s, a);
+    // 128 x 128 tiles (two workgroups per CU), or 64 x 64 when there are fewer 128-tiles than CUs: a batch-1 backbone pass has 66 tiles of
+    // proj / fc2 (29 -> 19 us per launch with the small tile; 264 tiles of fc1 are already better off with 128 x 128).  Variant 12 forces
+    // the small tile, 1 / 2 the large one.
+    const int t128 = a.tiles_m * a.tiles_n;
+    const bool small = variant == 12 || (variant == 2 && auto_small && t128 < device_cus());
+    dim3 block(256);
+    if (small) {
+      a.tiles_m = cdiv(a.M, 64);
+      a.tiles_n = cdiv(a.N, 64);
+      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, true, 64>), dim3(a.tiles_m * a.tiles_n), block, 0, s, a);
+    } else if (variant == 1) {
+      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, false>), dim3(t128), block, 0, s, a);
+    } else {
+      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, true>), dim3(t128), block, 0, s, a);
+    }
   }
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
