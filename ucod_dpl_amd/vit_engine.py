@@ -258,7 +258,8 @@ class ViTLoRAEngine(ViTEngine):
     encoder layer, as models/modules/full_model.py:47-72 configures it (r=2, lora_alpha=4, bias='none', target
     query/key/value; lora_A kaiming_uniform(a=sqrt 5), lora_B zeros).  ``forward_train`` saves activations,
     ``backward`` turns the cotangent of the key map into LoRA gradients -- both entirely in the HIP library
-    (``ucod_vit_forward_train`` / ``ucod_vit_backward``).  LoRA dropout (0.05 in the reference config) is not applied.
+    (``ucod_vit_forward_train`` / ``ucod_vit_backward``).  LoRA dropout (``lora_dropout``, 0.05 in the reference config) is a counter-based
+    hash mask on the LoRA branch's input in ``train()`` mode and off in ``eval()`` (include/ucod_dpl.h: ucod_lora_dropout).
 
     Parameters live in ONE flat f32 arena ``self.lora`` [L, 6*r*D] (layer-major: A_q | B_q | A_k | B_k | A_v | B_v), gradients
     in ``self.lora_grad`` with the same layout -- ready for a single flat all-reduce and the fused AdamW kernel."""
