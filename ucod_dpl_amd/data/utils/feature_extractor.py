@@ -86,7 +86,10 @@ class backbone(nn.Module):
                 raise ValueError(f"Unsupported model type: {config.type}")
             state_dict, hf_cfg = _read_checkpoint(config.backbone_weights)
             heads = heads or hf_cfg.get("num_attention_heads") or ARCHS[HUB_TO_ARCH[config.backbone]][1]
-            eps = eps or hf_cfg.get("layer_norm_eps", 1e-6)
+            if eps is None:
+                # transformers' defaults when config.json omits the key: ViTConfig (the DINOv1 checkpoints) 1e-12, Dinov2Config 1e-6
+                is_v2 = hf_cfg.get("model_type", "dinov2" if "dinov2" in config.type or "dinov2" in str(config.backbone) else "vit") == "dinov2"
+                eps = hf_cfg.get("layer_norm_eps", 1e-6 if is_v2 else 1e-12)
         if heads is None:
             raise ValueError("heads is required with an explicit state_dict")
         self.engine = ViTEngine(state_dict, heads=heads, eps=eps or 1e-6, device=device, **engine_kw)

@@ -216,17 +216,20 @@ class TrainLoop(BaseLoop):
         if native_grid:                                       # pull the gradient back through the resize (its transpose)
             gd = ops.bilinear_resize_adjoint(gd.view(B, 128, fs, fs), fh, fw).view(B, 128, fh * fw)
         ops.dba_wgrad(gd, features, gW=g_W)
-        parallel.allreduce_prescaled_(A.g)                    # RCCL: one flat 128C+386-float buffer, pre-scaled by 1/world
+        # RCCL: one flat 128C+386-float buffer, pre-scaled by 1/world, issued asynchronously on the process group's stream; the
+        # loss scalars below are assembled meanwhile and the optimiser launch is the first consumer.
+        reduced = parallel.allreduce_prescaled_async(A.g)
+        loss = losses[0] + losses[1] + extra[0]
+        if not self.finetune:
+            loss = loss - losses[2]
 
         # AdamW + StepLR + EMA (:178-181,186-191)
         alpha = min(1 - 1 / (self.global_step + 1), self.ema_alpha)
+        reduced.wait()
         r.optimizer.step(ema=A.ema, alpha=alpha)
         r.lr_scheduler.step()
         self.global_step += 1
 
-        loss = losses[0] + losses[1] + extra[0]
-        if not self.finetune:
-            loss = loss - losses[2]
         self.last = dict(loss=loss, dis_loss=losses[2], extra=extra[0], w=w, merged=merged, fg=fg, bg=bg, teacher=teacher, p_s=p_s, p_p=p_p)
         if self.log_scalars:
             r.logger.log("train/dis_loss:{:.4f}".format(losses[2].item()))
@@ -279,6 +282,9 @@ class TrainLoop(BaseLoop):
                                          lr if lr is not None else r.optimizer.param_groups[0]["initial_lr"])
         self.lora_lr_scheduler = StepLR(self.lora_optimizer, self.cfg.train_cfg.step_lr_size, self.cfg.train_cfg.step_lr_gamma)
         parallel.broadcast_state([engine.lora, self.lora_engine_ema.lora])
+        if parallel.world_size() > 1:                         # ranks above 0 just received rank 0's matrices: rebuild the packed columns
+            engine.repack()
+            self.lora_engine_ema.repack()
 
     def _process_batch_full(self, images, pseudo_labels):
         """One optimiser step from IMAGES: LoRA backbone forward (student, saved activations) + EMA backbone forward (teacher)
@@ -339,12 +345,16 @@ class TrainLoop(BaseLoop):
         if getattr(self, "_zero_c", None) is None or self._zero_c.numel() != A.C:
             self._zero_c = torch.zeros(A.C, device=dev)
         dfeat = ops.dba_project(gd.view(B, 128, fh, fw), W_s.t().contiguous(), self._zero_c).view(B, A.C, fh, fw)
+        # The decoder's gradient arena is final here: its all-reduce (128C+386 floats) goes out on the RCCL stream now and
+        # travels over xGMI UNDER the backbone backward; the LoRA arena (6*r*D*L floats) exists only after that backward.
+        reduced_dec = parallel.allreduce_prescaled_async(A.g)
         eng.backward(dfeat)
-        parallel.allreduce_prescaled_(A.g)                    # decoder: 128C+386 floats; LoRA: 6*r*D*L floats -- two flat buffers
-        parallel.allreduce_prescaled_(eng.lora_grad.view(-1))
+        reduced_lora = parallel.allreduce_prescaled_async(eng.lora_grad.view(-1))
         alpha = min(1 - 1 / (self.global_step + 1), self.ema_alpha)
+        reduced_dec.wait()
         r.optimizer.step(ema=A.ema, alpha=alpha)
         r.lr_scheduler.step()
+        reduced_lora.wait()
         self.lora_optimizer.step(ema=eng_t.lora.view(-1), alpha=alpha)
         self.lora_lr_scheduler.step()
         eng.repack()
@@ -419,10 +429,11 @@ class TrainLoop(BaseLoop):
         r.discriminator._bump_num_batches()
         probs_student, saved_s = ops.disc_fwd(preds, t, update_running=True)                                          # :245
         r.discriminator._bump_num_batches()
-        # BCELoss(cat(student, pseudo), [0..0, 1..1]) mean over 2B (:246-247); torch clamps log at -100
-        eps_guard = 1e-43
-        g_student = (1.0 / (2 * B * world)) / (1.0 - probs_student).clamp_min(eps_guard)
-        g_pseudo = (-1.0 / (2 * B * world)) / probs_pseudo.clamp_min(eps_guard)
+        # BCELoss(cat(student, pseudo), [0..0, 1..1]) mean over 2B (:246-247); torch clamps log at -100 and its backward is
+        # (p - t) / max(p (1 - p), 1e-12): finite (about 1e12) when the sigmoid saturates to exactly 0 or 1 in f32
+        inv = 1.0 / (2 * B * world)
+        g_student = probs_student / (probs_student * (1.0 - probs_student)).clamp_min(1e-12) * inv
+        g_pseudo = (probs_pseudo - 1.0) / (probs_pseudo * (1.0 - probs_pseudo)).clamp_min(1e-12) * inv
         loss = (-(torch.log(1 - probs_student).clamp_min(-100.0).sum() + torch.log(probs_pseudo).clamp_min(-100.0).sum())) / (2 * B)
         ops.disc_bwd(pl, t, saved_p, g_pseudo, grads=DA.grad_views, accumulate=False)
         ops.disc_bwd(preds, t, saved_s, g_student, grads=DA.grad_views, accumulate=True)

@@ -113,8 +113,102 @@ class StandardRunner:
         return ValLoop_Look_Twice(self.config, self).run()
 
 
-def create_runner(config, **kw):
-    """engine/runner/runner.py:688-699 surface; only the first-stage (UCOD-DPL) runner is on the hot path."""
-    if config.model_cfg.get("window_size", None) is not None or config.train_cfg.get("refiner_path", None):
-        raise NotImplementedError("CORAL second stage (LocalRefineRunner) is a 'next' row of SURVEY.md 8(f)")
-    return StandardRunner(config, **kw)
+class LocalRefineRunner(StandardRunner):
+    """CORAL second stage -- host-side mirror of engine/runner/runner.py::LocalRefineRunner (:400-590): the frozen first-stage
+    ``baseline`` (checkpoint from ``train_cfg.checkpoint``), the ``SparseRefiner`` built by ``SparseRefiner.from_config(model_cfg)``
+    (weights from ``train_cfg.refiner_path``), ``launch_val`` -> ``LocalRefineValidationLoop`` on the HIP decoder / refiner.
+    The reference's second-stage TRAINING loop is empty (``LocalRefineTrainLoop: pass``, loop_CORAL.py:38-39) and so is this one:
+    the AdamW/StepLR pair over the refiner's parameters is built with the reference's hyper-parameters for parity of the object,
+    ``launch_train`` raises.  No first-stage discriminator, arena or dataloader factory is needed here."""
+
+    def __init__(self, config, train_dataloader=None, val_dataloader=None, device=None, window_features=None):
+        self.refiner = None
+        self.window_features = window_features
+        super().__init__(config, train_dataloader, val_dataloader, device)
+
+    def _build_model(self):
+        from ...models.UDLR import SparseRefiner
+        self.model = baseline(self.config.model_cfg)
+        self.refiner = SparseRefiner.from_config(self.config.model_cfg)
+        ckpt = self.config.train_cfg.get("checkpoint", None)
+        if ckpt:
+            self.load_checkpoint(ckpt)
+        self._freeze_model(self.model)
+        self.model.to(self.device)
+        self.refiner.to(self.device)
+        self.load_refiner_checkpoint()
+        parallel.broadcast_state([p.data for p in self.model.parameters()] + [p.data for p in self.refiner.parameters()])
+
+    def _freeze_model(self, model):                            # :439-444
+        model.eval()
+        for p in model.parameters():
+            p.requires_grad_(False)
+
+    def _build_optimizer(self):                                # :446-468 (refiner parameters only)
+        tc = self.config.train_cfg
+        self.optimizer = torch.optim.AdamW(self.refiner.parameters(), lr=tc.lr0)
+        self.lr_scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=tc.step_lr_size, gamma=tc.step_lr_gamma)
+
+    def save_checkpoint(self, epoch, save_mode="model"):       # :532-551: <log_path>/refiner_ckp/epochN.pth/model.safetensors
+        from safetensors.torch import save_file
+        parallel.barrier()
+        if self.rank == 0:
+            path = os.path.join(self.config.log_cfg.log_path, "refiner_ckp", f"epoch{epoch}.pth")
+            os.makedirs(path, exist_ok=True)
+            save_file({k: v.detach().cpu().contiguous() for k, v in self.refiner.state_dict().items()}, os.path.join(path, "model.safetensors"))
+
+    def load_refiner_checkpoint(self, refiner_path=None):      # :553-573; raises instead of logging the failure (documented deviation)
+        from safetensors.torch import load_file
+        if refiner_path is None:
+            refiner_path = self.config.train_cfg.get("refiner_path", None)
+        if refiner_path is None:
+            return
+        if os.path.isdir(refiner_path):
+            refiner_path = os.path.join(refiner_path, "model.safetensors")
+        self.refiner.load_state_dict(load_file(refiner_path), strict=True)
+        self.refiner._prepared = None
+        self.logger.info("Successfully loaded refiner weights")
+
+    def launch_train(self):
+        raise NotImplementedError("the reference ships no second-stage training loop (LocalRefineTrainLoop: pass, loop_CORAL.py:38-39)")
+
+    def launch_val(self):                                      # :584-590
+        from .loop_CORAL import LocalRefineValidationLoop
+        return LocalRefineValidationLoop(self.config, self, window_features=self.window_features).run()
+
+
+Runner_local_refine = LocalRefineRunner                       # legacy alias (runner.py:681)
+
+
+class RunnerFactory:
+    """engine/runner/runner.py:597-655: runner type by name, or detected from the configuration."""
+    _RUNNER_TYPES = {"standard": StandardRunner, "local_refine": LocalRefineRunner, "lr": LocalRefineRunner}
+
+    @classmethod
+    def create_runner(cls, config, runner_type=None, **kw):
+        if runner_type is None:
+            runner_type = cls._detect_runner_type(config)
+        if runner_type not in cls._RUNNER_TYPES:
+            raise ValueError(f"Unknown runner type '{runner_type}'. Available: {list(cls._RUNNER_TYPES.keys())}")
+        return cls._RUNNER_TYPES[runner_type](config, **kw)
+
+    @classmethod
+    def _detect_runner_type(cls, config):
+        if hasattr(config, "model_cfg") and hasattr(config.model_cfg, "window_size"):
+            return "local_refine"
+        if hasattr(config, "train_cfg") and config.train_cfg.get("refiner_path"):
+            return "local_refine"
+        return "standard"
+
+    @classmethod
+    def get_available_runners(cls):
+        return list(cls._RUNNER_TYPES.keys())
+
+
+def create_runner(config, runner_type=None, **kw):
+    """engine/runner/runner.py:688-699."""
+    return RunnerFactory.create_runner(config, runner_type, **kw)
+
+
+def get_available_runner_types():
+    return RunnerFactory.get_available_runners()

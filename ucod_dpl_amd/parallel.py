@@ -6,6 +6,11 @@ xGMI on ROCm; ``gloo`` in the CPU tests).  The path is pure data parallel over i
 * ``allreduce_prescaled_``: ONE all-reduce(SUM) of the flat gradient arena per step.  The gradient kernels already scale
   by 1/world (the ``gscale`` / ``gextra`` arguments of ``ucod_apm_bce`` / ``ucod_dba_bwd``), so the sum IS the mean over
   the global batch and no extra pass touches the buffer.  395 KB at C=768: latency-bound, not link-bound;
+* ``allreduce_prescaled_async``: the same collective issued asynchronously.  With ``nccl`` the collective runs on the
+  process group's own RCCL stream behind an event recorded on the launch stream (so it starts when the kernels that
+  produced the buffer have finished) and ``handle.wait()`` makes the CURRENT stream wait for it without blocking the
+  host: everything enqueued on the launch stream between issue and wait (the backbone backward in LoRA mode) overlaps
+  the xGMI transfer.  With ``gloo`` (CPU tests) ``wait()`` blocks the host; same call sequence, same result;
 * ``max_over_ranks``: timing reduction used by bench.py.
 """
 import os
@@ -41,6 +46,21 @@ def allreduce_prescaled_(flat):
     if world_size() > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
+
+
+class _Done:
+    """Handle of a collective that did not have to run (world_size 1)."""
+
+    def wait(self):
+        return True
+
+
+def allreduce_prescaled_async(flat):
+    """Issue the SUM all-reduce of a pre-scaled flat buffer and return a handle; ``handle.wait()`` before the first consumer
+    (the optimiser launch).  The buffer must not be written between issue and wait."""
+    if world_size() > 1:
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    return _Done()
 
 
 def grad_prescale():

@@ -454,6 +454,10 @@ class ViTLoRAEngine(ViTEngine):
         other.train_layers = [[tl[0].clone(), tl[1].clone()] + tl[2:] for tl in self.train_layers]
         other._tside, other._saved_for = None, None
         other._pos_cache = dict(self._pos_cache)
+        # The reference's teacher is a deepcopy that stays in train mode (full_model.py:84; nobody calls eval() on it), so its LoRA
+        # dropout is active too, with masks drawn independently of the student's: own seed stream, own step counter.
+        other._seed = (self._seed * 0x2545F4914F6CDD1D + 0x5DEECE66D) & 0xFFFFFFFFFFFFFFFF
+        other._step, other._step_seed = 0, 0
         other.repack()
         return other
 
