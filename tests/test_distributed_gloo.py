@@ -66,7 +66,8 @@ def _worker(rank, world, port, out):
     feats, pl = g["features0"], g["pl0"]
     lo, hi = rank * 2, rank * 2 + 2                     # images [r*B, (r+1)*B)
     grads = _rank_grads(dec, ema, {k: v.clone() for k, v in disc.items()}, feats[lo:hi], pl[lo:hi], parallel.grad_prescale())
-    parallel.allreduce_prescaled_(grads)
+    handle = parallel.allreduce_prescaled_async(grads)      # the call sequence of TrainLoop._process_batch: issue, (other work), wait
+    assert handle.wait() in (True, None)
     t = parallel.max_over_ranks(float(rank), "cpu")
     assert t == world - 1
     parallel.barrier()
@@ -86,3 +87,41 @@ def test_two_rank_gradient_allreduce_equals_global_batch_with_per_rank_bn(tmp_pa
               for r in range(2))
     assert torch.allclose(got, ref, rtol=0, atol=1e-9)
     assert got.abs().max() > 1e-4
+
+
+def _val_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, ROOT)
+    from ucod_dpl_amd import parallel
+    from ucod_dpl_amd.engine.utils.metrics import statistics
+    parallel.init_from_env("gloo")
+    g = torch.Generator().manual_seed(5)
+    rec = torch.rand(7, 1032, generator=g, dtype=torch.float64)
+    st = statistics()
+    shard = rec[:5] if rank == 0 else rec[5:]               # ragged shards: 5 images on rank 0, 2 on rank 1
+    st._records = [shard[i:i + 1] for i in range(shard.shape[0])]
+    st.gather_records()
+    res = st.get_result()
+    empty = statistics()                                     # a rank with no image at all must not hang or crash
+    if rank == 0:
+        empty._records = [rec[:3]]
+    empty.gather_records()
+    torch.save((res, st.per_image(), empty.per_image()), out + str(rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_validation_records_are_gathered_across_ragged_ranks(tmp_path):
+    """Multi-rank validation: each rank steps over its own shard; gather_records() makes get_result() the measure over the WHOLE
+    set, identical on every rank (rank order), with unequal and empty shards."""
+    from ucod_dpl_amd.engine.utils.metrics import statistics
+    out = str(tmp_path / "val")
+    mp.start_processes(_val_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    rec = torch.rand(7, 1032, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    whole = statistics()
+    whole._records = [rec]
+    ref = whole.get_result()
+    for r in range(2):
+        res, per_image, small = torch.load(out + str(r))
+        assert res == ref
+        assert torch.equal(per_image, rec) and torch.equal(small, rec[:3])

@@ -1,0 +1,127 @@
+"""GPU: the data-parallel path of the HIP step.
+
+* one GPU: the gradient kernels' ``gscale`` / ``gextra`` = 1/world arguments (``ucod_apm_bce`` / ``ucod_dba_bwd`` through
+  TrainLoop._process_batch with ``runner.world_size = 2``): the two half-batch gradient arenas SUM to the gradient of the global
+  batch seen as two per-rank BatchNorm groups -- the same reference the world-2 gloo test uses (tests/test_distributed_gloo.py);
+* two GPUs (skipped on a one-GPU lease): two real ranks over RCCL -- broadcast at construction, asynchronous all-reduce of the flat
+  gradient arena inside ``_process_batch`` -- reproduce that gradient and leave both ranks with identical parameters.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import load_golden, sub, maxdiff, ROOT
+
+pytestmark = pytest.mark.gpu
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from test_distributed_gloo import _rank_grads  # noqa: E402  (oracle-side per-rank gradient of the 1/world-scaled loss)
+from test_gpu_train_step import build  # noqa: E402
+
+
+def _reference(g):
+    dec, ema, disc = sub(g, "model0.decoder."), sub(g, "model0.decoder_ema."), sub(g, "disc0.")
+    return sum(_rank_grads(dec, ema, {k: v.clone() for k, v in disc.items()}, g["features0"][r * 2:r * 2 + 2], g["pl0"][r * 2:r * 2 + 2], 0.5)
+               for r in range(2))
+
+
+def _check_against_reference(got, ref, A):
+    scale = ref[A.o_W:A.o_b].abs().max().item()
+    assert maxdiff(got[A.o_W:A.o_b], ref[A.o_W:A.o_b]) < 2e-3 * scale          # same bar as the G5 single-process test
+    for lo, hi in ((A.o_b, A.o_hw), (A.o_hw, A.o_hb), (A.o_hb, A.n)):
+        assert maxdiff(got[lo:hi], ref[lo:hi]) < 1e-6 + 2e-3 * ref[lo:hi].abs().max().item()
+    assert got[A.o_emb:A.o_W].abs().max().item() == 0.0                          # analytically gradient-free (exact zeros here)
+
+
+def test_half_batches_with_gscale_half_sum_to_the_global_batch_gradient():
+    g = load_golden("g5_process_batch")
+    ref = _reference(g)
+    total = None
+    for r in range(2):
+        runner, loop = build(g)                                  # fresh parameters / discriminator for each "rank"
+        runner.world_size = 2                                    # -> gscale = gextra = 0.5 in the HIP kernels; no process group exists
+        loop._process_batch((g["pl0"][r * 2:r * 2 + 2], g["features0"][r * 2:r * 2 + 2]))
+        part = runner.arena.g.detach().cpu().clone()
+        total = part if total is None else total + part
+        A = runner.arena
+    _check_against_reference(total, ref, A)
+    # and the scaling is exactly linear: the same half batch with world_size 1 gives twice the arena, bit for bit (x0.5 is exact)
+    runner1, loop1 = build(g)
+    loop1._process_batch((g["pl0"][2:4], g["features0"][2:4]))
+    w1 = runner1.arena.g.cpu()
+    assert maxdiff(part[A.o_b:] * 2, w1[A.o_b:]) < 1e-9 + 1e-6 * w1[A.o_b:].abs().max().item()
+    assert maxdiff(part[A.o_W:A.o_b] * 2, w1[A.o_W:A.o_b]) < 1e-5 * w1[A.o_W:A.o_b].abs().max().item()   # f32-atomic split-K sums
+
+
+def test_discriminator_phase_gradient_scales_with_world_size():
+    g = load_golden("g6_discriminator_step")
+    outs = []
+    for world in (1, 2):
+        runner, loop = build(g)
+        runner.world_size = world
+        loop._discriminator_batch((g["pl"], g["features"]))
+        outs.append(runner.disc_arena.g.cpu().clone())
+    assert outs[0].abs().max() > 0
+    assert maxdiff(outs[1] * 2, outs[0]) < 1e-5 * outs[0].abs().max().item()
+
+
+def test_discriminator_bce_backward_is_finite_at_saturation():
+    """torch's BCELoss backward divides by max(p(1-p), 1e-12): a probability that saturates to exactly 1.0 / 0.0 in f32 must give
+    a large finite gradient, not inf/NaN in the fused AdamW moments (advisor finding, loop_UCOD_DPL.py discriminator phase)."""
+    g = load_golden("g6_discriminator_step")
+    runner, loop = build(g)
+    with torch.no_grad():
+        runner.discriminator.linear.bias.add_(200.0)             # push the head's sigmoid into saturation (the arena view is the storage)
+    loss = loop._discriminator_batch((g["pl"], g["features"]))
+    assert float(loop.last["probs_student"].max()) == 1.0
+    assert torch.isfinite(loss) and torch.isfinite(runner.disc_arena.g).all() and torch.isfinite(runner.disc_arena.p).all()
+    assert torch.isfinite(runner.disc_arena.m).all() and torch.isfinite(runner.disc_arena.v).all()
+
+
+# ------------------------------------------------------------------------------------------------ two real ranks over RCCL
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _nccl_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_train_step import make_cfg
+    from ucod_dpl_amd.engine.runner import StandardRunner, TrainLoop
+    g = load_golden("g5_process_batch")
+    runner = StandardRunner(make_cfg())                          # initialises the RCCL group, broadcasts rank 0's arenas
+    dev = runner.device
+    if rank == 0:                                                # only rank 0 holds the golden parameters: the broadcast must carry them
+        runner.model.load_state_dict({k: v.to(dev) for k, v in sub(g, "model0.").items()}, strict=True)
+        runner.discriminator.load_state_dict({k: v.to(dev) for k, v in sub(g, "disc0.").items()}, strict=True)
+    from ucod_dpl_amd import parallel
+    bn = [b.layers[1] for b in (runner.discriminator.maskConv, runner.discriminator.convs[0], runner.discriminator.convs[1])]
+    parallel.broadcast_state([runner.arena.p, runner.arena.ema, runner.disc_arena.p] + [m.running_mean for m in bn] + [m.running_var for m in bn])
+    loop = TrainLoop(runner.config, runner)
+    loop._process_batch((g["pl0"][rank * 2:rank * 2 + 2], g["features0"][rank * 2:rank * 2 + 2]))
+    torch.cuda.synchronize()
+    torch.save((runner.arena.g.cpu(), runner.arena.p.cpu()), out + str(rank))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (a 2-GPU lease); the one-GPU box runs the gscale test above")
+def test_two_ranks_over_rccl_match_the_global_batch(tmp_path):
+    out = str(tmp_path / "rank")
+    mp.start_processes(_nccl_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    g = load_golden("g5_process_batch")
+    ref = _reference(g)
+    (g0, p0), (g1, p1) = torch.load(out + "0"), torch.load(out + "1")
+    assert torch.equal(g0, g1) and torch.equal(p0, p1)           # the all-reduce leaves every rank with the same arena -> same step
+    runner, _ = build(g)
+    _check_against_reference(g0, ref, runner.arena)

@@ -260,21 +260,19 @@ class ValLoop_Look_Twice(BaseLoop):
         stats = statistics()                                                       # all nine COD measures, on the device (:299)
         self.runner.model.eval()
         fs = self.cfg.model_cfg.feature_size
-        world = self.runner.world_size
+        # Multi-rank: every rank walks ITS shard of the validation set (the reference's accelerator.prepare shards the loader) with no
+        # per-image collective; the per-image records meet once, before get_result (the role of gather_for_metrics, :310).
         for batch in self.runner.val_dataloader:
             _, label_tensor, features, img_path = batch.values()
             features = ops.bilinear_resize(features.to(self.device, torch.float32), fs, fs)
             with torch.no_grad():
                 preds = self.runner.model(features)[0]
-            if world > 1:                                                         # accelerator.gather_for_metrics (:310)
-                gathered = [torch.empty_like(preds) for _ in range(world)]
-                torch.distributed.all_gather(gathered, preds.contiguous())
-                preds = gathered[self.runner.rank]
             preds_up, bboxes = self.process_preds(preds, label_tensor)
             if bboxes is not None and self.cfg.val_cfg.look_twice:
                 preds_up = self.look_twice(img_path[0], bboxes, preds_up).to(self.device)
             out = ops.bilinear_resize(preds_up.reshape(1, 1, *preds_up.shape[-2:]).to(self.device), label_tensor.shape[-2], label_tensor.shape[-1])
             stats.step(label_tensor.to(self.device), (out.reshape(1, *out.shape[-2:]) > 0.5))
+        stats.gather_records()
         result = stats.get_result()
         self.runner.logger.log_table({k: [round(v, 4)] for k, v in result.items()})
         return result

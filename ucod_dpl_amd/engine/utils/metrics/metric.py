@@ -46,6 +46,32 @@ class statistics:
         """f64 [images, 1032] on the device (layout: include/ucod_dpl.h)."""
         return torch.cat(self._records, dim=0)
 
+    def gather_records(self):
+        """Multi-rank validation (what ``accelerator.gather_for_metrics`` is for in the reference, loop_UCOD_DPL.py:310): every rank
+        has stepped over ITS shard of the validation set; collect all ranks' per-image records so that ``get_result`` is the
+        measure over the whole set and identical on every rank.  Two collectives per validation run (counts, then the records
+        padded to the longest shard), none per image; ranks may hold different numbers of images, including none."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        world = dist.get_world_size()
+        if self._records:
+            mine = self.per_image()
+        else:
+            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            mine = torch.zeros(0, 1032, dtype=torch.float64, device=dev)
+        counts = [torch.zeros(1, dtype=torch.int64, device=mine.device) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([mine.shape[0]], dtype=torch.int64, device=mine.device))
+        counts = [int(c.item()) for c in counts]
+        longest = max(counts)
+        if longest == 0:
+            return
+        padded = torch.zeros(longest, mine.shape[1], dtype=mine.dtype, device=mine.device)
+        padded[:mine.shape[0]] = mine
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded)
+        self._records = [torch.cat([p[:n] for p, n in zip(parts, counts)], dim=0)]      # rank order: deterministic on every rank
+
     def get_result(self):
         r = self.per_image()
         mean = r.mean(dim=0)                                   # over images
