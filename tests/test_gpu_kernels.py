@@ -84,7 +84,12 @@ def test_gemm_bf16_large_tile_is_race_free_and_deterministic():
 
 
 @pytest.mark.parametrize("variant,M,Nn,K", [(9, 21916, 768, 768), (9, 21916, 768, 3072), (10, 16401, 768, 3136), (9, 43840, 768, 192),
-                                            (0, 43840, 768, 3072), (5, 65600, 512, 64), (3, 22000, 768, 768)])
+                                            (0, 43840, 768, 3072), (5, 65600, 512, 64), (3, 22000, 768, 768),
+                                            # mixed-height launches (variants 13 / 14, gemm_bf16_mixed_kernel): a few 288-row tiles among
+                                            # the 256-row ones so that the launch is whole rounds -- 85 row-tiles, 5 tall; 64, 1 tall;
+                                            # the backbone's own QKV (170, 10 tall, 9 column tiles) and fc1 (12 column tiles) shapes
+                                            (13, 21916, 768, 768), (13, 21916, 768, 3072), (14, 16401, 768, 3136), (13, 43840, 2304, 768),
+                                            (13, 43840, 3072, 128), (13, 24480, 768, 128), (13, 21761, 768, 128)])
 def test_gemm_bf16_leftover_tiles_as_patches(variant, M, Nn, K):
     """Shapes a few tiles past one or two rounds of 256 large tiles: the launch has rounds x 256 workgroups and the remaining tiles
     are computed as 16 x 32 patches on the side (gemm_bf16.hip patch_phase).  Every output of every epilogue against an f32

@@ -22,6 +22,11 @@
 namespace ucod {
 
 constexpr int BM = 128, BN = 128, BK = 64;
+// cache policy of the large-tile epilogue's output stores (aux bits of buffer_store: 0 default, 2 nt, 16 sc1 = write-through, the line
+// is dropped from the XCD's L2 instead of displacing operand panels)
+#ifndef UCOD_ST_AUX
+#define UCOD_ST_AUX 0
+#endif
 
 
 struct GemmArgs {
@@ -40,7 +45,28 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int main_tiles;      // large-tile kernel, leftover-as-patches mode (see patch_phase): workgroups launched = whole tiles computed; 0 = off
   int patches_per_wg;  // 16 x 32 patches of the remaining tiles each workgroup computes on the side
+  int group_m;         // large-tile kernels: row-tiles per group of the tile order inside an XCD's chunk (see tile_of)
+  int col_fast;        // 1: column-tile fastest inside a group (one A panel's N-sweep back to back), 0: row-tile fastest
 };
+
+// Tile order of the large-tile kernels inside one XCD's contiguous chunk of the grid: groups of `group_m` row-tiles x all column-tiles.
+// row-tile fastest (col_fast = 0): the 32 workgroups resident on an XCD share group_m A panels and 32/group_m B panels;
+// column-tile fastest (col_fast = 1): they share 32/tiles_n A panels and ALL B panels, which then stay hot in the XCD's L2 while the A
+// panels stream through once -- the better order when the whole weight matrix fits beside the streaming panels (4 MiB L2 per XCD).
+__device__ __forceinline__ void tile_of(const GemmArgs& a, int wg, int& tm, int& tn) {
+  const int gm = a.group_m;
+  const int per_group = gm * a.tiles_n;
+  const int grp = wg / per_group, first_m = grp * gm;
+  const int gsz = (a.tiles_m - first_m) < gm ? (a.tiles_m - first_m) : gm;
+  const int in_grp = wg - grp * per_group;
+  if (a.col_fast) {
+    tm = first_m + in_grp / a.tiles_n;
+    tn = in_grp - (in_grp / a.tiles_n) * a.tiles_n;
+  } else {
+    tm = first_m + in_grp % gsz;
+    tn = in_grp / gsz;
+  }
+}
 
 // 16-byte chunk swizzle inside a 128-byte (64 x bf16) tile row: conflict-free ds_read_b128 for the
 // 16x16x32 fragment pattern (rows l&15, chunk l>>4) under the 64-bank / 16-lane-group rule.
@@ -383,16 +409,20 @@ __device__ __forceinline__ void finish_col_consts(const GemmArgs& a, float (&cb)
 
 // acc: the wave's 128 x 16*NT tile (8 row-tiles x NT column-tiles, C layout col = lane&15, row = (lane>>4)*4 + reg), bias
 // already inside for the fused epilogues; cs = per-column scale.  wbase: wave-private 32 x WCOLS f32 staging area.  Four passes of 32 rows.
-template <int EPI, int NT>
-__device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][NT], const float (&cs)[NT], char* wbase,
+template <int EPI, int NT, int NI = 8, int AUX = UCOD_ST_AUX>
+__device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI][NT], const float (&cs)[NT], char* wbase,
                                              int m_first, int n_first, int lane) {
   constexpr int WCOLS = 16 * NT, PR = 32;
+  constexpr int NP = (NI + 1) / 2;                    // passes of 32 rows; with NI odd the last pass holds 16 rows (rows 16..31 masked off)
+  static_assert(NI == 8 || kColFused<EPI>, "odd row-tile counts only in the column-fused epilogues");
+  auto rows_in = [&](int pass) { return (NI - 2 * pass) >= 2 ? 32 : 16; };
   auto stage = [&](int pass) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        f32x4 v = acc[pass * 2 + i][j];
+        if (pass * 2 + i >= NI) continue;
+        f32x4 v = acc[pass * 2 + i < NI ? pass * 2 + i : 0][j];
         if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) v = v * cs[j];
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
@@ -437,17 +467,17 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][
         off[it] = n < a.N ? (unsigned)lrow[it] * row_bytes + (unsigned)n * 4u : OOB;
       }
       // (the pass offset goes into the VGPR offset, not soffset: the range check covers only voffset + inst_offset)
-      auto at = [&](int it, int pass) { return off[it] == OOB ? OOB : off[it] + (unsigned)pass * pass_bytes; };
+      auto at = [&](int it, int pass) { return (off[it] == OOB || lrow[it] >= rows_in(pass)) ? OOB : off[it] + (unsigned)pass * pass_bytes; };
       u32x4 rb[2][ITS];
       if constexpr (RESID) {
 #pragma unroll
         for (int it = 0; it < ITS; ++it) rb[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off[it], 0, 0);
       }
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
+      for (int pass = 0; pass < NP; ++pass) {
         stage(pass);
         if constexpr (RESID) {
-          if (pass + 1 < 4) {
+          if (pass + 1 < NP) {
 #pragma unroll
             for (int it = 0; it < ITS; ++it)
               rb[(pass + 1) & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, at(it, pass + 1), 0, 0);
@@ -458,7 +488,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][
         for (int it = 0; it < ITS; ++it) {
           f32x4 o = *reinterpret_cast<const f32x4*>(wbase + lrow[it] * (WCOLS * 4) + lchk[it] * 16);
           if constexpr (RESID) o = o + __builtin_bit_cast(f32x4, rb[pass & 1][it]);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, at(it, pass), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, at(it, pass), 0, AUX);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
@@ -475,7 +505,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][
       auto lchk = [&](int it) { return (it * 64 + lane) - lrow(it) * CH; };
       auto at = [&](int it, int pass) {
         const int n = n_first + lchk(it) * 8;
-        return n < a.N ? (unsigned)(pass * PR + lrow(it)) * row_bytes + (unsigned)n * 2u : OOB;
+        return (n < a.N && lrow(it) < rows_in(pass)) ? (unsigned)(pass * PR + lrow(it)) * row_bytes + (unsigned)n * 2u : OOB;
       };
       u32x4 pre[2][ITS];
       if constexpr (GBWD) {
@@ -483,10 +513,10 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][
         for (int it = 0; it < ITS; ++it) pre[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_2, at(it, 0), 0, 0);
       }
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
+      for (int pass = 0; pass < NP; ++pass) {
         stage(pass);
         if constexpr (GBWD) {
-          if (pass + 1 < 4) {
+          if (pass + 1 < NP) {
 #pragma unroll
             for (int it = 0; it < ITS; ++it) pre[(pass + 1) & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_2, at(it, pass + 1), 0, 0);
           }
@@ -525,7 +555,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[8][
           w[1] = pack_bf16x2(v0[2], v0[3]);
           w[2] = pack_bf16x2(v1[0], v1[1]);
           w[3] = pack_bf16x2(v1[2], v1[3]);
-          __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, at(it, pass), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, at(it, pass), 0, AUX);
           __builtin_amdgcn_sched_barrier(0);                      // keep chunks in order: hoisting every ds_read/cvt of a pass spills in the persistent kernel
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -553,7 +583,6 @@ constexpr bool kPatchPrefetch = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BI
 template <int EPI, int BN_>
 __device__ __forceinline__ void patch_phase(const GemmArgs& a, char* scratch /* 16 KiB */, int orig, int wave, int lane) {
   constexpr int PC = BN_ / 32, PPT = 16 * PC;                   // patches per leftover tile
-  constexpr int GROUP_M = 8;
   const int total = a.tiles_m * a.tiles_n;
   const int npatch = (total - a.main_tiles) * PPT;
   const int K = a.K, steps = K >> 5;
@@ -562,12 +591,10 @@ __device__ __forceinline__ void patch_phase(const GemmArgs& a, char* scratch /* 
     const int p = orig * a.patches_per_wg + pi;
     if (p >= npatch) break;
     const int wg = a.main_tiles + p / PPT, rem = p % PPT;
-    const int per_group = GROUP_M * a.tiles_n;
-    const int grp = wg / per_group, first_m = grp * GROUP_M;
-    const int gsz = (a.tiles_m - first_m) < GROUP_M ? (a.tiles_m - first_m) : GROUP_M;
-    const int in_grp = wg - grp * per_group;
-    const int r0 = (first_m + in_grp % gsz) * 256 + (rem / PC) * 16;
-    const int c0 = (in_grp / gsz) * BN_ + (rem % PC) * 32;
+    int ptm, ptn;
+    tile_of(a, wg, ptm, ptn);
+    const int r0 = ptm * 256 + (rem / PC) * 16;
+    const int c0 = ptn * BN_ + (rem % PC) * 32;
     if (r0 >= a.M || c0 >= a.N) continue;                       // ragged last row / column tile: nothing there
     // this thread's output of the patch (one of 16 x 32) and its epilogue operands, requested before the operand loads so that
     // nothing is left to fetch once the partial sums meet
@@ -696,12 +723,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   // grouped order inside each XCD's chunk: GROUP_M row-tiles x all column-tiles, row-tile fastest -- the workgroups that are
   // resident together on an XCD then share a few B (weight) panels and GROUP_M A panels that fit its 4 MiB L2, instead of
   // every row-tile streaming the whole weight matrix through L2 (FETCH_SIZE was 5x the algorithmic bytes on fc1).
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * a.tiles_n;
-  const int grp = wg / per_group, first_m = grp * GROUP_M;
-  const int gsz = (a.tiles_m - first_m) < GROUP_M ? (a.tiles_m - first_m) : GROUP_M;
-  const int in_grp = wg - grp * per_group;
-  const int tm = first_m + in_grp % gsz, tn = in_grp / gsz;
+  int tm, tn;
+  tile_of(a, wg, tm, tn);
   const int m0 = tm * 256, n0 = tn * Cfg::BN_;
   const int K = a.K, nt = K / BK;
 
@@ -836,6 +859,169 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
 }
 
 // =====================================================================================================
+// Mixed-height launch of the large-tile kernel: whole rounds instead of a nearly empty last one.
+// One large-tile workgroup fills a CU, so a launch runs in rounds of n_cu tiles, and 32 x 1370 rows put the backbone's shapes just
+// past a whole number of rounds: QKV 172 x 9 = 1548 tiles = 6.05 rounds, fc1 172 x 12 = 2064 = 8.06 -- the 7th / 9th round runs on 12
+// / 16 CUs.  Here the M axis is cut into tm' = floor(rounds * n_cu / tiles_n) row-tiles instead: n_tall of them 288 rows high (nine
+// 16-row MFMA tiles per wave group instead of eight), the others 256, tall ones spread evenly over the grid (every `stride`-th
+// row-tile) so that each XCD gets its share.  QKV: 160 x 256 + 10 x 288 rows = 43 840, 170 x 9 = 1530 tiles <= 6 x 256: six rounds, 90 of
+// the tiles 12.5 % longer.  The tall body is a second instantiation of the same loop (three barrier intervals of 24 MFMAs per K-tile
+// and group instead of two of 32, so that its A fragments fit the register budget), selected by one wave-uniform branch at the top.
+// =====================================================================================================
+template <int NT, int XT>
+struct MixCfg {
+  static constexpr int RG = 128 + 16 * XT;            // rows per wave group
+  static constexpr int NI = 8 + XT;                   // 16-row MFMA tiles per wave group
+  static constexpr int NPH = XT ? 3 : 2;              // barrier intervals per K-tile and group
+  static constexpr int IT = NI / NPH;
+  static constexpr int SLOT = RG * 128;               // bytes of one group's A slot (64 bf16 per row)
+  static constexpr int BN_ = 64 * NT, NB = BN_ / 64;
+  static constexpr int BUF = 2 * SLOT + BN_ * 128;
+  static_assert(NI % NPH == 0, "whole phases");
+};
+
+template <int EPI, int NT, int XT, int AUX>
+__device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0, int n0, int wave, int lane) {
+  using Cfg = MixCfg<NT, XT>;
+  constexpr int NPH = Cfg::NPH, IT = Cfg::IT, NI = Cfg::NI;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int K = a.K, nt = K / BK;
+  // per-thread LDS-DMA source rows: two instructions cover 128 rows of a group's slot, a third (waves 0 and 1 only) the 16 extra rows
+  const bf16_raw* srcA[2][2 + XT];
+  const bf16_raw* srcB[Cfg::NB];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2 + XT; ++i) {
+      const int r = (i * 8 + wave) * 8 + (lane >> 3);
+      int gr = m0 + h * Cfg::RG + r;
+      gr = gr < a.M ? gr : a.M - 1;
+      srcA[h][i] = a.A + (size_t)gr * K + swz(r, lane & 7) * 8;
+    }
+#pragma unroll
+  for (int i = 0; i < Cfg::NB; ++i) {
+    const int r = (i * 8 + wave) * 8 + (lane >> 3);
+    int gr = n0 + r;
+    gr = gr < a.N ? gr : a.N - 1;
+    srcB[i] = a.B + (size_t)gr * K + swz(r, lane & 7) * 8;
+  }
+  auto dma = [&](const bf16_raw* src, char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto stageA = [&](int t, int h) {
+    char* slot = smem + (t & 1) * Cfg::BUF + h * Cfg::SLOT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma(srcA[h][i] + t * BK, slot + (i * 8 + wave) * 1024);
+    if constexpr (XT == 1) {
+      if (wave < 2) dma(srcA[h][2] + t * BK, slot + (16 + wave) * 1024);      // rows 128..143 (wave-uniform: `wave` is an SGPR)
+    }
+  };
+  auto stageB = [&](int t) {
+    char* slot = smem + (t & 1) * Cfg::BUF + 2 * Cfg::SLOT;
+#pragma unroll
+    for (int i = 0; i < Cfg::NB; ++i) dma(srcB[i] + t * BK, slot + (i * 8 + wave) * 1024);
+  };
+
+  float cb[NT], cs[NT];
+  load_col_consts<EPI, NT>(a, n0 + wn * 16 * NT + (lane & 15), cb, cs);
+  stageA(0, 0);
+  stageA(0, 1);
+  stageB(0);
+  if (nt > 1) stageB(1);
+  if (nt > 1) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
+  finish_col_consts<EPI, NT>(a, cb, cs);
+  f32x4 acc[NI][NT];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){cb[j], cb[j], cb[j], cb[j]};
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();            // staggered wave groups (see gemm_bf16_big_kernel)
+
+  for (int t = 0; t < nt; ++t) {
+    const char* bufA = smem + (t & 1) * Cfg::BUF + wm * Cfg::SLOT;
+    const char* bufB = smem + (t & 1) * Cfg::BUF + 2 * Cfg::SLOT;
+    const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+    bf16x8 fb[NT][2];
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+      if constexpr (NPH == 2) {
+        if (ph == 0 && more1) { stageA(t + 1, 0); stageA(t + 1, 1); }
+        if (ph == 1 && more2) stageB(t + 2);
+      } else {
+        if (ph == 0 && more1) stageA(t + 1, 0);
+        if (ph == 1 && more1) stageA(t + 1, 1);
+        if (ph == 2 && more2) stageB(t + 2);
+      }
+      if (ph == 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int r = wn * 16 * NT + j * 16 + (lane & 15);
+            fb[j][ks] = *reinterpret_cast<const bf16x8*>(bufB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+          }
+      }
+      bf16x8 fa[IT][2];
+#pragma unroll
+      for (int i = 0; i < IT; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int r = ph * (IT * 16) + i * 16 + (lane & 15);
+          fa[i][ks] = *reinterpret_cast<const bf16x8*>(bufA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+        }
+      if (ph == NPH - 1) {                               // RAW: every wave retires its tile-(t+1) DMAs before the barrier ahead of the first read
+        if (more2) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[ph * IT + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[ph * IT + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+  big_epilogue<EPI, NT, NI, AUX>(a, acc, cs, smem + wave * (32 * 16 * NT * 4), m0 + wm * Cfg::RG, n0 + wn * 16 * NT, lane);
+}
+
+// first row of row-tile tm when every `stride`-th row-tile (n_tall of them in all) is 32 rows taller
+__device__ __forceinline__ int mixed_row0(int tm, int n_tall, int stride, bool& tall) {
+  const int before = tm / stride + (tm % stride ? 1 : 0);       // tall row-tiles among 0 .. tm-1 are 0, stride, 2*stride, ...
+  const int nb = before < n_tall ? before : n_tall;
+  tall = (tm % stride) == 0 && (tm / stride) < n_tall;
+  return tm * 256 + nb * 32;
+}
+
+template <int EPI, int NT, int AUX = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_mixed_kernel(const GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * MixCfg<NT, 1>::BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+  int tm, tn;
+  tile_of(a, wg, tm, tn);
+  bool tall;
+  const int m0 = mixed_row0(tm, a.main_tiles /* n_tall */, a.patches_per_wg /* stride */, tall);
+  const int n0 = tn * MixCfg<NT, 0>::BN_;
+  if (tall) mixed_body<EPI, NT, 1, AUX>(a, smem, m0, n0, wave, lane);
+  else mixed_body<EPI, NT, 0, AUX>(a, smem, m0, n0, wave, lane);
+}
+
+// =====================================================================================================
 // Persistent form of the large-tile kernel: one workgroup per CU walks tiles vt = blockIdx.x, +gridDim.x, ...
 // What it buys: the first K-tile of the NEXT output tile (A0|A1|B, 9-11 LDS-DMAs per thread) is issued BEFORE the epilogue of
 // the current tile, into the K-tile buffer the main loop has just vacated, so the ~3 us of first-tile HBM/L2 latency that every
@@ -856,18 +1042,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
   const int wm = wave >> 2, wn = wave & 3;
   const int ntiles = a.tiles_m * a.tiles_n;
   const int K = a.K, nt = K / BK;
-  constexpr int GROUP_M = 8;
   constexpr int WCOLS = 16 * NT;
 
   auto decode = [&](int vt, int& m0, int& n0) {
     const int q = ntiles >> 3, r8 = ntiles & 7, xcd = vt & 7;
     const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (vt >> 3);
-    const int per_group = GROUP_M * a.tiles_n;
-    const int grp = wg / per_group, first_m = grp * GROUP_M;
-    const int gsz = (a.tiles_m - first_m) < GROUP_M ? (a.tiles_m - first_m) : GROUP_M;
-    const int in_grp = wg - grp * per_group;
-    m0 = (first_m + in_grp % gsz) * 256;
-    n0 = (in_grp / gsz) * Cfg::BN_;
+    int tm, tn;
+    tile_of(a, wg, tm, tn);
+    m0 = tm * 256;
+    n0 = tn * Cfg::BN_;
   };
   // DMA source rows as 32-bit element offsets from the tile's first A / B row (64-bit per-tile bases stay in SGPRs): the
   // persistent kernel keeps the next tile's sources live across the epilogue, and 64-bit pointers there spilled VGPRs.
@@ -1065,6 +1248,27 @@ static BigPlan big_plan(int M, int N, int K, int bn, bool patch_epi) {
   return p;
 }
 
+// Mixed-height plan (see gemm_bf16_mixed_kernel): row-tiles, how many of them tall, and their spacing; feasible = false when the shape
+// already fills whole rounds or when 32 extra rows on every row-tile would not be enough.
+struct MixedPlan { bool feasible; int tiles_m, n_tall, stride, rounds; };
+static MixedPlan mixed_plan(int M, int N, int bn) {
+  MixedPlan p{false, 0, 0, 1, 0};
+  const int n_cu = device_cus(), tiles_n = cdiv(N, bn), t0 = cdiv(M, 256) * tiles_n;
+  const int rounds = t0 / n_cu;
+  if (rounds < 1 || t0 == rounds * n_cu) return p;
+  const int tm = (rounds * n_cu) / tiles_n;                     // row-tiles that fit `rounds` whole rounds
+  const long short_rows = (long)M - 256L * tm;
+  if (tm < 1 || short_rows <= 0) return p;
+  const int n_tall = (int)cdiv(short_rows, 32L);
+  if (n_tall > tm) return p;
+  p.feasible = true;
+  p.tiles_m = tm;
+  p.n_tall = n_tall;
+  p.stride = tm / n_tall;
+  p.rounds = rounds;
+  return p;
+}
+
 template <int EPI>
 static int launch(GemmArgs a, int variant, hipStream_t s) {
   constexpr bool kTrainEpi = (EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
@@ -1079,6 +1283,10 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
       // two 32-MFMA barrier intervals per K-tile (variants 9/10) beat four 16-MFMA ones (5/6) by 2-4 % and the persistent
       // form (7/8) by 1-5 % on every backbone shape (tools/gemm_bench.py); the width with the shorter modelled makespan
       variant = (big_plan(a.M, a.N, a.K, 192, kPatchEpi).cost < big_plan(a.M, a.N, a.K, 256, kPatchEpi).cost) ? 10 : 9;
+      // three or more rounds with a nearly empty last one (QKV 6.05, fc1 8.06): mixed-height tiles make it whole rounds (-7 % / -8 %,
+      // tools/gemm_order_sweep.py); at one or two rounds the patches above already do that at the same cost
+      const MixedPlan mp = mixed_plan(a.M, a.N, 256);
+      if (kColFused<EPI> && mp.feasible && mp.rounds >= 3 && !getenv("UCOD_GEMM_NO_MIXED")) variant = 13;
     }
   }
   if (kTrainEpi || ((EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_F32) && !a.bias)) {   // large-tile kernels only
@@ -1087,10 +1295,46 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
   }
   constexpr bool kBf16Out = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || kTrainEpi);
   if (variant >= 3 && variant <= 10 && ((a.N & 3) != 0 || (kBf16Out && (a.N & 7) != 0))) return UCOD_EINVAL;   // 16-byte row stores
+  if constexpr (kColFused<EPI>) {
+    if (variant == 13 || variant == 14) {                     // mixed-height tiles; falls back to 9 / 10 when the plan is not feasible
+      const MixedPlan mp = mixed_plan(a.M, a.N, variant == 13 ? 256 : 192);
+      if (!mp.feasible || (a.N & 3) != 0 || (kBf16Out && (a.N & 7) != 0) || a.K < 128) {
+        variant -= 4;
+      } else {
+        a.tiles_m = mp.tiles_m;
+        a.tiles_n = cdiv(a.N, variant == 13 ? 256 : 192);
+        a.main_tiles = mp.n_tall;                               // (the two fields are free in this mode: no patches)
+        a.patches_per_wg = mp.stride;
+        a.col_fast = a.tiles_n <= 4;
+        if (const char* e = getenv("UCOD_GEMM_GROUP_M")) a.group_m = atoi(e) > 0 ? atoi(e) : a.tiles_m;
+        if (const char* e = getenv("UCOD_GEMM_COL_FAST")) a.col_fast = atoi(e);
+        // bf16 outputs of the two forward epilogues (qkv, MLP hidden) leave with the non-temporal policy: they are read once, by the
+        // next kernel, and displace less of what the running launch re-reads (in the step: QKV 153.5 -> 145.8 us, fc1 223.7 -> 216.7)
+        int aux = 2;
+        if (const char* e = getenv("UCOD_GEMM_ST_AUX")) aux = atoi(e);
+        dim3 grid(a.tiles_m * a.tiles_n), block(512);
+        if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) {   // store-policy experiment builds exist for the two bf16 forward epilogues
+          if (aux == 2 && variant == 13) { hipLaunchKernelGGL((gemm_bf16_mixed_kernel<EPI, 4, 2>), grid, block, 0, s, a); UCOD_CHECK_LAUNCH(); return UCOD_OK; }
+          if (aux == 16 && variant == 13) { hipLaunchKernelGGL((gemm_bf16_mixed_kernel<EPI, 4, 16>), grid, block, 0, s, a); UCOD_CHECK_LAUNCH(); return UCOD_OK; }
+        }
+        if (variant == 13) hipLaunchKernelGGL((gemm_bf16_mixed_kernel<EPI, 4>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_bf16_mixed_kernel<EPI, 3>), grid, block, 0, s, a);
+        UCOD_CHECK_LAUNCH();
+        return UCOD_OK;
+      }
+    }
+  } else {
+    if (variant == 13 || variant == 14) variant -= 4;
+  }
   if (variant >= 3 && variant <= 10) {
     const bool wide = (variant == 3 || variant == 5 || variant == 7 || variant == 9);
     a.tiles_m = cdiv(a.M, 256);
     a.tiles_n = cdiv(a.N, wide ? 256 : 192);
+    // few column tiles (proj / fc2: N = 768): sweep one A panel's columns back to back (proj 75 -> 70 us, L2 fetch 263 -> 230 MB);
+    // many (QKV 9, fc1 12): row-tile fastest in groups of 8 (fc1 is 3-6 % slower column-fastest: its weight matrix alone exceeds the L2)
+    a.col_fast = a.tiles_n <= 4;
+    if (const char* e = getenv("UCOD_GEMM_GROUP_M")) a.group_m = atoi(e) > 0 ? atoi(e) : a.tiles_m;   // tuning knobs (tools/gemm_order_sweep.py)
+    if (const char* e = getenv("UCOD_GEMM_COL_FAST")) a.col_fast = atoi(e);
     dim3 grid(a.tiles_m * a.tiles_n), block(512);
     if (variant != 7 && variant != 8) {
       const BigPlan pl = big_plan(a.M, a.N, a.K, wide ? 256 : 192, kPatchEpi);
@@ -1168,6 +1412,8 @@ static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int
   a.tiles_n = cdiv(N, BN);
   a.main_tiles = 0;
   a.patches_per_wg = 0;
+  a.group_m = 8;
+  a.col_fast = 0;
   hipStream_t s = (hipStream_t)stream;
   UCOD_PROF(epilogue >= 0 && epilogue <= 5 ? epilogue : (epilogue == UCOD_EPI_GELU_BWD_BF16 ? PROF_GEMM_EPI6 : PROF_GEMM_EPI7), s);
   switch (epilogue) {

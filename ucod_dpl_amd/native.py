@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_native", "libucod_dpl.so")
+LIB_PATH = os.environ.get("UCOD_DPL_LIB") or os.path.join(_HERE, "_native", "libucod_dpl.so")   # the override selects an experiment build (tools/)
 
 EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_SCALE_RESID_F32, EPI_PATCH_TOKENS_F32, EPI_KEY_NCHW_F32, EPI_BIAS_F32 = range(6)
 EPI_GELU_BWD_BF16, EPI_BIAS_GELU_SAVE_BF16 = 6, 7          # ucod_gemm_bf16_train only (backbone-backward mode)
