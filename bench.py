@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--attn-variant", type=int, default=2)
     ap.add_argument("--streams", type=int, default=2, help="image-parallel sub-batches of the backbone pass on independent HIP streams")
     ap.add_argument("--no-pipeline", action="store_true", help="serial order: backbone pass, then decoder step, on one stream")
+    ap.add_argument("--half", default="bf16", choices=["bf16", "f16"], help="16-bit operand type of the backbone (bf16 = BASELINE configs[1])")
     ap.add_argument("--lora-steps", type=int, default=4, help="steps of the separate backbone-backward (LoRA) measurement; 0 = skip")
     return ap.parse_args()
 
@@ -128,7 +129,7 @@ def main():
     runner = StandardRunner(cfg)                              # initialises the RCCL process group when WORLD_SIZE > 1
     loop = TrainLoop(cfg, runner)
     bb = backbone.random_init(a.arch, seed=0, image_size=a.image, device=dev, full_last_layer=a.full_last_layer,
-                              gemm_variant=a.gemm_variant, attn_variant=a.attn_variant)
+                              gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half=a.half)
     bb.engine.streams = a.streams
     B = a.batch
     g = torch.Generator().manual_seed(1234 + rank)
@@ -186,19 +187,26 @@ def main():
         loop.global_step += 1
     barrier()
     dt_serial_plain = time.perf_counter() - t1
-    lib.ucod_prof_enable(1)
+    libs = [lib] + ([bb.engine.lib] if bb.engine.lib is not lib else [])     # (the fp16 build is a second library with its own event log)
+    for l_ in libs:
+        l_.ucod_prof_enable(1)
     t1 = time.perf_counter()
     for _ in range(a.steps):
         serial_step()
         loop.global_step += 1
     barrier()
     dt_serial = time.perf_counter() - t1
-    lib.ucod_prof_enable(0)
     bb.engine.streams = a.streams
     ncls = lib.ucod_prof_num_classes()
     tot = (C.c_double * ncls)()
     cnt = (C.c_longlong * ncls)()
-    lib.ucod_prof_collect(tot, cnt)
+    for l_ in libs:
+        l_.ucod_prof_enable(0)
+        t_, c_ = (C.c_double * ncls)(), (C.c_longlong * ncls)()
+        l_.ucod_prof_collect(t_, c_)
+        for i in range(ncls):
+            tot[i] += t_[i]
+            cnt[i] += c_[i]
     if world > 1:
         tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
@@ -221,6 +229,36 @@ def main():
                  "loss": round(float(dl.item()), 6),
                  "what": "discriminator step on resident key maps: student decoder fwd (no grad), 2 discriminator fwd + bwd, all-reduce, fused AdamW"}
 
+    # The same step with IEEE fp16 GEMM / attention operands (ViTEngine(half="f16"): the reference's own autocast type, 8x finer rounding
+    # than bf16 -- the build that meets the 1e-3 logit bar, see cpu_baseline.parity_full_size.f16_operands), same schedule, reported
+    # SEPARATELY (never part of `value`)
+    f16_option = None
+    del bb, pipe
+    torch.cuda.empty_cache()
+    if a.half == "bf16" and a.lora_steps >= 0:
+        bb16 = backbone.random_init(a.arch, seed=0, image_size=a.image, device=dev, full_last_layer=a.full_last_layer,
+                                    gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half="f16")
+        bb16.engine.streams = a.streams
+        pipe16 = FeaturePipeline(bb16.engine)
+        pipe16.submit(images)
+        for _ in range(3):
+            k16 = pipe16.next_features(); pipe16.submit(images); loop._process_batch((pl, k16)); loop.global_step += 1
+        barrier()
+        t3 = time.perf_counter()
+        for _ in range(a.steps):
+            k16 = pipe16.next_features(); pipe16.submit(images); loop._process_batch((pl, k16)); loop.global_step += 1
+        barrier()
+        dt16 = time.perf_counter() - t3
+        if world > 1:
+            tdt = torch.tensor([dt16], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
+            dt16 = tdt.item()
+        pipe16.next_features()
+        f16_option = {"value": round(world * B * a.steps / dt16, 2), "unit": "images/s", "ms_per_step": round(dt16 / a.steps * 1e3, 3),
+                      "what": "the timed step with fp16 backbone operands (libucod_dpl_f16.so), same schedule"}
+        del bb16, pipe16
+        torch.cuda.empty_cache()
+
     # Optional mode of SURVEY.md 8a row B9, reported SEPARATELY (never part of `value`): images -> LoRA backbone (student,
     # activations saved) + EMA backbone (teacher) -> the same decoder/APM/discriminator step -> backbone backward -> all-reduce
     # of decoder and LoRA gradients -> both fused optimisers.
@@ -228,8 +266,6 @@ def main():
     if a.lora_steps > 0:
         from ucod_dpl_amd.vit_engine import ViTLoRAEngine
         from ucod_dpl_amd.data.utils.feature_extractor import random_state_dict
-        del bb
-        torch.cuda.empty_cache()
         eng = ViTLoRAEngine(random_state_dict(a.arch, 0, a.image), heads, r=2, lora_alpha=4, device=dev, gemm_variant=a.gemm_variant,
                             generator=torch.Generator().manual_seed(7), lora_dropout=0.05, seed=1234 + rank)
         loop.attach_lora_backbone(eng)
@@ -279,9 +315,12 @@ def main():
         elif fl:
             k["tflops"] = round(fl / (avg_us * 1e-6) / 1e12, 1)
         kernels[name] = k
-    # HBM-bound representative: LayerNorm moves rows*D*(4 B f32 read + 2 B bf16 write) per launch
+    # HBM-bound representative: LayerNorm.  ALGORITHMIC bytes per SURVEY.md 8(d) / BASELINE.md section 3 = rows*D*(2 B read + 2 B write);
+    # this build keeps the residual stream in f32 (accuracy: it is what the GEMM epilogues accumulate into), so a launch MOVES
+    # rows*D*(4 + 2) B (PMC: 202 MB) -- reported beside it as `moved_gbs`
     if "layernorm" in kernels:
-        kernels["layernorm"]["gbs"] = round(B * tok * D * 6 / (kernels["layernorm"]["avg_us"] * 1e-6) / 1e9, 1)
+        kernels["layernorm"]["gbs"] = round(B * tok * D * 4 / (kernels["layernorm"]["avg_us"] * 1e-6) / 1e9, 1)
+        kernels["layernorm"]["moved_gbs"] = round(B * tok * D * 6 / (kernels["layernorm"]["avg_us"] * 1e-6) / 1e9, 1)
     dom = max((n for n in kernels if "tflops" in kernels[n] and n.startswith(("gemm_bf16", "attention"))),
               key=lambda n: kernels[n]["ms_per_step"])
     traffic = None                                            # HBM-side bytes per launch from committed PMC passes (see the file's "source")
@@ -296,7 +335,10 @@ def main():
                 "serial_ms_per_step_without_events": round(dt_serial_plain / a.steps * 1e3, 3)}
     if "layernorm" in kernels:
         roofline["hbm_row"] = {"kernel": "layernorm", "achieved": kernels["layernorm"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(kernels["layernorm"]["gbs"] / HBM_PEAK_GBS, 4)}
+                               "frac": round(kernels["layernorm"]["gbs"] / HBM_PEAK_GBS, 4),
+                               "bytes": "algorithmic (SURVEY 8d): bf16 read + bf16 write = 4 B/element",
+                               "moved": {"achieved": kernels["layernorm"]["moved_gbs"], "frac": round(kernels["layernorm"]["moved_gbs"] / HBM_PEAK_GBS, 4),
+                                         "bytes": "f32 residual read + bf16 write = 6 B/element (what the launch moves; PMC 202 MB)"}}
 
     cpu = None
     if not a.no_cpu_baseline and world == 1:                  # rank 0 at N = 1 only (the contract); the N > 1 lines carry null
@@ -307,15 +349,15 @@ def main():
         "metric": "training images/sec at 3x518x518, DINOv2-B (frozen backbone fwd + DBA/APM/discriminator train step)",
         "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": a.half, "data": "synthetic",
         "config": {"workload": f"{which_config(a.arch, a.image, B)}: {a.arch} @{a.image}x{a.image}, batch {B}/GPU, full APM+DBA+discriminator step, "
-                               f"decoder path exact f32, backbone bf16 MFMA", "global_batch": B * world, "parallelism": f"dp{world}",
+                               f"decoder path exact f32, backbone {a.half} MFMA", "global_batch": B * world, "parallelism": f"dp{world}",
                    "backbone_last_layer": "full (as reference)" if a.full_last_layer else "key-minimal (identical key output; 279.6 of 303.1 GFLOP/img)",
                    "random_init_weights": True,
                    "schedule": "serial, one stream" if a.no_pipeline else
                                f"backbone pass of step k+1 on {a.streams} side stream(s) overlapped with the decoder step of step k"},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "final_loss": round(final_loss, 6),
-        "backbone_backward_mode": lora_mode, "discriminator_phase": dis_phase,
+        "backbone_backward_mode": lora_mode, "discriminator_phase": dis_phase, "f16_operands_option": f16_option,
     }
     print(json.dumps(out))
 
@@ -347,23 +389,37 @@ def cpu_baseline(a, D, heads, L, P):
            "sample": f"{n} images: oracle Dinov2 fwd f32 ({t1 - t0:.1f}s) + oracle _process_batch with the reference's naive orth loss ({t2 - t1:.1f}s)"}
     # Parity of the bf16 device path at FULL size against the f32 oracle on the same images and weights (report max-abs,
     # relative L2 and the fraction of mask pixels that land on the other side of the 0.5 threshold).  The oracle is the checker here.
-    if True:                                                    # an error here is an error of the bench (non-zero exit), never a green line
-        from ucod_dpl_amd import ops
-        from ucod_dpl_amd.vit_engine import ViTEngine
-        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-        eng = ViTEngine(sd, heads=heads, eps=1e-6, device=dev, attn_variant=a.attn_variant)
-        key_dev = eng(img.to(dev))
+    # (an error here is an error of the bench -- non-zero exit -- never a green line)
+    from ucod_dpl_amd import ops
+    from ucod_dpl_amd.vit_engine import ViTEngine
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    layer_ref = list(OV.dinov2_forward.layer_keys)             # the key hook's map after every layer, f32 oracle
+    emb = dec["learnable_embedding"].reshape(128).to(dev)
+    hw = torch.cat((dec["conv_out_fg.weight"].reshape(64), dec["conv_out_bg.weight"].reshape(64))).to(dev)
+    hb = torch.cat((dec["conv_out_fg.bias"], dec["conv_out_bg.bias"])).to(dev)
+
+    def device_logits(key_dev):
         d = ops.bilinear_resize(ops.dba_project(key_dev, dec["decoupling.weight"].reshape(128, D).to(dev), dec["decoupling.bias"].to(dev)).view(n, 128, *key_dev.shape[-2:]), 68, 68).view(n, 128, 68 * 68)
-        emb = dec["learnable_embedding"].reshape(128).to(dev)
-        hw = torch.cat((dec["conv_out_fg.weight"].reshape(64), dec["conv_out_bg.weight"].reshape(64))).to(dev)
-        hb = torch.cat((dec["conv_out_fg.bias"], dec["conv_out_bg.bias"])).to(dev)
-        fg_dev, _, _ = ops.dba_heads(d, 0, emb, ops.dba_colnorm(d, 0, emb), hw, hb, want_bg=False)
-        kd, fd = key_dev.cpu(), fg_dev.view(n, 1, 68, 68).cpu()
-        out["parity_full_size"] = {
-            "what": f"{n} images at {a.image}x{a.image}, {a.arch}: bf16 device backbone + f32 device decoder vs the f32 oracle (same random-init weights)",
-            "key_rel_l2": round(float((kd - key).norm() / key.norm()), 6), "key_max_abs": round(float((kd - key).abs().max()), 5),
-            "logit_max_abs": round(float((fd - fg_ref).abs().max()), 6), "logit_rel_l2": round(float((fd - fg_ref).norm() / fg_ref.norm()), 6),
-            "mask_flipped_fraction": round(float(((fd > 0) != (fg_ref > 0)).float().mean()), 6)}
+        return ops.dba_heads(d, 0, emb, ops.dba_colnorm(d, 0, emb), hw, hb, want_bg=False)[0].view(n, 1, 68, 68).cpu()
+
+    def parity(half):
+        eng = ViTEngine(sd, heads=heads, eps=1e-6, device=dev, attn_variant=a.attn_variant, half=half)
+        key_dev = eng(img.to(dev))
+        kd, fd = key_dev.cpu(), device_logits(key_dev)
+        per_layer = []
+        for li in range(1, L + 1):                              # error budget: key map after li layers vs the oracle's
+            kl = eng.forward(img.to(dev), n_layers=li).cpu()
+            per_layer.append(round(float((kl - layer_ref[li - 1]).norm() / layer_ref[li - 1].norm()), 6))
+        return {"key_rel_l2": round(float((kd - key).norm() / key.norm()), 6), "key_max_abs": round(float((kd - key).abs().max()), 5),
+                "logit_max_abs": round(float((fd - fg_ref).abs().max()), 6), "logit_rel_l2": round(float((fd - fg_ref).norm() / fg_ref.norm()), 6),
+                "mask_flipped_fraction": round(float(((fd > 0) != (fg_ref > 0)).float().mean()), 6),
+                "key_rel_l2_after_layer": per_layer}
+
+    out["parity_full_size"] = {
+        "what": f"{n} images at {a.image}x{a.image}, {a.arch}: device backbone + f32 device decoder vs the f32 oracle (same random-init weights); "
+                f"north-star bar: logit max-abs <= 1e-3",
+        **parity("bf16"),
+        "f16_operands": parity("f16")}
     return out
 
 

@@ -37,6 +37,12 @@ extern "C" {
 int ucod_abi_version(void);
 /* 1 when a gfx950 device is visible to this process (hipGetDeviceProperties().gcnArchName) */
 int ucod_device_is_gfx950(void);
+/* 16-bit operand type this library was built for: "bf16" (libucod_dpl.so, BASELINE configs[1]) or "f16" (libucod_dpl_f16.so, built with
+ * -DUCOD_HALF_F16: IEEE fp16 GEMM / attention operands, the arithmetic of the reference's fp16-autocast launcher,
+ * scripts/launch_train_first_stage.sh; every "bf16" in the names and comments below then reads fp16; the backbone-backward entry points
+ * (ucod_vit_forward_train, ucod_vit_backward, ucod_gemm_bf16_train, ucod_layernorm_*lora*, ucod_lora_*, ucod_attention_bwd, ...)
+ * return UCOD_EINVAL there) */
+const char* ucod_half_name(void);
 
 /* Optional per-op timing with HIP events recorded on the launch stream around every launcher below (off by default;
  * bench.py turns it on over its timed region to price each kernel class against its roofline).

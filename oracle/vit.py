@@ -97,12 +97,15 @@ def dinov2_forward(img, sd, heads, patch=14, eps=1e-6, n_layers=None, full_last_
     x = x + dinov2_pos_embed(sd[pre + "position_embeddings"], H // patch, W // patch)
     L = n_layers if n_layers is not None else 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.layer."))
     key = None
+    gh, gw = H // patch, W // patch
+    dinov2_forward.layer_keys = []                      # the key hook's map after EVERY layer (per-layer error budget of the device path)
     for i in range(L):
         p = f"encoder.layer.{i}."
         h = layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
         a = p + "attention.attention."
         lm = (lambda nm: None) if lora_masks is None else (lambda nm: lora_masks.get((i, nm)))
         k = _lora_linear(h, sd, a + "key", lora_scale, lm("key"))
+        dinov2_forward.layer_keys.append(k[:, 1:, :].reshape(B, gh, gw, -1).permute(0, 3, 1, 2))
         if i == L - 1:
             key = k
             dinov2_forward.last_ln1 = h                 # LN1 output of the last layer (CLS-attention row of the pseudo-label generator)
@@ -118,7 +121,6 @@ def dinov2_forward(img, sd, heads, patch=14, eps=1e-6, n_layers=None, full_last_
         h = h @ sd[p + "mlp.fc2.weight"].t() + sd[p + "mlp.fc2.bias"]
         x = h * sd[p + "layer_scale2.lambda1"] + x
     last = layer_norm(x, sd["layernorm.weight"], sd["layernorm.bias"], eps) if full_last_layer else None
-    gh, gw = H // patch, W // patch
     key_map = key[:, 1:, :].reshape(B, gh, gw, -1).permute(0, 3, 1, 2)   # feature_extractor.py:55-58
     return last, key_map
 

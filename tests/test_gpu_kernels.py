@@ -336,6 +336,55 @@ def test_config_c4_dinov2_vitl14_518():
     assert rel_l2(key.cpu(), ref) < 3e-2, rel_l2(key.cpu(), ref)
 
 
+def test_config_c4_vitl14_batch16_properties():
+    """BASELINE.json configs[3] per-GPU geometry: DINOv2 ViT-L/14, 518x518, batch 16 -- too big for the CPU oracle (16 x 1 TFLOP), so the
+    size-independent properties of the C2 test at this geometry (D = 1024: 4-column-tile GEMMs, 16 heads, 24 layers): batch
+    permutation permutes the key maps, the two-stream pass equals the single-stream pass, one image alone agrees with its slot in the
+    batch, finite non-degenerate output.  (test_config_c4_dinov2_vitl14_518 pins one image of this geometry on the oracle.)"""
+    from ucod_dpl_amd.data.utils.feature_extractor import backbone
+    bb = backbone.random_init("dinov2_vitl14", seed=3, image_size=518, device=DEV, attn_variant=2)
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(16, 3, 518, 518, generator=g).to(DEV)
+    perm = torch.randperm(16, generator=g).to(DEV)
+    bb.engine.streams = 1
+    k0 = bb.engine(x).clone()
+    assert k0.shape == (16, 1024, 37, 37) and bool(torch.isfinite(k0).all()) and float(k0.std()) > 1e-3
+    kp = bb.engine(x[perm].contiguous()).clone()
+    bb.engine.streams = 2
+    k2 = bb.engine(x).clone()
+    bb.engine.streams = 1
+    k1 = bb.engine(x[5:6].contiguous())
+    assert torch.equal(bb.engine(x), k0)                          # repeatable
+    # rows that land in different tiles / patches are summed over K in a different f32 order; bf16 re-rounding of those low-bit
+    # differences compounds over 24 layers (ViT-B's 12 layers stay under 3e-3, test_backbone_full_size_properties)
+    assert torch.equal(k2, k0) or rel_l2(k2, k0) < 1e-2
+    for other, same in ((kp, k0[perm]), (k2, k0), (k1, k0[5:6])):
+        assert rel_l2(other, same) < 1e-2, rel_l2(other, same)
+
+
+@pytest.mark.parametrize("name,heads,fn", [("g8_dinov2_native", 2, "v2"), ("g8_dinov2_interp", 2, "v2"), ("g8_dinov1_native", 2, "v1")])
+def test_vit_key_fp16_operands_against_reference_golden(name, heads, fn):
+    """ViTEngine(half="f16") -- the same kernels built on IEEE fp16 operands (libucod_dpl_f16.so), the arithmetic type of the
+    reference's fp16-autocast launcher -- against the reference's own key maps (G8): 8x finer operand rounding than bf16, so a 5x
+    tighter tolerance than the bf16 test above (1e-3 relative L2 through 3 layers), and strictly closer than the bf16 engine."""
+    from ucod_dpl_amd.vit_engine import ViTEngine
+    gd = load_golden(name)
+    ref = gd["key"]
+    e16 = ViTEngine(sub(gd, "sd."), heads=heads, eps=1e-6, device=DEV, attn_variant=2, half="f16")
+    ebf = ViTEngine(sub(gd, "sd."), heads=heads, eps=1e-6, device=DEV, attn_variant=2)
+    k16, kbf = e16(gd["x"].to(DEV)).cpu(), ebf(gd["x"].to(DEV)).cpu()
+    assert e16.lib.ucod_half_name() == b"f16" and ebf.lib.ucod_half_name() == b"bf16"
+    assert rel_l2(k16, ref) < 1e-3, rel_l2(k16, ref)
+    assert rel_l2(k16, ref) < 0.5 * rel_l2(kbf, ref)
+
+
+def test_fp16_library_refuses_the_bf16_only_entry_points():
+    from ucod_dpl_amd import native
+    lib = native.load("f16")
+    assert lib.ucod_attention_bwd(None, None, None, None, None, None, 1, 1, 1, 0, None) == -1
+    assert lib.ucod_vit_backward(None, None, None, None, None, 0, None) == -1
+
+
 # ----------------------------------------------------------------------------------------- decoder (exact f32)
 def test_bilinear_matches_aten_semantics():
     g = torch.Generator().manual_seed(1)

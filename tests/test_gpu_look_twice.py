@@ -118,6 +118,43 @@ def test_look_twice_matches_the_reference_run_g11():
         assert torch.equal(out, g["new_mask"]), tail
 
 
+def test_look_twice_second_pass_at_vitl14_geometry():
+    """BASELINE.json configs[3]: the Look-Twice second pass with the ViT-L/14 backbone at 518x518 on the reference's fallback box
+    [129,129,259,259] (loop_UCOD_DPL.py:370) of a 640x427 image, batch 1: crop bit-identical to the Pillow path, device logits vs the
+    f32 oracle (HF Dinov2 restatement + decoder) on the same crop within the bf16 tolerance, and the pasted mask equal to the
+    oracle's composition of the device's predictions (crop / resize / paste arithmetic) with at most 1 % of the 37x37 predictions on
+    the other side of the threshold than the f32 oracle's."""
+    from oracle import vit as OV, decoder as OD
+    dev = torch.device("cuda", 0)
+    sd = random_state_dict("dinov2_vitl14", seed=21, image_size=518)
+    bb = backbone.from_state_dict(sd, heads=16, device=dev)
+    torch.manual_seed(22)
+    model = baseline(CfgNode(dict(dim=1024, feature_size=68, ema_weight=0.99, dis_use_features=False))).to(dev)
+    runner = types.SimpleNamespace(device=dev, model=model, world_size=1, rank=0, val_dataloader=[], logger=None)
+    cfg = CfgNode(dict(train_cfg=dict(dist_train=False), model_cfg=dict(feature_size=68), val_cfg=dict(look_twice=True, look_twice_th=0.15, expand_type="dynamic"),
+                       dataset_cfg=dict(valset_cfg=dict(image_size=(518, 518)))))
+    loop = LT.ValLoop_Look_Twice(cfg, runner, feature_extractor=bb)
+    img = synthetic_image(seed=9)
+    box = list(LT.DEFAULT_BOX)
+    H, W = img.shape[:2]
+    src = loop.resize_bbox(box, 518, 518, W, H)
+    crop = loop.crop_batch(img, [src])
+    ref_crop = OLT.crop_resize_normalize(img, src, (518, 518))
+    assert torch.equal(crop[0].cpu(), ref_crop)
+    dec = {k[len("decoder."):]: v.detach().cpu() for k, v in model.state_dict().items() if k.startswith("decoder.")}
+    with torch.no_grad():
+        _, key_ref = OV.dinov2_forward(ref_crop.unsqueeze(0), sd, heads=16, patch=14, eps=1e-6, full_last_layer=False)
+        logits_ref = OD.rev_decoder_forward(key_ref, dec, orth="gram")[0]
+        _, key = bb(crop)
+        logits = model(key)[0].cpu()
+    assert (logits - logits_ref).norm() / logits_ref.norm() < 3e-2
+    assert float(((logits > 0) != (logits_ref > 0)).float().mean()) <= 0.01
+    old = torch.zeros(1, 518, 518)
+    got = loop.look_twice(img, [box], old.clone()).cpu()
+    ref = OLT.look_twice(img, [box], old.clone(), (518, 518), lambda c: logits)
+    assert torch.equal(got, ref)
+
+
 # ------------------------------------------------------------------------------------------------ GPU tail (row N2)
 def _box_str(bx):
     return "none" if bx is None else ";".join(",".join(str(v) for v in b) for b in bx)

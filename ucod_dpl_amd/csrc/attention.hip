@@ -40,13 +40,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_raw* __rest
   const bf16_raw* base = qkv + (size_t)b * N * ld + head * HD;
 
   // Q^T B-operand fragments: lane (q = l31, half h5) holds Q[q][16s + 8*h5 .. +7]
-  bf16x8 qf[4];
+  hx8 qf[4];
   {
     int qr = q0 + l31;
     qr = qr < N ? qr : N - 1;
     const bf16_raw* qp = base + (size_t)qr * ld + 8 * h5;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const hx8*>(qp + 16 * s);
   }
 
   f32x16 o[2];
@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_raw* __rest
       const int row = kt * 32 + l31;
 #pragma unroll
       for (int sd = 0; sd < 4; ++sd) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + row * 128 + swz_k(row, 2 * sd + h5) * 16);
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sd], s[kt], 0, 0, 0);
+        const hx8 kf = *reinterpret_cast<const hx8*>(kb + row * 128 + swz_k(row, 2 * sd + h5) * 16);
+        s[kt] = UCOD_MFMA32(kf, qf[sd], s[kt]);
       }
     }
     if (t == nt - 1) {  // wave-uniform: mask keys >= N
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_raw* __rest
     const float mc = m_new * c;
     m_run = m_new;
     float psum = 0.f;
-    bf16x8 pb[2][2];
+    hx8 pb[2][2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_raw* __rest
         for (int j = 0; j < 8; ++j) {
           const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][8 * ks + j], c, -mc));
           psum += p;
-          pb[kt][ks][j] = (__bf16)p;
+          pb[kt][ks][j] = (half_t)p;
         }
     l_run = l_run * alpha + psum;
 #pragma unroll
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_raw* __rest
         const int key0 = kt * 32 + ks * 16 + 4 * h5;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          bf16x8 vf;
+          hx8 vf;
           if constexpr (VMODE == 0) {
             // ds_read_b64_tr_b16: lane i of each 16-lane group addresses row (i>>2), columns 4*(i&3)..+3 of a
             // 4 x 16 block and receives column i of the 4 rows.
@@ -166,16 +166,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_raw* __rest
             const int ch = dst >> 3, sub = (dst & 7) * 2;
             const char* p0 = vb + key * 128 + swz_v(key, ch) * 16 + sub;
             const char* p1 = vb + (key + 8) * 128 + swz_v(key + 8, ch) * 16 + sub;
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
-            vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const hx4 lo = UCOD_TR16(p0);
+            const hx4 hi = UCOD_TR16(p1);
+            vf = (hx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           } else {
             const bf16_raw* vt = reinterpret_cast<const bf16_raw*>(vb) + (dt * 32 + l31) * VT_STRIDE + key0;
-            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vt);
-            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vt + 8);
-            vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const hx4 lo = *reinterpret_cast<const hx4*>(vt);
+            const hx4 hi = *reinterpret_cast<const hx4*>(vt + 8);
+            vf = (hx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           }
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kt][ks], o[dt], 0, 0, 0);
+          o[dt] = UCOD_MFMA32(vf, pb[kt][ks], o[dt]);
         }
       }
 
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_raw* __rest
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         u32x2 w;
-        w[0] = pack_bf16x2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
-        w[1] = pack_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        w[0] = pack_h2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+        w[1] = pack_h2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
         *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
       }
   }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_raw* __rest
 // compiler inserts no VALU->MFMA-operand wait states behind an asm statement, and the first MFMA that consumes P would
 // read stale registers.)
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef hx2 bf16x2_t;        // (name kept: the packed pair of the build's 16-bit operand type, bf16 by default)
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
   const f32x2_t v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
@@ -243,17 +243,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __r
   const int q0 = qt * QT + wave * 32;
   const bf16_raw* base = qkv + (size_t)b * N * ld + head * HD;
 
-  bf16x8 qf[4];
+  hx8 qf[4];
   {
     int qr = q0 + l31;
     qr = qr < N ? qr : N - 1;
     const bf16_raw* qp = base + (size_t)qr * ld + 8 * h5;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const hx8*>(qp + 16 * s);
   }
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
   const u32x4_t ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+  const hx8 ones = __builtin_bit_cast(hx8, ones_u);
 
   f32x16 o[2], osum;
 #pragma unroll
@@ -351,8 +351,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __r
       for (int i = 0; i < 16; ++i) s[kt][i] = neg_m;
 #pragma unroll
       for (int sd = 0; sd < 4; ++sd) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + koff[kt][sd]);
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sd], s[kt], 0, 0, 0);
+        const hx8 kf = *reinterpret_cast<const hx8*>(kb + koff[kt][sd]);
+        s[kt] = UCOD_MFMA32(kf, qf[sd], s[kt]);
       }
     }
     if (t == nt - 1 && (N & (KT - 1)) != 0) {
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __r
         osum[0] *= alpha;
         lsum *= alpha;
       }
-      bf16x8 pb[2];
+      hx8 pb[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         u32x4_t w;
@@ -400,19 +400,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __r
           if constexpr (VSUM) lsum += e0 + e1;
           w[jj] = cvt_pk_bf16(e0, e1);
         }
-        pb[ks] = __builtin_bit_cast(bf16x8, w);
+        pb[ks] = __builtin_bit_cast(hx8, w);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        if constexpr (!VSUM) osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[ks], osum, 0, 0, 0);
+        if constexpr (!VSUM) osum = UCOD_MFMA32(ones, pb[ks], osum);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const char* p0 = kb + voff[kt][ks][dt];
           const char* p1 = p0 + 8 * 128;
-          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
-          const bf16x8 vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[ks], o[dt], 0, 0, 0);
+          const hx4 lo = UCOD_TR16(p0);
+          const hx4 hi = UCOD_TR16(p1);
+          const hx8 vf = (hx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[dt] = UCOD_MFMA32(vf, pb[ks], o[dt]);
         }
       }
     }
@@ -477,13 +477,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
   const int q0 = qt * QT + wave * 32;
   const bf16_raw* base = qkv + (size_t)b * N * ld + head * HD;
 
-  bf16x8 qf[4];
+  hx8 qf[4];
   {
     int qr = q0 + l31;
     qr = qr < N ? qr : N - 1;
     const bf16_raw* qp = base + (size_t)qr * ld + 8 * h5;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const hx8*>(qp + 16 * s);
   }
 
   // this image's qkv rows as one buffer: byte offsets fit 32 bits, a key row >= N is out of range and reads as zero
@@ -543,8 +543,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
       for (int i = 0; i < 16; ++i) s[kt][i] = neg_m;
 #pragma unroll
       for (int sd = 0; sd < 4; ++sd) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + kt * 4096 + koff[sd]);
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sd], s[kt], 0, 0, 0);
+        const hx8 kf = *reinterpret_cast<const hx8*>(kb + kt * 4096 + koff[sd]);
+        s[kt] = UCOD_MFMA32(kf, qf[sd], s[kt]);
       }
     }
     if (t == nt - 1 && (N & (KT - 1)) != 0) {
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
         }
         lsum *= alpha;
       }
-      bf16x8 pb[2];
+      hx8 pb[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         u32x4 w;
@@ -589,17 +589,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
           lsum += e;
           w[jj] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_t));
         }
-        pb[ks] = __builtin_bit_cast(bf16x8, w);
+        pb[ks] = __builtin_bit_cast(hx8, w);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const char* p0 = kb + (kt * 32 + ks * 16) * 128 + voff[dt];
-          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p0 + 8 * 128));
-          const bf16x8 vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[ks], o[dt], 0, 0, 0);
+          const hx4 lo = UCOD_TR16(p0);
+          const hx4 hi = UCOD_TR16(p0 + 8 * 128);
+          const hx8 vf = (hx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[dt] = UCOD_MFMA32(vf, pb[ks], o[dt]);
         }
     }
   };
@@ -653,17 +653,17 @@ __global__ __launch_bounds__(256, 2) void attn_cross96_kernel(const bf16_raw* __
   const bf16_raw* kbase = kp_ + (size_t)b * Nk * ldkv + head * HDX;
   const bf16_raw* vbase = vp_ + (size_t)b * Nk * ldkv + head * HDX;
 
-  bf16x8 qf[6];
+  hx8 qf[6];
   {
     int qr = q0 + l31;
     qr = qr < Nq ? qr : Nq - 1;
     const bf16_raw* qp = qb + (size_t)qr * ldq + 8 * h5;
 #pragma unroll
-    for (int s = 0; s < 6; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    for (int s = 0; s < 6; ++s) qf[s] = *reinterpret_cast<const hx8*>(qp + 16 * s);
   }
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
   const u32x4_t ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+  const hx8 ones = __builtin_bit_cast(hx8, ones_u);
 
   f32x16 o[3], osum;
 #pragma unroll
@@ -727,8 +727,8 @@ __global__ __launch_bounds__(256, 2) void attn_cross96_kernel(const bf16_raw* __
       for (int i = 0; i < 16; ++i) s[kt][i] = neg_m;
 #pragma unroll
       for (int sd = 0; sd < 6; ++sd) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + koff[kt][sd]);
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sd], s[kt], 0, 0, 0);
+        const hx8 kf = *reinterpret_cast<const hx8*>(kb + koff[kt][sd]);
+        s[kt] = UCOD_MFMA32(kf, qf[sd], s[kt]);
       }
     }
     if (t == nt - 1 && (Nk & (KT - 1)) != 0) {
@@ -762,26 +762,26 @@ __global__ __launch_bounds__(256, 2) void attn_cross96_kernel(const bf16_raw* __
         }
         osum[0] *= alpha;
       }
-      bf16x8 pb[2];
+      hx8 pb[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         u32x4_t w;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
           w[jj] = cvt_pk_bf16(__builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj + 1]));
-        pb[ks] = __builtin_bit_cast(bf16x8, w);
+        pb[ks] = __builtin_bit_cast(hx8, w);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[ks], osum, 0, 0, 0);
+        osum = UCOD_MFMA32(ones, pb[ks], osum);
 #pragma unroll
         for (int dt = 0; dt < 3; ++dt) {
           const char* p0 = kb + voff[kt][ks][dt];
           const char* p1 = p0 + 8 * XROW;
-          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
-          const bf16x8 vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[ks], o[dt], 0, 0, 0);
+          const hx4 lo = UCOD_TR16(p0);
+          const hx4 hi = UCOD_TR16(p1);
+          const hx8 vf = (hx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[dt] = UCOD_MFMA32(vf, pb[ks], o[dt]);
         }
       }
     }

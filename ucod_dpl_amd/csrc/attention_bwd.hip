@@ -360,6 +360,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_raw* __
 
 extern "C" int ucod_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                                   int ld_dqkv, int B, int tok, int heads, void* stream) {
+  UCOD_BF16_ONLY();
   using namespace ucod;
   if (!qkv || !out || !dout || !lse || !delta || !dqkv || B <= 0 || tok <= 0 || heads <= 0 || ld_dqkv < 3 * heads * HD || (ld_dqkv & 3))
     return UCOD_EINVAL;

@@ -22,9 +22,57 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef unsigned short bf16_raw;
 
+// ---- 16-bit operand type of the FORWARD path (GEMM operands, LayerNorm output, attention) ----------------------------------
+// Default build: bf16 (BASELINE configs[1]).  -DUCOD_HALF_F16 builds the same kernels on IEEE fp16 operands (11 significand bits
+// instead of 8; the arithmetic type of the reference's own fp16-autocast launcher): libucod_dpl_f16.so, selected per engine with
+// ViTEngine(half="f16").  Same MFMA rate, same bytes; the backbone-backward entry points are bf16-only and refuse to run there.
+#ifdef UCOD_HALF_F16
+typedef _Float16 half_t;
+#define UCOD_HALF_NAME "f16"
+#define UCOD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define UCOD_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+typedef __fp16 ucod_fp16x4_b __attribute__((__vector_size__(4 * sizeof(__fp16))));    // the builtin's own vector type
+#define UCOD_TR16(p) __builtin_bit_cast(hx4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) ucod_fp16x4_b*)(p)))
+#else
+typedef __bf16 half_t;
+#define UCOD_HALF_NAME "bf16"
+#define UCOD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define UCOD_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define UCOD_TR16(p) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) hx4*)(p))
+#endif
+typedef __attribute__((ext_vector_type(8))) half_t hx8;
+typedef __attribute__((ext_vector_type(4))) half_t hx4;
+typedef __attribute__((ext_vector_type(2))) half_t hx2;
+typedef unsigned short h_raw;
+// backbone-backward entry points: bf16 only (their kernels unpack operands by bit tricks that are bf16-specific)
+#ifdef UCOD_HALF_F16
+#define UCOD_BF16_ONLY() return UCOD_EINVAL
+#else
+#define UCOD_BF16_ONLY() do { } while (0)
+#endif
+
 namespace ucod {
 
 constexpr int WAVE = 64;
+
+__device__ __forceinline__ float h_to_f32(h_raw v) { return (float)__builtin_bit_cast(half_t, v); }
+__device__ __forceinline__ h_raw f32_to_h(float f) { return __builtin_bit_cast(h_raw, (half_t)f); }      // round-to-nearest-even
+// two conversions in one instruction (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
+__device__ __forceinline__ unsigned pack_h2(float lo, float hi) {
+  typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((pk_f32x2){lo, hi}, hx2));
+}
+// the two values of a packed register as f32
+__device__ __forceinline__ void unpack_h2(unsigned w, float& lo, float& hi) {
+#ifdef UCOD_HALF_F16
+  const hx2 v = __builtin_bit_cast(hx2, w);
+  lo = (float)v[0];
+  hi = (float)v[1];
+#else
+  lo = __uint_as_float(w << 16);
+  hi = __uint_as_float(w & 0xFFFF0000u);
+#endif
+}
 
 __device__ __forceinline__ float bf16_to_f32(bf16_raw v) { return __uint_as_float(((unsigned)v) << 16); }
 

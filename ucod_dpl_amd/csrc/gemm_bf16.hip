@@ -139,9 +139,9 @@ template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& a, int m, int n, float v) {
   if (m >= a.M || n >= a.N) return;
   if constexpr (EPI == UCOD_EPI_BIAS_BF16) {
-    reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_bf16((v + a.bias[n]) * (a.scale ? a.scale[n] : 1.f));
+    reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_h((v + a.bias[n]) * (a.scale ? a.scale[n] : 1.f));
   } else if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) {
-    reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_bf16(gelu_erf(v + a.bias[n]));
+    reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_h(gelu_erf(v + a.bias[n]));
   } else if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) {
     const size_t i = (size_t)m * a.N + n;
     reinterpret_cast<float*>(a.out)[i] = a.resid[i] + a.scale[n] * (v + a.bias[n]);
@@ -188,8 +188,8 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& a, int m, int n,
         o = (f32x4){g0[0], g0[1], g1[0], g1[1]};
       }
       u32x2 w;
-      w[0] = pack_bf16x2(o[0], o[1]);
-      w[1] = pack_bf16x2(o[2], o[3]);
+      w[0] = pack_h2(o[0], o[1]);
+      w[1] = pack_h2(o[2], o[3]);
       *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_raw*>(a.out) + (size_t)m * a.N + n) = w;
     } else if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) {
       const size_t i = (size_t)m * a.N + n;
@@ -227,10 +227,10 @@ __device__ __forceinline__ void epilogue_store8_bf16(const GemmArgs& a, int m, i
     o1 = (f32x4){g2[0], g2[1], g3[0], g3[1]};
   }
   u32x4 w;
-  w[0] = pack_bf16x2(o0[0], o0[1]);
-  w[1] = pack_bf16x2(o0[2], o0[3]);
-  w[2] = pack_bf16x2(o1[0], o1[1]);
-  w[3] = pack_bf16x2(o1[2], o1[3]);
+  w[0] = pack_h2(o0[0], o0[1]);
+  w[1] = pack_h2(o0[2], o0[3]);
+  w[2] = pack_h2(o1[0], o1[1]);
+  w[3] = pack_h2(o1[2], o1[3]);
   *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_raw*>(a.out) + (size_t)m * a.N + n) = w;
 }
 
@@ -308,21 +308,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[FI], fb[FI];
+      hx8 fa[FI], fb[FI];
 #pragma unroll
       for (int i = 0; i < FI; ++i) {
         const int r = wr * (T / 2) + i * 16 + (lane & 15);
-        fa[i] = *reinterpret_cast<const bf16x8*>(curA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+        fa[i] = *reinterpret_cast<const hx8*>(curA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
       }
 #pragma unroll
       for (int j = 0; j < FI; ++j) {
         const int r = wc * (T / 2) + j * 16 + (lane & 15);
-        fb[j] = *reinterpret_cast<const bf16x8*>(curB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+        fb[j] = *reinterpret_cast<const hx8*>(curB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
       }
 #pragma unroll
       for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < FI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FI; ++j) acc[i][j] = UCOD_MFMA16(fa[i], fb[j], acc[i][j]);
     }
     if constexpr (!GLDS) {
       if (more) {
@@ -528,10 +528,10 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
           f32x4 v1 = *reinterpret_cast<const f32x4*>(wbase + lrow(it) * (WCOLS * 4) + lchk(it) * 32 + 16);
           if constexpr (SAVE) {                                   // pre-activation out first
             u32x4 w;
-            w[0] = pack_bf16x2(v0[0], v0[1]);
-            w[1] = pack_bf16x2(v0[2], v0[3]);
-            w[2] = pack_bf16x2(v1[0], v1[1]);
-            w[3] = pack_bf16x2(v1[2], v1[3]);
+            w[0] = pack_h2(v0[0], v0[1]);
+            w[1] = pack_h2(v0[2], v0[3]);
+            w[2] = pack_h2(v1[0], v1[1]);
+            w[3] = pack_h2(v1[2], v1[3]);
             __builtin_amdgcn_raw_buffer_store_b128(w, rs_2, at(it, pass), 0, 0);
           }
           if constexpr (SAVE || EPI == UCOD_EPI_BIAS_GELU_BF16) {  // GELU in the row-major layout (fewer live registers than in the C layout)
@@ -544,17 +544,22 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
             const u32x4 pw = pre[pass & 1][it];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const f32x2 x = {__uint_as_float(pw[e] << 16), __uint_as_float(pw[e] & 0xFFFF0000u)};
+              f32x2 x;
+              {
+                float x0, x1;
+                unpack_h2(pw[e], x0, x1);
+                x = (f32x2){x0, x1};
+              }
               const f32x2 g = gelu_grad2(x);
               if (e < 2) { v0[2 * e] *= g[0]; v0[2 * e + 1] *= g[1]; }
               else { v1[2 * (e - 2)] *= g[0]; v1[2 * (e - 2) + 1] *= g[1]; }
             }
           }
           u32x4 w;
-          w[0] = pack_bf16x2(v0[0], v0[1]);
-          w[1] = pack_bf16x2(v0[2], v0[3]);
-          w[2] = pack_bf16x2(v1[0], v1[1]);
-          w[3] = pack_bf16x2(v1[2], v1[3]);
+          w[0] = pack_h2(v0[0], v0[1]);
+          w[1] = pack_h2(v0[2], v0[3]);
+          w[2] = pack_h2(v1[0], v1[1]);
+          w[3] = pack_h2(v1[2], v1[3]);
           __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, at(it, pass), 0, AUX);
           __builtin_amdgcn_sched_barrier(0);                      // keep chunks in order: hoisting every ds_read/cvt of a pass spills in the persistent kernel
         }
@@ -622,18 +627,18 @@ __device__ __forceinline__ void patch_phase(const GemmArgs& a, char* scratch /* 
     // bound by the 64 B/clk/CU of the vector-memory path, 48 rows x K x 2 bytes per patch)
     auto chunk = [&](int s0, auto cnt) {
       constexpr int C = decltype(cnt)::value;
-      bf16x8 fa[C], f0[C], f1[C];
+      hx8 fa[C], f0[C], f1[C];
 #pragma unroll
       for (int i = 0; i < C; ++i) {
         const int st = s0 + 8 * i;
-        fa[i] = *reinterpret_cast<const bf16x8*>(pa + st * 32);
-        f0[i] = *reinterpret_cast<const bf16x8*>(pb0 + st * 32);
-        f1[i] = *reinterpret_cast<const bf16x8*>(pb1 + st * 32);
+        fa[i] = *reinterpret_cast<const hx8*>(pa + st * 32);
+        f0[i] = *reinterpret_cast<const hx8*>(pb0 + st * 32);
+        f1[i] = *reinterpret_cast<const hx8*>(pb1 + st * 32);
       }
 #pragma unroll
       for (int i = 0; i < C; ++i) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], f0[i], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], f1[i], acc1, 0, 0, 0);
+        acc0 = UCOD_MFMA16(fa[i], f0[i], acc0);
+        acc1 = UCOD_MFMA16(fa[i], f1[i], acc1);
       }
     };
     {
@@ -659,8 +664,8 @@ __device__ __forceinline__ void patch_phase(const GemmArgs& a, char* scratch /* 
       if constexpr (kPatchPrefetch<EPI>) {
         if (live) {
           const size_t o = (size_t)om * a.N + on;
-          if constexpr (EPI == UCOD_EPI_BIAS_BF16) reinterpret_cast<bf16_raw*>(a.out)[o] = f32_to_bf16((v + e_bias) * e_scale);
-          else if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) reinterpret_cast<bf16_raw*>(a.out)[o] = f32_to_bf16(gelu_erf(v + e_bias));
+          if constexpr (EPI == UCOD_EPI_BIAS_BF16) reinterpret_cast<bf16_raw*>(a.out)[o] = f32_to_h((v + e_bias) * e_scale);
+          else if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) reinterpret_cast<bf16_raw*>(a.out)[o] = f32_to_h(gelu_erf(v + e_bias));
           else if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) reinterpret_cast<float*>(a.out)[o] = e_resid + e_scale * (v + e_bias);
           else reinterpret_cast<float*>(a.out)[o] = v + e_bias;
         }
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
     const char* bufA = smem + (t & 1) * Cfg::BUF + wm * SLOT_A;
     const char* bufB = smem + (t & 1) * Cfg::BUF + 2 * SLOT_A;
     const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
-    bf16x8 fb[NT][2];
+    hx8 fb[NT][2];
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
       if constexpr (NPH == 4) {
@@ -813,16 +818,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             const int r = wn * 16 * NT + j * 16 + (lane & 15);
-            fb[j][ks] = *reinterpret_cast<const bf16x8*>(bufB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+            fb[j][ks] = *reinterpret_cast<const hx8*>(bufB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
           }
       }
-      bf16x8 fa[IT][2];
+      hx8 fa[IT][2];
 #pragma unroll
       for (int i = 0; i < IT; ++i)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const int r = ph * (128 / NPH) + i * 16 + (lane & 15);
-          fa[i][ks] = *reinterpret_cast<const bf16x8*>(bufA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+          fa[i][ks] = *reinterpret_cast<const hx8*>(bufA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
         }
       if constexpr (STAGGER) {
         // RAW: every wave retires its tile-(t+1) DMAs BEFORE the barrier that precedes the leading group's first read
@@ -840,7 +845,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
         for (int i = 0; i < IT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[ph * IT + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[ph * IT + i][j], 0, 0, 0);
+            acc[ph * IT + i][j] = UCOD_MFMA16(fa[i][ks], fb[j][ks], acc[ph * IT + i][j]);
       __builtin_amdgcn_s_setprio(0);
       if constexpr (!STAGGER) {
         if (ph == NPH - 1) {
@@ -943,7 +948,7 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
     const char* bufA = smem + (t & 1) * Cfg::BUF + wm * Cfg::SLOT;
     const char* bufB = smem + (t & 1) * Cfg::BUF + 2 * Cfg::SLOT;
     const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
-    bf16x8 fb[NT][2];
+    hx8 fb[NT][2];
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
       if constexpr (NPH == 2) {
@@ -960,16 +965,16 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             const int r = wn * 16 * NT + j * 16 + (lane & 15);
-            fb[j][ks] = *reinterpret_cast<const bf16x8*>(bufB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+            fb[j][ks] = *reinterpret_cast<const hx8*>(bufB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
           }
       }
-      bf16x8 fa[IT][2];
+      hx8 fa[IT][2];
 #pragma unroll
       for (int i = 0; i < IT; ++i)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const int r = ph * (IT * 16) + i * 16 + (lane & 15);
-          fa[i][ks] = *reinterpret_cast<const bf16x8*>(bufA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+          fa[i][ks] = *reinterpret_cast<const hx8*>(bufA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
         }
       if (ph == NPH - 1) {                               // RAW: every wave retires its tile-(t+1) DMAs before the barrier ahead of the first read
         if (more2) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
@@ -984,7 +989,7 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
         for (int i = 0; i < IT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[ph * IT + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[ph * IT + i][j], 0, 0, 0);
+            acc[ph * IT + i][j] = UCOD_MFMA16(fa[i][ks], fb[j][ks], acc[ph * IT + i][j]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -1128,7 +1133,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
       const char* bufA = smem + ((t + pb) & 1) * Cfg::BUF + wm * SLOT_A;
       const char* bufB = smem + ((t + pb) & 1) * Cfg::BUF + 2 * SLOT_A;
       const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
-      bf16x8 fb[NT][2];
+      hx8 fb[NT][2];
 #pragma unroll
       for (int ph = 0; ph < 4; ++ph) {
         if (ph == 0 && more1) stageA(t + 1, 0, pb);
@@ -1141,16 +1146,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
               const int r = wn * 16 * NT + j * 16 + (lane & 15);
-              fb[j][ks] = *reinterpret_cast<const bf16x8*>(bufB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+              fb[j][ks] = *reinterpret_cast<const hx8*>(bufB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
             }
         }
-        bf16x8 fa[2][2];
+        hx8 fa[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             const int r = ph * 32 + i * 16 + (lane & 15);
-            fa[i][ks] = *reinterpret_cast<const bf16x8*>(bufA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+            fa[i][ks] = *reinterpret_cast<const hx8*>(bufA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
           }
         if (ph == 3) {
           if (more2) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
@@ -1165,7 +1170,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-              acc[ph * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[ph * 2 + i][j], 0, 0, 0);
+              acc[ph * 2 + i][j] = UCOD_MFMA16(fa[i][ks], fb[j][ks], acc[ph * 2 + i][j]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -1448,5 +1453,6 @@ extern "C" int ucod_gemm_bf16(int epilogue, const void* A, const void* B, void* 
 
 extern "C" int ucod_gemm_bf16_train(int epilogue, const void* A, const void* B, void* out, int M, int N, int K, const float* bias,
                                     const void* aux_bf16, void* out2_bf16, int variant, void* stream) {
+  UCOD_BF16_ONLY();
   return gemm_entry(epilogue, A, B, out, M, N, K, bias, nullptr, nullptr, nullptr, 0, variant, stream, aux_bf16, out2_bf16);
 }

@@ -48,12 +48,12 @@ __global__ __launch_bounds__(256) void cls_qk_kernel(const bf16_raw* __restrict_
   extern __shared__ float x[];                               // LN1(x_cls) as f32
   const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bf16_raw* hr = h + (size_t)b * tok * D;
-  for (int i = threadIdx.x; i < D; i += 256) x[i] = bf16_to_f32(hr[i]);
+  for (int i = threadIdx.x; i < D; i += 256) x[i] = h_to_f32(hr[i]);
   __syncthreads();
   for (int n = wv; n < 2 * D; n += 4) {
     const bf16_raw* wr = w + (size_t)n * D;
     float s = 0.f;
-    for (int i = lane; i < D; i += 64) s += bf16_to_f32(wr[i]) * x[i];
+    for (int i = lane; i < D; i += 64) s += h_to_f32(wr[i]) * x[i];
     s = wave_sum(s) + bias[n];
     if (lane == 0) {
       if (n < D) q[(size_t)b * D + n] = s;

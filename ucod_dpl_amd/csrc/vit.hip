@@ -94,3 +94,5 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
   }
   return UCOD_OK;
 }
+
+extern "C" const char* ucod_half_name(void) { return UCOD_HALF_NAME; }

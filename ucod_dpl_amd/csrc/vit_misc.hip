@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       if constexpr (OUT_F32) {
         reinterpret_cast<float2*>(reinterpret_cast<float*>(y) + (size_t)row * D)[lane + 64 * i] = make_float2(o0, o1);
       } else {
-        reinterpret_cast<unsigned*>(reinterpret_cast<bf16_raw*>(y) + (size_t)row * D)[lane + 64 * i] = pack_bf16x2(o0, o1);
+        reinterpret_cast<unsigned*>(reinterpret_cast<bf16_raw*>(y) + (size_t)row * D)[lane + 64 * i] = pack_h2(o0, o1);
       }
     }
   }
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void layernorm4_kernel(const float* __restrict
         reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + (size_t)row * D)[lane + 64 * i] = make_float4(o0, o1, o2, o3);
       } else {
         u32x2 w;
-        w[0] = pack_bf16x2(o0, o1);
-        w[1] = pack_bf16x2(o2, o3);
+        w[0] = pack_h2(o0, o1);
+        w[1] = pack_h2(o2, o3);
         reinterpret_cast<u32x2*>(reinterpret_cast<bf16_raw*>(y) + (size_t)row * D)[lane + 64 * i] = w;
       }
     }
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
         v[j] = 0.f;
       }
     }
-    reinterpret_cast<unsigned*>(out)[idx] = pack_bf16x2(v[0], v[1]);
+    reinterpret_cast<unsigned*>(out)[idx] = pack_h2(v[0], v[1]);
   }
 }
 
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restric
     const int px = q / chunks, j = q - px * chunks;
     const float* pr = rows + px * P;
     u32x2 w;
-    w[0] = pack_bf16x2(pr[lut[4 * j]], pr[lut[4 * j + 1]]);
-    w[1] = pack_bf16x2(pr[lut[4 * j + 2]], pr[lut[4 * j + 3]]);
+    w[0] = pack_h2(pr[lut[4 * j]], pr[lut[4 * j + 1]]);
+    w[1] = pack_h2(pr[lut[4 * j + 2]], pr[lut[4 * j + 3]]);
     *reinterpret_cast<u32x2*>(obase + (size_t)px * Kpad + 4 * j) = w;
   }
   if (c == C - 1) {                                                      // zero padding K .. Kpad-1 of every patch of the row
@@ -205,7 +205,7 @@ __global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__
 }
 
 __global__ void cast_kernel(const float* __restrict__ s, bf16_raw* __restrict__ d, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = f32_to_bf16(s[i]);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = f32_to_h(s[i]);
 }
 
 }  // namespace ucod

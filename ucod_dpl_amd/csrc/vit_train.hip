@@ -454,6 +454,7 @@ using namespace ucod;
 
 extern "C" int ucod_layernorm_lora(const float* x, const float* gamma, const float* beta, const float* lora, int r, void* y_aug, int rows,
                                    int D, float eps, const ucod_lora_dropout* dropout, void* stream) {
+  UCOD_BF16_ONLY();
   if (!x || !gamma || !beta || !lora || !y_aug || rows <= 0 || D <= 0 || (D % 128) != 0 || r < 1 || 3 * r > AUG) return UCOD_EINVAL;
   if (dropout && (dropout->p < 0.f || dropout->p >= 1.f)) return UCOD_EINVAL;
   UCOD_PROF(PROF_LN, stream);
@@ -492,6 +493,7 @@ static int launch_ln_bwd(const float* dy, const float* x, const float* gamma, co
 
 extern "C" int ucod_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
                                   void* s_bf16, int rows, int D, float eps, void* stream) {
+  UCOD_BF16_ONLY();
   if (!dy || !x || !gamma || (!dx && !s_bf16) || rows <= 0 || D <= 0 || (D % 128) != 0) return UCOD_EINVAL;
   UCOD_PROF(PROF_LN_BWD, stream);
   return launch_ln_bwd(dy, x, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, nullptr, 0, nullptr, 0, make_drop(nullptr), (hipStream_t)stream);
@@ -500,6 +502,7 @@ extern "C" int ucod_layernorm_bwd(const float* dy, const float* x, const float* 
 extern "C" int ucod_layernorm_bwd_lora(const float* dy, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
                                        void* s_bf16, int rows, int D, float eps, const void* dqkv_aug, const float* lora_layer, int r,
                                        const ucod_lora_dropout* dropout, void* stream) {
+  UCOD_BF16_ONLY();
   if (!dy || !x || !gamma || (!dx && !s_bf16) || rows <= 0 || D <= 0 || (D % 128) != 0 || !dqkv_aug || !lora_layer || r < 1 || 3 * r > AUG ||
       !dropout || dropout->p < 0.f || dropout->p >= 1.f)
     return UCOD_EINVAL;
@@ -509,6 +512,7 @@ extern "C" int ucod_layernorm_bwd_lora(const float* dy, const float* x, const fl
 }
 
 extern "C" int ucod_key_grad_tokens(const float* dkey, void* dqkv_aug, int B, int tok, int D, void* stream) {
+  UCOD_BF16_ONLY();
   if (!dkey || !dqkv_aug || B <= 0 || tok < 2 || D <= 0 || (D % 32) != 0) return UCOD_EINVAL;
   UCOD_PROF(PROF_LORA, stream);
   hipLaunchKernelGGL(key_grad_tokens_kernel, dim3(cdiv(tok, 32), B), dim3(256), 0, (hipStream_t)stream, dkey, (bf16_raw*)dqkv_aug, tok, D);
@@ -517,6 +521,7 @@ extern "C" int ucod_key_grad_tokens(const float* dkey, void* dqkv_aug, int B, in
 }
 
 extern "C" int ucod_lora_pack(const float* lora_layer, int r, float scaling, void* w_aug, void* wt_aug, int D, int zero_a_columns, void* stream) {
+  UCOD_BF16_ONLY();
   if (!lora_layer || (!w_aug && !wt_aug) || r < 1 || 3 * r > AUG || D <= 0) return UCOD_EINVAL;
   UCOD_PROF(PROF_LORA, stream);
   const int n = 3 * D * AUG + D * AUG;
@@ -531,6 +536,7 @@ extern "C" size_t ucod_lora_grad_workspace_bytes(int D) { return (size_t)LORA_GR
 extern "C" int ucod_lora_grad(void* dqkv_aug, const void* h_aug, const float* lora_layer, int r, float scaling, float* grad_layer,
                               int accumulate, void* workspace, size_t workspace_bytes, int rows, int D, const ucod_lora_dropout* dropout,
                               void* stream) {
+  UCOD_BF16_ONLY();
   if (!dqkv_aug || !h_aug || !lora_layer || !grad_layer || !workspace || r < 1 || 3 * r > AUG || rows <= 0 || D <= 0 || (D % 128) != 0)
     return UCOD_EINVAL;
   if (dropout && (dropout->p < 0.f || dropout->p >= 1.f)) return UCOD_EINVAL;

@@ -79,6 +79,7 @@ extern "C" size_t ucod_vit_train_workspace_bytes(const ucod_vit_train_desc* t) {
 
 extern "C" int ucod_vit_forward_train(const ucod_vit_train_desc* t, const void* const* T, const void* const* TT, const float* img,
                                       float* key_out, void* workspace, size_t workspace_bytes, void* stream) {
+  UCOD_BF16_ONLY();
   if (!valid(t) || !T || !TT || !img || !key_out || !workspace) return UCOD_EINVAL;
   const ucod_vit_desc* d = &t->vit;
   const TPlan p = make_plan(t);
@@ -129,6 +130,7 @@ extern "C" int ucod_vit_forward_train(const ucod_vit_train_desc* t, const void* 
 
 extern "C" int ucod_vit_backward(const ucod_vit_train_desc* t, const void* const* T, const void* const* TT, const float* dkey,
                                  void* workspace, size_t workspace_bytes, void* stream) {
+  UCOD_BF16_ONLY();
   if (!valid(t) || !T || !TT || !dkey || !workspace) return UCOD_EINVAL;
   const ucod_vit_desc* d = &t->vit;
   const TPlan p = make_plan(t);

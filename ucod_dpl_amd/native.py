@@ -46,6 +46,7 @@ class DiscGrads(C.Structure):
 SIGNATURES = {
     "ucod_abi_version": (ci, []),
     "ucod_device_is_gfx950": (ci, []),
+    "ucod_half_name": (C.c_char_p, []),
     "ucod_prof_enable": (ci, [ci]),
     "ucod_prof_num_classes": (ci, []),
     "ucod_prof_class_name": (C.c_char_p, [ci]),
@@ -113,22 +114,29 @@ SIGNATURES = {
 }
 COD_RECORD = 1032
 
-_lib = None
+LIB_PATH_F16 = os.path.join(_HERE, "_native", "libucod_dpl_f16.so")   # same sources built with -DUCOD_HALF_F16 (fp16 forward-path operands)
+_libs = {}
 
 
-def load():
-    """Load the shared library (once).  Raises if it has not been built -- never falls back."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+def load(half="bf16"):
+    """Load a shared library (once each).  ``half`` selects the build: "bf16" (default, the product path of BASELINE configs[1]) or
+    "f16" (the same kernels on IEEE fp16 operands -- the arithmetic type of the reference's fp16-autocast launcher).
+    Raises if the library has not been built -- never falls back."""
+    if half not in ("bf16", "f16"):
+        raise ValueError(f"half must be 'bf16' or 'f16', got {half!r}")
+    if half not in _libs:
+        path = LIB_PATH if half == "bf16" else LIB_PATH_F16
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               f"or `make -C ucod_dpl_amd/csrc` (hipcc --offload-arch=gfx950). There is no fallback path.")
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        _lib = lib
-    return _lib
+        if lib.ucod_half_name().decode() != half:
+            raise ImportError(f"{path} was built for {lib.ucod_half_name().decode()} operands, expected {half}")
+        _libs[half] = lib
+    return _libs[half]
 
 
 def ptr(t):

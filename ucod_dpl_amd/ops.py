@@ -64,10 +64,12 @@ def patch_im2col(img, P, Kpad):
     return out
 
 
-def cast_bf16(t):
+def cast_bf16(t, lib=None):
+    """f32 -> the 16-bit operand type of ``lib`` (bf16 for the default library, fp16 for the f16 build; round-to-nearest-even)."""
+    lib = lib or N.load()
     t = _f32(t).contiguous()
-    out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
-    check(N.load().ucod_cast_f32_bf16(ptr(t), ptr(out), t.numel(), stream()), "ucod_cast_f32_bf16")
+    out = torch.empty(t.shape, dtype=torch.float16 if lib.ucod_half_name() == b"f16" else torch.bfloat16, device=t.device)
+    check(lib.ucod_cast_f32_bf16(ptr(t), ptr(out), t.numel(), stream()), "ucod_cast_f32_bf16")
     return out
 
 

@@ -99,7 +99,12 @@ def normalize_state_dict(sd):
 class ViTEngine:
     """HIP ViT forward -> last-layer key map [B, D, H/P, W/P] (f32)."""
 
-    def __init__(self, state_dict, heads, eps=1e-6, device="cuda", full_last_layer=False, gemm_variant=0, attn_variant=0):
+    def __init__(self, state_dict, heads, eps=1e-6, device="cuda", full_last_layer=False, gemm_variant=0, attn_variant=0, half="bf16"):
+        """``half``: 16-bit type of the GEMM / attention operands -- "bf16" (default; BASELINE configs[1]) or "f16" (IEEE fp16, what
+        the reference's fp16-autocast launcher computes in: 8x finer rounding, logits within 1e-3 of the f32 reference at full
+        depth; same speed).  Each choice is its own build of the same kernels (native.load)."""
+        self.half = half
+        self.lib = N.load(half)
         c = normalize_state_dict(state_dict)
         self.kind = c["kind"]
         self.device = torch.device(device)
@@ -119,13 +124,13 @@ class ViTEngine:
         self.Kpad = (K + 63) // 64 * 64
         dev = self.device
         f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()  # noqa: E731
-        bf = lambda t: ops.cast_bf16(f32(t))  # noqa: E731
+        bf = lambda t: ops.cast_bf16(f32(t), lib=self.lib)  # noqa: E731
         pw = torch.zeros(self.D, self.Kpad, dtype=torch.float32, device=dev)
         pw[:, :K] = f32(c["patch_w"]).reshape(self.D, K)
         self._keep = []
         self._pos_src = c["pos"].detach().float().cpu()
         self._pos_cache = {}
-        self.patch_w, self.patch_b, self.cls = ops.cast_bf16(pw), f32(c["patch_b"]), f32(c["cls"])
+        self.patch_w, self.patch_b, self.cls = bf(pw), f32(c["patch_b"]), f32(c["cls"])
         ones = torch.ones(self.D, dtype=torch.float32, device=dev)
         self.layers = []
         for l in c["layers"]:
@@ -148,22 +153,26 @@ class ViTEngine:
             self._pos_cache[key] = fn(self._pos_src, gh, gw)[0].to(self.device, torch.float32).contiguous()
         return self._pos_cache[key]
 
-    def _desc(self, B, H, W):
+    def _desc(self, B, H, W, L=None):
         d = N.VitDesc()
         d.B, d.C, d.H, d.W, d.P = B, self.C, H, W, self.P
-        d.D, d.heads, d.F, d.L, d.Kpad = self.D, self.heads, self.F, self.L, self.Kpad
+        d.D, d.heads, d.F, d.L, d.Kpad = self.D, self.heads, self.F, (self.L if L is None else L), self.Kpad
         d.eps = self.eps
         d.full_last_layer = int(self.full_last_layer)
         d.gemm_variant, d.attn_variant = self.gemm_variant, self.attn_variant
         return d
 
-    def forward(self, img, out=None, _async=False):
+    def forward(self, img, out=None, _async=False, n_layers=None):
+        """``n_layers``: stop after that many encoder layers and return THAT layer's key map (diagnostics: the per-layer error
+        table of bench.py); default = the whole backbone."""
+        if n_layers is not None and not 1 <= n_layers <= self.L:
+            raise ValueError(f"n_layers must be in [1, {self.L}]")
         if not img.is_cuda:
             raise RuntimeError("ViTEngine needs a CUDA(ROCm) tensor; there is no CPU path")
         img = img.to(torch.float32).contiguous()
         B, Cc, H, W = img.shape
         gh, gw = H // self.P, W // self.P
-        lib = N.load()
+        lib = self.lib
         pos = self._pos(gh, gw)
         ptrs = [self.patch_w, self.patch_b, self.cls, pos]
         for l in self.layers:
@@ -172,7 +181,7 @@ class ViTEngine:
         key = out if out is not None else torch.empty(B, self.D, gh, gw, dtype=torch.float32, device=self.device)
         ns = max(1, min(int(getattr(self, "streams", 1)), B))
         if ns == 1 and not _async:
-            d = self._desc(B, H, W)
+            d = self._desc(B, H, W, n_layers)
             need = lib.ucod_vit_workspace_bytes(C.byref(d))
             if need == 0:
                 raise ValueError("unsupported ViT geometry")
@@ -194,7 +203,7 @@ class ViTEngine:
         events = []
         for i in range(ns):
             b0, b1 = bounds[i], bounds[i + 1]
-            d = self._desc(b1 - b0, H, W)
+            d = self._desc(b1 - b0, H, W, n_layers)
             need = lib.ucod_vit_workspace_bytes(C.byref(d))
             if need == 0:
                 raise ValueError("unsupported ViT geometry")
@@ -229,7 +238,7 @@ class ViTEngine:
         finally:
             self.streams = ns
         B, _, H, W = img.shape
-        lib = N.load()
+        lib = self.lib
         d = self._desc(B, H, W)
         off = lib.ucod_vit_last_ln1_offset(C.byref(d))
         tok = key.shape[-2] * key.shape[-1] + 1
