@@ -60,12 +60,16 @@ def make_cfg(fs=68, dim=768):
     return cfg
 
 
-def which_config(arch, image, batch):
+def which_config(arch, image, batch, attn_variant=2):
     """Label of the BASELINE.json configuration a command line corresponds to (configs[1] is the one the metric is quoted on)."""
     table = {("dinov2_vitb14", 518, 32): "BASELINE configs[1]", ("dino_vits8", 224, 2): "BASELINE configs[0] geometry (full step instead of decoder only)",
              ("dinov2_vitl14", 518, 16): "BASELINE configs[3] per-GPU geometry (first stage)",
-             ("dinov2_vitb14", 518, 64): "BASELINE configs[4] geometry on the bf16 attention path (the fp8 path is not built, DESIGN.md section 7)"}
-    return table.get((arch, image, batch), "non-BASELINE geometry")
+             ("dinov2_vitb14", 518, 64): "BASELINE configs[4] geometry on the bf16 attention path (--attn-variant 8 selects the fp8 path)"}
+    label = table.get((arch, image, batch), "non-BASELINE geometry")
+    if attn_variant == 8:
+        label = ("BASELINE configs[4] (fp8 e4m3 attention path on v_mfma_scale_f32_32x32x64_f8f6f4)" if (arch, image, batch) == ("dinov2_vitb14", 518, 64)
+                 else label + " with the fp8 attention path")
+    return label
 
 
 def algorithmic_work(name, B, tok, D, F, heads, Kpad, C_dec, HW):
@@ -350,7 +354,7 @@ def main():
         "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.half, "data": "synthetic",
-        "config": {"workload": f"{which_config(a.arch, a.image, B)}: {a.arch} @{a.image}x{a.image}, batch {B}/GPU, full APM+DBA+discriminator step, "
+        "config": {"workload": f"{which_config(a.arch, a.image, B, a.attn_variant)}: {a.arch} @{a.image}x{a.image}, batch {B}/GPU, full APM+DBA+discriminator step, "
                                f"decoder path exact f32, backbone {a.half} MFMA", "global_batch": B * world, "parallelism": f"dp{world}",
                    "backbone_last_layer": "full (as reference)" if a.full_last_layer else "key-minimal (identical key output; 279.6 of 303.1 GFLOP/img)",
                    "random_init_weights": True,

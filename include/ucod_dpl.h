@@ -95,6 +95,18 @@ int ucod_layernorm(const float* x, const float* gamma, const float* beta, void* 
 int ucod_attention_fwd(const void* qkv_bf16, void* out_bf16, int B, int tok, int heads, float scale, int variant,
                        void* stream);
 
+/* The same attention with Q, K, V and the probabilities quantised to OCP e4m3 and both products on the block-scaled CDNA4 matrix
+ * instruction v_mfma_scale_f32_32x32x64_f8f6f4 (BASELINE.json configs[4], the "fp8 attention path"; same reference lines as above).
+ * qkv is the QKV projection's 16-bit output with Q pre-scaled by head_dim^-0.5 * log2(e) (as for scale == 0 above).  A first kernel
+ * writes Q8 / K8 [B*heads][Npad][64] and the per-tile transposed Vt8 into `workspace` (ucod_attention_fp8_workspace_bytes), each
+ * tensor multiplied by 2^q_exp / 2^k_exp / 2^v_exp before rounding (clamped to +-448); the inverse powers of two ride on the
+ * instruction's E8M0 block scales.  ucod_vit_forward takes this path for attn_variant == 8 with (q_exp, k_exp, v_exp) = (5, 3, 3).
+ * Tolerance (tests/test_gpu_fp8_attention.py): exact on e4m3-representable inputs; relative L2 <= 1e-1 against the f32 softmax
+ * attention on Gaussian inputs (7.2e-2 measured: the error of a 64-term e4m3 score in the exponent). */
+size_t ucod_attention_fp8_workspace_bytes(int B, int tok, int heads);
+int ucod_attention_fwd_fp8(const void* qkv_bf16, void* out_bf16, void* workspace, size_t workspace_bytes, int B, int tok, int heads,
+                           int q_exp, int k_exp, int v_exp, void* stream);
+
 /* patch gather: img f32 [B,C,H,W] -> bf16 rows [B*(H/P)*(W/P), Kpad], k = c*P*P + py*P + px, zero padded
  * (the im2col view of the stride-P conv, modeling_dinov2.py:139-149 / dino.py:154-158).  Kpad % 64 == 0. */
 int ucod_patch_im2col(const float* img, void* patches_bf16, int B, int C, int H, int W, int P, int Kpad, void* stream);

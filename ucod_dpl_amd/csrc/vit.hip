@@ -8,7 +8,7 @@
 namespace {
 
 struct Plan {
-  size_t off_x, off_h, off_qkv, off_a, off_g, off_patch, off_qscale, total;
+  size_t off_x, off_h, off_qkv, off_a, off_g, off_patch, off_qscale, off_f8, f8_bytes, total;
   int M, tok;
 };
 
@@ -28,6 +28,8 @@ Plan make_plan(const ucod_vit_desc* d) {
   p.off_g = take((size_t)p.M * d->F * 2);
   p.off_patch = take((size_t)d->B * gh * gw * d->Kpad * 2);
   p.off_qscale = take((size_t)3 * d->D * 4);
+  p.f8_bytes = d->attn_variant == 8 ? ucod_attention_fp8_workspace_bytes(d->B, p.tok, d->heads) : 0;   // Q8 | K8 | Vt8 of the fp8 attention path
+  p.off_f8 = take(p.f8_bytes);
   p.total = o;
   return p;
 }
@@ -64,7 +66,8 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
   const int M = p.M, tok = p.tok, D = d->D, F = d->F, gv = d->gemm_variant, av = d->attn_variant;
   const float scale = 0.125f;  // head_dim^-0.5, head_dim = 64
   // attn_variant 2: fold head_dim^-0.5 * log2(e) into the Q third of the QKV epilogue (before its bf16 rounding)
-  const bool prescale = (av == 2);
+  // attn_variant 8: the fp8 (e4m3, block-scaled MFMA) attention path of BASELINE configs[4]; same pre-scaled Q
+  const bool prescale = (av == 2 || av == 8);
   float* qscale = (float*)(ws + p.off_qscale);
   if (prescale) RUN(ucod_fill_qscale(qscale, D, scale * 1.4426950408889634f, stream));
 
@@ -86,7 +89,8 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
       if (!d->full_last_layer) break;
     }
     RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_BF16, h, W[2], qkv, M, 3 * D, D, (const float*)W[3], prescale ? qscale : nullptr, nullptr, nullptr, tok, gv, stream));
-    RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, prescale ? 0.f : scale, av, stream));
+    if (av == 8) RUN(ucod_attention_fwd_fp8(qkv, a, ws + p.off_f8, p.f8_bytes, d->B, tok, d->heads, 5, 3, 3, stream));
+    else RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, prescale ? 0.f : scale, av, stream));
     RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_SCALE_RESID_F32, a, W[4], x, M, D, D, (const float*)W[5], (const float*)W[6], x, nullptr, tok, gv, stream));
     RUN(ucod_layernorm(x, (const float*)W[7], (const float*)W[8], h, M, D, d->eps, 0, stream));
     RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_GELU_BF16, h, W[9], g, M, F, D, (const float*)W[10], nullptr, nullptr, nullptr, tok, gv, stream));

@@ -54,6 +54,8 @@ SIGNATURES = {
     "ucod_gemm_bf16": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
     "ucod_layernorm": (ci, [vp, vp, vp, vp, ci, ci, cf, ci, vp]),
     "ucod_attention_fwd": (ci, [vp, vp, ci, ci, ci, cf, ci, vp]),
+    "ucod_attention_fp8_workspace_bytes": (sz, [ci, ci, ci]),
+    "ucod_attention_fwd_fp8": (ci, [vp, vp, vp, sz, ci, ci, ci, ci, ci, ci, vp]),
     "ucod_patch_im2col": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "ucod_cls_rows": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "ucod_fill_qscale": (ci, [vp, ci, cf, vp]),

@@ -57,6 +57,16 @@ def attention(qkv, B, tok, heads, scale=0.125, variant=0):
     return out
 
 
+def attention_fp8(qkv, B, tok, heads, q_exp=5, k_exp=3, v_exp=3):
+    """The fp8 (e4m3, block-scaled MFMA) attention path of BASELINE configs[4]; ``qkv`` bf16 with Q pre-scaled by hd^-1/2 * log2 e."""
+    lib = N.load()
+    out = torch.empty(B * tok, heads * 64, dtype=torch.bfloat16, device=qkv.device)
+    ws = torch.empty(lib.ucod_attention_fp8_workspace_bytes(B, tok, heads), dtype=torch.uint8, device=qkv.device)
+    check(lib.ucod_attention_fwd_fp8(ptr(_bf16(qkv)), ptr(out), ptr(ws), ws.numel(), B, tok, heads, q_exp, k_exp, v_exp, stream()),
+          "ucod_attention_fwd_fp8")
+    return out
+
+
 def patch_im2col(img, P, Kpad):
     B, Cc, H, W = img.shape
     out = torch.empty(B * (H // P) * (W // P), Kpad, dtype=torch.bfloat16, device=img.device)
