@@ -96,7 +96,7 @@ def launch_ranks(a):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < a.gpus:
+    if have < a.gpus and os.environ.get("UCOD_SINGLE_DEVICE") != "1":
         raise SystemExit(f"bench.py: --gpus {a.gpus} requested but this node exposes {have} GPU(s)")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -118,6 +118,8 @@ def main():
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {a.gpus}: launch with --nproc-per-node equal to --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path is HIP-only)")
+    from ucod_dpl_amd import parallel
+    local_rank = parallel.device_index()                      # = LOCAL_RANK (UCOD_SINGLE_DEVICE=1: test rigs with one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -328,7 +330,7 @@ def main():
     dom = max((n for n in kernels if "tflops" in kernels[n] and n.startswith(("gemm_bf16", "attention"))),
               key=lambda n: kernels[n]["ms_per_step"])
     traffic = None                                            # HBM-side bytes per launch from committed PMC passes (see the file's "source")
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if os.path.exists(tpath) and a.arch == "dinov2_vitb14" and B == 32 and a.image == 518:
         traffic = json.load(open(tpath)).get("kernels", {}).get(dom, {}).get("traffic_bytes")
     roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -396,7 +398,8 @@ def cpu_baseline(a, D, heads, L, P):
     # (an error here is an error of the bench -- non-zero exit -- never a green line)
     from ucod_dpl_amd import ops
     from ucod_dpl_amd.vit_engine import ViTEngine
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    from ucod_dpl_amd import parallel
+    dev = torch.device("cuda", parallel.device_index())
     layer_ref = list(OV.dinov2_forward.layer_keys)             # the key hook's map after every layer, f32 oracle
     emb = dec["learnable_embedding"].reshape(128).to(dev)
     hw = torch.cat((dec["conv_out_fg.weight"].reshape(64), dec["conv_out_bg.weight"].reshape(64))).to(dev)

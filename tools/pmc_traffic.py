@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r01_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the serial bench run.
+"""profiles/rNN_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the serial bench run.
 
 usage: pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <state label> > profiles/r01_pmc_traffic.json
 bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950
@@ -8,8 +8,8 @@ import collections, csv, glob, json, os, sys
 
 CLASSES = {                                  # bench.py kernel class -> substring of the kernel name
     "gemm_bf16_proj_fc2_scale_resid": "gemm_bf16_big_kernel<2,",
-    "gemm_bf16_fc1_gelu": "gemm_bf16_big_kernel<1,",
-    "gemm_bf16_qkv_bias": "gemm_bf16_big_kernel<0,",
+    "gemm_bf16_fc1_gelu": "gemm_bf16_mixed_kernel<1,",
+    "gemm_bf16_qkv_bias": "gemm_bf16_mixed_kernel<0,",
     "attention_fwd": "attn_fwd_v5_kernel",
     "layernorm": "layernorm",
 }
@@ -33,7 +33,7 @@ def mean_per_kernel(d, counter):
 fetch, names = mean_per_kernel(sys.argv[1], "FETCH_SIZE")
 write, _ = mean_per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no tracing domains) over `bench.py --steps 2 --warmup 1 "
-                 "--no-cpu-baseline --lora-steps 0 --no-pipeline --streams 1`, MI355X, round-1 state '%s'; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+                 "--no-cpu-baseline --lora-steps 0 --no-pipeline --streams 1`, MI355X, state '%s'; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                  "launch: FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950 (MI355X_MICROARCH.md, HBM section); FETCH_SIZE counts "
                  "L2 fabric requests, Infinity-Cache hits included, so this is an upper bound on HBM traffic; made by tools/pmc_traffic.py" % sys.argv[3],
        "kernels": {}}

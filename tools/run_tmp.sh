@@ -1,9 +1,7 @@
-python -m pytest tests/test_gpu_fp8_attention.py -x -q 2>&1 | grep -E "^E|passed|failed|assert" | head -20
-for av in 2 8; do
-python bench.py --steps 10 --warmup 3 --batch 64 --attn-variant $av --lora-steps 0 --no-cpu-baseline > gpurun_out/bench_b64_av$av.json 2> gpurun_out/bench_b64_av$av.err || tail -3 gpurun_out/bench_b64_av$av.err
-python - <<PY
+python bench.py > gpurun_out/bench_r02c.json 2> gpurun_out/bench_r02c.err; tail -2 gpurun_out/bench_r02c.err
+bash tools/refresh_evidence.sh r02c > gpurun_out/refresh_r02c.log 2>&1; tail -5 gpurun_out/refresh_r02c.log
+python - <<'PY'
 import json
-d=json.load(open("gpurun_out/bench_b64_av$av.json")); k=d["kernels"]
-print("av=$av", d["config"]["workload"][:60], d["value"], d["roofline"]["serial_ms_per_step_without_events"], {n:k[n]["avg_us"] for n in ("gemm_bf16_qkv_bias","attention_fwd","layernorm")})
+d=json.load(open("gpurun_out/bench_r02c.json"))
+print(d["value"], d["ms_per_step"], d["roofline"]["achieved"], d["roofline"]["kernel"], d["f16_operands_option"], d["backbone_backward_mode"])
 PY
-done

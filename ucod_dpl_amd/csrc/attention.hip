@@ -462,8 +462,18 @@ __device__ __forceinline__ float xhalf_max(float v) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// ONE_DECISION: one deferred-rescale decision per 64-key tile (maximum over both 32-key blocks) instead of one per block: one
+// branch less per tile, and the second block's exponentials share a basic block with the first block's P V products, so the
+// compiler can overlap them inside a wave (VALU beside MFMA) instead of leaving all overlap to the other waves of the SIMD.
+template <bool ONE_DECISION, int STAGGER = 0>
 __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N, int heads,
                                                               int npairs, float* __restrict__ lse) {
+  // STAGGER (experiment): co-resident workgroups run the same phases (Q K^T, softmax, P V) at the same time unless something sets them
+  // apart; delaying every other workgroup by about half a tile at the start tests how much of the missing MFMA / VALU overlap that is
+  if constexpr (STAGGER > 0) {
+    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_sleep(STAGGER);
+    if ((blockIdx.x >> 4) & 1) __builtin_amdgcn_s_sleep(STAGGER / 2);
+  }
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_BYTES];       // [buffer][K | V]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -557,15 +567,39 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
           if (key >= N) s[kt][r] = -1e30f;
         }
     }
+    if constexpr (ONE_DECISION) {
+      float mloc = __builtin_elementwise_maximum(s[0][0], s[0][1]);
+#pragma unroll
+      for (int r = 2; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[0][r]), s[0][r + 1]);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[1][r]), s[1][r + 1]);
+      const bool first = (t == 0);
+      if (first || __any(mloc > DEFER_THR)) {
+        mloc = xhalf_max(mloc);
+        const float delta = first ? mloc : fmaxf(mloc, 0.f);
+        const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+        m_run += delta;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          s[0][i] -= delta;
+          s[1][i] -= delta;
+          o[0][i] *= alpha;
+          o[1][i] *= alpha;
+        }
+        lsum *= alpha;
+      }
+    }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       // v_maximum3_f32 (IEEE maximum: no operand canonicalisation), two scores per instruction.  The lane's 16 keys are enough
       // for the wave-wide "does any score run away" test; the other half's keys are fetched only when the rescale fires.
-      float mloc = __builtin_elementwise_maximum(s[kt][0], s[kt][1]);
+      float mloc = ONE_DECISION ? 0.f : __builtin_elementwise_maximum(s[kt][0], s[kt][1]);
+      if constexpr (!ONE_DECISION) {
 #pragma unroll
-      for (int r = 2; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[kt][r]), s[kt][r + 1]);
+        for (int r = 2; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[kt][r]), s[kt][r + 1]);
+      }
       const bool first = (t == 0 && kt == 0);
-      if (first || __any(mloc > DEFER_THR)) {
+      if (!ONE_DECISION && (first || __any(mloc > DEFER_THR))) {
         mloc = xhalf_max(mloc);
         const float delta = first ? mloc : fmaxf(mloc, 0.f);
         const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
@@ -822,8 +856,14 @@ extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, in
       hipLaunchKernelGGL((attn_fwd_v2_kernel<false>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
     else if (variant == 6)
       hipLaunchKernelGGL((attn_fwd_v2_kernel<true, true>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
+    else if (variant == 10)
+      hipLaunchKernelGGL((attn_fwd_v5_kernel<true, 8>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
+    else if (variant == 11)
+      hipLaunchKernelGGL((attn_fwd_v5_kernel<true, 16>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
+    else if (variant == 7)                               // v5 with one rescale decision per 64-key tile
+      hipLaunchKernelGGL(attn_fwd_v5_kernel<true>, grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
     else                                                 // 0 / 2 / 5: the trimmed-issue kernel (buffer DMA, constant LDS offsets), 7-10 % faster than 6
-      hipLaunchKernelGGL(attn_fwd_v5_kernel, grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
+      hipLaunchKernelGGL(attn_fwd_v5_kernel<false>, grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
     UCOD_CHECK_LAUNCH();
     return UCOD_OK;
   }
@@ -852,7 +892,7 @@ extern "C" int ucod_attention_fwd_lse(const void* qkv, void* out, float* lse, in
   if (!qkv || !out || !lse || B <= 0 || tok <= 0 || heads <= 0) return UCOD_EINVAL;
   UCOD_PROF(PROF_ATTN, stream);
   const int npairs = B * heads, nq = cdiv(tok, QT);
-  hipLaunchKernelGGL(attn_fwd_v5_kernel, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs,
+  hipLaunchKernelGGL(attn_fwd_v5_kernel<false>, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs,
                      lse);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;

@@ -47,8 +47,8 @@ class StandardRunner:
             raise RuntimeError("StandardRunner needs a GPU: the hot path is HIP-only (no CPU fallback)")
         native.load()
         self.rank, self.local_rank, self.world_size = parallel.env_world()
-        torch.cuda.set_device(self.local_rank)
-        self.device = torch.device("cuda", self.local_rank) if device is None else torch.device(device)
+        torch.cuda.set_device(parallel.device_index())
+        self.device = torch.device("cuda", parallel.device_index()) if device is None else torch.device(device)
         parallel.init_from_env("nccl")                         # RCCL over xGMI; no-op on one GPU
         self.logger = Logger(self.rank, config.log_cfg.get("multi_rank", [0]))
         self.train_dataloader = train_dataloader if train_dataloader is not None else []

@@ -23,9 +23,18 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def device_index():
+    """GPU of this rank: LOCAL_RANK (one process per GPU).  UCOD_SINGLE_DEVICE=1 (test rigs with ONE GPU) puts every rank on device 0,
+    which together with UCOD_DIST_BACKEND=gloo lets the whole multi-rank path -- broadcast at construction, the asynchronous
+    all-reduce inside the step, bench.py's launcher and max-over-ranks timing -- run on a one-GPU box (RCCL itself refuses two ranks
+    on one device; the product launch uses neither variable)."""
+    return 0 if os.environ.get("UCOD_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+
+
 def init_from_env(backend="nccl"):
     """Initialise the default process group from torchrun's environment (no-op for world_size 1)."""
     rank, local_rank, world = env_world()
+    backend = os.environ.get("UCOD_DIST_BACKEND", backend)
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
