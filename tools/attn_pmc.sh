@@ -1,26 +1,29 @@
 #!/bin/bash
-# PMC passes over the attention micro-benchmark (variant 2 = attn_fwd_v5_kernel, the product path).  Run on the GPU box from the repo
-# root: bash tools/attn_pmc.sh > profiles/rNN_attention_pmc.txt      (separate --pmc passes, no tracing domains)
+# PMC passes over the attention micro-benchmark.  Run on the GPU box from the repo root:
+#   bash tools/attn_pmc.sh [variant] [kernel-name substring] > profiles/rNN_attention_pmc.txt
+# defaults: variant 2 = attn_fwd_v5_kernel, the product path; 9 + attn_fwd_pp = the 8-wave ping-pong form.  Separate --pmc passes.
+V=${1:-2}; KN=${2:-attn_fwd_v5}; export KN
 R=$PWD; cd /tmp; export TMPDIR=/tmp
 rm -rf $R/gpurun_out/attn_pmc
 for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_LEVEL_WAVES SQ_INSTS_VALU_TRANS_F32" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_BUSY_CU_CYCLES"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/attn_pmc/$tag -- python3 $R/tools/attn_bench.py 2 3 > /dev/null 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/attn_pmc/$tag -- python3 $R/tools/attn_bench.py $V 3 > /dev/null 2>&1
 done
 cd $R; python3 - <<'PY'
-import csv, glob, collections
+import csv, glob, collections, os
+KN = os.environ['KN']
 agg = collections.defaultdict(list)
 dur = []
 for f in glob.glob("gpurun_out/attn_pmc/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "attn_fwd_v5" in r["Kernel_Name"]:
+        if KN in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob("gpurun_out/attn_pmc/*/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
-        if "attn_fwd_v5" in r["Kernel_Name"]:
+        if KN in r["Kernel_Name"]:
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
 m = {k: sum(v) / len(v) for k, v in agg.items()}
-print("# attention forward (attn_fwd_v5_kernel) at C2: B=32, 12 heads, N=1370, head_dim 64; means per launch over the profiled launches")
+print(f"# attention forward ({KN} kernel) at C2: B=32, 12 heads, N=1370, head_dim 64; means per launch over the profiled launches")
 for k in sorted(m):
     print(f"{k:32s} n={len(agg[k]):3d} mean={m[k]:.6g}")
 us = sum(dur) / max(1, len(dur))

@@ -665,6 +665,226 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
 
 
 // =====================================================================================================
+// pp ("ping-pong"): the v5 arithmetic in an 8-wave workgroup whose two wave groups run half a tile apart.
+// One workgroup = 256 query rows = two 128-row groups A (waves 0-3) and B (waves 4-7); wave w and wave w + 4 share a SIMD.  A tile
+// is processed in two segments separated by workgroup barriers:
+//     M(t): O^T += V(t-1)^T P(t-1)   then   S(t)^T = K(t) Q^T - m      16 MFMAs, (almost) no VALU
+//     V(t): deferred max, 32 x exp2, bf16 pack, row sums                no MFMA
+// and B runs one segment behind A: while A's wave on a SIMD is in M(t) its partner is in V(t-1), so the matrix pipe and the vector
+// ALU of every SIMD are both busy by construction instead of by chance (with four independent 4-wave workgroups per CU the v5
+// kernel leaves that overlap to the hardware's arbitration: matrix pipe 0.51 busy, vector issue 0.69 busy,
+// profiles/r02_attention_pmc.txt).  K / V tiles are DMA'd once per 256 rows (half the LDS-DMA traffic per FLOP of v5).
+// Segment clock s (one barrier each): A runs M(t) at s = 2t, V(t) at 2t + 1; B runs M(t) at 2t + 1, V(t) at 2t + 2.
+//   DMA batch u = {K(u+1), V(u)} is issued by ALL waves at the top of s = 2u (A: start of M(u); B: start of V(u-1)) and every wave
+//   waits for its own part (vmcnt(0)) before the barrier that ends s = 2u + 1; first read at s = 2u + 2 (A's M(u+1)).
+//   WAR: K(u+1) lands in the buffer of K(u-1) and V(u) in the buffer of V(u-2), both last read by B's M(u-1) at s = 2u - 1.
+// =====================================================================================================
+constexpr int QT2 = 256;
+
+template <bool ONE_PRIO>
+__global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N, int heads,
+                                                              int npairs) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * KV_BYTES];       // K ring [2] | V ring [2]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                             // 0 = A (leads), 1 = B (one segment behind)
+  const int h5 = lane >> 5, l31 = lane & 31;
+  const int nq = (N + QT2 - 1) / QT2;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pair = (slot / nq) * 8 + xcd, qt = slot - (slot / nq) * nq;
+  if (pair >= npairs) return;
+  const int head = pair % heads, b = pair / heads;
+  const int D = heads * HD, ld = 3 * D;
+  const int q0 = qt * QT2 + wave * 32;                   // group A: rows 0..127 of the block, group B: 128..255
+  const bf16_raw* base = qkv + (size_t)b * N * ld + head * HD;
+
+  hx8 qf[4];
+  {
+    int qr = q0 + l31;
+    qr = qr < N ? qr : N - 1;
+    const bf16_raw* qp = base + (size_t)qr * ld + 8 * h5;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const hx8*>(qp + 16 * s);
+  }
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(qkv + (size_t)b * N * ld), 0, (unsigned)N * (unsigned)ld * 2u, 0x00020000);
+  // one 16-byte chunk of K and one of V per thread and tile: row = wave * 8 + lane / 8 (0..63), chunk = lane & 7
+  unsigned sk, sv;
+  {
+    const int row = wave * 8 + (lane >> 3), ch = lane & 7;
+    sk = (unsigned)(row * ld + D + head * HD + swz_k(row, ch) * 8) * 2u;
+    sv = (unsigned)(row * ld + 2 * D + head * HD + swz_v(row, ch) * 8) * 2u;
+  }
+  const unsigned tile_step = (unsigned)(KT * ld) * 2u;
+  char* const kring = smem;
+  char* const vring = smem + 2 * KV_BYTES;
+  auto dma_k = [&](int buf, unsigned off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(kring + buf * KV_BYTES + wave * 1024), 16, off, 0, 0, 0);
+  };
+  auto dma_v = [&](int buf, unsigned off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(vring + buf * KV_BYTES + wave * 1024), 16, off, 0, 0, 0);
+  };
+  const int nt = (N + KT - 1) / KT;
+  // batch u = {K(u+1), V(u)}; rows past the last token fail the range check and arrive as zeros
+  auto batch = [&](int u) {
+    if (u + 1 < nt) dma_k((u + 1) & 1, sk + (unsigned)(u + 1) * tile_step);
+    if (u < nt) dma_v(u & 1, sv + (unsigned)u * tile_step);
+  };
+
+  int koff[4], voff[2];
+#pragma unroll
+  for (int sd = 0; sd < 4; ++sd) koff[sd] = l31 * 128 + swz_k(l31, 2 * sd + h5) * 16;
+  {
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    const int key = 4 * h5 + (i16 >> 2);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int dst = dt * 32 + g1 * 16 + 4 * (i16 & 3);
+      voff[dt] = key * 128 + swz_v(key, dst >> 3) * 16 + (dst & 7) * 2;
+    }
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m_run = 0.f;
+  f32x2_t lsum = {0.f, 0.f};
+  f32x16 s[2];
+  hx8 pb[2][2];                                          // P(t) as the B operand of the next M segment: [32-key block][16-key step]
+
+  auto wait_dma = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  auto seg_m = [&](int t) {                              // P V of tile t-1, then Q K^T of tile t
+    if (t > 0) {
+      const char* vb = vring + ((t - 1) & 1) * KV_BYTES;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const char* p0 = vb + (kt * 32 + ks * 16) * 128 + voff[dt];
+            const hx4 lo = UCOD_TR16(p0);
+            const hx4 hi = UCOD_TR16(p0 + 8 * 128);
+            const hx8 vf = (hx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[dt] = UCOD_MFMA32(vf, pb[kt][ks], o[dt]);
+          }
+    }
+    if (t < nt) {
+      const char* kb = kring + (t & 1) * KV_BYTES;
+      const float neg_m = -m_run;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[kt][i] = neg_m;
+#pragma unroll
+        for (int sd = 0; sd < 4; ++sd) {
+          const hx8 kf = *reinterpret_cast<const hx8*>(kb + kt * 4096 + koff[sd]);
+          s[kt] = UCOD_MFMA32(kf, qf[sd], s[kt]);
+        }
+      }
+    }
+  };
+  auto seg_v = [&](int t) {                              // softmax of tile t: s -> pb, lsum, (rare) rescale of o
+    if (t == nt - 1 && (N & (KT - 1)) != 0) {
+      const int kbase = t * KT + 4 * h5;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + kt * 32 + (r & 3) + 8 * (r >> 2);
+          if (key >= N) s[kt][r] = -1e30f;
+        }
+    }
+    float mloc = __builtin_elementwise_maximum(s[0][0], s[0][1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[0][r]), s[0][r + 1]);
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[1][r]), s[1][r + 1]);
+    const bool first = (t == 0);
+    if (first || __any(mloc > DEFER_THR)) {
+      mloc = xhalf_max(mloc);
+      const float delta = first ? mloc : fmaxf(mloc, 0.f);
+      const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+      m_run += delta;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s[0][i] -= delta;
+        s[1][i] -= delta;
+        o[0][i] *= alpha;
+        o[1][i] *= alpha;
+      }
+      lsum *= alpha;
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 w;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const f32x2_t e = {__builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj + 1])};
+          lsum += e;
+          w[jj] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_t));
+        }
+        pb[kt][ks] = __builtin_bit_cast(hx8, w);
+      }
+  };
+
+  // prologue: K(0) for everyone, then the segment clock starts
+  dma_k(0, sk);
+  wait_dma();
+  bar();
+  if (ONE_PRIO && grp == 1) __builtin_amdgcn_s_setprio(1);  // the later-dispatched half loses VALU arbitration by age: static priority
+  if (grp == 0) {
+    for (int u = 0; u < nt; ++u) {
+      batch(u);                                            // s = 2u
+      seg_m(u);
+      bar();
+      seg_v(u);                                            // s = 2u + 1
+      wait_dma();
+      bar();
+    }
+    seg_m(nt);                                             // s = 2 nt: the last P V
+    bar();
+  } else {
+    batch(0);                                              // s = 0
+    bar();
+    for (int u = 0; u < nt; ++u) {
+      seg_m(u);                                            // s = 2u + 1
+      wait_dma();
+      bar();
+      batch(u + 1);                                        // s = 2u + 2
+      seg_v(u);
+      bar();
+    }
+    seg_m(nt);
+  }
+
+  const float lane_sum = lsum[0] + lsum[1];
+  const float denom = lane_sum + __shfl_xor(lane_sum, 32, 64);
+  const float inv = 1.0f / denom;
+  const int q = q0 + l31;
+  if (q < N) {
+    bf16_raw* op = out + ((size_t)b * N + q) * D + head * HD + 4 * h5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w;
+        w[0] = cvt_pk_bf16(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+        w[1] = cvt_pk_bf16(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
+      }
+  }
+}
+
+
+// =====================================================================================================
 // Cross-attention, head_dim 96 (CORAL refiner: nn.MultiheadAttention with 8 heads on C=768, models/modules/mlp.py:122,143).
 // Same structure as attn_fwd_v2_kernel (pre-scaled Q, accumulator initialised with -m, per-half deferred max, denominator on
 // the matrix pipe, V through ds_read_b64_tr_b16) with separate query / key-value sources and lengths.  LDS rows are padded
@@ -856,7 +1076,12 @@ extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, in
       hipLaunchKernelGGL((attn_fwd_v2_kernel<false>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
     else if (variant == 6)
       hipLaunchKernelGGL((attn_fwd_v2_kernel<true, true>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
-    else if (variant == 10)
+    else if (variant == 9 || variant == 12) {              // 8-wave ping-pong (256 query rows per workgroup); 12 = with static priority for group B
+      const int nq2 = cdiv(tok, QT2);
+      dim3 grid2(cdiv(npairs, 8) * 8 * nq2), block2(512);
+      if (variant == 9) hipLaunchKernelGGL((attn_fwd_pp_kernel<false>), grid2, block2, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs);
+      else hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), grid2, block2, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs);
+    } else if (variant == 10)
       hipLaunchKernelGGL((attn_fwd_v5_kernel<true, 8>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
     else if (variant == 11)
       hipLaunchKernelGGL((attn_fwd_v5_kernel<true, 16>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
