@@ -465,15 +465,9 @@ __device__ __forceinline__ float xhalf_max(float v) {
 // ONE_DECISION: one deferred-rescale decision per 64-key tile (maximum over both 32-key blocks) instead of one per block: one
 // branch less per tile, and the second block's exponentials share a basic block with the first block's P V products, so the
 // compiler can overlap them inside a wave (VALU beside MFMA) instead of leaving all overlap to the other waves of the SIMD.
-template <bool ONE_DECISION, int STAGGER = 0>
+template <bool ONE_DECISION>
 __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N, int heads,
                                                               int npairs, float* __restrict__ lse) {
-  // STAGGER (experiment): co-resident workgroups run the same phases (Q K^T, softmax, P V) at the same time unless something sets them
-  // apart; delaying every other workgroup by about half a tile at the start tests how much of the missing MFMA / VALU overlap that is
-  if constexpr (STAGGER > 0) {
-    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_sleep(STAGGER);
-    if ((blockIdx.x >> 4) & 1) __builtin_amdgcn_s_sleep(STAGGER / 2);
-  }
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_BYTES];       // [buffer][K | V]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1081,11 +1075,7 @@ extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, in
       dim3 grid2(cdiv(npairs, 8) * 8 * nq2), block2(512);
       if (variant == 9) hipLaunchKernelGGL((attn_fwd_pp_kernel<false>), grid2, block2, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs);
       else hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), grid2, block2, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs);
-    } else if (variant == 10)
-      hipLaunchKernelGGL((attn_fwd_v5_kernel<true, 8>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
-    else if (variant == 11)
-      hipLaunchKernelGGL((attn_fwd_v5_kernel<true, 16>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
-    else if (variant == 7)                               // v5 with one rescale decision per 64-key tile
+    } else if (variant == 7)                               // v5 with one rescale decision per 64-key tile
       hipLaunchKernelGGL(attn_fwd_v5_kernel<true>, grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
     else                                                 // 0 / 2 / 5: the trimmed-issue kernel (buffer DMA, constant LDS offsets), 7-10 % faster than 6
       hipLaunchKernelGGL(attn_fwd_v5_kernel<false>, grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
