@@ -67,7 +67,10 @@ enum {
   UCOD_EPI_BIAS_F32 = 5,             /* out f32[M,N] = C + bias[n] (final LayerNorm consumers / tests; dgrad GEMMs with bias NULL) */
   /* backbone-backward mode (row B9), ucod_gemm_bf16_train only: */
   UCOD_EPI_GELU_BWD_BF16 = 6,        /* out bf16[M,N] = C * gelu'(aux[m][n]), aux = saved fc1 pre-activation (fc2 dgrad) */
-  UCOD_EPI_BIAS_GELU_SAVE_BF16 = 7   /* out bf16 = gelu_erf(C + bias[n]) and out2 bf16 = C + bias[n] (training-mode fc1) */
+  UCOD_EPI_BIAS_GELU_SAVE_BF16 = 7,  /* out bf16 = gelu_erf(C + bias[n]) and out2 bf16 = C + bias[n] (training-mode fc1) */
+  UCOD_EPI_QKV_FP8 = 8               /* QKV projection of the fp8 attention path (BASELINE configs[4]): out = e4m3 bytes
+                                        [3 (q|k|v)][Bimg*heads][Npad][64], Npad = tokens rounded up to 64, value = clamp((C + bias[n]) *
+                                        scale[n], +-448); N = 3*heads*64, M = Bimg*tokens_per_image; large-tile kernel only */
 };
 /* variant: 0 = auto, 1 = 128x128 register staging, 2 = 128x128 LDS-DMA, 3/4 = 256x256 / 256x192 large tile,
  * 5/6 = 3/4 with staggered wave groups, 7/8 = persistent forms of 5/6, 9/10 = 5/6 with two (instead of four) barrier
@@ -104,6 +107,12 @@ int ucod_attention_fwd(const void* qkv_bf16, void* out_bf16, int B, int tok, int
  * Tolerance (tests/test_gpu_fp8_attention.py): exact on e4m3-representable inputs; relative L2 <= 1e-1 against the f32 softmax
  * attention on Gaussian inputs (7.2e-2 measured: the error of a 64-term e4m3 score in the exponent). */
 size_t ucod_attention_fp8_workspace_bytes(int B, int tok, int heads);
+/* Fused form: `q8k8v8` is what ucod_gemm_bf16(UCOD_EPI_QKV_FP8, ...) wrote (column scales 2^q_exp * head_dim^-0.5 * log2 e, 2^k_exp,
+ * 2^v_exp folded into its `scale` vector), V row-major like K and transposed on the fly by ds_read_b64_tr_b8: no conversion pass and
+ * half the QKV output bytes.  ucod_attention_fp8_zero_pad clears the rows tokens..Npad-1 of all three tensors (once per workspace:
+ * nothing writes them afterwards; a NaN byte there would survive the multiplication by a zero probability). */
+int ucod_attention_fp8_zero_pad(void* q8k8v8, int B, int tok, int heads, void* stream);
+int ucod_attention_fwd_fp8_fused(const void* q8k8v8, void* out_bf16, int B, int tok, int heads, int q_exp, int k_exp, int v_exp, void* stream);
 int ucod_attention_fwd_fp8(const void* qkv_bf16, void* out_bf16, void* workspace, size_t workspace_bytes, int B, int tok, int heads,
                            int q_exp, int k_exp, int v_exp, void* stream);
 
@@ -116,6 +125,8 @@ int ucod_cls_rows(float* x, const float* cls, const float* pos, int B, int tok, 
 
 /* v[0..D) = c, v[D..3D) = 1: the per-column factor of the fused QKV epilogue */
 int ucod_fill_qscale(float* v, int D, float c, void* stream);
+/* v[3*D] = cq for the q columns, ck for k, cv for v: the column scales of UCOD_EPI_QKV_FP8 (pre-scale and power-of-two range scales) */
+int ucod_fill_qscale3(float* v, int D, float cq, float ck, float cv, void* stream);
 
 /* f32 -> bf16 cast of n elements (weight preparation) */
 int ucod_cast_f32_bf16(const float* src, void* dst_bf16, size_t n, void* stream);

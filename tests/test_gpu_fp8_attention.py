@@ -111,3 +111,36 @@ def test_vit_engine_with_the_fp8_attention_path():
     key = e8(gd["x"].to(DEV)).cpu()
     rel = ((key - ref).norm() / ref.norm()).item()
     assert rel < 8e-2, rel                                       # fp8 attention in 2 of 3 layers; the bf16 engine is at 3.4e-3 here
+
+
+@pytest.mark.parametrize("B,N,heads", [(2, 1370, 12), (3, 197, 2), (1, 64, 2), (32, 1370, 12)])
+def test_fused_fp8_projection_and_attention(B, N, heads):
+    """The fused form: QKV GEMM with the e4m3 epilogue (UCOD_EPI_QKV_FP8, mixed-height large-tile kernel) + the attention kernel that
+    transposes row-major V8 with ds_read_b64_tr_b8.  (1) Q8 / K8 / V8 equal the e4m3 rounding of the bf16 GEMM's f32 result (checked
+    through the decoded bytes); (2) the attention output matches the unfused fp8 path on the same projection to fp8 rounding of one
+    extra bf16 step, and the f32 oracle within the fp8 tolerance."""
+    g = torch.Generator().manual_seed(B * 7 + N)
+    D = heads * 64
+    h = (torch.randn(B * N, D, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(3 * D, D, generator=g) / math.sqrt(D)).to(torch.bfloat16)
+    bias = torch.randn(3 * D, generator=g) * 0.1
+    exps = (3, 5, 5)
+    out, ws = ops.qkv_fp8_attention(h.to(DEV), w.to(DEV), bias.to(DEV), B, N, heads, *exps)
+    out = out.float().cpu().reshape(B, N, D)
+    qkv = h.float() @ w.float().t() + bias                        # f32 reference of the projection
+    q, k, v = (qkv[:, i * D:(i + 1) * D].reshape(B, N, D) for i in range(3))
+    ref = reference(q, k, v, heads)
+    rel = ((out - ref).norm() / ref.norm()).item()
+    assert rel < 1e-1, rel
+    # decoded Q8 | K8 | V8 of the first image / head against the scaled projection (e4m3: 3 mantissa bits -> 2^-4 relative, clamp at 448)
+    npad = (N + 63) // 64 * 64
+    raw = ws.view(torch.float8_e4m3fn).float().cpu().reshape(3, B * heads, npad, 64)
+    sc = (C * 2.0 ** exps[0], 2.0 ** exps[1], 2.0 ** exps[2])
+    for r, t in enumerate((q, k, v)):
+        want = (t[0, :, :64] * sc[r]).clamp(-448, 448)
+        got = raw[r, 0, :N]
+        assert maxdiff(got, want) <= 2.0 ** -4 * want.abs().max().item() + 2.0 ** -9
+        assert float(raw[r, :, N:].abs().max()) == 0.0 if npad > N else True
+    if B <= 3:                                                   # against the unfused path fed with the bf16-rounded projection
+        un = run_fp8(q, k, v, heads, exps)
+        assert ((out - un).norm() / un.norm()).item() < 5e-2

@@ -16,6 +16,13 @@
 //     v_mfma_scale_f32_32x32x64_f8f6f4: ONE instruction per 32-key block for Q K^T (K = head_dim = 64) and ONE per 32-wide d half
 //     for P V (K = the tile's 64 keys): 4 matrix instructions of 64 cycles per tile instead of 16 of 32.
 //
+// Fused form (ucod_attention_fwd_fp8_fused): the QKV GEMM's UCOD_EPI_QKV_FP8 epilogue writes Q8 / K8 / V8 itself, all three row-major
+// [Npad][64]; the kernel (VROW = true) then fetches the V operand with ds_read_b64_tr_b8.  Measured semantics of that instruction on
+// gfx950 (tools/probes/tr8_probe.hip): in each group of 16 lanes the EVEN lanes 2q supply the addresses of the 8 rows (8 bytes each)
+// of one 8x8 byte block and the ODD lanes 2q+1 those of a second block; lane i < 8 of the group receives column i of the first
+// block, lane 8 + i column i of the second -- rows in the order of the supplying lanes.  With lane = 16 G + u: rows = the 8 keys of
+// slots 8 i .. 8 i + 7 of lane half G >> 1, columns = d 16 (G & 1) .. + 7 (even block) and + 8 .. + 15 (odd block) of the 32-wide d half.
+//
 // Operand slots.  For this instruction a lane holds 32 bytes of A (row = lane & 31) and 32 bytes of B (column = lane & 31); the
 // two lanes l and l + 32 of a row / column hold the two halves of K.  Byte j of lane half h of A multiplies byte j of lane half h
 // of B, so any assignment of k to (h, j) is valid as long as both operands use the same one:
@@ -120,6 +127,7 @@ __device__ __forceinline__ float xhalf_max(float v) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+template <bool VROW>
 __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const char* __restrict__ q8, const char* __restrict__ k8, const char* __restrict__ vt8,
                                                                h_raw* __restrict__ out, int N, int heads, int npairs, int nt, int qk_scale_bytes,
                                                                int v_scale_bytes) {
@@ -167,6 +175,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const char* __rest
   auto frag = [&](const char* base) {
     const u32x4 a = *reinterpret_cast<const u32x4*>(base + off0), c = *reinterpret_cast<const u32x4*>(base + off1);
     return (v8i){(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
+  };
+  // VROW: this lane's row address in the transposed 8x8-block reads of a row-major V8 tile (header comment): key of row q = u >> 1 of
+  // slot group i = 32 (i >> 1) + 16 (i & 1) + 4 h5 + {0,1,2,3,8,9,10,11}[q]; the chunk swizzle (key >> 2) & 3 = (h5 + 2 (q >> 2)) & 3 does
+  // not depend on i, so one offset per d half and an immediate per i
+  int voff[2] = {0, 0};
+  if constexpr (VROW) {
+    const int G = lane >> 4, u = lane & 15, qrow = u >> 1, odd = u & 1;
+    const int key0 = 4 * h5 + (qrow & 3) + 8 * (qrow >> 2);
+    const int sw = (h5 + 2 * (qrow >> 2)) & 3;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) voff[dt] = key0 * 64 + (((2 * dt + (G & 1)) ^ sw) * 16) + 8 * odd;
+  }
+  typedef int v2i __attribute__((ext_vector_type(2)));
+  auto vfrag = [&](const char* vb, int dt) {
+    if constexpr (VROW) {
+      v8i r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const v2i w = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)(vb + voff[dt] + (i >> 1) * 2048 + (i & 1) * 1024));
+        r[2 * i] = w[0];
+        r[2 * i + 1] = w[1];
+      }
+      return r;
+    } else {
+      return frag(vb + dt * 2048);
+    }
   };
 
   f32x16 o[2];
@@ -236,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const char* __rest
     // O^T[d][q] += sum_key Vt8[d][key] P[key][q] * 2^-v_exp: A = 32 d rows of the tile's Vt8 block, B = P (64 keys x 32 queries)
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
-      o[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(vb + dt * 2048), pf, o[dt], 0, 0, 0, v_scale_bytes, 0, 0x7F7F7F7F);
+      o[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vfrag(vb, dt), pf, o[dt], 0, 0, 0, v_scale_bytes, 0, 0x7F7F7F7F);
   };
 
   stage(IntC<0>{});
@@ -291,8 +325,52 @@ extern "C" int ucod_attention_fwd_fp8(const void* qkv, void* out, void* workspac
   // 2^-(q_exp + k_exp) on the K8 operand and 2^-v_exp on the Vt8 operand, the other operand keeps 2^0
   const int qk = 127 - (q_exp + k_exp), vs = 127 - v_exp;
   const int qk_bytes = qk | (qk << 8) | (qk << 16) | (qk << 24), v_bytes = vs | (vs << 8) | (vs << 16) | (vs << 24);
-  hipLaunchKernelGGL(attn_fwd_fp8_kernel, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, q8, k8, vt8, (h_raw*)out, tok, heads,
+  hipLaunchKernelGGL(attn_fwd_fp8_kernel<false>, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, q8, k8, vt8, (h_raw*)out, tok, heads,
                      npairs, nt, qk_bytes, v_bytes);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+namespace ucod {
+namespace f8 {
+// rows tok .. npad-1 of every (tensor, image, head): 64 bytes each
+__global__ __launch_bounds__(256) void zero_pad_kernel(char* __restrict__ ws, int tok, int npad, int total_pairs3) {
+  const int pad = npad - tok;
+  const long n = (long)total_pairs3 * pad * 4;                // 16-byte chunks
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long row = i >> 2;
+    const long p = row / pad, r = row - p * pad;
+    *reinterpret_cast<u32x4*>(ws + ((size_t)p * npad + tok + r) * 64 + (i & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
+  }
+}
+}  // namespace f8
+}  // namespace ucod
+
+extern "C" int ucod_attention_fp8_zero_pad(void* q8k8v8, int B, int tok, int heads, void* stream) {
+  using namespace ucod;
+  using namespace ucod::f8;
+  if (!q8k8v8 || B <= 0 || tok <= 0 || heads <= 0) return UCOD_EINVAL;
+  const int npad = cdiv(tok, KT) * KT;
+  if (npad == tok) return UCOD_OK;
+  const int total = 3 * B * heads;
+  hipLaunchKernelGGL(zero_pad_kernel, dim3(cdiv((long)total * (npad - tok) * 4, 256)), dim3(256), 0, (hipStream_t)stream, (char*)q8k8v8, tok, npad, total);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_attention_fwd_fp8_fused(const void* q8k8v8, void* out, int B, int tok, int heads, int q_exp, int k_exp, int v_exp, void* stream) {
+  using namespace ucod;
+  using namespace ucod::f8;
+  if (!q8k8v8 || !out || B <= 0 || tok <= 0 || heads <= 0) return UCOD_EINVAL;
+  if (q_exp + k_exp < -60 || q_exp + k_exp > 60 || v_exp < -60 || v_exp > 60) return UCOD_EINVAL;
+  const size_t third = ucod_attention_fp8_workspace_bytes(B, tok, heads) / 3;
+  const int nt = cdiv(tok, KT), npairs = B * heads, nq = cdiv(tok, QT);
+  const char* q8 = (const char*)q8k8v8;
+  UCOD_PROF(PROF_ATTN, stream);
+  const int qk = 127 - (q_exp + k_exp), vs = 127 - v_exp;
+  const int qk_bytes = qk | (qk << 8) | (qk << 16) | (qk << 24), v_bytes = vs | (vs << 8) | (vs << 16) | (vs << 24);
+  hipLaunchKernelGGL(attn_fwd_fp8_kernel<true>, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, q8, q8 + third, q8 + 2 * third,
+                     (h_raw*)out, tok, heads, npairs, nt, qk_bytes, v_bytes);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }

@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
 //     in order, so the wait for them leaves pass p's stores in flight.  (out may alias resid: passes touch disjoint rows.)
 template <int EPI>
 constexpr bool kColFused = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 ||
-                            EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
+                            EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16 ||
+                            EPI == UCOD_EPI_QKV_FP8);
 template <int EPI>
 constexpr bool kF32Out = (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_BIAS_F32);
 
@@ -382,7 +383,7 @@ __device__ __forceinline__ void load_col_consts(const GemmArgs& a, int ncol0, fl
     if constexpr (kColFused<EPI>) {
       int n = ncol0 + j * 16;
       n = n < a.N ? n : a.N - 1;
-      if constexpr (EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_BIAS_BF16) {
+      if constexpr (EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8) {
         cb[j] = (a.bias ? a.bias : reinterpret_cast<const float*>(a.B))[n];   // NULL bias = plain product (dgrad GEMMs): selected in finish_col_consts
       } else if constexpr (EPI != UCOD_EPI_GELU_BWD_BF16) {
         cb[j] = a.bias[n];
@@ -390,18 +391,18 @@ __device__ __forceinline__ void load_col_consts(const GemmArgs& a, int ncol0, fl
       if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) cs[j] = a.scale[n];
       // optional scale: unconditional load now (a branch here costs a vmcnt(0) at the join, ahead of the operand DMAs),
       // select at the point of use (finish_col_consts) so nothing waits on the load before the DMAs are out
-      if constexpr (EPI == UCOD_EPI_BIAS_BF16) cs[j] = (a.scale ? a.scale : reinterpret_cast<const float*>(a.B))[n];
+      if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8) cs[j] = (a.scale ? a.scale : reinterpret_cast<const float*>(a.B))[n];
     }
   }
 }
 
 template <int EPI, int NT>
 __device__ __forceinline__ void finish_col_consts(const GemmArgs& a, float (&cb)[NT], float (&cs)[NT]) {
-  if constexpr (EPI == UCOD_EPI_BIAS_BF16) {
+  if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) cs[j] = a.scale ? cs[j] : 1.f;
   }
-  if constexpr (EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_BIAS_BF16) {
+  if constexpr (EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) cb[j] = a.bias ? cb[j] : 0.f;
   }
@@ -423,7 +424,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
       for (int j = 0; j < NT; ++j) {
         if (pass * 2 + i >= NI) continue;
         f32x4 v = acc[pass * 2 + i < NI ? pass * 2 + i : 0][j];
-        if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) v = v * cs[j];
+        if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_QKV_FP8) v = v * cs[j];
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
           *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * (WCOLS * 4) + (j * 16 + (lane & 15)) * 4) = v[rg];
@@ -450,7 +451,38 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
     const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + base, 0, records, 0x00020000);
     const unsigned row_bytes = (unsigned)a.N * ELT;
     const unsigned pass_bytes = PR * row_bytes;
-    if constexpr (kF32Out<EPI>) {
+    if constexpr (EPI == UCOD_EPI_QKV_FP8) {
+      // The wave's 64 columns are one head of q, k or v (n_first is a multiple of 64): e4m3 rows of 64 bytes into
+      // [q|k|v][image * heads + head][Npad][64].  Lane -> (row, 16-column chunk): one 16-byte store per 16 outputs.
+      static_assert(NT == 4, "one head per wave");
+      const int Dm = a.N / 3, heads = Dm >> 6, tok = a.tok, npad = ((tok + 63) >> 6) << 6;
+      const int region = n_first / Dm, head = (n_first - region * Dm) >> 6;
+      const size_t npairs = (size_t)(a.M / tok) * heads;
+      char* dst0 = reinterpret_cast<char*>(a.out) + (size_t)region * npairs * npad * 64;
+#pragma unroll
+      for (int pass = 0; pass < NP; ++pass) {
+        stage(pass);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int idx = it * 64 + lane, r = idx >> 2, c = idx & 3;
+          const int m = m_first + pass * PR + r;
+          u32x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + r * (WCOLS * 4) + c * 64 + e * 16);
+            int p = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[0], -448.f), 448.f), fminf(fmaxf(v[1], -448.f), 448.f), 0, false);
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[2], -448.f), 448.f), fminf(fmaxf(v[3], -448.f), 448.f), p, true);
+            w[e] = (unsigned)p;
+          }
+          if (m < a.M && r < rows_in(pass) && n_first < a.N) {
+            const int bimg = m / tok, t = m - bimg * tok;
+            *reinterpret_cast<u32x4*>(dst0 + (((size_t)bimg * heads + head) * npad + t) * 64 + c * 16) = w;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    } else if constexpr (kF32Out<EPI>) {
       constexpr bool RESID = (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32);
       constexpr int CH = WCOLS / 4, ITS = PR * CH / 64;          // 16-byte chunks per row; wave instructions per pass
       static_assert((PR * CH) % 64 == 0, "whole wave instructions");
@@ -1390,6 +1422,28 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
 
 }  // namespace ucod
 
+// QKV projection with e4m3 output (UCOD_EPI_QKV_FP8): always the mixed-height large-tile kernel, 256 wide (a wave's 64 columns are one
+// head), with tall tiles where that makes whole rounds and without them otherwise.
+static int launch_qkv_fp8(ucod::GemmArgs a, hipStream_t s) {
+  using namespace ucod;
+  if (a.N % 192 != 0 || a.K < 128 || a.tok < 1 || a.M % a.tok != 0 || !a.bias) return UCOD_EINVAL;
+  const MixedPlan mp = mixed_plan(a.M, a.N, 256);
+  a.tiles_n = cdiv(a.N, 256);
+  if (mp.feasible) {
+    a.tiles_m = mp.tiles_m;
+    a.main_tiles = mp.n_tall;
+    a.patches_per_wg = mp.stride;
+  } else {
+    a.tiles_m = cdiv(a.M, 256);
+    a.main_tiles = 0;                                           // no tall row-tiles
+    a.patches_per_wg = 1 << 30;
+  }
+  a.col_fast = a.tiles_n <= 4;
+  hipLaunchKernelGGL((gemm_bf16_mixed_kernel<UCOD_EPI_QKV_FP8, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
 static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int M, int N, int K, const float* bias,
                       const float* scale, const float* resid, const float* pos, int tokens_per_image, int variant,
                       void* stream, const void* aux, void* out2) {
@@ -1420,7 +1474,7 @@ static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int
   a.group_m = 8;
   a.col_fast = 0;
   hipStream_t s = (hipStream_t)stream;
-  UCOD_PROF(epilogue >= 0 && epilogue <= 5 ? epilogue : (epilogue == UCOD_EPI_GELU_BWD_BF16 ? PROF_GEMM_EPI6 : PROF_GEMM_EPI7), s);
+  UCOD_PROF(epilogue == UCOD_EPI_QKV_FP8 ? 0 : (epilogue >= 0 && epilogue <= 5 ? epilogue : (epilogue == UCOD_EPI_GELU_BWD_BF16 ? PROF_GEMM_EPI6 : PROF_GEMM_EPI7)), s);
   switch (epilogue) {
     case UCOD_EPI_BIAS_BF16:                                   // NULL bias (plain product) only in the large-tile kernels
       if (!bias && (variant == 1 || variant == 2 || K < 128 || (N & 3))) return UCOD_EINVAL;
@@ -1440,6 +1494,7 @@ static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int
     case UCOD_EPI_BIAS_F32:
       if (!bias && (variant == 1 || variant == 2 || K < 128 || (N & 3))) return UCOD_EINVAL;
       return launch<UCOD_EPI_BIAS_F32>(a, variant, s);
+    case UCOD_EPI_QKV_FP8: return launch_qkv_fp8(a, s);
     default: return UCOD_EINVAL;
   }
 }

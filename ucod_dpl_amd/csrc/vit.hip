@@ -70,6 +70,12 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
   const bool prescale = (av == 2 || av == 8);
   float* qscale = (float*)(ws + p.off_qscale);
   if (prescale) RUN(ucod_fill_qscale(qscale, D, scale * 1.4426950408889634f, stream));
+  // fp8 path: the QKV epilogue writes e4m3 Q8 | K8 | V8 itself; its column scales carry 2^q_exp (times the pre-scale), 2^k_exp, 2^v_exp
+  constexpr int QE = 5, KE = 3, VE = 3;
+  if (av == 8) {
+    RUN(ucod_fill_qscale3(qscale, D, scale * 1.4426950408889634f * 32.f, 8.f, 8.f, stream));
+    RUN(ucod_attention_fp8_zero_pad(ws + p.off_f8, d->B, tok, d->heads, stream));
+  }
 
   // embeddings: patch conv as GEMM (+bias +pos), CLS rows
   RUN(ucod_patch_im2col(img, patches, d->B, d->C, d->H, d->W, d->P, d->Kpad, stream));
@@ -88,9 +94,13 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
       RUN(ucod_gemm_bf16(UCOD_EPI_KEY_NCHW_F32, wk, h, key_out, D, M, D, bk, nullptr, nullptr, nullptr, tok, gv, stream));
       if (!d->full_last_layer) break;
     }
-    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_BF16, h, W[2], qkv, M, 3 * D, D, (const float*)W[3], prescale ? qscale : nullptr, nullptr, nullptr, tok, gv, stream));
-    if (av == 8) RUN(ucod_attention_fwd_fp8(qkv, a, ws + p.off_f8, p.f8_bytes, d->B, tok, d->heads, 5, 3, 3, stream));
-    else RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, prescale ? 0.f : scale, av, stream));
+    if (av == 8) {
+      RUN(ucod_gemm_bf16(UCOD_EPI_QKV_FP8, h, W[2], ws + p.off_f8, M, 3 * D, D, (const float*)W[3], qscale, nullptr, nullptr, tok, gv, stream));
+      RUN(ucod_attention_fwd_fp8_fused(ws + p.off_f8, a, d->B, tok, d->heads, QE, KE, VE, stream));
+    } else {
+      RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_BF16, h, W[2], qkv, M, 3 * D, D, (const float*)W[3], prescale ? qscale : nullptr, nullptr, nullptr, tok, gv, stream));
+      RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, prescale ? 0.f : scale, av, stream));
+    }
     RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_SCALE_RESID_F32, a, W[4], x, M, D, D, (const float*)W[5], (const float*)W[6], x, nullptr, tok, gv, stream));
     RUN(ucod_layernorm(x, (const float*)W[7], (const float*)W[8], h, M, D, d->eps, 0, stream));
     RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_GELU_BF16, h, W[9], g, M, F, D, (const float*)W[10], nullptr, nullptr, nullptr, tok, gv, stream));

@@ -265,6 +265,17 @@ extern "C" int ucod_fill_qscale(float* v, int D, float c, void* stream) {
   return UCOD_OK;
 }
 
+__global__ void fill_qscale3_kernel(float* v, int D, float cq, float ck, float cv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3 * D) v[i] = i < D ? cq : (i < 2 * D ? ck : cv);
+}
+extern "C" int ucod_fill_qscale3(float* v, int D, float cq, float ck, float cv, void* stream) {
+  if (!v || D <= 0) return UCOD_EINVAL;
+  hipLaunchKernelGGL(fill_qscale3_kernel, dim3(ucod::cdiv(3L * D, 256)), dim3(256), 0, (hipStream_t)stream, v, D, cq, ck, cv);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
 extern "C" int ucod_abi_version(void) { return UCOD_ABI_VERSION; }
 
 extern "C" int ucod_device_is_gfx950(void) {

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("UCOD_DPL_LIB") or os.path.join(_HERE, "_native", "lib
 
 EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_SCALE_RESID_F32, EPI_PATCH_TOKENS_F32, EPI_KEY_NCHW_F32, EPI_BIAS_F32 = range(6)
 EPI_GELU_BWD_BF16, EPI_BIAS_GELU_SAVE_BF16 = 6, 7          # ucod_gemm_bf16_train only (backbone-backward mode)
+EPI_QKV_FP8 = 8                                            # QKV projection of the fp8 attention path
 VIT_LAYER_STRIDE = 14
 VIT_TRAIN_STRIDE = 7
 LORA_AUG = 64
@@ -56,9 +57,12 @@ SIGNATURES = {
     "ucod_attention_fwd": (ci, [vp, vp, ci, ci, ci, cf, ci, vp]),
     "ucod_attention_fp8_workspace_bytes": (sz, [ci, ci, ci]),
     "ucod_attention_fwd_fp8": (ci, [vp, vp, vp, sz, ci, ci, ci, ci, ci, ci, vp]),
+    "ucod_attention_fp8_zero_pad": (ci, [vp, ci, ci, ci, vp]),
+    "ucod_attention_fwd_fp8_fused": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "ucod_patch_im2col": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "ucod_cls_rows": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "ucod_fill_qscale": (ci, [vp, ci, cf, vp]),
+    "ucod_fill_qscale3": (ci, [vp, ci, cf, cf, cf, vp]),
     "ucod_cast_f32_bf16": (ci, [vp, vp, sz, vp]),
     "ucod_vit_workspace_bytes": (sz, [C.POINTER(VitDesc)]),
     "ucod_vit_forward": (ci, [C.POINTER(VitDesc), C.POINTER(vp), vp, vp, vp, sz, vp]),

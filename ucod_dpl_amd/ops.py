@@ -67,6 +67,24 @@ def attention_fp8(qkv, B, tok, heads, q_exp=5, k_exp=3, v_exp=3):
     return out
 
 
+def qkv_fp8_attention(h, w_qkv, b_qkv, B, tok, heads, q_exp=5, k_exp=3, v_exp=3):
+    """Fused fp8 path: QKV projection with the e4m3 epilogue (UCOD_EPI_QKV_FP8) straight into Q8 | K8 | V8, then the fp8 attention
+    kernel that transposes V on the fly.  ``h`` bf16 [B*tok, D] (LayerNorm output), ``w_qkv`` bf16 [3D, D], ``b_qkv`` f32 [3D]."""
+    import math
+    lib = N.load()
+    D = heads * 64
+    M = B * tok
+    ws = torch.empty(lib.ucod_attention_fp8_workspace_bytes(B, tok, heads), dtype=torch.uint8, device=h.device)
+    scale = torch.empty(3 * D, dtype=torch.float32, device=h.device)
+    check(lib.ucod_fill_qscale3(ptr(scale), D, 0.125 * math.log2(math.e) * 2.0 ** q_exp, 2.0 ** k_exp, 2.0 ** v_exp, stream()), "ucod_fill_qscale3")
+    check(lib.ucod_attention_fp8_zero_pad(ptr(ws), B, tok, heads, stream()), "ucod_attention_fp8_zero_pad")
+    check(lib.ucod_gemm_bf16(N.EPI_QKV_FP8, ptr(_bf16(h)), ptr(_bf16(w_qkv)), ptr(ws), M, 3 * D, D, ptr(_f32(b_qkv)), ptr(scale), None, None, tok, 0,
+                             stream()), "ucod_gemm_bf16(QKV_FP8)")
+    out = torch.empty(M, D, dtype=torch.bfloat16, device=h.device)
+    check(lib.ucod_attention_fwd_fp8_fused(ptr(ws), ptr(out), B, tok, heads, q_exp, k_exp, v_exp, stream()), "ucod_attention_fwd_fp8_fused")
+    return out, ws
+
+
 def patch_im2col(img, P, Kpad):
     B, Cc, H, W = img.shape
     out = torch.empty(B * (H // P) * (W // P), Kpad, dtype=torch.bfloat16, device=img.device)
