@@ -135,7 +135,7 @@ def main():
     runner = StandardRunner(cfg)                              # initialises the RCCL process group when WORLD_SIZE > 1
     loop = TrainLoop(cfg, runner)
     bb = backbone.random_init(a.arch, seed=0, image_size=a.image, device=dev, full_last_layer=a.full_last_layer,
-                              gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half=a.half)
+                              gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half=a.half, resid=os.environ.get("UCOD_RESID", "auto"))
     bb.engine.streams = a.streams
     B = a.batch
     g = torch.Generator().manual_seed(1234 + rank)

@@ -68,6 +68,9 @@ enum {
   /* backbone-backward mode (row B9), ucod_gemm_bf16_train only: */
   UCOD_EPI_GELU_BWD_BF16 = 6,        /* out bf16[M,N] = C * gelu'(aux[m][n]), aux = saved fc1 pre-activation (fc2 dgrad) */
   UCOD_EPI_BIAS_GELU_SAVE_BF16 = 7,  /* out bf16 = gelu_erf(C + bias[n]) and out2 bf16 = C + bias[n] (training-mode fc1) */
+  UCOD_EPI_BIAS_SCALE_RESID_H16 = 9, /* as UCOD_EPI_BIAS_SCALE_RESID_F32 with the residual stream kept in IEEE fp16: out f16[M,N] = resid f16 +
+                                        scale[n]*(C+bias[n]) (ucod_vit_desc.resid16); large-tile kernel only */
+  UCOD_EPI_PATCH_TOKENS_H16 = 10,    /* as UCOD_EPI_PATCH_TOKENS_F32 with f16 token rows */
   UCOD_EPI_QKV_FP8 = 8               /* QKV projection of the fp8 attention path (BASELINE configs[4]): out = e4m3 bytes
                                         [3 (q|k|v)][Bimg*heads][Npad][64], Npad = tokens rounded up to 64, value = clamp((C + bias[n]) *
                                         scale[n], +-448); N = 3*heads*64, M = Bimg*tokens_per_image; large-tile kernel only */
@@ -86,6 +89,8 @@ int ucod_gemm_bf16(int epilogue, const void* A_bf16, const void* B_bf16, void* o
  * x f32 [rows,D] -> y bf16 [rows,D] (or f32 when out_f32 != 0).  D % 128 == 0. */
 int ucod_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int D, float eps,
                    int out_f32, void* stream);
+/* the same with the residual stream in IEEE fp16 (ucod_vit_desc.resid16): x f16 [rows,D] -> y bf16 [rows,D]; statistics in f32 */
+int ucod_layernorm_h16(const void* x_f16, const float* gamma, const float* beta, void* y, int rows, int D, float eps, void* stream);
 
 /* softmax(Q K^T * scale) V per (image, head), head_dim 64 (modeling_dinov2.py:153-179; dino.py:113-117).
  * qkv bf16 [B*tok, 3*heads*64] rows = [q | k | v], heads contiguous; out bf16 [B*tok, heads*64].
@@ -122,6 +127,7 @@ int ucod_patch_im2col(const float* img, void* patches_bf16, int B, int C, int H,
 
 /* x f32 [B*tok, D]: row b*tok = cls + pos[0]  (modeling_dinov2.py:107-112; dino.py:227-232) */
 int ucod_cls_rows(float* x, const float* cls, const float* pos, int B, int tok, int D, void* stream);
+int ucod_cls_rows_h16(void* x_f16, const float* cls, const float* pos, int B, int tok, int D, void* stream);
 
 /* v[0..D) = c, v[D..3D) = 1: the per-column factor of the fused QKV epilogue */
 int ucod_fill_qscale(float* v, int D, float c, void* stream);
@@ -217,6 +223,10 @@ typedef struct {
   float eps;              /* LayerNorm eps (1e-6 for DINOv2 / DINO) */
   int full_last_layer;
   int gemm_variant, attn_variant;
+  int resid16;            /* 1: the residual stream x lives in IEEE fp16 instead of f32 (11 significand bits: finer than the bf16 GEMM operands
+                             it feeds, so the bf16 build's accuracy is unchanged to its own rounding; values must stay below 65504).  Halves
+                             the bytes of LayerNorm's read and of the out-proj / fc2 read-modify-write epilogues.  0: f32 (exact
+                             accumulation; what the fp16-operand build uses to stay within 1e-3 of the f32 reference). */
 } ucod_vit_desc;
 size_t ucod_vit_workspace_bytes(const ucod_vit_desc* d);
 int ucod_vit_forward(const ucod_vit_desc* d, const void* const* table_host, const float* img, float* key_out,

@@ -378,6 +378,54 @@ def test_vit_key_fp16_operands_against_reference_golden(name, heads, fn):
     assert rel_l2(k16, ref) < 0.5 * rel_l2(kbf, ref)
 
 
+@pytest.mark.parametrize("name,heads", [("g8_dinov2_native", 2), ("g8_dinov2_interp", 2), ("g8_dinov1_native", 2)])
+def test_vit_key_with_fp16_residual_stream(name, heads):
+    """ViTEngine(resid="f16"): the residual stream between the GEMM epilogues and LayerNorm kept in IEEE fp16 (ucod_vit_desc.resid16:
+    patch / out-proj / fc2 epilogues and LayerNorm on 2-byte rows).  fp16 rounds 8x finer than the bf16 operands the stream is
+    rounded to anyway, so the key map must stay at the bf16 engine's distance from the reference (G8) and within 1.5e-3 of the
+    f32-stream engine itself."""
+    from ucod_dpl_amd.vit_engine import ViTEngine
+    gd = load_golden(name)
+    ref = gd["key"]
+    e32 = ViTEngine(sub(gd, "sd."), heads=heads, eps=1e-6, device=DEV, attn_variant=2, resid="f32")
+    e16 = ViTEngine(sub(gd, "sd."), heads=heads, eps=1e-6, device=DEV, attn_variant=2, resid="f16")
+    k32, k16 = e32(gd["x"].to(DEV)).cpu(), e16(gd["x"].to(DEV)).cpu()
+    assert e16._desc(2, gd["x"].shape[-2], gd["x"].shape[-1]).resid16 == 1 and e32._desc(2, 70, 70).resid16 == 0
+    assert rel_l2(k16, ref) < 2e-2 and rel_l2(k16, ref) < 1.3 * rel_l2(k32, ref) + 1e-4
+    assert rel_l2(k16, k32) < 1.5e-3, rel_l2(k16, k32)
+
+
+def test_fp16_residual_stream_kernels():
+    """The pieces of the fp16 residual stream against f32 arithmetic on the same inputs: LayerNorm from f16 rows (D = 128 / 384 / 768 /
+    1024), out-proj epilogue x_f16 += scale * (A W^T + b) in place (mixed-height kernel, rows past M untouched, repeatable), CLS rows."""
+    g = torch.Generator().manual_seed(3)
+    lib = N.load()
+    for D in (128, 384, 768, 1024):
+        x = (torch.randn(777, D, generator=g) * 3 + 0.5).to(torch.float16)
+        w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+        ref = OV.layer_norm(x.float(), w, b, 1e-6)
+        y = torch.empty(777, D, dtype=torch.bfloat16, device=DEV)
+        xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)            # (named: a temporary would be recycled before the launch)
+        N.check(lib.ucod_layernorm_h16(N.ptr(xd), N.ptr(wd), N.ptr(bd), N.ptr(y), 777, D, 1e-6, N.stream()), "ln_h16")
+        assert maxdiff(y.float().cpu(), ref) < 4e-2 and rel_l2(y.float().cpu(), ref) < 4e-3
+    for (M, Nn, K) in ((21916, 768, 768), (43840, 768, 3072), (5000, 1024, 256), (300, 256, 192)):
+        A = bf(torch.randn(M, K, generator=g)).to(DEV)
+        W = bf(torch.randn(Nn, K, generator=g) * 0.05).to(DEV)
+        bias, sc = torch.randn(Nn, generator=g).to(DEV), (torch.rand(Nn, generator=g) + 0.5).to(DEV)
+        resid = (torch.randn(M, Nn, generator=g) * 4).to(torch.float16).to(DEV)
+        buf = torch.full((M + 64, Nn), 7.0, dtype=torch.float16, device=DEV)
+        xx = buf[:M]
+        want = resid.float() + sc * (A.float() @ W.float().t() + bias)
+        outs = []
+        for _ in range(3):
+            xx.copy_(resid)
+            ops.gemm_bf16(N.EPI_BIAS_SCALE_RESID_H16, A, W, xx, M, Nn, K, bias=bias, scale=sc, resid=xx)
+            outs.append(xx.clone())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        assert maxdiff(outs[0].float(), want) < 2e-3 * max(1.0, want.abs().max().item()) + 2.0 ** -10 * want.abs().max().item()
+        assert torch.all(buf[M:] == 7.0)
+
+
 def test_fp16_library_refuses_the_bf16_only_entry_points():
     from ucod_dpl_amd import native
     lib = native.load("f16")

@@ -80,3 +80,26 @@ def test_mae_statistics_semantics():
     pred = torch.zeros(1, 4, 4); pred[..., :1, :] = 1
     st.step(gt, pred > 0.5)
     assert abs(st.get_result()["MAE"] - 0.25) < 1e-12
+
+
+def test_component_label_order_against_real_opencv_when_installed():
+    """The goldens (G7 / G14 / G15) were generated with cv2.connectedComponents replaced by scipy.ndimage.label (raster order of each
+    component's first pixel): OpenCV is not installed in the build container.  OpenCV's 8-connectivity labelling scans 2x2 blocks, so
+    its label ORDER can differ for components that start in the same 2-row strip; label order feeds the stable-sort ties and the paste
+    order of process_preds.  Where the real library is available this test pins the claim on it; elsewhere it is skipped and the
+    limitation stands as documented (README.md)."""
+    cv2 = pytest.importorskip("cv2")
+    import numpy as np
+    from oracle import look_twice as OLT
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        m = (rng.random((48, 64)) > 0.72).astype(np.uint8) * 255
+        n_ref, lab_ref = cv2.connectedComponents(m, connectivity=8)
+        n, lab = OLT.connected_components(m)
+        assert n == n_ref
+        # same partition; the ORDER is what may differ
+        pairs = {(int(a), int(b)) for a, b in zip(lab.ravel(), lab_ref.ravel())}
+        assert len(pairs) == n
+        if not np.array_equal(lab, lab_ref):
+            pytest.xfail("OpenCV numbers components in a different order than raster-first-pixel on this mask: order-dependent steps "
+                         "(tie order of equal-area boxes, paste order) follow the scipy convention of the goldens")

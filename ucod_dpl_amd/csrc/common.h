@@ -62,6 +62,17 @@ __device__ __forceinline__ unsigned pack_h2(float lo, float hi) {
   typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(unsigned, __builtin_convertvector((pk_f32x2){lo, hi}, hx2));
 }
+// IEEE fp16 pairs regardless of the build's operand type (the f16 residual stream, ucod_vit_desc.resid16)
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
+  typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((pk_f32x2){lo, hi}, f16x2_t));
+}
+__device__ __forceinline__ void unpack_f16x2(unsigned w, float& lo, float& hi) {
+  const f16x2_t v = __builtin_bit_cast(f16x2_t, w);
+  lo = (float)v[0];
+  hi = (float)v[1];
+}
 // the two values of a packed register as f32
 __device__ __forceinline__ void unpack_h2(unsigned w, float& lo, float& hi) {
 #ifdef UCOD_HALF_F16

@@ -150,6 +150,11 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& a, int m, int n, 
     const int np = a.tok - 1;
     const int b = m / np, p = m - b * np;
     reinterpret_cast<float*>(a.out)[((size_t)b * a.tok + 1 + p) * a.N + n] = v + a.bias[n] + a.pos[(size_t)(1 + p) * a.N + n];
+  } else if constexpr (EPI == UCOD_EPI_PATCH_TOKENS_H16) {
+    const int np = a.tok - 1;
+    const int b = m / np, p = m - b * np;
+    reinterpret_cast<unsigned short*>(a.out)[((size_t)b * a.tok + 1 + p) * a.N + n] =
+        __builtin_bit_cast(unsigned short, (_Float16)(v + a.bias[n] + a.pos[(size_t)(1 + p) * a.N + n]));
   } else if constexpr (EPI == UCOD_EPI_KEY_NCHW_F32) {
     // m = channel, n = global token index; drop CLS, write [B, C, tok-1]
     const int b = n / a.tok, t = n - b * a.tok;
@@ -196,11 +201,19 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& a, int m, int n,
       const f32x4 r = *reinterpret_cast<const f32x4*>(a.resid + i);
       const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
       *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + i) = r + sc * (v + b);
-    } else if constexpr (EPI == UCOD_EPI_PATCH_TOKENS_F32) {
+    } else if constexpr (EPI == UCOD_EPI_PATCH_TOKENS_F32 || EPI == UCOD_EPI_PATCH_TOKENS_H16) {
       const int np = a.tok - 1;
       const int bi = m / np, p = m - bi * np;
       const f32x4 ps = *reinterpret_cast<const f32x4*>(a.pos + (size_t)(1 + p) * a.N + n);
-      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + ((size_t)bi * a.tok + 1 + p) * a.N + n) = v + b + ps;
+      const f32x4 o = v + b + ps;
+      if constexpr (EPI == UCOD_EPI_PATCH_TOKENS_H16) {
+        u32x2 w;
+        w[0] = pack_f16x2(o[0], o[1]);
+        w[1] = pack_f16x2(o[2], o[3]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(a.out) + ((size_t)bi * a.tok + 1 + p) * a.N + n) = w;
+      } else {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + ((size_t)bi * a.tok + 1 + p) * a.N + n) = o;
+      }
     } else {
       *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.N + n) = v + b;
     }
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
 template <int EPI>
 constexpr bool kColFused = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 ||
                             EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16 ||
-                            EPI == UCOD_EPI_QKV_FP8);
+                            EPI == UCOD_EPI_QKV_FP8 || EPI == UCOD_EPI_BIAS_SCALE_RESID_H16);
 template <int EPI>
 constexpr bool kF32Out = (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_BIAS_F32);
 
@@ -388,7 +401,7 @@ __device__ __forceinline__ void load_col_consts(const GemmArgs& a, int ncol0, fl
       } else if constexpr (EPI != UCOD_EPI_GELU_BWD_BF16) {
         cb[j] = a.bias[n];
       }
-      if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) cs[j] = a.scale[n];
+      if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_BIAS_SCALE_RESID_H16) cs[j] = a.scale[n];
       // optional scale: unconditional load now (a branch here costs a vmcnt(0) at the join, ahead of the operand DMAs),
       // select at the point of use (finish_col_consts) so nothing waits on the load before the DMAs are out
       if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8) cs[j] = (a.scale ? a.scale : reinterpret_cast<const float*>(a.B))[n];
@@ -424,7 +437,8 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
       for (int j = 0; j < NT; ++j) {
         if (pass * 2 + i >= NI) continue;
         f32x4 v = acc[pass * 2 + i < NI ? pass * 2 + i : 0][j];
-        if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_QKV_FP8) v = v * cs[j];
+        if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_QKV_FP8 ||
+                      EPI == UCOD_EPI_BIAS_SCALE_RESID_H16) v = v * cs[j];
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
           *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * (WCOLS * 4) + (j * 16 + (lane & 15)) * 4) = v[rg];
@@ -526,12 +540,13 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
       }
     } else {                                                      // bf16 out: 16-byte stores (launch() guarantees N % 8 == 0)
       constexpr bool GBWD = (EPI == UCOD_EPI_GELU_BWD_BF16), SAVE = (EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
+      constexpr bool RH16 = (EPI == UCOD_EPI_BIAS_SCALE_RESID_H16);   // second matrix = the f16 residual stream (may alias out)
       constexpr int CH = WCOLS / 8, ITS = PR * CH / 64;
       static_assert((PR * CH) % 64 == 0, "whole wave instructions");
       // second bf16 [M,N] matrix with the same geometry: the saved pre-activation, read (GELU_BWD) or written (GELU_SAVE)
-      const void* second = GBWD ? a.aux : (SAVE ? (const void*)a.out2 : (const void*)a.out);
+      const void* second = GBWD ? a.aux : (SAVE ? (const void*)a.out2 : (RH16 ? (const void*)a.resid : (const void*)a.out));
       const auto rs_2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(second)) + base, 0,
-                                                          (GBWD || SAVE) ? records : 0u, 0x00020000);
+                                                          (GBWD || SAVE || RH16) ? records : 0u, 0x00020000);
       // (row, chunk) of wave instruction `it`: recomputed where needed -- index arrays cost registers the persistent kernel lacks
       auto lrow = [&](int it) { return (it * 64 + lane) / CH; };
       auto lchk = [&](int it) { return (it * 64 + lane) - lrow(it) * CH; };
@@ -540,14 +555,14 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
         return (n < a.N && lrow(it) < rows_in(pass)) ? (unsigned)(pass * PR + lrow(it)) * row_bytes + (unsigned)n * 2u : OOB;
       };
       u32x4 pre[2][ITS];
-      if constexpr (GBWD) {
+      if constexpr (GBWD || RH16) {
 #pragma unroll
         for (int it = 0; it < ITS; ++it) pre[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_2, at(it, 0), 0, 0);
       }
 #pragma unroll
       for (int pass = 0; pass < NP; ++pass) {
         stage(pass);
-        if constexpr (GBWD) {
+        if constexpr (GBWD || RH16) {
           if (pass + 1 < NP) {
 #pragma unroll
             for (int it = 0; it < ITS; ++it) pre[(pass + 1) & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_2, at(it, pass + 1), 0, 0);
@@ -588,10 +603,21 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
             }
           }
           u32x4 w;
-          w[0] = pack_h2(v0[0], v0[1]);
-          w[1] = pack_h2(v0[2], v0[3]);
-          w[2] = pack_h2(v1[0], v1[1]);
-          w[3] = pack_h2(v1[2], v1[3]);
+          if constexpr (RH16) {                                   // x_new = x_old + lambda (acc + b), all in IEEE fp16 storage
+            const u32x4 pw = pre[pass & 1][it];
+            float r[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) unpack_f16x2(pw[e], r[2 * e], r[2 * e + 1]);
+            w[0] = pack_f16x2(v0[0] + r[0], v0[1] + r[1]);
+            w[1] = pack_f16x2(v0[2] + r[2], v0[3] + r[3]);
+            w[2] = pack_f16x2(v1[0] + r[4], v1[1] + r[5]);
+            w[3] = pack_f16x2(v1[2] + r[6], v1[3] + r[7]);
+          } else {
+            w[0] = pack_h2(v0[0], v0[1]);
+            w[1] = pack_h2(v0[2], v0[3]);
+            w[2] = pack_h2(v1[0], v1[1]);
+            w[3] = pack_h2(v1[2], v1[3]);
+          }
           __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, at(it, pass), 0, AUX);
           __builtin_amdgcn_sched_barrier(0);                      // keep chunks in order: hoisting every ds_read/cvt of a pass spills in the persistent kernel
         }
@@ -1444,6 +1470,29 @@ static int launch_qkv_fp8(ucod::GemmArgs a, hipStream_t s) {
   return UCOD_OK;
 }
 
+// Out-projection / fc2 with the f16 residual stream (UCOD_EPI_BIAS_SCALE_RESID_H16): the mixed-height large-tile kernel, 256 wide.
+static int launch_resid_h16(ucod::GemmArgs a, hipStream_t s) {
+  using namespace ucod;
+  if ((a.N & 7) != 0 || a.K < 128 || !a.bias || !a.scale || !a.resid) return UCOD_EINVAL;
+  const MixedPlan mp = mixed_plan(a.M, a.N, 256);
+  a.tiles_n = cdiv(a.N, 256);
+  if (mp.feasible) {
+    a.tiles_m = mp.tiles_m;
+    a.main_tiles = mp.n_tall;
+    a.patches_per_wg = mp.stride;
+  } else {
+    a.tiles_m = cdiv(a.M, 256);
+    a.main_tiles = 0;
+    a.patches_per_wg = 1 << 30;
+  }
+  a.col_fast = a.tiles_n <= 4;
+  if (const char* e = getenv("UCOD_GEMM_GROUP_M")) a.group_m = atoi(e) > 0 ? atoi(e) : a.tiles_m;
+  if (const char* e = getenv("UCOD_GEMM_COL_FAST")) a.col_fast = atoi(e);
+  hipLaunchKernelGGL((gemm_bf16_mixed_kernel<UCOD_EPI_BIAS_SCALE_RESID_H16, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
 static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int M, int N, int K, const float* bias,
                       const float* scale, const float* resid, const float* pos, int tokens_per_image, int variant,
                       void* stream, const void* aux, void* out2) {
@@ -1474,7 +1523,7 @@ static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int
   a.group_m = 8;
   a.col_fast = 0;
   hipStream_t s = (hipStream_t)stream;
-  UCOD_PROF(epilogue == UCOD_EPI_QKV_FP8 ? 0 : (epilogue >= 0 && epilogue <= 5 ? epilogue : (epilogue == UCOD_EPI_GELU_BWD_BF16 ? PROF_GEMM_EPI6 : PROF_GEMM_EPI7)), s);
+  UCOD_PROF(epilogue == UCOD_EPI_QKV_FP8 ? 0 : epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16 ? 2 : epilogue == UCOD_EPI_PATCH_TOKENS_H16 ? 3 : (epilogue >= 0 && epilogue <= 5 ? epilogue : (epilogue == UCOD_EPI_GELU_BWD_BF16 ? PROF_GEMM_EPI6 : PROF_GEMM_EPI7)), s);
   switch (epilogue) {
     case UCOD_EPI_BIAS_BF16:                                   // NULL bias (plain product) only in the large-tile kernels
       if (!bias && (variant == 1 || variant == 2 || K < 128 || (N & 3))) return UCOD_EINVAL;
@@ -1495,6 +1544,10 @@ static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int
       if (!bias && (variant == 1 || variant == 2 || K < 128 || (N & 3))) return UCOD_EINVAL;
       return launch<UCOD_EPI_BIAS_F32>(a, variant, s);
     case UCOD_EPI_QKV_FP8: return launch_qkv_fp8(a, s);
+    case UCOD_EPI_BIAS_SCALE_RESID_H16: return launch_resid_h16(a, s);
+    case UCOD_EPI_PATCH_TOKENS_H16:
+      if (!bias || !pos || tokens_per_image < 2) return UCOD_EINVAL;
+      return launch<UCOD_EPI_PATCH_TOKENS_H16>(a, variant, s);
     default: return UCOD_EINVAL;
   }
 }

@@ -21,7 +21,7 @@ Plan make_plan(const ucod_vit_desc* d) {
   p.M = d->B * p.tok;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-  p.off_x = take((size_t)p.M * d->D * 4);
+  p.off_x = take((size_t)p.M * d->D * (d->resid16 ? 2 : 4));
   p.off_h = take((size_t)p.M * d->D * 2);
   p.off_qkv = take((size_t)p.M * 3 * d->D * 2);
   p.off_a = take((size_t)p.M * d->D * 2);
@@ -37,7 +37,7 @@ Plan make_plan(const ucod_vit_desc* d) {
 bool valid(const ucod_vit_desc* d) {
   return d && d->B > 0 && d->C > 0 && d->P > 0 && d->H > 0 && d->W > 0 && d->H % d->P == 0 && d->W % d->P == 0 && d->D > 0 &&
          d->heads > 0 && d->D == d->heads * 64 && d->D % 128 == 0 && d->F % 128 == 0 && d->L >= 1 && d->Kpad % 64 == 0 &&
-         d->Kpad >= d->C * d->P * d->P;
+         d->Kpad >= d->C * d->P * d->P && (d->resid16 == 0 || d->resid16 == 1);
 }
 
 }  // namespace
@@ -77,16 +77,24 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
     RUN(ucod_attention_fp8_zero_pad(ws + p.off_f8, d->B, tok, d->heads, stream));
   }
 
+  // residual stream x: f32, or IEEE fp16 with resid16 (half the bytes of LayerNorm's read and of the out-proj / fc2 epilogues)
+  const bool r16 = d->resid16 != 0;
+  const int epi_patch = r16 ? UCOD_EPI_PATCH_TOKENS_H16 : UCOD_EPI_PATCH_TOKENS_F32;
+  const int epi_resid = r16 ? UCOD_EPI_BIAS_SCALE_RESID_H16 : UCOD_EPI_BIAS_SCALE_RESID_F32;
+  auto layernorm = [&](const float* g, const float* b) {
+    return r16 ? ucod_layernorm_h16(x, g, b, h, M, D, d->eps, stream) : ucod_layernorm(x, g, b, h, M, D, d->eps, 0, stream);
+  };
   // embeddings: patch conv as GEMM (+bias +pos), CLS rows
   RUN(ucod_patch_im2col(img, patches, d->B, d->C, d->H, d->W, d->P, d->Kpad, stream));
-  RUN(ucod_gemm_bf16(UCOD_EPI_PATCH_TOKENS_F32, patches, T[0], x, d->B * (tok - 1), D, d->Kpad, (const float*)T[1], nullptr, nullptr,
+  RUN(ucod_gemm_bf16(epi_patch, patches, T[0], x, d->B * (tok - 1), D, d->Kpad, (const float*)T[1], nullptr, nullptr,
                      (const float*)T[3], tok, gv, stream));
-  RUN(ucod_cls_rows(x, (const float*)T[2], (const float*)T[3], d->B, tok, D, stream));
+  if (r16) RUN(ucod_cls_rows_h16(x, (const float*)T[2], (const float*)T[3], d->B, tok, D, stream));
+  else RUN(ucod_cls_rows(x, (const float*)T[2], (const float*)T[3], d->B, tok, D, stream));
 
   for (int l = 0; l < d->L; ++l) {
     const void* const* W = T + 4 + UCOD_VIT_LAYER_STRIDE * l;
     const bool last = (l == d->L - 1);
-    RUN(ucod_layernorm(x, (const float*)W[0], (const float*)W[1], h, M, D, d->eps, 0, stream));
+    RUN(layernorm((const float*)W[0], (const float*)W[1]));
     if (last) {
       // key hook: only the K slice (rows D..2D-1) of the fused qkv weight; output written as [B,D,h,w]
       const char* wk = (const char*)W[2] + (size_t)D * D * 2;
@@ -101,10 +109,10 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
       RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_BF16, h, W[2], qkv, M, 3 * D, D, (const float*)W[3], prescale ? qscale : nullptr, nullptr, nullptr, tok, gv, stream));
       RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, prescale ? 0.f : scale, av, stream));
     }
-    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_SCALE_RESID_F32, a, W[4], x, M, D, D, (const float*)W[5], (const float*)W[6], x, nullptr, tok, gv, stream));
-    RUN(ucod_layernorm(x, (const float*)W[7], (const float*)W[8], h, M, D, d->eps, 0, stream));
+    RUN(ucod_gemm_bf16(epi_resid, a, W[4], x, M, D, D, (const float*)W[5], (const float*)W[6], x, nullptr, tok, gv, stream));
+    RUN(layernorm((const float*)W[7], (const float*)W[8]));
     RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_GELU_BF16, h, W[9], g, M, F, D, (const float*)W[10], nullptr, nullptr, nullptr, tok, gv, stream));
-    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_SCALE_RESID_F32, g, W[11], x, M, D, F, (const float*)W[12], (const float*)W[13], x, nullptr, tok, gv, stream));
+    RUN(ucod_gemm_bf16(epi_resid, g, W[11], x, M, D, F, (const float*)W[12], (const float*)W[13], x, nullptr, tok, gv, stream));
   }
   return UCOD_OK;
 }

@@ -109,6 +109,70 @@ __global__ __launch_bounds__(256) void layernorm4_kernel(const float* __restrict
   }
 }
 
+// LayerNorm of an IEEE-fp16 residual stream (ucod_vit_desc.resid16): the row arrives as 8-byte (4 x f16, D % 256 == 0) or 4-byte
+// (2 x f16) chunks per lane, is widened to f32 in registers, and the same two-pass f32 statistics follow; output = operand type.
+template <int NV, int W>                                  // NV chunks of W f16 per lane: D = 64 * NV * W
+__global__ __launch_bounds__(256) void layernorm_h16_kernel(const unsigned* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_raw* __restrict__ y, int rows, int D, float eps) {
+  constexpr int R = 2, PW = W / 2;                         // packed dwords per chunk
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
+  float v[R][NV][W];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = (row0 + r) < rows ? (row0 + r) : rows - 1;
+    const unsigned* xr = x + (size_t)row * (D / 2);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      unsigned w[PW];
+      if constexpr (PW == 2) {
+        const u32x2 t = reinterpret_cast<const u32x2*>(xr)[lane + 64 * i];
+        w[0] = t[0];
+        w[1] = t[1];
+      } else {
+        w[0] = xr[lane + 64 * i];
+      }
+#pragma unroll
+      for (int e = 0; e < PW; ++e) unpack_f16x2(w[e], v[r][i][2 * e], v[r][i][2 * e + 1]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < W; ++e) s += v[r][i][e];
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < W; ++e) {
+        const float a = v[r][i][e] - mean;
+        q += a * a;
+      }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    const int row = row0 + r;
+    if (row >= rows) break;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c0 = (lane + 64 * i) * W;
+      unsigned o[PW];
+#pragma unroll
+      for (int e = 0; e < PW; ++e) {
+        const float o0 = (v[r][i][2 * e] - mean) * rstd * gamma[c0 + 2 * e] + beta[c0 + 2 * e];
+        const float o1 = (v[r][i][2 * e + 1] - mean) * rstd * gamma[c0 + 2 * e + 1] + beta[c0 + 2 * e + 1];
+        o[e] = pack_h2(o0, o1);
+      }
+      unsigned* yr = reinterpret_cast<unsigned*>(y + (size_t)row * D);
+      if constexpr (PW == 2) reinterpret_cast<u32x2*>(yr)[lane + 64 * i] = (u32x2){o[0], o[1]};
+      else yr[lane + 64 * i] = o[0];
+    }
+  }
+}
+
 template <bool OUT_F32>
 static int launch_ln(const float* x, const float* g, const float* b, void* y, int rows, int D, float eps, hipStream_t s) {
   dim3 grid(cdiv(rows, 8)), block(256);
@@ -204,6 +268,14 @@ __global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__
   x[(size_t)b * tok * D + j] = cls[j] + pos[j];
 }
 
+__global__ void cls_rows_h16_kernel(unsigned short* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos, int B,
+                                    int tok, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, j = i - b * D;
+  x[(size_t)b * tok * D + j] = __builtin_bit_cast(unsigned short, (_Float16)(cls[j] + pos[j]));
+}
+
 __global__ void cast_kernel(const float* __restrict__ s, bf16_raw* __restrict__ d, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = f32_to_h(s[i]);
 }
@@ -216,6 +288,43 @@ extern "C" int ucod_layernorm(const float* x, const float* gamma, const float* b
   UCOD_PROF(ucod::PROF_LN, stream);
   return out_f32 ? ucod::launch_ln<true>(x, gamma, beta, y, rows, D, eps, (hipStream_t)stream)
                  : ucod::launch_ln<false>(x, gamma, beta, y, rows, D, eps, (hipStream_t)stream);
+}
+
+extern "C" int ucod_layernorm_h16(const void* x, const float* gamma, const float* beta, void* y, int rows, int D, float eps, void* stream) {
+  using namespace ucod;
+  if (!x || !gamma || !beta || !y || rows <= 0 || D <= 0 || (D % 128) != 0 || D > 1536) return UCOD_EINVAL;
+  UCOD_PROF(PROF_LN, stream);
+  dim3 grid(cdiv(rows, 8)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned* xp = (const unsigned*)x;
+  bf16_raw* yp = (bf16_raw*)y;
+  if ((D % 256) == 0) {
+    switch (D / 256) {
+#define LNH_CASE(n) \
+  case n: hipLaunchKernelGGL((layernorm_h16_kernel<n, 4>), grid, block, 0, s, xp, gamma, beta, yp, rows, D, eps); break;
+      LNH_CASE(1) LNH_CASE(2) LNH_CASE(3) LNH_CASE(4) LNH_CASE(5) LNH_CASE(6)
+#undef LNH_CASE
+      default: return UCOD_EINVAL;
+    }
+  } else {
+    switch (D / 128) {
+#define LNH_CASE(n) \
+  case n: hipLaunchKernelGGL((layernorm_h16_kernel<n, 2>), grid, block, 0, s, xp, gamma, beta, yp, rows, D, eps); break;
+      LNH_CASE(1) LNH_CASE(3) LNH_CASE(5) LNH_CASE(7) LNH_CASE(9) LNH_CASE(11)
+#undef LNH_CASE
+      default: return UCOD_EINVAL;
+    }
+  }
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_cls_rows_h16(void* x, const float* cls, const float* pos, int B, int tok, int D, void* stream) {
+  if (!x || !cls || !pos || B <= 0 || tok <= 0 || D <= 0) return UCOD_EINVAL;
+  UCOD_PROF(ucod::PROF_CLS, stream);
+  hipLaunchKernelGGL(ucod::cls_rows_h16_kernel, dim3(ucod::cdiv((long)B * D, 256)), dim3(256), 0, (hipStream_t)stream, (unsigned short*)x, cls, pos, B, tok, D);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
 }
 
 extern "C" int ucod_patch_im2col(const float* img, void* patches, int B, int C, int H, int W, int P, int Kpad, void* stream) {

@@ -26,7 +26,8 @@ bool valid(const ucod_vit_train_desc* t) {
   const ucod_vit_desc* d = &t->vit;
   return d->B > 0 && d->C > 0 && d->P > 0 && d->H > 0 && d->W > 0 && d->H % d->P == 0 && d->W % d->P == 0 && d->D > 0 && d->heads > 0 &&
          d->D == d->heads * 64 && d->D % 128 == 0 && d->F % 128 == 0 && d->L >= 1 && d->Kpad % 64 == 0 && d->Kpad >= d->C * d->P * d->P &&
-         t->lora_r >= 1 && 3 * t->lora_r <= UCOD_LORA_AUG && t->lora_dropout >= 0.f && t->lora_dropout < 1.f;
+         t->lora_r >= 1 && 3 * t->lora_r <= UCOD_LORA_AUG && t->lora_dropout >= 0.f && t->lora_dropout < 1.f &&
+         d->resid16 == 0;                                        // the backward kernels read the f32 residual stream
 }
 
 TPlan make_plan(const ucod_vit_train_desc* t) {

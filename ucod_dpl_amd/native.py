@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("UCOD_DPL_LIB") or os.path.join(_HERE, "_native", "lib
 EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_SCALE_RESID_F32, EPI_PATCH_TOKENS_F32, EPI_KEY_NCHW_F32, EPI_BIAS_F32 = range(6)
 EPI_GELU_BWD_BF16, EPI_BIAS_GELU_SAVE_BF16 = 6, 7          # ucod_gemm_bf16_train only (backbone-backward mode)
 EPI_QKV_FP8 = 8                                            # QKV projection of the fp8 attention path
+EPI_BIAS_SCALE_RESID_H16, EPI_PATCH_TOKENS_H16 = 9, 10     # f16 residual stream (VitDesc.resid16)
 VIT_LAYER_STRIDE = 14
 VIT_TRAIN_STRIDE = 7
 LORA_AUG = 64
@@ -23,7 +24,7 @@ vp, ci, cf, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 class VitDesc(C.Structure):
     _fields_ = [(n, ci) for n in ("B", "C", "H", "W", "P", "D", "heads", "F", "L", "Kpad")] + [("eps", cf)] + \
-               [(n, ci) for n in ("full_last_layer", "gemm_variant", "attn_variant")]
+               [(n, ci) for n in ("full_last_layer", "gemm_variant", "attn_variant", "resid16")]
 
 
 class VitTrainDesc(C.Structure):
@@ -54,6 +55,7 @@ SIGNATURES = {
     "ucod_prof_collect": (ci, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ucod_gemm_bf16": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
     "ucod_layernorm": (ci, [vp, vp, vp, vp, ci, ci, cf, ci, vp]),
+    "ucod_layernorm_h16": (ci, [vp, vp, vp, vp, ci, ci, cf, vp]),
     "ucod_attention_fwd": (ci, [vp, vp, ci, ci, ci, cf, ci, vp]),
     "ucod_attention_fp8_workspace_bytes": (sz, [ci, ci, ci]),
     "ucod_attention_fwd_fp8": (ci, [vp, vp, vp, sz, ci, ci, ci, ci, ci, ci, vp]),
@@ -61,6 +63,7 @@ SIGNATURES = {
     "ucod_attention_fwd_fp8_fused": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "ucod_patch_im2col": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "ucod_cls_rows": (ci, [vp, vp, vp, ci, ci, ci, vp]),
+    "ucod_cls_rows_h16": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "ucod_fill_qscale": (ci, [vp, ci, cf, vp]),
     "ucod_fill_qscale3": (ci, [vp, ci, cf, cf, cf, vp]),
     "ucod_cast_f32_bf16": (ci, [vp, vp, sz, vp]),

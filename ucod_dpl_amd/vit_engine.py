@@ -99,12 +99,20 @@ def normalize_state_dict(sd):
 class ViTEngine:
     """HIP ViT forward -> last-layer key map [B, D, H/P, W/P] (f32)."""
 
-    def __init__(self, state_dict, heads, eps=1e-6, device="cuda", full_last_layer=False, gemm_variant=0, attn_variant=0, half="bf16"):
+    def __init__(self, state_dict, heads, eps=1e-6, device="cuda", full_last_layer=False, gemm_variant=0, attn_variant=0, half="bf16",
+                 resid="auto"):
         """``half``: 16-bit type of the GEMM / attention operands -- "bf16" (default; BASELINE configs[1]) or "f16" (IEEE fp16, what
         the reference's fp16-autocast launcher computes in: 8x finer rounding, logits within 1e-3 of the f32 reference at full
         depth; same speed).  Each choice is its own build of the same kernels (native.load)."""
         self.half = half
         self.lib = N.load(half)
+        # Residual stream x between the GEMM epilogues and LayerNorm: "f32", "f16" (IEEE fp16: 11 significand bits, finer than the bf16
+        # operands it is rounded to anyway; half the bytes of LayerNorm's read and of the out-proj / fc2 read-modify-write), or "auto":
+        # f16 for the bf16 build on passes of at least 4096 token rows (the large-tile GEMM regime; a batch-1 Look-Twice pass keeps the
+        # small-tile f32 path), f32 for the fp16-operand build (the one that stays within 1e-3 of the f32 reference).
+        if resid not in ("auto", "f32", "f16"):
+            raise ValueError(f"resid must be 'auto', 'f32' or 'f16', got {resid!r}")
+        self.resid = resid
         c = normalize_state_dict(state_dict)
         self.kind = c["kind"]
         self.device = torch.device(device)
@@ -160,7 +168,11 @@ class ViTEngine:
         d.eps = self.eps
         d.full_last_layer = int(self.full_last_layer)
         d.gemm_variant, d.attn_variant = self.gemm_variant, self.attn_variant
+        rows = B * ((H // self.P) * (W // self.P) + 1)
+        d.resid16 = int(self.resid == "f16" or (self.resid == "auto" and self.half == "bf16" and rows >= 4096 and self._allow_resid16))
         return d
+
+    _allow_resid16 = True                                      # the backbone-backward engine keeps the f32 stream (its kernels read it)
 
     def forward(self, img, out=None, _async=False, n_layers=None):
         """``n_layers``: stop after that many encoder layers and return THAT layer's key map (diagnostics: the per-layer error
@@ -263,6 +275,8 @@ _QKV = ("query", "key", "value")
 
 
 class ViTLoRAEngine(ViTEngine):
+    _allow_resid16 = False
+
     """Backbone-backward mode (SURVEY.md 8a row B9): the frozen ViT with peft-style LoRA on query / key / value of every
     encoder layer, as models/modules/full_model.py:47-72 configures it (r=2, lora_alpha=4, bias='none', target
     query/key/value; lora_A kaiming_uniform(a=sqrt 5), lora_B zeros).  ``forward_train`` saves activations,
