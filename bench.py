@@ -237,34 +237,13 @@ def main():
 
     # The same step with IEEE fp16 GEMM / attention operands (ViTEngine(half="f16"): the reference's own autocast type, 8x finer rounding
     # than bf16 -- the build that meets the 1e-3 logit bar, see cpu_baseline.parity_full_size.f16_operands), same schedule, reported
-    # SEPARATELY (never part of `value`)
+    # SEPARATELY (never part of `value`).  Measured by a CHILD process running this script with --half f16 once this process has
+    # finished its own GPU work (a second engine in the same process measures 10 % low: it inherits the allocator and clock state of
+    # everything that ran before it); N = 1 only.
     f16_option = None
     del bb, pipe
     torch.cuda.empty_cache()
-    if a.half == "bf16" and a.lora_steps >= 0:
-        bb16 = backbone.random_init(a.arch, seed=0, image_size=a.image, device=dev, full_last_layer=a.full_last_layer,
-                                    gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half="f16")
-        bb16.engine.streams = a.streams
-        pipe16 = FeaturePipeline(bb16.engine)
-        pipe16.submit(images)
-        for _ in range(3):
-            k16 = pipe16.next_features(); pipe16.submit(images); loop._process_batch((pl, k16)); loop.global_step += 1
-        barrier()
-        t3 = time.perf_counter()
-        for _ in range(a.steps):
-            k16 = pipe16.next_features(); pipe16.submit(images); loop._process_batch((pl, k16)); loop.global_step += 1
-        barrier()
-        dt16 = time.perf_counter() - t3
-        if world > 1:
-            tdt = torch.tensor([dt16], dtype=torch.float64, device=dev)
-            torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
-            dt16 = tdt.item()
-        pipe16.next_features()
-        f16_option = {"value": round(world * B * a.steps / dt16, 2), "unit": "images/s", "ms_per_step": round(dt16 / a.steps * 1e3, 3),
-                      "what": "the timed step with fp16 backbone operands (libucod_dpl_f16.so), same schedule"}
-        del bb16, pipe16
-        torch.cuda.empty_cache()
-
+    run_f16_child = a.half == "bf16" and a.lora_steps >= 0 and world == 1 and not os.environ.get("UCOD_BENCH_CHILD")
     # Optional mode of SURVEY.md 8a row B9, reported SEPARATELY (never part of `value`): images -> LoRA backbone (student,
     # activations saved) + EMA backbone (teacher) -> the same decoder/APM/discriminator step -> backbone backward -> all-reduce
     # of decoder and LoRA gradients -> both fused optimisers.
@@ -349,6 +328,20 @@ def main():
     cpu = None
     if not a.no_cpu_baseline and world == 1:                  # rank 0 at N = 1 only (the contract); the N > 1 lines carry null
         cpu = cpu_baseline(a, D, heads, L, P)
+
+    if run_f16_child:
+        import subprocess
+        torch.cuda.synchronize()
+        cmd = [sys.executable, os.path.abspath(__file__), "--half", "f16", "--steps", str(a.steps), "--warmup", str(a.warmup), "--batch", str(B),
+               "--arch", a.arch, "--image", str(a.image), "--streams", str(a.streams), "--attn-variant", str(a.attn_variant), "--lora-steps", "-1",
+               "--no-cpu-baseline"] + (["--no-pipeline"] if a.no_pipeline else []) + (["--full-last-layer"] if a.full_last_layer else [])
+        r = subprocess.run(cmd, env=dict(os.environ, UCOD_BENCH_CHILD="1"), capture_output=True, text=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            raise SystemExit("bench.py: the fp16-operand child run failed:\n" + r.stderr[-2000:])
+        c = json.loads(line[-1])
+        f16_option = {"value": c["value"], "unit": "images/s", "ms_per_step": c["ms_per_step"],
+                      "what": "the timed step with fp16 backbone operands (libucod_dpl_f16.so), same schedule, own process (python bench.py --half f16)"}
 
     ips = world * B * a.steps / dt
     out = {

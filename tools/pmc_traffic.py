@@ -7,7 +7,7 @@ bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE under-report
 import collections, csv, glob, json, os, sys
 
 CLASSES = {                                  # bench.py kernel class -> substring of the kernel name
-    "gemm_bf16_proj_fc2_scale_resid": "gemm_bf16_big_kernel<2,",
+    "gemm_bf16_proj_fc2_scale_resid": "gemm_bf16_mixed_kernel<9,",   # fp16 residual stream (the f32 form is gemm_bf16_big_kernel<2,)
     "gemm_bf16_fc1_gelu": "gemm_bf16_mixed_kernel<1,",
     "gemm_bf16_qkv_bias": "gemm_bf16_mixed_kernel<0,",
     "attention_fwd": "attn_fwd_v5_kernel",
