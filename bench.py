@@ -138,6 +138,7 @@ def main():
                               gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half=a.half, resid=os.environ.get("UCOD_RESID", "auto"))
     bb.engine.streams = a.streams
     B = a.batch
+    resid16 = bool(bb.engine._desc(B, a.image, a.image).resid16)      # fp16 residual stream on this pass (ViTEngine resid="auto")
     g = torch.Generator().manual_seed(1234 + rank)
     images = torch.randn(B, 3, a.image, a.image, generator=g).to(dev)
     pl = (torch.rand(B, 1, 16, 16, generator=g) > 0.7).float().to(dev)
@@ -301,11 +302,12 @@ def main():
             k["tflops"] = round(fl / (avg_us * 1e-6) / 1e12, 1)
         kernels[name] = k
     # HBM-bound representative: LayerNorm.  ALGORITHMIC bytes per SURVEY.md 8(d) / BASELINE.md section 3 = rows*D*(2 B read + 2 B write);
-    # this build keeps the residual stream in f32 (accuracy: it is what the GEMM epilogues accumulate into), so a launch MOVES
+    # with the fp16 residual stream (default on large passes) that is also what the launch moves; with the f32 stream it moves
     # rows*D*(4 + 2) B (PMC: 202 MB) -- reported beside it as `moved_gbs`
+    ln_moved = 4 if resid16 else 6
     if "layernorm" in kernels:
         kernels["layernorm"]["gbs"] = round(B * tok * D * 4 / (kernels["layernorm"]["avg_us"] * 1e-6) / 1e9, 1)
-        kernels["layernorm"]["moved_gbs"] = round(B * tok * D * 6 / (kernels["layernorm"]["avg_us"] * 1e-6) / 1e9, 1)
+        kernels["layernorm"]["moved_gbs"] = round(B * tok * D * ln_moved / (kernels["layernorm"]["avg_us"] * 1e-6) / 1e9, 1)
     dom = max((n for n in kernels if "tflops" in kernels[n] and n.startswith(("gemm_bf16", "attention"))),
               key=lambda n: kernels[n]["ms_per_step"])
     traffic = None                                            # HBM-side bytes per launch from committed PMC passes (see the file's "source")
@@ -323,7 +325,8 @@ def main():
                                "frac": round(kernels["layernorm"]["gbs"] / HBM_PEAK_GBS, 4),
                                "bytes": "algorithmic (SURVEY 8d): bf16 read + bf16 write = 4 B/element",
                                "moved": {"achieved": kernels["layernorm"]["moved_gbs"], "frac": round(kernels["layernorm"]["moved_gbs"] / HBM_PEAK_GBS, 4),
-                                         "bytes": "f32 residual read + bf16 write = 6 B/element (what the launch moves; PMC 202 MB)"}}
+                                         "bytes": "fp16 residual read + 16-bit write = 4 B/element: the launch moves exactly the algorithmic bytes (PMC 135 MB)" if resid16
+                                         else "f32 residual read + bf16 write = 6 B/element (what the launch moves; PMC 202 MB)"}}
 
     cpu = None
     if not a.no_cpu_baseline and world == 1:                  # rank 0 at N = 1 only (the contract); the N > 1 lines carry null
@@ -352,7 +355,7 @@ def main():
         "config": {"workload": f"{which_config(a.arch, a.image, B, a.attn_variant)}: {a.arch} @{a.image}x{a.image}, batch {B}/GPU, full APM+DBA+discriminator step, "
                                f"decoder path exact f32, backbone {a.half} MFMA", "global_batch": B * world, "parallelism": f"dp{world}",
                    "backbone_last_layer": "full (as reference)" if a.full_last_layer else "key-minimal (identical key output; 279.6 of 303.1 GFLOP/img)",
-                   "random_init_weights": True,
+                   "random_init_weights": True, "residual_stream": "fp16" if resid16 else "f32",
                    "schedule": "serial, one stream" if a.no_pipeline else
                                f"backbone pass of step k+1 on {a.streams} side stream(s) overlapped with the decoder step of step k"},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "final_loss": round(final_loss, 6),
