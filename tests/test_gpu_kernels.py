@@ -83,6 +83,50 @@ def test_gemm_bf16_large_tile_is_race_free_and_deterministic():
                 assert torch.equal(out, first), (variant, it)
 
 
+def test_gemm_mixed_height_kernel_is_race_free_and_deterministic():
+    """The mixed-height kernel keeps LDS-DMA in flight across barriers like the other large-tile kernels and adds a second (tall)
+    instantiation with three barrier intervals per K-tile and a third DMA instruction on two of the eight waves: hammer both bodies --
+    full-size K, every output against an f32 product once, then bitwise repeatability over many launches -- for the bf16 epilogue,
+    the fp16-residual read-modify-write epilogue and the e4m3 QKV epilogue."""
+    g = torch.Generator().manual_seed(78)
+    for (M, Nn, K) in ((43840, 2304, 768), (21916, 768, 3072), (43840, 768, 768), (21920, 3072, 768)):
+        A = bf(torch.randn(M, K, generator=g)).to(DEV)
+        W = bf(torch.randn(Nn, K, generator=g) * 0.05).to(DEV)
+        b, sc = torch.randn(Nn, generator=g).to(DEV), (torch.rand(Nn, generator=g) + 0.5).to(DEV)
+        ref = A.float() @ W.float().t() + b
+        first = None
+        for it in range(10):
+            out = ops.linear_bf16(A, W, b, variant=13)
+            if first is None:
+                first = out.clone()
+                assert rel_l2(out.float(), ref) < 4e-3
+            else:
+                assert torch.equal(out, first), ("bf16", M, Nn, K, it)
+        if Nn == 768:
+            resid = (torch.randn(M, Nn, generator=g) * 4).to(torch.float16).to(DEV)
+            x = torch.empty_like(resid)
+            first = None
+            for it in range(10):
+                x.copy_(resid)
+                ops.gemm_bf16(N.EPI_BIAS_SCALE_RESID_H16, A, W, x, M, Nn, K, bias=b, scale=sc, resid=x)
+                if first is None:
+                    first = x.clone()
+                    want = resid.float() + sc * ref
+                    assert maxdiff(first.float(), want) < 3e-3 * want.abs().max().item()
+                else:
+                    assert torch.equal(x, first), ("resid_h16", M, Nn, K, it)
+        if Nn % 192 == 0 and M % 1370 == 0:
+            heads = Nn // 192
+            ws = torch.zeros(N.load().ucod_attention_fp8_workspace_bytes(M // 1370, 1370, heads), dtype=torch.uint8, device=DEV)
+            first = None
+            for it in range(6):
+                ops.gemm_bf16(N.EPI_QKV_FP8, A, W, ws, M, Nn, K, bias=b, scale=sc, tok=1370)
+                if first is None:
+                    first = ws.clone()
+                else:
+                    assert torch.equal(ws, first), ("qkv_fp8", M, Nn, K, it)
+
+
 @pytest.mark.parametrize("variant,M,Nn,K", [(9, 21916, 768, 768), (9, 21916, 768, 3072), (10, 16401, 768, 3136), (9, 43840, 768, 192),
                                             (0, 43840, 768, 3072), (5, 65600, 512, 64), (3, 22000, 768, 768),
                                             # mixed-height launches (variants 13 / 14, gemm_bf16_mixed_kernel): a few 288-row tiles among
