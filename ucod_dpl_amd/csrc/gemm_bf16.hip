@@ -949,41 +949,43 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
   constexpr int NPH = Cfg::NPH, IT = Cfg::IT, NI = Cfg::NI;
   const int wm = wave >> 2, wn = wave & 3;
   const int K = a.K, nt = K / BK;
-  // per-thread LDS-DMA source rows: two instructions cover 128 rows of a group's slot, a third (waves 0 and 1 only) the 16 extra rows
-  const bf16_raw* srcA[2][2 + XT];
-  const bf16_raw* srcB[Cfg::NB];
+  // per-thread LDS-DMA sources as 32-bit byte offsets into buffer descriptors over A and B (two instructions cover 128 rows of a
+  // group's slot, a third -- waves 0 and 1 only -- the 16 extra rows; rows past the end of the matrix fail the range check and arrive
+  // as zeros; the K-tile offset rides in the scalar offset).  Half the address registers of per-lane 64-bit pointers: the kernel has
+  // to stay at 224 VGPRs so that 64 per SIMD lane remain for the small kernels of a concurrent stream (decoder step, LayerNorm).
+  const unsigned long bytesA = (unsigned long)a.M * K * 2ul, bytesB = (unsigned long)a.N * K * 2ul;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(a.A), 0, bytesA > 0xFFFFFFFFul ? 0xFFFFFFFFu : (unsigned)bytesA, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(a.B), 0, bytesB > 0xFFFFFFFFul ? 0xFFFFFFFFu : (unsigned)bytesB, 0x00020000);
+  unsigned offA[2][2 + XT], offB[Cfg::NB];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int i = 0; i < 2 + XT; ++i) {
       const int r = (i * 8 + wave) * 8 + (lane >> 3);
-      int gr = m0 + h * Cfg::RG + r;
-      gr = gr < a.M ? gr : a.M - 1;
-      srcA[h][i] = a.A + (size_t)gr * K + swz(r, lane & 7) * 8;
+      offA[h][i] = ((unsigned)(m0 + h * Cfg::RG + r) * (unsigned)K + (unsigned)swz(r, lane & 7) * 8u) * 2u;
     }
 #pragma unroll
   for (int i = 0; i < Cfg::NB; ++i) {
     const int r = (i * 8 + wave) * 8 + (lane >> 3);
-    int gr = n0 + r;
-    gr = gr < a.N ? gr : a.N - 1;
-    srcB[i] = a.B + (size_t)gr * K + swz(r, lane & 7) * 8;
+    offB[i] = ((unsigned)(n0 + r) * (unsigned)K + (unsigned)swz(r, lane & 7) * 8u) * 2u;
   }
-  auto dma = [&](const bf16_raw* src, char* dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  };
   auto stageA = [&](int t, int h) {
     char* slot = smem + (t & 1) * Cfg::BUF + h * Cfg::SLOT;
+    const unsigned kt = (unsigned)t * (BK * 2);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma(srcA[h][i] + t * BK, slot + (i * 8 + wave) * 1024);
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(slot + (i * 8 + wave) * 1024), 16, offA[h][i], kt, 0, 0);
     if constexpr (XT == 1) {
-      if (wave < 2) dma(srcA[h][2] + t * BK, slot + (16 + wave) * 1024);      // rows 128..143 (wave-uniform: `wave` is an SGPR)
+      if (wave < 2)                                          // rows 128..143 (wave-uniform: `wave` is an SGPR)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(slot + (16 + wave) * 1024), 16, offA[h][2], kt, 0, 0);
     }
   };
   auto stageB = [&](int t) {
     char* slot = smem + (t & 1) * Cfg::BUF + 2 * Cfg::SLOT;
+    const unsigned kt = (unsigned)t * (BK * 2);
 #pragma unroll
-    for (int i = 0; i < Cfg::NB; ++i) dma(srcB[i] + t * BK, slot + (i * 8 + wave) * 1024);
+    for (int i = 0; i < Cfg::NB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(slot + (i * 8 + wave) * 1024), 16, offB[i], kt, 0, 0);
   };
 
   float cb[NT], cs[NT];

@@ -1,6 +1,7 @@
 // Memory-bound helpers of the ViT backbone: LayerNorm, patch gather (im2col), CLS rows, casts.
 // All are HBM-bound streaming kernels: one wave per row with wave-shuffle reductions (LayerNorm),
 // vector loads/stores, no LDS.  SURVEY.md 8a rows B1,B2,B3.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/ucod_dpl.h"
 
@@ -111,10 +112,10 @@ __global__ __launch_bounds__(256) void layernorm4_kernel(const float* __restrict
 
 // LayerNorm of an IEEE-fp16 residual stream (ucod_vit_desc.resid16): the row arrives as 8-byte (4 x f16, D % 256 == 0) or 4-byte
 // (2 x f16) chunks per lane, is widened to f32 in registers, and the same two-pass f32 statistics follow; output = operand type.
-template <int NV, int W>                                  // NV chunks of W f16 per lane: D = 64 * NV * W
+template <int NV, int W, int R = 2>                       // NV chunks of W f16 per lane: D = 64 * NV * W; R rows per wave
 __global__ __launch_bounds__(256) void layernorm_h16_kernel(const unsigned* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_raw* __restrict__ y, int rows, int D, float eps) {
-  constexpr int R = 2, PW = W / 2;                         // packed dwords per chunk
+  constexpr int PW = W / 2;                                // packed dwords per chunk
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
   if (row0 >= rows) return;
