@@ -1363,7 +1363,8 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
   if constexpr (kColFused<EPI>) {
     if (variant == 13 || variant == 14) {                     // mixed-height tiles; falls back to 9 / 10 when the plan is not feasible
       const MixedPlan mp = mixed_plan(a.M, a.N, variant == 13 ? 256 : 192);
-      if (!mp.feasible || (a.N & 3) != 0 || (kBf16Out && (a.N & 7) != 0) || a.K < 128) {
+      const bool fits32 = (long)a.M * a.K * 2 < (1L << 32) && (long)a.N * a.K * 2 < (1L << 32);   // the kernel addresses its operands with 32-bit byte offsets
+      if (!mp.feasible || !fits32 || (a.N & 3) != 0 || (kBf16Out && (a.N & 7) != 0) || a.K < 128) {
         variant -= 4;
       } else {
         a.tiles_m = mp.tiles_m;
@@ -1455,6 +1456,7 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
 static int launch_qkv_fp8(ucod::GemmArgs a, hipStream_t s) {
   using namespace ucod;
   if (a.N % 192 != 0 || a.K < 128 || a.tok < 1 || a.M % a.tok != 0 || !a.bias) return UCOD_EINVAL;
+  if ((long)a.M * a.K * 2 >= (1L << 32) || (long)a.N * a.K * 2 >= (1L << 32)) return UCOD_EINVAL;      // 32-bit operand offsets
   const MixedPlan mp = mixed_plan(a.M, a.N, 256);
   a.tiles_n = cdiv(a.N, 256);
   if (mp.feasible) {
@@ -1476,6 +1478,7 @@ static int launch_qkv_fp8(ucod::GemmArgs a, hipStream_t s) {
 static int launch_resid_h16(ucod::GemmArgs a, hipStream_t s) {
   using namespace ucod;
   if ((a.N & 7) != 0 || a.K < 128 || !a.bias || !a.scale || !a.resid) return UCOD_EINVAL;
+  if ((long)a.M * a.K * 2 >= (1L << 32) || (long)a.N * a.K * 2 >= (1L << 32)) return UCOD_EINVAL;      // 32-bit operand offsets
   const MixedPlan mp = mixed_plan(a.M, a.N, 256);
   a.tiles_n = cdiv(a.N, 256);
   if (mp.feasible) {
