@@ -1,3 +1,6 @@
+# Tile-order / store-policy sweep of the large-tile GEMM kernels (profiles/r02_gemm_order_sweep_*.txt).  Run on the MI355X box from the
+# repo root.  The two store-policy libraries are experiment builds of the GEMM file only; make them first (in the build container):
+#   make -C ucod_dpl_amd/csrc variant NAME=sc1 DEFS=-DUCOD_ST_AUX=16 && make -C ucod_dpl_amd/csrc variant NAME=nt DEFS=-DUCOD_ST_AUX=2
 set -x
 python -m pytest tests/test_gpu_kernels.py -q -k "gemm" 2>&1 | tail -5
 python tools/gemm_order_sweep.py > gpurun_out/sweep_default.txt 2>&1
