@@ -221,7 +221,7 @@ def test_attention(variant, B, tok, heads):
     assert rel_l2(out, ref) < 1e-2
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 6, 7, 9, 12])
+@pytest.mark.parametrize("variant", [2, 3, 4, 6, 7, 9, 12, 13, 14, 15])
 @pytest.mark.parametrize("B,tok,heads", [(1, 26, 2), (2, 64, 1), (1, 200, 3), (2, 1370, 2), (1, 1, 1), (3, 129, 2)])
 def test_attention_prescaled_q_kernel(B, tok, heads, variant):
     """VALU-lean kernel: Q carries head_dim^-0.5*log2(e) already (scale=0 in the ABI).  Variants 3 (K/V through registers) and 4
@@ -262,7 +262,7 @@ def test_attention_prescaled_deferred_max_branches():
         q, k, v = (x.float()[:, i * D:(i + 1) * D] for i in range(3))
         p = torch.softmax((q @ k.t()) * math.log(2.0), dim=-1)
         ref = p @ v
-        for variant in (2, 6, 7, 9, 12):
+        for variant in (2, 6, 7, 9, 12, 13, 14, 15):
             out = ops.attention(x.to(DEV), 1, tok, 1, scale=0.0, variant=variant).float().cpu()
             assert maxdiff(out, ref) < 3e-2, (variant, maxdiff(out, ref))
 

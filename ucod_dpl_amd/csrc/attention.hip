@@ -225,6 +225,22 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 
 constexpr float DEFER_THR = 8.0f;
 
+// row-sum accumulation of a pair of probabilities: two v_add_f32, not one v_pk_add_f32 (MI355X_MICROARCH.md: packed f32 VALU is dearer
+// than two plain instructions beside MFMAs; measured here: v5 216 -> 210 us).  The file is built with -fno-slp-vectorize (Makefile),
+// otherwise hipcc re-packs the two adds.
+#ifndef UCOD_ATTN_SCALAR_SUM
+#define UCOD_ATTN_SCALAR_SUM 1
+#endif
+__device__ __forceinline__ void sum_pair(f32x2_t& acc, const f32x2_t& e) {
+#if UCOD_ATTN_SCALAR_SUM
+  acc[0] += e[0];
+  acc[1] += e[1];
+#else
+  acc += e;
+#endif
+}
+
+
 template <bool DMA, bool VSUM = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N,
                                                               int heads, int npairs, float* __restrict__ lse) {
@@ -333,7 +349,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v2_kernel(const bf16_raw* __r
     lwrite(0);
   }
   for (int t = 0; t < nt; ++t) {
-    __syncthreads();                                     // (DMA form: its vmcnt(0) retires this wave's DMAs of tile t before the barrier)
+    if constexpr (DMA) dma_landed_barrier();             // this wave's DMAs of tile t, then everyone's
+    else __syncthreads();
     const bool more = (t + 1 < nt);
     if constexpr (DMA) {
       if (more) stage(t + 1, (t + 1) & 1);               // the other buffer: every wave is past its reads of tile t-1
@@ -462,11 +479,30 @@ __device__ __forceinline__ float xhalf_max(float v) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// ds_read_b64_tr_b16 issued from an asm statement.  Why: hipcc's wait-count pass cannot tell which LDS bytes the transpose-read builtin
+// touches and therefore puts an `s_waitcnt vmcnt(0)` in front of the first one of every tile -- i.e. it force-completes the NEXT tile's
+// K/V LDS-DMA (issued at the top of the tile) in the middle of the current tile, a stall of several hundred cycles per tile and wave
+// that the double buffer exists to avoid.  An asm read is invisible to that pass; tr16_join() is the explicit lgkmcnt wait in front of
+// the consuming MFMA (tied to the fragment registers so that neither the read nor the MFMA can cross it).
+__device__ __forceinline__ hx4 tr16_issue(unsigned lds_addr, int imm) {
+  hx4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "i"(imm));
+  return r;
+}
+__device__ __forceinline__ void tr16_join(hx4& a, hx4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+// counted form: YOUNGER = the asm reads issued after (a, b).  LDS operations retire in order and lgkmcnt counts every one of them, so
+// reads the compiler issues in between only make the wait stricter, never too short.
+template <int YOUNGER>
+__device__ __forceinline__ void tr16_join_counted(hx4& a, hx4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(YOUNGER)); }
+
 // ONE_DECISION: one deferred-rescale decision per 64-key tile (maximum over both 32-key blocks) instead of one per block: one
 // branch less per tile, and the second block's exponentials share a basic block with the first block's P V products, so the
 // compiler can overlap them inside a wave (VALU beside MFMA) instead of leaving all overlap to the other waves of the SIMD.
-template <bool ONE_DECISION>
-__global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N, int heads,
+// NEGM_BLOCK: -m lives in a persistent 16-register block that is the C operand of each 32-key block's first MFMA (no 32 v_mov per
+// tile to initialise the score accumulators), and the two 32-key blocks of a tile are processed one after the other so that only
+// one score tile is live and the block fits the 128-register budget of 4 waves per SIMD.
+template <bool ONE_DECISION, bool NEGM_BLOCK = false, bool ASM_TR = false>
+__global__ __launch_bounds__(256, NEGM_BLOCK ? 4 : 2) void attn_fwd_v5_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N, int heads,
                                                               int npairs, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_BYTES];       // [buffer][K | V]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -526,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
     }
   }
 
+  const unsigned vaddr[2] = {(unsigned)(uintptr_t)smem + (unsigned)voff[0], (unsigned)(uintptr_t)smem + (unsigned)voff[1]};   // ASM_TR: LDS byte addresses
   f32x16 o[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
@@ -535,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
 
   auto tile = [&](int t, auto bufc) {
     constexpr int BUF = decltype(bufc)::value;
-    __syncthreads();                                     // retires this wave's DMAs of tile t (vmcnt(0)) and everyone's reads of tile t-1
+    dma_landed_barrier();                                // this wave's DMAs of tile t have landed; everyone is done reading tile t-1
     if (t + 1 < nt) stage(IntC<BUF ^ 1>{});
     const char* kb = smem + BUF * (2 * KV_BYTES);
 
@@ -614,11 +651,97 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const f32x2_t e = {__builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj + 1])};
-          lsum += e;
+          sum_pair(lsum, e);
           w[jj] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_t));
         }
         pb[ks] = __builtin_bit_cast(hx8, w);
       }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          hx4 lo, hi;
+          if constexpr (ASM_TR) {
+            const int imm = BUF * (2 * KV_BYTES) + (kt * 32 + ks * 16) * 128;
+            lo = tr16_issue(vaddr[dt], imm);
+            hi = tr16_issue(vaddr[dt], imm + 8 * 128);
+            tr16_join(lo, hi);
+          } else {
+            const char* p0 = kb + (kt * 32 + ks * 16) * 128 + voff[dt];
+            lo = UCOD_TR16(p0);
+            hi = UCOD_TR16(p0 + 8 * 128);
+          }
+          const hx8 vf = (hx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[dt] = UCOD_MFMA32(vf, pb[ks], o[dt]);
+        }
+    }
+  };
+
+  f32x16 nm;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) nm[i] = 0.f;
+  const unsigned half_step = (unsigned)(32 * ld) * 2u;    // the swizzles repeat every 16 rows: chunk i = 1 is chunk 0 plus 32 rows
+  auto stage_seq = [&](auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      char* dst = smem + BUF * (2 * KV_BYTES) + (i * 32 + wave * 8) * 128;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, sk[0] + i * half_step, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + KV_BYTES), 16, sv[0] + i * half_step, 0, 0, 0);
+    }
+    sk[0] += tile_step;
+    sv[0] += tile_step;
+  };
+  auto tile_seq = [&](int t, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    dma_landed_barrier();
+    if (t + 1 < nt) stage_seq(IntC<BUF ^ 1>{});
+    const char* kb = smem + BUF * (2 * KV_BYTES);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16 s = nm;
+#pragma unroll
+      for (int sd = 0; sd < 4; ++sd) {
+        const hx8 kf = *reinterpret_cast<const hx8*>(kb + kt * 4096 + koff[sd]);
+        s = UCOD_MFMA32(kf, qf[sd], s);
+      }
+      if (t == nt - 1 && (N & (KT - 1)) != 0) {
+        const int kbase = t * KT + 4 * h5 + kt * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kbase + (r & 3) + 8 * (r >> 2) >= N) s[r] = -1e30f;
+      }
+      float mloc = __builtin_elementwise_maximum(s[0], s[1]);
+#pragma unroll
+      for (int r = 2; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[r]), s[r + 1]);
+      const bool first = (t == 0 && kt == 0);
+      if (first || __any(mloc > DEFER_THR)) {
+        mloc = xhalf_max(mloc);
+        const float delta = first ? mloc : fmaxf(mloc, 0.f);
+        const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+        m_run += delta;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          s[i] -= delta;
+          nm[i] -= delta;                                  // = -m_run bit for bit (negation commutes with rounding)
+          o[0][i] *= alpha;
+          o[1][i] *= alpha;
+        }
+        lsum *= alpha;
+      }
+      hx8 pb[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 w;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const f32x2_t e = {__builtin_amdgcn_exp2f(s[8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(s[8 * ks + 2 * jj + 1])};
+          sum_pair(lsum, e);
+          w[jj] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_t));
+        }
+        pb[ks] = __builtin_bit_cast(hx8, w);
+      }
+__builtin_amdgcn_sched_barrier(0);                  // the score tile dies here: the next block's Q K^T must not start above this point (one live score tile)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -632,10 +755,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
     }
   };
 
-  stage(IntC<0>{});
+  if constexpr (NEGM_BLOCK) stage_seq(IntC<0>{});
+  else stage(IntC<0>{});
   for (int t = 0; t < nt; t += 2) {
-    tile(t, IntC<0>{});
-    if (t + 1 < nt) tile(t + 1, IntC<1>{});
+    if constexpr (NEGM_BLOCK) {
+      tile_seq(t, IntC<0>{});
+      if (t + 1 < nt) tile_seq(t + 1, IntC<1>{});
+    } else {
+      tile(t, IntC<0>{});
+      if (t + 1 < nt) tile(t + 1, IntC<1>{});
+    }
   }
 
   const float lane_sum = lsum[0] + lsum[1];
@@ -822,7 +951,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16_raw* __r
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const f32x2_t e = {__builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj + 1])};
-          lsum += e;
+          sum_pair(lsum, e);
           w[jj] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_t));
         }
         pb[kt][ks] = __builtin_bit_cast(hx8, w);
@@ -874,6 +1003,323 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16_raw* __r
         w[1] = cvt_pk_bf16(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
         *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
       }
+  }
+}
+
+
+// =====================================================================================================
+// w64: ping-pong INSIDE a wave.  One workgroup = 2 waves = 128 query rows; each wave owns 64 rows = two 32-row blocks A and B that run
+// half a tile apart in ONE instruction stream:
+//     block 1 of tile t:  S_B(t) = K(t) Q_B^T - m_B   (8 MFMAs)   beside   P_A(t) = exp2(S_A(t)), row sums   (VALU)
+//                         O_A += V(t)^T P_A(t)        (8 MFMAs)   beside   running-max check of S_B(t)       (VALU)
+//     block 2 of tile t:  S_A(t+1) = K(t+1) Q_A^T - m_A           beside   P_B(t) ...;   O_B += V(t)^T P_B(t)  beside  max check of S_A(t+1)
+// so the matrix instructions of one block always have the other block's softmax to run beside, by construction and without the
+// workgroup barriers the 8-wave ping-pong kernel pays for the same pairing (it lost to v5 on exactly those).  -m is a persistent
+// 16-register C operand per block (no accumulator initialisation), the rescale branch is the only branch of the hot loop and sits at
+// the end of each block; the key mask of a partial last tile lives in the peeled last two iterations.  K ring of three tiles (block A
+// reads K(t+1) in the iteration in which block B reads K(t)) and of three V tiles, DMA two tiles ahead: 48 KB, one barrier per tile between two waves.
+// =====================================================================================================
+constexpr int QT3 = 128;
+#ifndef W64_DEBUG
+#define W64_DEBUG 0      // timing ablations of the w64 kernel (wrong results): 1 no barrier, 2 no V-fragment waits, 4 no exp, 8 no P V MFMAs, 16 no Q K^T MFMAs, 32 no max chain
+#endif
+
+// O^T += V^T P^T with the accumulator pinned to the AccVGPR half of the register file: the w64 kernel owns more than 256 registers per
+// wave (one wave per SIMD) and O is touched by nothing but these MFMAs inside the tile loop, so the 64 O registers must not compete
+// with the softmax operands for architectural VGPRs (left to itself hipcc puts the SCORE tiles there and pays a v_accvgpr_read per
+// exponential).  The operands come from compiler-scheduled ds_read / v_cvt_pk (their waits are the compiler's); s_nop 1 covers the
+// VALU-write -> MFMA-read wait states the hazard recogniser cannot see through an asm statement.
+__device__ __forceinline__ void pv_mfma_acc(f32x16& acc, const hx8& a, const hx8& b) {
+  asm volatile("s_nop 1\n\t" UCOD_MFMA32_ASM " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// O *= alpha in place in the AccVGPRs (rare rescale path).  Written as asm on "+a" operands so that O never changes register class at
+// the join behind the branch: with a plain `o *= alpha` hipcc keeps the merged value in VGPRs and moves all 64 O registers of the block
+// out of and back into the AccVGPRs on EVERY tile.
+__device__ __forceinline__ void acc_scale(float& a, float alpha) {
+  float t;
+  asm volatile("v_accvgpr_read_b32 %1, %0\n\ts_nop 0\n\tv_mul_f32 %1, %1, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %0, %1" : "+a"(a), "=&v"(t) : "v"(alpha));
+}
+// before the compiler reads O out of the AccVGPRs (rescale branch, epilogue): the last asm MFMA (16 passes) must have retired
+__device__ __forceinline__ void pv_mfma_fence(f32x16& a0, f32x16& a1) {
+  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a0), "+a"(a1));
+}
+
+__global__ __launch_bounds__(128) void attn_fwd_w64_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N, int heads,
+                                                           int npairs) {
+  __shared__ __attribute__((aligned(16))) char smem[6 * KV_BYTES];       // K ring [3] | V ring [3]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h5 = lane >> 5, l31 = lane & 31;
+  const int nq = (N + QT3 - 1) / QT3;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pair = (slot / nq) * 8 + xcd, qt = slot - (slot / nq) * nq;
+  if (pair >= npairs) return;
+  const int head = pair % heads, b = pair / heads;
+  const int D = heads * HD, ld = 3 * D;
+  const int q0 = qt * QT3 + wave * 64;
+  const bf16_raw* base = qkv + (size_t)b * N * ld + head * HD;
+
+  hx8 qf[2][4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    int qr = q0 + 32 * x + l31;
+    qr = qr < N ? qr : N - 1;
+    const bf16_raw* qp = base + (size_t)qr * ld + 8 * h5;
+#pragma unroll
+    for (int sd = 0; sd < 4; ++sd) qf[x][sd] = *reinterpret_cast<const hx8*>(qp + 16 * sd);
+  }
+
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(qkv + (size_t)b * N * ld), 0, (unsigned)N * (unsigned)ld * 2u, 0x00020000);
+  // a 64-row tile = 4 DMA instructions per wave (1 KiB each: 8 rows); instruction i covers rows 16 i + 8 wave .. + 7 (the swizzles repeat every 16 rows)
+  unsigned sk, sv;
+  {
+    const int row = wave * 8 + (lane >> 3), ch = lane & 7;
+    sk = (unsigned)(row * ld + D + head * HD + swz_k(row, ch) * 8) * 2u;
+    sv = (unsigned)(row * ld + 2 * D + head * HD + swz_v(row, ch) * 8) * 2u;
+  }
+  const unsigned tile_step = (unsigned)(KT * ld) * 2u, step16 = (unsigned)(16 * ld) * 2u;
+  int kissue = 0, vissue = 0;
+  auto stageK = [&]() {
+    char* dst = smem + kissue * KV_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + i * 2048), 16, sk + i * step16, 0, 0, 0);
+    sk += tile_step;
+    kissue = kissue == 2 ? 0 : kissue + 1;
+  };
+  auto stageV = [&]() {
+    char* dst = smem + (3 + vissue) * KV_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + i * 2048), 16, sv + i * step16, 0, 0, 0);
+    sv += tile_step;
+    vissue = vissue == 2 ? 0 : vissue + 1;
+  };
+
+  int koff[4], voff[2];
+#pragma unroll
+  for (int sd = 0; sd < 4; ++sd) koff[sd] = l31 * 128 + swz_k(l31, 2 * sd + h5) * 16;
+  {
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    const int key = 4 * h5 + (i16 >> 2);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int dst = dt * 32 + g1 * 16 + 4 * (i16 & 3);
+      voff[dt] = 3 * KV_BYTES + key * 128 + swz_v(key, dst >> 3) * 16 + (dst & 7) * 2;
+    }
+  }
+
+  f32x16 o[2][2], s[2][2], nm[2];
+  f32x2_t lsum[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    lsum[x] = (f32x2_t){0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[x][0][i] = 0.f; o[x][1][i] = 0.f; nm[x][i] = 0.f; }
+  }
+  const int nt = (N + KT - 1) / KT;
+
+  // K fragments of the NEXT block's Q K^T are fetched into registers during the current block (one wave per SIMD: nothing else would
+  // cover the LDS latency in front of the first product)
+  hx8 kfr[2][4];
+  auto loadk = [&](int kslot) {
+    const char* kb = smem + kslot * KV_BYTES;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int sd = 0; sd < 4; ++sd) {
+        if constexpr (!(W64_DEBUG & 64)) kfr[kt][sd] = *reinterpret_cast<const hx8*>(kb + kt * 4096 + koff[sd]);
+        else kfr[kt][sd] = qf[kt][sd];
+      }
+  };
+  // S_X(t)^T = K(t) Q_X^T - m_X from the fragments in kfr
+  auto qk = [&](auto xc, auto maskc, int t) {
+    constexpr int X = decltype(xc)::value;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      s[X][kt] = nm[X];
+#pragma unroll
+      for (int sd = 0; sd < 4; ++sd) {
+        if constexpr (!(W64_DEBUG & 16)) s[X][kt] = UCOD_MFMA32(kfr[kt][sd], qf[X][sd], s[X][kt]);
+        else s[X][kt][sd] += h_to_f32(kfr[kt][sd][0]);
+      }
+    }
+    if constexpr (decltype(maskc)::value) {
+      if (t == nt - 1 && (N & (KT - 1)) != 0) {
+        const int kbase = t * KT + 4 * h5;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kbase + kt * 32 + (r & 3) + 8 * (r >> 2) >= N) s[X][kt][r] = -1e30f;
+      }
+    }
+  };
+  // deferred running max of block X: rescale only when a score runs away from -m by more than 2^DEFER_THR
+  auto rescale_if = [&](auto xc, float mloc, bool first) {
+    constexpr int X = decltype(xc)::value;
+    if (first || __any(mloc > DEFER_THR)) {
+      mloc = xhalf_max(mloc);
+      const float delta = first ? mloc : fmaxf(mloc, 0.f);
+      const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+      pv_mfma_fence(o[X][0], o[X][1]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s[X][0][i] -= delta;
+        s[X][1][i] -= delta;
+        nm[X][i] -= delta;
+      }
+      if (!first) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float a0 = o[X][0][i], a1 = o[X][1][i];
+          acc_scale(a0, alpha);
+          acc_scale(a1, alpha);
+          o[X][0][i] = a0;
+          o[X][1][i] = a1;
+        }
+      }
+      lsum[X] *= alpha;
+    }
+  };
+  auto maxfix = [&](auto xc, bool first) {                 // prologue only: the loop interleaves this chain with the P V products
+    constexpr int X = decltype(xc)::value;
+    float mloc = __builtin_elementwise_maximum(s[X][0][0], s[X][0][1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[X][0][r]), s[X][0][r + 1]);
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[X][1][r]), s[X][1][r + 1]);
+    rescale_if(xc, mloc, first);
+  };
+  // V fragments of the eight P V products (kt, ks, dt) of a block: a ring of five, four products ahead of their use; the first four are
+  // requested by pv_begin() at the TOP of the block (asm statements keep their order), i.e. a whole Q K^T ahead
+  constexpr int VAHEAD = 4, VRING = VAHEAD + 1;
+  hx4 lo[VRING], hi[VRING];
+  unsigned vbase[2];
+  auto issue = [&](auto ic) {
+    constexpr int I = decltype(ic)::value;
+    constexpr int imm = ((I >> 2) * 32 + ((I >> 1) & 1) * 16) * 128;
+    if constexpr (!(W64_DEBUG & 128)) {
+      lo[I % VRING] = tr16_issue(vbase[I & 1], imm);
+      hi[I % VRING] = tr16_issue(vbase[I & 1], imm + 8 * 128);
+    } else {
+      lo[I % VRING] = (hx4){qf[0][0][0], qf[0][0][1], qf[0][0][2], qf[0][0][3]};
+      hi[I % VRING] = lo[I % VRING];
+    }
+  };
+  auto pv_begin = [&](int vslot) {
+    vbase[0] = (unsigned)(uintptr_t)smem + (unsigned)(vslot * KV_BYTES + voff[0]);
+    vbase[1] = (unsigned)(uintptr_t)smem + (unsigned)(vslot * KV_BYTES + voff[1]);
+    issue(IntC<0>{});
+    issue(IntC<1>{});
+    issue(IntC<2>{});
+    issue(IntC<3>{});
+  };
+  // One block:  S_Y = K Q_Y^T - m_Y  (fragments already in kfr)  beside  P_X = exp2(S_X), row sums;  the next block's K fragments;
+  //             O_X^T += V^T P_X^T  beside  the running-max chain of S_Y;  rescale check of Y.   HAS_Y = 0: the very last block.
+  auto block = [&](auto xc, auto yc, auto hasyc, auto maskc, int vslot, int knext_slot, int ty, bool first_y) {
+    constexpr int X = decltype(xc)::value, Y = decltype(yc)::value;
+    constexpr bool HAS_Y = decltype(hasyc)::value != 0;
+    pv_begin(vslot);
+    if constexpr (HAS_Y) qk(yc, maskc, ty);
+    hx8 pb[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 w;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const f32x2_t e = (W64_DEBUG & 4) ? (f32x2_t){s[X][kt][8 * ks + 2 * jj], s[X][kt][8 * ks + 2 * jj + 1]}
+                                            : (f32x2_t){__builtin_amdgcn_exp2f(s[X][kt][8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(s[X][kt][8 * ks + 2 * jj + 1])};
+          sum_pair(lsum[X], e);
+          w[jj] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_t));
+        }
+        pb[kt][ks] = __builtin_bit_cast(hx8, w);
+      }
+    if constexpr (HAS_Y) loadk(knext_slot);
+    float mloc = 0.f;
+    auto product = [&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      if constexpr (I + VAHEAD < 8) issue(IntC<I + VAHEAD>{});
+      constexpr int ahead = (7 - I) < VAHEAD ? (7 - I) : VAHEAD;
+      constexpr int R = I % VRING;
+      if constexpr (!(W64_DEBUG & 2)) tr16_join_counted<2 * ahead>(lo[R], hi[R]);
+      const hx8 vf = (hx8){lo[R][0], lo[R][1], lo[R][2], lo[R][3], hi[R][0], hi[R][1], hi[R][2], hi[R][3]};
+      if constexpr (!(W64_DEBUG & 8)) pv_mfma_acc(o[X][I & 1], vf, pb[I >> 2][(I >> 1) & 1]);
+      else asm volatile("" :: "v"(vf), "v"(pb[I >> 2][(I >> 1) & 1]));
+      if constexpr (HAS_Y && !(W64_DEBUG & 32)) {            // two links of Y's max chain behind every product
+        constexpr int kt = I >> 2, r = (I & 3) * 4;
+        if constexpr (I == 0) mloc = __builtin_elementwise_maximum(s[Y][0][0], s[Y][0][1]);
+        else mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[Y][kt][r]), s[Y][kt][r + 1]);
+        mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[Y][kt][r + 2]), s[Y][kt][r + 3]);
+      }
+    };
+    product(IntC<0>{}); product(IntC<1>{}); product(IntC<2>{}); product(IntC<3>{});
+    product(IntC<4>{}); product(IntC<5>{}); product(IntC<6>{}); product(IntC<7>{});
+    if constexpr (HAS_Y) rescale_if(yc, mloc, first_y);
+  };
+
+  // DMA batches: batch(t) = {K(t+1), V(t)} is what iteration t needs at its top; it is issued at the top of iteration t-2 (two tiles of
+  // flight: with one wave per SIMD nobody else covers a late tile) and waited for with vmcnt(8) = "all but the youngest batch"
+  stageK();                                                // K(0)
+  if (nt > 1) stageK();                                    // batch(0)
+  stageV();
+  if (nt > 2) stageK();                                    // batch(1)
+  if (nt > 1) stageV();
+  dma_landed_barrier();
+  loadk(0);
+  qk(IntC<0>{}, IntC<1>{}, 0);
+  maxfix(IntC<0>{}, true);
+  loadk(0);                                                // block 1 of tile 0 reads K(0) again, for B
+  int kcur = 0, vcur = 0;
+  auto iter = [&](int t, auto maskc) {
+    constexpr bool TAIL = decltype(maskc)::value != 0;
+    // K(t+1), V(t) have landed (batch(t+1) may still fly); everyone is done with tile t-1; then batch(t+2) -> the slots of K(t), V(t-1)
+    if constexpr (TAIL) {
+      dma_landed_barrier();
+    } else {
+      if constexpr (!(W64_DEBUG & 1)) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __syncthreads();
+      }
+    }
+    if constexpr (!(W64_DEBUG & 256)) {
+      if (!TAIL || t + 3 < nt) stageK();
+      if (!TAIL || t + 2 < nt) stageV();
+    }
+    const int knext = kcur == 2 ? 0 : kcur + 1;
+    // block 1: S_B(t) beside softmax_A(t), O_A += ..; then the fragments of K(t+1) for block 2
+    block(IntC<0>{}, IntC<1>{}, IntC<1>{}, maskc, vcur, knext, t, t == 0);
+    // block 2: S_A(t+1) beside softmax_B(t), O_B += ..; then the fragments of K(t+1) again, for block 1 of the next tile
+    if (!TAIL || t + 1 < nt) block(IntC<1>{}, IntC<0>{}, IntC<1>{}, maskc, vcur, knext, t + 1, false);
+    else block(IntC<1>{}, IntC<0>{}, IntC<0>{}, maskc, vcur, knext, t + 1, false);
+    kcur = knext;
+    vcur = vcur == 2 ? 0 : vcur + 1;
+  };
+  int t = 0;
+  for (; t + 3 < nt; ++t) iter(t, IntC<0>{});
+  for (; t < nt; ++t) iter(t, IntC<1>{});
+
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    pv_mfma_fence(o[x][0], o[x][1]);
+    const float lane_sum = lsum[x][0] + lsum[x][1];
+    const float denom = lane_sum + __shfl_xor(lane_sum, 32, 64);
+    const float inv = 1.0f / denom;
+    const int q = q0 + 32 * x + l31;
+    if (q < N) {
+      bf16_raw* op = out + ((size_t)b * N + q) * D + head * HD + 4 * h5;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2 w;
+          w[0] = cvt_pk_bf16(o[x][dt][4 * g + 0] * inv, o[x][dt][4 * g + 1] * inv);
+          w[1] = cvt_pk_bf16(o[x][dt][4 * g + 2] * inv, o[x][dt][4 * g + 3] * inv);
+          *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
+        }
+    }
   }
 }
 
@@ -1075,7 +1521,14 @@ extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, in
       dim3 grid2(cdiv(npairs, 8) * 8 * nq2), block2(512);
       if (variant == 9) hipLaunchKernelGGL((attn_fwd_pp_kernel<false>), grid2, block2, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs);
       else hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), grid2, block2, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs);
-    } else if (variant == 7)                               // v5 with one rescale decision per 64-key tile
+    } else if (variant == 14) {                            // in-wave ping-pong: 2 waves x 64 query rows per workgroup
+      const int nq3 = cdiv(tok, QT3);
+      hipLaunchKernelGGL(attn_fwd_w64_kernel, dim3(cdiv(npairs, 8) * 8 * nq3), dim3(128), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs);
+    } else if (variant == 13)                              // v5 with -m as a persistent C-operand block, 32-key blocks in sequence
+      hipLaunchKernelGGL((attn_fwd_v5_kernel<false, true>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
+    else if (variant == 15)                                // v5 with the V transpose-reads issued from asm (no vmcnt(0) in the tile)
+      hipLaunchKernelGGL((attn_fwd_v5_kernel<false, false, true>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
+    else if (variant == 7)                                 // v5 with one rescale decision per 64-key tile
       hipLaunchKernelGGL(attn_fwd_v5_kernel<true>, grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
     else                                                 // 0 / 2 / 5: the trimmed-issue kernel (buffer DMA, constant LDS offsets), 7-10 % faster than 6
       hipLaunchKernelGGL(attn_fwd_v5_kernel<false>, grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const char* __rest
 
   auto tile = [&](int t, auto bufc) {
     constexpr int BUF = decltype(bufc)::value;
-    __syncthreads();                                     // this wave's DMAs of tile t have landed (vmcnt(0)); everyone is done with tile t-1
+    dma_landed_barrier();                                // this wave's DMAs of tile t have landed; everyone is done with tile t-1
     if (t + 1 < nt) stage(IntC<BUF ^ 1>{});
     const char* kb = smem + BUF * (2 * TILE_BYTES);
     const char* vb = kb + TILE_BYTES;

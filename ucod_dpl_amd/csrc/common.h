@@ -31,6 +31,7 @@ typedef _Float16 half_t;
 #define UCOD_HALF_NAME "f16"
 #define UCOD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 #define UCOD_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define UCOD_MFMA32_ASM "v_mfma_f32_32x32x16_f16"
 typedef __fp16 ucod_fp16x4_b __attribute__((__vector_size__(4 * sizeof(__fp16))));    // the builtin's own vector type
 #define UCOD_TR16(p) __builtin_bit_cast(hx4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) ucod_fp16x4_b*)(p)))
 #else
@@ -38,6 +39,7 @@ typedef __bf16 half_t;
 #define UCOD_HALF_NAME "bf16"
 #define UCOD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 #define UCOD_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define UCOD_MFMA32_ASM "v_mfma_f32_32x32x16_bf16"
 #define UCOD_TR16(p) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) hx4*)(p))
 #endif
 typedef __attribute__((ext_vector_type(8))) half_t hx8;
@@ -150,4 +152,15 @@ struct ProfScope {
 };
 #define UCOD_PROF(cls, stream) ucod::ProfScope prof_scope__((cls), (hipStream_t)(stream))
 
+
+// Workgroup barrier of a kernel that stages tiles by LDS-DMA (buffer_load / global_load ... lds): every wave first waits for ITS OWN
+// DMAs (vmcnt(0)), then the barrier makes all waves' pieces visible.  __syncthreads() alone does not imply the vmcnt wait on gfx950 (a
+// workgroup-scope fence needs none for global memory); hipcc usually adds one in front of the first LDS read that may alias a DMA in
+// flight, but that is a property of its alias analysis, not a guarantee -- and reads issued from asm statements get none.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void dma_landed_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+#endif
 }  // namespace ucod

@@ -29,6 +29,14 @@ constexpr int BM = 128, BN = 128, BK = 64;
 #endif
 
 
+// Cache policy of the operand LDS-DMA loads (experiment builds: make variant NAME=.. DEFS=-DUCOD_LD_AUX_A=2): 0 default, 2 = nt
+#ifndef UCOD_LD_AUX_A
+#define UCOD_LD_AUX_A 0
+#endif
+#ifndef UCOD_LD_AUX_B
+#define UCOD_LD_AUX_B 0
+#endif
+
 struct GemmArgs {
   unsigned long long* stamps;   // diagnostic builds only (UCOD_GEMM_STAMPS): per-workgroup segment cycle sums, never read by kernels
   const bf16_raw* A;
@@ -810,20 +818,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
     gr = gr < a.N ? gr : a.N - 1;
     srcB[i] = a.B + (size_t)gr * K + swz(r, lane & 7) * 8;
   }
-  auto dma = [&](const bf16_raw* src, char* dst) {
+  auto dmaA = [&](const bf16_raw* src, char* dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, UCOD_LD_AUX_A);
+  };
+  auto dmaB = [&](const bf16_raw* src, char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, UCOD_LD_AUX_B);
   };
   auto stageA = [&](int t, int h) {
     char* slot = smem + (t & 1) * Cfg::BUF + h * SLOT_A;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma(srcA[h][i] + t * BK, slot + (i * 8 + wave) * 1024);
+    for (int i = 0; i < 2; ++i) dmaA(srcA[h][i] + t * BK, slot + (i * 8 + wave) * 1024);
   };
   auto stageB = [&](int t, int i0, int i1) {
     char* slot = smem + (t & 1) * Cfg::BUF + 2 * SLOT_A;
 #pragma unroll
     for (int i = 0; i < Cfg::NB; ++i)
-      if (i >= i0 && i < i1) dma(srcB[i] + t * BK, slot + (i * 8 + wave) * 1024);
+      if (i >= i0 && i < i1) dmaB(srcB[i] + t * BK, slot + (i * 8 + wave) * 1024);
   };
   constexpr int B_SPLIT = Cfg::NB >= 2 ? 2 : 1;   // phase 3 issues [0,B_SPLIT), phase 4 the rest
 
@@ -974,10 +986,10 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
     const unsigned kt = (unsigned)t * (BK * 2);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(slot + (i * 8 + wave) * 1024), 16, offA[h][i], kt, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(slot + (i * 8 + wave) * 1024), 16, offA[h][i], kt, 0, UCOD_LD_AUX_A);
     if constexpr (XT == 1) {
       if (wave < 2)                                          // rows 128..143 (wave-uniform: `wave` is an SGPR)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(slot + (16 + wave) * 1024), 16, offA[h][2], kt, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(slot + (16 + wave) * 1024), 16, offA[h][2], kt, 0, UCOD_LD_AUX_A);
     }
   };
   auto stageB = [&](int t) {
@@ -985,7 +997,7 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
     const unsigned kt = (unsigned)t * (BK * 2);
 #pragma unroll
     for (int i = 0; i < Cfg::NB; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(slot + (i * 8 + wave) * 1024), 16, offB[i], kt, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(slot + (i * 8 + wave) * 1024), 16, offB[i], kt, 0, UCOD_LD_AUX_B);
   };
 
   float cb[NT], cs[NT];

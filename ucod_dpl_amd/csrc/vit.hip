@@ -67,7 +67,7 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
   const float scale = 0.125f;  // head_dim^-0.5, head_dim = 64
   // attn_variant 2: fold head_dim^-0.5 * log2(e) into the Q third of the QKV epilogue (before its bf16 rounding)
   // attn_variant 8: the fp8 (e4m3, block-scaled MFMA) attention path of BASELINE configs[4]; same pre-scaled Q
-  const bool prescale = (av == 2 || av == 8);
+  const bool prescale = (av == 2 || av == 8 || av == 7 || av == 9 || av == 12 || av == 13);   // every kernel that takes Q pre-scaled by hd^-1/2 log2 e
   float* qscale = (float*)(ws + p.off_qscale);
   if (prescale) RUN(ucod_fill_qscale(qscale, D, scale * 1.4426950408889634f, stream));
   // fp8 path: the QKV epilogue writes e4m3 Q8 | K8 | V8 itself; its column scales carry 2^q_exp (times the pre-scale), 2^k_exp, 2^v_exp
