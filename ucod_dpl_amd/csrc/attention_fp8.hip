@@ -263,8 +263,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const char* __rest
       for (int g = 0; g < 4; ++g) {
         const f32x2_t e0 = {__builtin_amdgcn_exp2f(s[kt][4 * g]), __builtin_amdgcn_exp2f(s[kt][4 * g + 1])};
         const f32x2_t e1 = {__builtin_amdgcn_exp2f(s[kt][4 * g + 2]), __builtin_amdgcn_exp2f(s[kt][4 * g + 3])};
-        lsum += e0;
-        lsum += e1;
+        lsum[0] += e0[0];                                 // plain v_add_f32 (file built with -fno-slp-vectorize): packed f32 adds cost more beside MFMAs
+        lsum[1] += e0[1];
+        lsum[0] += e1[0];
+        lsum[1] += e1[1];
         pf[kt * 4 + g] = (int)pack4_fp8(e0[0], e0[1], e1[0], e1[1]);
       }
     // O^T[d][q] += sum_key Vt8[d][key] P[key][q] * 2^-v_exp: A = 32 d rows of the tile's Vt8 block, B = P (64 keys x 32 queries)
