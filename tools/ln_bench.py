@@ -16,3 +16,19 @@ for r in range(5):
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / 20 * 1e3)
 print(f"layernorm {M}x{D}: {best:.1f} us  {M * D * 6 / best / 1e3:.0f} GB/s")
+
+# fp16 residual stream -> operand halves (the form the backbone pass uses on >= 4096 rows); UCOD_LN_NO_STRIP=1 selects the 8-byte kernel
+from ucod_dpl_amd import native as N
+lib = N.load()
+xh = x.to(torch.float16); y = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+def run(): N.check(lib.ucod_layernorm_h16(N.ptr(xh), N.ptr(g), N.ptr(b), N.ptr(y), M, D, 1e-6, N.stream()), "ln_h16")
+for _ in range(3): run()
+torch.cuda.synchronize()
+best = 1e9
+for r in range(5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): run()
+    e1.record(); torch.cuda.synchronize()
+    best = min(best, e0.elapsed_time(e1) / 20 * 1e3)
+print(f"layernorm_h16 {M}x{D} ({'8-byte' if os.environ.get('UCOD_LN_NO_STRIP') else '16-byte strip'} form): {best:.1f} us  {M * D * 4 / best / 1e3:.0f} GB/s")

@@ -110,6 +110,72 @@ __global__ __launch_bounds__(256) void layernorm4_kernel(const float* __restrict
   }
 }
 
+// 16-byte form of the fp16-stream LayerNorm (D % 256 == 0): a wave owns a STRIP of two consecutive rows = D / 4 chunks of 16 bytes that are
+// contiguous in memory on both sides (8 f16 in, 8 operand halves out), lane l takes chunks l, l + 64, ... of the strip, so a lane may
+// hold pieces of both rows and keeps one set of statistics per row.  Why: the 8-byte stores of the form below run at the per-CU
+// store-issue rate (~7 B/clk/CU, MI355X_MICROARCH.md), 263 KB of output per CU = 22 of the launch's 26 us; 16-byte stores issue 2.4x
+// the bytes per clock.
+template <int NC>                                          // NC = D / 256 chunks per lane
+__global__ __launch_bounds__(256) void layernorm_h16_strip_kernel(const u32x4* __restrict__ x, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, u32x4* __restrict__ y, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+  if (row0 >= rows) return;
+  const bool two = row0 + 1 < rows;
+  const int cpr = D >> 3;                                  // chunks per row
+  const u32x4* xs = x + (size_t)row0 * cpr;
+  float v[NC][8];
+  bool second[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    second[i] = c >= cpr;
+    const u32x4 w = xs[(second[i] && !two) ? c - cpr : c];  // an odd last row: re-read row 0 (never used)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unpack_f16x2(w[e], v[i][2 * e], v[i][2 * e + 1]);
+  }
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const float t = ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+    s0 += second[i] ? 0.f : t;
+    s1 += second[i] ? t : 0.f;
+  }
+  const float inv_d = 1.0f / (float)D;
+  const float mean0 = wave_sum(s0) * inv_d, mean1 = wave_sum(s1) * inv_d;
+  float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const float m = second[i] ? mean1 : mean0;
+    float t = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[i][e] -= m;
+      t += v[i][e] * v[i][e];
+    }
+    q0 += second[i] ? 0.f : t;
+    q1 += second[i] ? t : 0.f;
+  }
+  const float rstd0 = rsqrtf(wave_sum(q0) * inv_d + eps), rstd1 = rsqrtf(wave_sum(q1) * inv_d + eps);
+  u32x4* ys = y + (size_t)row0 * cpr;
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (second[i] && !two) continue;
+    const int col = second[i] ? c - cpr : c;
+    const float rstd = second[i] ? rstd1 : rstd0;
+    const float4 ga = g4[2 * col], gb = g4[2 * col + 1], ba = b4[2 * col], bb = b4[2 * col + 1];
+    u32x4 w;
+    w[0] = pack_h2(v[i][0] * rstd * ga.x + ba.x, v[i][1] * rstd * ga.y + ba.y);
+    w[1] = pack_h2(v[i][2] * rstd * ga.z + ba.z, v[i][3] * rstd * ga.w + ba.w);
+    w[2] = pack_h2(v[i][4] * rstd * gb.x + bb.x, v[i][5] * rstd * gb.y + bb.y);
+    w[3] = pack_h2(v[i][6] * rstd * gb.z + bb.z, v[i][7] * rstd * gb.w + bb.w);
+    ys[c] = w;
+  }
+}
+
 // LayerNorm of an IEEE-fp16 residual stream (ucod_vit_desc.resid16): the row arrives as 8-byte (4 x f16, D % 256 == 0) or 4-byte
 // (2 x f16) chunks per lane, is widened to f32 in registers, and the same two-pass f32 statistics follow; output = operand type.
 template <int NV, int W, int R = 2>                       // NV chunks of W f16 per lane: D = 64 * NV * W; R rows per wave
@@ -299,7 +365,16 @@ extern "C" int ucod_layernorm_h16(const void* x, const float* gamma, const float
   hipStream_t s = (hipStream_t)stream;
   const unsigned* xp = (const unsigned*)x;
   bf16_raw* yp = (bf16_raw*)y;
-  if ((D % 256) == 0) {
+  static const bool no_strip = getenv("UCOD_LN_NO_STRIP") != nullptr;     // measurement knob: the 8-byte form
+  if ((D % 256) == 0 && !no_strip) {
+    switch (D / 256) {
+#define LNS_CASE(n) \
+  case n: hipLaunchKernelGGL(layernorm_h16_strip_kernel<n>, grid, block, 0, s, (const u32x4*)x, gamma, beta, (u32x4*)y, rows, D, eps); break;
+      LNS_CASE(1) LNS_CASE(2) LNS_CASE(3) LNS_CASE(4) LNS_CASE(5) LNS_CASE(6)
+#undef LNS_CASE
+      default: return UCOD_EINVAL;
+    }
+  } else if ((D % 256) == 0) {
     switch (D / 256) {
 #define LNH_CASE(n) \
   case n: hipLaunchKernelGGL((layernorm_h16_kernel<n, 4>), grid, block, 0, s, xp, gamma, beta, yp, rows, D, eps); break;
