@@ -207,10 +207,11 @@ class ViTEngine:
         # independent and the tail of one stream's GEMM (a partial last round of 256-row tiles leaves most CUs idle) is filled by
         # the other stream's next kernel.  Results are identical to the single-stream pass (same kernels, same per-image math).
         if getattr(self, "_side", None) is None or len(self._side) != ns:
-            # (high priority: in the pipelined schedule the backbone pass is the critical path and the decoder step of the previous batch,
-            # on the caller's normal-priority stream, should only fill the CUs the pass leaves idle; UCOD_SIDE_PRIORITY=0 disables)
+            # Normal priority.  High-priority side streams (UCOD_SIDE_PRIORITY=-1) were measured: nothing on the pipelined frozen-backbone
+            # step (10.16 vs 10.19 ms) and MINUS 17 % in backbone-backward mode (585 vs 702 images/s: the EMA teacher's pass on these
+            # streams then starves the student's forward / backward on the training streams).
             import os
-            prio = int(os.environ.get("UCOD_SIDE_PRIORITY", "-1"))
+            prio = int(os.environ.get("UCOD_SIDE_PRIORITY", "0"))
             self._side = [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(ns)]
             self._side_ws = [None] * ns
         cur = torch.cuda.current_stream(self.device)
