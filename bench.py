@@ -353,7 +353,7 @@ def main():
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.half, "data": "synthetic",
         "config": {"workload": f"{which_config(a.arch, a.image, B, a.attn_variant)}: {a.arch} @{a.image}x{a.image}, batch {B}/GPU, full APM+DBA+discriminator step, "
-                               f"decoder path exact f32, backbone {a.half} MFMA", "global_batch": B * world, "parallelism": f"dp{world}",
+                               f"decoder path f32 (1x1 conv as a three-way bf16 split on the matrix pipe: f32-equivalent), backbone {a.half} MFMA", "global_batch": B * world, "parallelism": f"dp{world}",
                    "backbone_last_layer": "full (as reference)" if a.full_last_layer else "key-minimal (identical key output; 279.6 of 303.1 GFLOP/img)",
                    "random_init_weights": True, "residual_stream": "fp16" if resid16 else "f32",
                    "schedule": "serial, one stream" if a.no_pipeline else

@@ -271,6 +271,13 @@ int ucod_bilinear_resize_adjoint(const float* gout, float* gin, int planes, int 
  * Nout = 128 (one decoder) or 256 (student rows 0..127 | teacher rows 128..255 sharing the x read). */
 int ucod_dba_project(const float* x, const float* W, const float* bias, float* d, int B, int C, int HW, int Nout,
                      void* stream);
+/* The same contraction on the bf16 matrix pipe with every f32 operand split into three bf16 terms (24 significand bits) and the six
+ * partial products of weight >= 2^-16 accumulated in f32: f32-equivalent (what is dropped is below 2^-24 |W x| per term, the rounding of
+ * an f32 FMA chain), 2.7x less matrix-pipe time than v_mfma_f32_32x32x2_f32.  C % 16 == 0, Nout = 128 or 256.
+ * ws: ucod_dba_project_split_workspace_bytes(C, Nout) bytes, 16-byte aligned (the pre-split W planes). */
+size_t ucod_dba_project_split_workspace_bytes(int C, int Nout);
+int ucod_dba_project_split(const float* x, const float* W, const float* bias, float* d, void* ws, size_t ws_bytes, int B, int C, int HW,
+                           int Nout, void* stream);
 
 /* L2 norm over the PIXEL axis of (d * emb) per (image, channel), clamped at 1e-12
  * (F.normalize(dim=1) on [B,HW,64], DBA.py:40-41).  d is a [B, ld_c, HW] buffer, channels c0..c0+127 used;

@@ -528,15 +528,19 @@ def test_bilinear_lds_paths_match_the_elementwise_kernels(ih, oh, planes):
     assert torch.equal(off, up[1:])
 
 
-@pytest.mark.parametrize("B,C,H,Nout", [(2, 384, 28, 128), (1, 768, 37, 256), (3, 768, 68, 256), (2, 128, 5, 128)])
-def test_dba_project(B, C, H, Nout):
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("B,C,H,Nout", [(2, 384, 28, 128), (1, 768, 37, 256), (3, 768, 68, 256), (2, 128, 5, 128), (17, 768, 37, 256)])
+def test_dba_project(B, C, H, Nout, exact):
+    """exact=True: v_mfma_f32_32x32x2_f32; exact=False: the three-way bf16 split on the bf16 matrix pipe (csrc/gemm_split.hip), which must
+    be as close to the f64 product as the f32 kernel is (f32-equivalent), incl. wide-range inputs and partial 96-pixel tiles."""
     g = torch.Generator().manual_seed(C + H)
-    x = torch.randn(B, C, H, H, generator=g)
+    x = torch.randn(B, C, H, H, generator=g) * torch.exp(2 * torch.randn(B, C, 1, 1, generator=g))     # channel scales over ~4 decades
     W = torch.randn(Nout, C, generator=g) / math.sqrt(C)
     b = torch.randn(Nout, generator=g)
     ref = torch.einsum("nc,bcp->bnp", W.double(), x.reshape(B, C, -1).double()) + b.double().view(1, -1, 1)
-    d = ops.dba_project(x.to(DEV), W.to(DEV), b.to(DEV)).cpu()
-    assert maxdiff(d, ref) < 2e-5 * math.sqrt(C)
+    d = ops.dba_project(x.to(DEV), W.to(DEV), b.to(DEV), exact=exact).cpu()
+    scale = torch.einsum("nc,bcp->bnp", W.abs().double(), x.reshape(B, C, -1).abs().double()).max().item()
+    assert maxdiff(d, ref) < 2e-6 * scale, (maxdiff(d, ref), scale)          # a few f32 ulps of sum |W||x|
 
 
 def _decoder_on_gpu(x, p, r1, r2, gextra):

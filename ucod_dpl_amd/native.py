@@ -85,6 +85,8 @@ SIGNATURES = {
     "ucod_bilinear_resize": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "ucod_bilinear_resize_adjoint": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "ucod_dba_project": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "ucod_dba_project_split_workspace_bytes": (sz, [ci, ci]),
+    "ucod_dba_project_split": (ci, [vp, vp, vp, vp, vp, sz, ci, ci, ci, ci, vp]),
     "ucod_dba_colnorm": (ci, [vp, ci, ci, vp, vp, ci, ci, vp]),
     "ucod_dba_heads_fwd": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]),
     "ucod_orth_workspace_bytes": (sz, [ci, ci]),

@@ -3,6 +3,7 @@
 Every function requires CUDA (ROCm) tensors and raises otherwise -- there is no CPU path here.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -141,12 +142,28 @@ def bilinear_resize_autograd(x, oh, ow):
     return _BilinearResizeFn.apply(x, oh, ow)
 
 
-def dba_project(x, W, bias):
-    """x [B,C,H,W] f32, W [Nout,C], bias [Nout] -> d [B,Nout,HW]."""
+_EXACT_F32 = bool(os.environ.get("UCOD_DBA_EXACT_F32"))          # the v_mfma_f32_32x32x2_f32 forms of the two decoder GEMMs
+
+
+def dba_project(x, W, bias, exact=None):
+    """x [B,C,H,W] f32, W [Nout,C], bias [Nout] -> d [B,Nout,HW].  Default: the f32-equivalent three-way bf16 split on the bf16 matrix
+    pipe (csrc/gemm_split.hip); exact=True (or UCOD_DBA_EXACT_F32=1, or a shape the split kernel does not take): the f32 MFMA kernel."""
     B, Cc, H, Wd = x.shape
     Nout = W.shape[0]
     d = torch.empty(B, Nout, H * Wd, dtype=torch.float32, device=x.device)
-    check(N.load().ucod_dba_project(ptr(_f32(x)), ptr(_f32(W)), ptr(_f32(bias)), ptr(d), B, Cc, H * Wd, Nout, stream()), "ucod_dba_project")
+    lib = N.load()
+    if exact is None and _EXACT_F32:
+        exact = True
+    if exact is False and not (Cc % 16 == 0 and Nout in (128, 256)):
+        raise ValueError("dba_project(exact=False): the split kernel needs C % 16 == 0 and Nout in (128, 256)")
+    # (the split kernel runs one 96-pixel tile per workgroup, two per CU: below ~200 workgroups the f32 kernel's finer grid is faster)
+    if exact is False or (not exact and Cc % 16 == 0 and Nout in (128, 256) and B * ((H * Wd + 95) // 96) >= 200):
+        nb = lib.ucod_dba_project_split_workspace_bytes(Cc, Nout)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        check(lib.ucod_dba_project_split(ptr(_f32(x)), ptr(_f32(W)), ptr(_f32(bias)), ptr(d), ptr(ws), nb, B, Cc, H * Wd, Nout, stream()),
+              "ucod_dba_project_split")
+        return d
+    check(lib.ucod_dba_project(ptr(_f32(x)), ptr(_f32(W)), ptr(_f32(bias)), ptr(d), B, Cc, H * Wd, Nout, stream()), "ucod_dba_project")
     return d
 
 
