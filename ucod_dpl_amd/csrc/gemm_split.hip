@@ -66,6 +66,11 @@ __device__ __forceinline__ b16x4 lds_read_tr16_asm(unsigned addr, int imm) {
   return r;
 }
 __device__ __forceinline__ void lds_join() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void lds_join_counted() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }   // all but the N youngest LDS operations
+__device__ __forceinline__ void lds_write_b32_asm(unsigned addr, unsigned v, int imm) {
+  asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "i"(imm) : "memory");
+}
 template <typename T>
 __device__ __forceinline__ void pin(T& v) { asm volatile("" : "+v"(v)); }
 
@@ -73,91 +78,99 @@ constexpr int XROW = 128;                 // bytes per k-row of the x image: 64 
 __device__ __forceinline__ int swz_x(int row, int chunk) { return chunk ^ (((row >> 1) & 1) << 2); }   // as the attention V tile
 
 // ------------------------------------------------------------------------------------------- project
-// block: 4 waves = NR*128 output channels x 96 pixels of one image, TWO workgroups per CU (72 KB of LDS each) so that one's matrix
-// phase runs beside the other's staging / split / barrier phase (a single 8-wave workgroup per CU ran every phase in lockstep: 50 % matrix
-// pipe).  1369 = 14 x 96 + 25: 15 x B = 480 workgroups on 512 slots at B = 32.  Wave w: channels 32 NR w .. + 32 NR - 1, all 96 pixels
-// (three 32-pixel column blocks).  K-tile 16 input channels.  LDS per stage: W planes [3][NR*128 rows][32 B] by LDS-DMA (the two 16-byte
-// halves of a row swapped on odd 8-row groups: conflict-free ds_read_b128), x planes [3][2 groups of 64 pixels][16 k][128 B] written
-// after the split and read back transposed by ds_read_b64_tr_b16 (the attention V-tile layout).
-constexpr int PXT = 96;
+// block: 8 waves = NR*128 output channels x 192 pixels of one image (1369 = 7 x 192 + 25: 8 x B workgroups, ONE per CU at B = 32).
+// Wave (wr, wc): channels 32 NR wr .. + 32 NR - 1, pixels 96 wc .. + 95 (three 32-pixel column blocks).  K-tile 16 input channels.
+// A tile lasts ~1.4 us, less than a memory round trip under load, so every operand is requested TWO tiles ahead: the W planes by
+// LDS-DMA into a ring of three stages, x into three rotating register sets (split + written to LDS one tile before use).  LDS per stage:
+// W planes [3][NR*128 rows][32 B] (the two 16-byte halves of a row swapped on odd 8-row groups: conflict-free ds_read_b128), x planes
+// [3][3 groups of 64 pixels][16 k][128 B] read back transposed by ds_read_b64_tr_b16 (the attention V-tile layout).  Every LDS access of
+// the loop is issued from asm and waited for by hand: hipcc would put `s_waitcnt vmcnt(0)` in front of each one while a DMA is in flight.
+// (Measured alternatives: 64- and 96-pixel tiles with two workgroups per CU -- the W planes re-streamed per workgroup sit at the
+// L2 -> LDS limit, and two co-resident workgroups overlapped only 18 %: 157 us; this form: see DESIGN.md.)
+constexpr int PXT = 192;
 template <int NR>
-__global__ __launch_bounds__(256, 2) void dba_project_b3_kernel(const float* __restrict__ x, const unsigned short* __restrict__ Wp,
+__global__ __launch_bounds__(512, 2) void dba_project_b3_kernel(const float* __restrict__ x, const unsigned short* __restrict__ Wp,
                                                                 const float* __restrict__ bias, float* __restrict__ d, int C, int HW, int Nout) {
   constexpr int ROWS = NR * 128;
   constexpr int WPL = ROWS * 32;           // bytes of one W plane per stage
   constexpr int XG = 16 * XROW;            // one 64-pixel group of one x plane
-  constexpr int XPL = 2 * XG;              // bytes of one x plane per stage (pixels 64..95 use half of the second group)
+  constexpr int XPL = 3 * XG;              // bytes of one x plane per stage
   constexpr int STAGE = 3 * WPL + 3 * XPL;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
   const int h5 = lane >> 5, l31 = lane & 31;
   const int p0 = blockIdx.x * PXT, b = blockIdx.y;
   const float* xb = x + (long)b * C * HW;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
 
   // W DMA: one instruction = 64 lanes x 16 B = 32 rows; lane l -> row l/2, slot l&1 holding k-half (l&1) ^ ((row >> 3) & 1).
-  // 3 planes x 4 NR groups of 32 rows = 12 NR instructions per stage, 3 NR per wave
+  // 3 planes x 4 NR groups of 32 rows = 12 NR instructions per stage; NDMA per wave (waves past the count repeat the last one, so that
+  // every wave has the same number of vector-memory operations in flight and one counted wait fits all)
+  constexpr int NDMA = (12 * NR + 7) / 8;
   const int wrow = lane >> 1, whalf = (lane & 1) ^ ((wrow >> 3) & 1);
-  auto stage_w = [&](int t, int buf) {
-    char* base = smem + buf * STAGE;
+  auto stage_w = [&](int t, auto bufc) {
+    constexpr int BUFW = decltype(bufc)::value;
+    char* base = smem + BUFW * STAGE;
 #pragma unroll
-    for (int j = 0; j < 3 * NR; ++j) {
-      const int q = wave + 4 * j;                               // (plane, group)
+    for (int j = 0; j < NDMA; ++j) {
+      int q = wave + 8 * j;                                     // (plane, group)
+      q = q < 12 * NR ? q : 12 * NR - 1;
       const int s = q / (4 * NR), g = q - s * (4 * NR), row = g * 32 + wrow;
       const unsigned short* src = Wp + ((long)s * Nout + (row < Nout ? row : Nout - 1)) * C + t * 16 + whalf * 8;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(base + s * WPL + g * 1024), 16, 0, 0);
     }
   };
-  // x: 16 k x 48 pixel PAIRS = 3 pairs per thread, pair index e = tid + 256 i -> (k, pair) = (e / 48, e % 48); the two pixels of a pair
-  // go to LDS as one dword per plane (a ds_write_b16 per pixel is a 2-way bank conflict).  Loads are clamped, not branched around.
+  // x: 16 k x 96 pixel PAIRS = 3 pairs per thread, pair index e = tid + 512 i -> (k, pair) = (e / 96, e % 96); the two pixels of a pair
+  // go to LDS as one dword per plane.  Loads are clamped, not branched around.
   int xsrc[3][2], xdst[3];
   bool xin[3][2];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int e = tid + 256 * i, k = e / 48, col = 2 * (e - k * 48);
+    const int e = tid + 512 * i, k = e / 96, col = 2 * (e - k * 96);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int px = p0 + col + j;
       xin[i][j] = px < HW;
       xsrc[i][j] = k * HW + (px < HW ? px : HW - 1);
     }
-    xdst[i] = (col >> 6) * XG + k * XROW + swz_x(k, (col & 63) >> 3) * 16 + (col & 7) * 2;
+    xdst[i] = 3 * WPL + (col >> 6) * XG + k * XROW + swz_x(k, (col & 63) >> 3) * 16 + (col & 7) * 2;
   }
-  float rxa[6], rxb[6];
-  auto load_x = [&](int t, float (&rx)[6]) {
+  float rx[3][6];                                                // x(j) travels in rx[j % 3]
+  auto load_x = [&](int t, float (&r)[6]) {
     const float* xt = xb + (long)t * 16 * HW;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) rx[2 * i + j] = xt[xsrc[i][j]];
+      for (int j = 0; j < 2; ++j) r[2 * i + j] = xt[xsrc[i][j]];
   };
-  auto store_x = [&](int buf, const float (&rx)[6]) {
-    char* base = smem + buf * STAGE + 3 * WPL;
+  auto store_x = [&](auto bufc, const float (&r)[6]) {
+    constexpr int BUFX = decltype(bufc)::value;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       unsigned short t0[3], t1[3];
-      split3(xin[i][0] ? rx[2 * i] : 0.f, t0);
-      split3(xin[i][1] ? rx[2 * i + 1] : 0.f, t1);
+      split3(xin[i][0] ? r[2 * i] : 0.f, t0);
+      split3(xin[i][1] ? r[2 * i + 1] : 0.f, t1);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) *reinterpret_cast<unsigned*>(base + s * XPL + xdst[i]) = (unsigned)t0[s] | ((unsigned)t1[s] << 16);
+      for (int s = 0; s < 3; ++s) lds_write_b32_asm(lds0 + (unsigned)(xdst[i] + BUFX * STAGE), (unsigned)t0[s] | ((unsigned)t1[s] << 16), s * XPL);
     }
   };
   // fragment addresses
-  int aoff[NR];                                                  // W fragment of row-block i: row = 32 (NR wave + i) + l31, slot h5 ^ ((row>>3)&1)
+  unsigned aaddr[NR], xaddr[3];
 #pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    const int row = 32 * (NR * wave + i) + l31;
-    aoff[i] = row * 32 + ((h5 ^ ((row >> 3) & 1)) * 16);
+  for (int i = 0; i < NR; ++i) {                                 // W fragment of row-block i: row = 32 (NR wr + i) + l31, slot h5 ^ ((row>>3)&1)
+    const int row = 32 * (NR * wr + i) + l31;
+    aaddr[i] = lds0 + (unsigned)(row * 32 + ((h5 ^ ((row >> 3) & 1)) * 16));
   }
-  int xoff[3];                                                   // x fragment of column block cb (pixels 32 cb ..) via ds_read_b64_tr_b16
   {
     const int i16 = lane & 15, g1 = (lane >> 4) & 1;
     const int krow = 4 * h5 + (i16 >> 2);
 #pragma unroll
-    for (int cb = 0; cb < 3; ++cb) {
-      const int dst = 32 * cb + g1 * 16 + 4 * (i16 & 3);        // first pixel of this lane's 4-pixel piece
-      xoff[cb] = 3 * WPL + (dst >> 6) * XG + krow * XROW + swz_x(krow, (dst & 63) >> 3) * 16 + (dst & 7) * 2;
+    for (int cb = 0; cb < 3; ++cb) {                             // x fragment of column block cb (pixels 96 wc + 32 cb ..) via ds_read_b64_tr_b16
+      const int dst = 96 * wc + 32 * cb + g1 * 16 + 4 * (i16 & 3);
+      xaddr[cb] = lds0 + (unsigned)(3 * WPL + (dst >> 6) * XG + krow * XROW + swz_x(krow, (dst & 63) >> 3) * 16 + (dst & 7) * 2);
     }
   }
 
@@ -169,79 +182,90 @@ __global__ __launch_bounds__(256, 2) void dba_project_b3_kernel(const float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][cb][r] = 0.f;
 
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
   const int nt = C / 16;
-  stage_w(0, 0);
-  load_x(0, rxa);
-  store_x(0, rxa);
-  if (nt > 1) load_x(1, rxb);
-  // x (HBM) travels two tiles ahead in registers, W (L2) one tile ahead by LDS-DMA.  Program order inside a tile: fragment reads,
-  // DMA of W(t+1), products, split + LDS writes of x(t+1), loads of x(t+2) -- so that the `s_waitcnt vmcnt` hipcc puts in front of any LDS
-  // access that follows an LDS-DMA in flight never covers a request younger than a tile.
-  const unsigned lds0 = (unsigned)(uintptr_t)smem;
-  unsigned aaddr[NR], xaddr[3];
-#pragma unroll
-  for (int i = 0; i < NR; ++i) aaddr[i] = lds0 + (unsigned)aoff[i];
-#pragma unroll
-  for (int cb = 0; cb < 3; ++cb) xaddr[cb] = lds0 + (unsigned)xoff[cb];
-  auto tile = [&](int t, auto bufc, float (&r_next)[6], float (&r_far)[6]) {   // r_next holds x(t+1), r_far receives x(t+2)
-    constexpr int BUF = decltype(bufc)::value;
-    // this wave's W(t) DMAs have landed (only the six loads of x(t+1) may still fly), its x(t) writes are done; then everyone's
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // prologue.  Vector-memory issue order from here on: W(0) x(0) | W(1) x(1) x(2) | tile t: W(t+2) x(t+3)
+  stage_w(0, I0{});
+  load_x(0, rx[0]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  store_x(I0{}, rx[0]);
+  if (nt > 1) {
+    stage_w(1, I1{});
+    load_x(1, rx[1]);
+  }
+  if (nt > 2) load_x(2, rx[2]);
+  constexpr int IN_FLIGHT = NDMA + 12;                           // behind W(t): x(t+1) [may be needed: see below], W(t+1), x(t+2) -- or W(t+1) x(t+2) | W(t+2)..
+  auto tile = [&](int t, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value, B1 = (BUF + 1) % 3, B2 = (BUF + 2) % 3;
+    // this wave's W(t) DMAs have landed, its x(t) writes are done; then everyone's.  Younger than W(t) and allowed to fly on:
+    // x(t+1)? no -- it was waited for by the split of the previous tile; W(t+1) [NDMA], x(t+2) [6], x(t+3)? not issued yet ... at most NDMA + 12
+    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(IN_FLIGHT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     b16x8 af[NR][3], xf[3][3];
     b16x4 lo[3][3], hi[3][3];
+    constexpr int RPP = NR + 6;                                  // LDS reads per plane
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
 #pragma unroll
-      for (int i = 0; i < NR; ++i) af[i][s] = lds_read_b128_asm(aaddr[i], BUF * STAGE + s * WPL);
+      for (int i = 0; i < NR; ++i) af[i][s] = lds_read_b128_asm(aaddr[i] + BUF * STAGE, s * WPL);   // (stage offset in the register: 16-bit immediates)
 #pragma unroll
       for (int cb = 0; cb < 3; ++cb) {
-        lo[cb][s] = lds_read_tr16_asm(xaddr[cb], BUF * STAGE + s * XPL);       // (xoff already carries the 3 WPL offset)
-        hi[cb][s] = lds_read_tr16_asm(xaddr[cb], BUF * STAGE + s * XPL + 8 * XROW);
+        lo[cb][s] = lds_read_tr16_asm(xaddr[cb] + BUF * STAGE, s * XPL);
+        hi[cb][s] = lds_read_tr16_asm(xaddr[cb] + BUF * STAGE, s * XPL + 8 * XROW);
       }
     }
-    if (t + 1 < nt) stage_w(t + 1, BUF ^ 1);
-    lds_join();
+    if (t + 2 < nt) stage_w(t + 2, std::integral_constant<int, B2>{});
+    auto plane_ready = [&](auto sc) {
+      constexpr int S = decltype(sc)::value;
+      lds_join_counted<((2 - S) * RPP > 15 ? 15 : (2 - S) * RPP)>();     // (the counter saturates at 15: a little stricter for plane 0)
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-#pragma unroll
-      for (int i = 0; i < NR; ++i) pin(af[i][s]);
+      for (int i = 0; i < NR; ++i) pin(af[i][S]);
 #pragma unroll
       for (int cb = 0; cb < 3; ++cb) {
-        pin(lo[cb][s]);
-        pin(hi[cb][s]);
-        xf[cb][s] = (b16x8){lo[cb][s][0], lo[cb][s][1], lo[cb][s][2], lo[cb][s][3], hi[cb][s][0], hi[cb][s][1], hi[cb][s][2], hi[cb][s][3]};
+        pin(lo[cb][S]);
+        pin(hi[cb][S]);
+        xf[cb][S] = (b16x8){lo[cb][S][0], lo[cb][S][1], lo[cb][S][2], lo[cb][S][3], hi[cb][S][0], hi[cb][S][1], hi[cb][S][2], hi[cb][S][3]};
       }
-    }
-    // smallest partial products first; the accumulators in the inner loops: consecutive MFMAs never touch the same accumulator
-    constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SX[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
+    };
+    auto product = [&](auto sac, auto sxc) {                     // one partial product over all accumulators (consecutive MFMAs never share one)
+      constexpr int SA = decltype(sac)::value, SX = decltype(sxc)::value;
 #pragma unroll
       for (int i = 0; i < NR; ++i)
 #pragma unroll
-        for (int cb = 0; cb < 3; ++cb)
-          acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][SA[q]], xf[cb][SX[q]], acc[i][cb], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < nt) store_x(BUF ^ 1, r_next);                    // (at the END of the tile: x(t+1) was requested a whole tile ago)
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 2 < nt) load_x(t + 2, r_far);
+        for (int cb = 0; cb < 3; ++cb) acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][SA], xf[cb][SX], acc[i][cb], 0, 0, 0);
+    };
+    // products in the order their planes arrive; the split of x(t+1) (VALU + asm LDS writes) is free to sit among the MFMAs
+    plane_ready(I0{});
+    product(I0{}, I0{});
+    plane_ready(I1{});
+    product(I0{}, I1{});
+    product(I1{}, I0{});
+    product(I1{}, I1{});
+    plane_ready(I2{});
+    product(I0{}, I2{});
+    product(I2{}, I0{});
+    if (t + 1 < nt) store_x(std::integral_constant<int, B1>{}, rx[B1]);       // x(t+1), requested two tiles ago
+    if (t + 3 < nt) load_x(t + 3, rx[BUF]);                                    // x(t+3) takes the registers x(t) left
   };
-  for (int t = 0; t < nt; t += 2) {
-    tile(t, std::integral_constant<int, 0>{}, rxb, rxa);
-    if (t + 1 < nt) tile(t + 1, std::integral_constant<int, 1>{}, rxa, rxb);
+  for (int t = 0; t < nt; t += 3) {
+    tile(t, I0{});
+    if (t + 1 < nt) tile(t + 1, I1{});
+    if (t + 2 < nt) tile(t + 2, I2{});
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // C/D map of the 32x32 accumulator: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
   float* db = d + (long)b * Nout * HW;
 #pragma unroll
   for (int cb = 0; cb < 3; ++cb) {
-    const int p = p0 + 32 * cb + l31;
+    const int p = p0 + 96 * wc + 32 * cb + l31;
     if (p >= HW) continue;
 #pragma unroll
     for (int i = 0; i < NR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = 32 * (NR * wave + i) + (r & 3) + 8 * (r >> 2) + 4 * h5;
+        const int n = 32 * (NR * wr + i) + (r & 3) + 8 * (r >> 2) + 4 * h5;
         if (n < Nout) db[(long)n * HW + p] = acc[i][cb][r] + bias[n];
       }
   }
@@ -260,7 +284,7 @@ extern "C" int ucod_dba_project_split(const float* x, const float* W, const floa
   hipStream_t s = (hipStream_t)stream;
   UCOD_PROF(PROF_DBA_PROJECT, s);
   hipLaunchKernelGGL(split3_rows_kernel, dim3(cdiv((long)Nout * C, 256)), dim3(256), 0, s, W, (unsigned short*)ws, Nout, C);
-  dim3 grid(cdiv(HW, PXT), B), block(256);
+  dim3 grid(cdiv(HW, PXT), B), block(512);
   if (Nout == 256) hipLaunchKernelGGL(dba_project_b3_kernel<2>, grid, block, 0, s, x, (const unsigned short*)ws, bias, d, C, HW, Nout);
   else hipLaunchKernelGGL(dba_project_b3_kernel<1>, grid, block, 0, s, x, (const unsigned short*)ws, bias, d, C, HW, Nout);
   UCOD_CHECK_LAUNCH();

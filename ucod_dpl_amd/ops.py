@@ -156,8 +156,8 @@ def dba_project(x, W, bias, exact=None):
         exact = True
     if exact is False and not (Cc % 16 == 0 and Nout in (128, 256)):
         raise ValueError("dba_project(exact=False): the split kernel needs C % 16 == 0 and Nout in (128, 256)")
-    # (the split kernel runs one 96-pixel tile per workgroup, two per CU: below ~200 workgroups the f32 kernel's finer grid is faster)
-    if exact is False or (not exact and Cc % 16 == 0 and Nout in (128, 256) and B * ((H * Wd + 95) // 96) >= 200):
+    # (the split kernel runs one 192-pixel tile per workgroup, one workgroup per CU: below ~100 workgroups the f32 kernel's finer grid is faster)
+    if exact is False or (not exact and Cc % 16 == 0 and Nout in (128, 256) and B * ((H * Wd + 191) // 192) >= 100):
         nb = lib.ucod_dba_project_split_workspace_bytes(Cc, Nout)
         ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
         check(lib.ucod_dba_project_split(ptr(_f32(x)), ptr(_f32(W)), ptr(_f32(bias)), ptr(d), ptr(ws), nb, B, Cc, H * Wd, Nout, stream()),
