@@ -310,6 +310,9 @@ int ucod_dba_bwd(const float* d, int ld_c, int c0, const float* emb, const float
 /* weight gradient of the decoupling conv: gW[n][c] += sum_{b,p} gd[b][n][p]*x[b][c][p]  (f32 MFMA, split-K
  * over (b, pixel chunks) with f32 atomics into gW [128,C], which is zeroed inside first). */
 int ucod_dba_wgrad(const float* gd, const float* x, float* gW, int B, int C, int HW, void* stream);
+/* The same weight gradient on the bf16 matrix pipe, both operands split into three bf16 terms while staged (see ucod_dba_project_split:
+ * f32-equivalent); split-K over (image, pixel chunk) with f32 atomics, gW zeroed inside first. */
+int ucod_dba_wgrad_split(const float* gd, const float* x, float* gW, int B, int C, int HW, void* stream);
 
 /* APM discriminator forward, always train-mode BatchNorm (models/discriminator.py:60-70,86-95;
  * dis_use_features=False).  params (f32, reference state_dict order):

@@ -543,6 +543,20 @@ def test_dba_project(B, C, H, Nout, exact):
     assert maxdiff(d, ref) < 2e-6 * scale, (maxdiff(d, ref), scale)          # a few f32 ulps of sum |W||x|
 
 
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("B,C,H", [(2, 384, 28), (3, 768, 37), (2, 768, 68), (2, 128, 5), (9, 768, 37)])
+def test_dba_wgrad(B, C, H, exact):
+    """Weight gradient of the 1x1 conv: f32 MFMA kernel (exact=True) and the three-way bf16 split (exact=False) against the f64 product;
+    gradient-sized gd (1e-5), channel scales over two decades, pixel chunks that are not K-tile multiples."""
+    g = torch.Generator().manual_seed(C + H + 1)
+    x = torch.randn(B, C, H, H, generator=g) * torch.exp(torch.randn(B, C, 1, 1, generator=g))
+    gd = torch.randn(B, 128, H * H, generator=g) * 1e-5
+    ref = torch.einsum("bnp,bcp->nc", gd.double(), x.reshape(B, C, -1).double())
+    scale = torch.einsum("bnp,bcp->nc", gd.abs().double(), x.reshape(B, C, -1).abs().double()).max().item()
+    gW = ops.dba_wgrad(gd.to(DEV), x.to(DEV), exact=exact).cpu()
+    assert maxdiff(gW, ref) < 5e-7 * scale, (maxdiff(gW, ref), scale)
+
+
 def _decoder_on_gpu(x, p, r1, r2, gextra):
     B, C, H, W = x.shape
     dev = DEV

@@ -271,6 +271,153 @@ __global__ __launch_bounds__(512, 2) void dba_project_b3_kernel(const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------- wgrad
+// gW[n][c] += sum over one (image, pixel chunk) of gd[n][p] x[c][p]: both operands are f32 activations with the reduction index (pixels)
+// contiguous, so both are split while staged and both fragments are plain ds_read_b128 from [row][16 k] images (32-byte rows, the two
+// halves swapped on odd 8-row groups).  block: 8 waves = all 128 n x CT = 384 channels (C = 768: two channel tiles, x is read exactly
+// once); wave (wr, wc): n 64 wr .., channels 96 wc ..; K-tile 16 pixels; ring of three stages, loads two K-tiles ahead in registers.
+// Split-K over (image, pixel chunk) with f32 atomics into gW, as the f32 kernel.
+constexpr int WCT = 384;
+__global__ __launch_bounds__(512, 2) void dba_wgrad_b3_kernel(const float* __restrict__ gd, const float* __restrict__ x, float* __restrict__ gW,
+                                                              int C, int HW, int chunk) {
+  constexpr int ROWS = 128 + WCT;          // gd rows 0..127 | x rows 128..
+  constexpr int PL = ROWS * 32;            // bytes of one plane per stage
+  constexpr int STAGE = 3 * PL;
+  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int h5 = lane >> 5, l31 = lane & 31;
+  const int c0 = blockIdx.x * WCT, b = blockIdx.z;
+  const int ps = blockIdx.y * chunk, pe = min(ps + chunk, HW);
+  const float* gdb = gd + (long)b * 128 * HW;
+  const float* xb = x + (long)b * C * HW;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+
+  // staging: 512 rows x 8 pixel pairs = 4096 pairs, 8 per thread: pair e = tid + 512 i -> (row, pair) = (e / 8, e % 8); a load instruction
+  // covers 8 rows x 64 contiguous bytes
+  constexpr int NP = ROWS * 8 / 512;       // 8: row = tid / 8 + 64 i, so i < 2 are gd rows and i >= 2 are x rows; the pair index is tid % 8 for all
+  const int kp = 2 * (tid & 7);
+  int rbase[NP];                           // element offset of the row in its tensor (rows past C clamped, masked at the split)
+  unsigned wdst[NP];
+  bool rowok[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int row = (tid >> 3) + 64 * i;
+    const int c = c0 + row - 128;
+    rowok[i] = i < 2 || c < C;
+    rbase[i] = (i < 2 ? row : (c < C ? c : C - 1)) * HW;
+    wdst[i] = lds0 + (unsigned)(row * 32 + (((kp >> 3) ^ ((row >> 3) & 1)) * 16) + (kp & 7) * 2);
+  }
+  float rv[3][2 * NP];
+  auto load_t = [&](int t, float (&r)[2 * NP]) {
+    const int p = ps + t * 16 + kp;
+    const int p0c = p < pe ? p : pe - 1, p1c = p + 1 < pe ? p + 1 : pe - 1;     // clamped (pe >= 1); masked to zero at the split
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const float* src = (i < 2 ? gdb : xb) + rbase[i];
+      r[2 * i] = src[p0c];
+      r[2 * i + 1] = src[p1c];
+    }
+  };
+  auto store_t = [&](int t, auto bufc, const float (&r)[2 * NP]) {
+    constexpr int BUFX = decltype(bufc)::value;
+    const int p = ps + t * 16 + kp;
+    const bool in0 = p < pe, in1 = p + 1 < pe;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      unsigned short t0[3], t1[3];
+      split3((rowok[i] && in0) ? r[2 * i] : 0.f, t0);
+      split3((rowok[i] && in1) ? r[2 * i + 1] : 0.f, t1);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) lds_write_b32_asm(wdst[i] + BUFX * STAGE, (unsigned)t0[s] | ((unsigned)t1[s] << 16), s * PL);
+    }
+  };
+  unsigned aaddr[2], baddr[3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 64 * wr + 32 * i + l31;
+    aaddr[i] = lds0 + (unsigned)(row * 32 + ((h5 ^ ((row >> 3) & 1)) * 16));
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int row = 128 + 96 * wc + 32 * j + l31;
+    baddr[j] = lds0 + (unsigned)(row * 32 + ((h5 ^ ((row >> 3) & 1)) * 16));
+  }
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  const int nt = (pe - ps + 15) / 16;
+  load_t(0, rv[0]);
+  if (nt > 1) load_t(1, rv[1]);
+  if (nt > 2) load_t(2, rv[2]);
+  store_t(0, I0{}, rv[0]);                                       // (the compiler waits for rv[0] only: the loads retire in order)
+  auto tile = [&](int t, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value, B1 = (BUF + 1) % 3;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // this wave's LDS writes of tile t are done; then everyone's
+    b16x8 af[2][3], bf[3][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i][s] = lds_read_b128_asm(aaddr[i] + BUF * STAGE, s * PL);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) bf[j][s] = lds_read_b128_asm(baddr[j] + BUF * STAGE, s * PL);
+    }
+    auto plane_ready = [&](auto sc) {
+      constexpr int S = decltype(sc)::value;
+      lds_join_counted<(2 - S) * 5>();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) pin(af[i][S]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) pin(bf[j][S]);
+    };
+    auto product = [&](auto sac, auto sbc) {
+      constexpr int SA = decltype(sac)::value, SB = decltype(sbc)::value;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][SA], bf[j][SB], acc[i][j], 0, 0, 0);
+    };
+    plane_ready(I0{});
+    product(I0{}, I0{});
+    plane_ready(I1{});
+    product(I0{}, I1{});
+    product(I1{}, I0{});
+    product(I1{}, I1{});
+    plane_ready(I2{});
+    product(I0{}, I2{});
+    product(I2{}, I0{});
+    if (t + 1 < nt) store_t(t + 1, std::integral_constant<int, B1>{}, rv[B1]);   // requested two tiles ago
+    if (t + 3 < nt) load_t(t + 3, rv[BUF]);
+  };
+  for (int t = 0; t < nt; t += 3) {
+    tile(t, I0{});
+    if (t + 1 < nt) tile(t + 1, I1{});
+    if (t + 2 < nt) tile(t + 2, I2{});
+  }
+  // C/D map: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (n)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int c = c0 + 96 * wc + 32 * j + l31;
+      if (c >= C) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h5;
+        atomicAdd(&gW[(long)n * C + c], acc[i][j][r]);
+      }
+    }
+}
+
 }  // namespace ucod
 
 extern "C" size_t ucod_dba_project_split_workspace_bytes(int C, int Nout) { return (size_t)3 * Nout * C * sizeof(unsigned short); }
@@ -287,6 +434,23 @@ extern "C" int ucod_dba_project_split(const float* x, const float* W, const floa
   dim3 grid(cdiv(HW, PXT), B), block(512);
   if (Nout == 256) hipLaunchKernelGGL(dba_project_b3_kernel<2>, grid, block, 0, s, x, (const unsigned short*)ws, bias, d, C, HW, Nout);
   else hipLaunchKernelGGL(dba_project_b3_kernel<1>, grid, block, 0, s, x, (const unsigned short*)ws, bias, d, C, HW, Nout);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_dba_wgrad_split(const float* gd, const float* x, float* gW, int B, int C, int HW, void* stream) {
+  using namespace ucod;
+  if (!gd || !x || !gW || B <= 0 || C <= 0 || HW <= 0) return UCOD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int ctiles = cdiv(C, WCT);
+  // split-K granularity: about one workgroup per CU (chunk a multiple of the 16-pixel K-tile)
+  int nchunk = max(1, 256 / (ctiles * B));
+  int chunk = cdiv(cdiv(HW, nchunk), 16) * 16;
+  nchunk = cdiv(HW, chunk);
+  UCOD_PROF(PROF_DBA_WGRAD, s);
+  hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * 128 * (size_t)C, s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(dba_wgrad_b3_kernel, dim3(ctiles, nchunk, B), dim3(512), 0, s, gd, x, gW, C, HW, chunk);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }

@@ -94,6 +94,7 @@ SIGNATURES = {
     "ucod_dba_bwd_workspace_bytes": (sz, [ci, ci]),
     "ucod_dba_bwd": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, ci, ci, vp]),
     "ucod_dba_wgrad": (ci, [vp, vp, vp, ci, ci, ci, vp]),
+    "ucod_dba_wgrad_split": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "ucod_disc_saved_bytes": (sz, [ci, ci]),
     "ucod_disc_fwd": (ci, [vp, C.POINTER(DiscParams), vp, vp, ci, ci, ci, vp]),
     "ucod_disc_bwd_workspace_bytes": (sz, [ci, ci]),

@@ -209,11 +209,18 @@ def dba_bwd(d, c0, emb, norm, head_w, gram, gfg, gbg, gextra, g_head_w=None, g_h
     return gd, g_head_w, g_head_b, g_dec_bias
 
 
-def dba_wgrad(gd, x, gW=None):
+def dba_wgrad(gd, x, gW=None, exact=None):
+    """gW [128,C] = sum_{b,p} gd[b,n,p] x[b,c,p].  Default on large batches: the three-way bf16 split on the bf16 matrix pipe
+    (csrc/gemm_split.hip, f32-equivalent); exact=True / UCOD_DBA_EXACT_F32=1 / small batches: the f32 MFMA kernel."""
     B, Cc = x.shape[0], x.shape[1]
     HW = gd.shape[2]
     gW = torch.empty(128, Cc, dtype=torch.float32, device=x.device) if gW is None else gW
-    check(N.load().ucod_dba_wgrad(ptr(gd), ptr(_f32(x)), ptr(gW), B, Cc, HW, stream()), "ucod_dba_wgrad")
+    if exact is None and _EXACT_F32:
+        exact = True
+    if exact is False or (not exact and B * ((Cc + 383) // 384) >= 32):
+        check(N.load().ucod_dba_wgrad_split(ptr(gd), ptr(_f32(x)), ptr(gW), B, Cc, HW, stream()), "ucod_dba_wgrad_split")
+    else:
+        check(N.load().ucod_dba_wgrad(ptr(gd), ptr(_f32(x)), ptr(gW), B, Cc, HW, stream()), "ucod_dba_wgrad")
     return gW
 
 
