@@ -529,7 +529,7 @@ def test_bilinear_lds_paths_match_the_elementwise_kernels(ih, oh, planes):
 
 
 @pytest.mark.parametrize("exact", [True, False])
-@pytest.mark.parametrize("B,C,H,Nout", [(2, 384, 28, 128), (1, 768, 37, 256), (3, 768, 68, 256), (2, 128, 5, 128), (17, 768, 37, 256)])
+@pytest.mark.parametrize("B,C,H,Nout", [(2, 384, 28, 128), (1, 768, 37, 256), (3, 768, 68, 256), (2, 128, 5, 128), (17, 768, 37, 256), (2, 1024, 37, 256)])
 def test_dba_project(B, C, H, Nout, exact):
     """exact=True: v_mfma_f32_32x32x2_f32; exact=False: the three-way bf16 split on the bf16 matrix pipe (csrc/gemm_split.hip), which must
     be as close to the f64 product as the f32 kernel is (f32-equivalent), incl. wide-range inputs and partial 96-pixel tiles."""
@@ -544,7 +544,7 @@ def test_dba_project(B, C, H, Nout, exact):
 
 
 @pytest.mark.parametrize("exact", [True, False])
-@pytest.mark.parametrize("B,C,H", [(2, 384, 28), (3, 768, 37), (2, 768, 68), (2, 128, 5), (9, 768, 37)])
+@pytest.mark.parametrize("B,C,H", [(2, 384, 28), (3, 768, 37), (2, 768, 68), (2, 128, 5), (9, 768, 37), (2, 1024, 37), (40, 384, 14)])
 def test_dba_wgrad(B, C, H, exact):
     """Weight gradient of the 1x1 conv: f32 MFMA kernel (exact=True) and the three-way bf16 split (exact=False) against the f64 product;
     gradient-sized gd (1e-5), channel scales over two decades, pixel chunks that are not K-tile multiples."""
