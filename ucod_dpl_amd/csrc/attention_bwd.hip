@@ -46,6 +46,24 @@ __device__ __forceinline__ bf16x8 read_tr(const char* tile, int off) {
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(tile + off + 8 * 128));
   return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
+// The same transposed fragment with its two ds_read_b64_tr_b16 issued from asm, and the wait by hand.  Why: hipcc puts `s_waitcnt vmcnt(0)`
+// in front of the first transpose-read builtin of every tile (it cannot tell that the LDS-DMA in flight targets the other stage), which
+// force-completes the NEXT tile's K / V / dO DMA a third of the way into the current tile; at the 2-3 waves per SIMD of these kernels
+// that latency is not covered.  tr_issue() requests a fragment, tr_take<YOUNGER>() waits for it (YOUNGER = asm reads issued after it: LDS
+// operations retire in order, so reads the compiler issues in between only make the wait stricter).
+struct TrFrag { bf16x4 lo, hi; };
+__device__ __forceinline__ TrFrag tr_issue(const char* tile, int off) {
+  TrFrag f;
+  const unsigned a = (unsigned)(uintptr_t)(tile + off);
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(f.hi) : "v"(a));
+  return f;
+}
+template <int YOUNGER>
+__device__ __forceinline__ bf16x8 tr_take(TrFrag& f) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.lo), "+v"(f.hi) : "n"(YOUNGER));
+  return (bf16x8){f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
+}
 
 struct Map {            // XCD-aware 1-D grid -> (image, head, row block): all blocks of one (image, head) on one XCD
   int b, head, blk;
@@ -181,12 +199,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_raw* __r
         }
         s[r] = p * dp[r];                                            // dS^T
       }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 dsb = pack_b(s, ks);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr(kb + TILE + (kt * 32 + ks * 16) * 128, toff[dt]), dsb, acc[dt], 0, 0, 0);
+      {                                                          // four K^T fragments requested together, taken in order
+        TrFrag f00 = tr_issue(kb + TILE + (kt * 32) * 128, toff[0]), f01 = tr_issue(kb + TILE + (kt * 32) * 128, toff[1]);
+        TrFrag f10 = tr_issue(kb + TILE + (kt * 32 + 16) * 128, toff[0]), f11 = tr_issue(kb + TILE + (kt * 32 + 16) * 128, toff[1]);
+        const bf16x8 ds0 = pack_b(s, 0), ds1 = pack_b(s, 1);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_take<6>(f00), ds0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_take<4>(f01), ds0, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_take<2>(f10), ds1, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_take<0>(f11), ds1, acc[1], 0, 0, 0);
       }
     }
   };
@@ -334,13 +354,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_raw* __
         dp[r] = s[r] * dp[r];                                        // -dS
       }
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < 2; ++ks) {                           // four dO^T / Q^T fragments requested together, taken in order
+        const char* rows = sb + (qt * 32 + ks * 16) * 128;
+        TrFrag fv0 = tr_issue(rows + 3 * TILE, toff[0]), fk0 = tr_issue(rows + TILE, toff[0]);
+        TrFrag fv1 = tr_issue(rows + 3 * TILE, toff[1]), fk1 = tr_issue(rows + TILE, toff[1]);
         const bf16x8 pb = pack_b(s, ks), dsb = pack_b(dp, ks);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr(sb + 3 * TILE + (qt * 32 + ks * 16) * 128, toff[dt]), pb, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr(sb + TILE + (qt * 32 + ks * 16) * 128, toff[dt]), dsb, dk[dt], 0, 0, 0);
-        }
+        dv[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_take<6>(fv0), pb, dv[0], 0, 0, 0);
+        dk[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_take<4>(fk0), dsb, dk[0], 0, 0, 0);
+        dv[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_take<2>(fv1), pb, dv[1], 0, 0, 0);
+        dk[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_take<0>(fk1), dsb, dk[1], 0, 0, 0);
       }
     }
   };
