@@ -492,6 +492,13 @@ __device__ __forceinline__ hx4 tr16_issue(unsigned lds_addr, int imm) {
 __device__ __forceinline__ void tr16_join(hx4& a, hx4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 // counted form: YOUNGER = the asm reads issued after (a, b).  LDS operations retire in order and lgkmcnt counts every one of them, so
 // reads the compiler issues in between only make the wait stricter, never too short.
+__device__ __forceinline__ hx8 lds_b128_issue(unsigned lds_addr, int imm) {
+  hx8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "i"(imm));
+  return r;
+}
+template <int YOUNGER>
+__device__ __forceinline__ void lds_b128_join_counted(hx8& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(YOUNGER)); }
 template <int YOUNGER>
 __device__ __forceinline__ void tr16_join_counted(hx4& a, hx4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(YOUNGER)); }
 
@@ -883,19 +890,30 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16_raw* __r
 
   auto seg_m = [&](int t) {                              // P V of tile t-1, then Q K^T of tile t
     if (t > 0) {
-      const char* vb = vring + ((t - 1) & 1) * KV_BYTES;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const char* p0 = vb + (kt * 32 + ks * 16) * 128 + voff[dt];
-            const hx4 lo = UCOD_TR16(p0);
-            const hx4 hi = UCOD_TR16(p0 + 8 * 128);
-            const hx8 vf = (hx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            o[dt] = UCOD_MFMA32(vf, pb[kt][ks], o[dt]);
-          }
+      // V fragments through asm reads (tr16_issue: a transpose-read BUILTIN right behind this group's DMA batch gets an
+      // `s_waitcnt vmcnt(0)` from hipcc, i.e. the whole DMA round trip at the head of every M segment of group A, with group B
+      // waiting at the barrier for it); ring of three, two products ahead, counted waits
+      const unsigned vb0 = (unsigned)(uintptr_t)(vring + ((t - 1) & 1) * KV_BYTES) + (unsigned)voff[0];
+      const unsigned vb1 = (unsigned)(uintptr_t)(vring + ((t - 1) & 1) * KV_BYTES) + (unsigned)voff[1];
+      hx4 lo[3], hi[3];
+      auto issue = [&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        constexpr int imm = ((I >> 2) * 32 + ((I >> 1) & 1) * 16) * 128;
+        lo[I % 3] = tr16_issue((I & 1) ? vb1 : vb0, imm);
+        hi[I % 3] = tr16_issue((I & 1) ? vb1 : vb0, imm + 8 * 128);
+      };
+      auto product = [&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        if constexpr (I + 2 < 8) issue(IntC<I + 2>{});
+        constexpr int ahead = (7 - I) < 2 ? (7 - I) : 2;
+        tr16_join_counted<2 * ahead>(lo[I % 3], hi[I % 3]);
+        const hx8 vf = (hx8){lo[I % 3][0], lo[I % 3][1], lo[I % 3][2], lo[I % 3][3], hi[I % 3][0], hi[I % 3][1], hi[I % 3][2], hi[I % 3][3]};
+        o[I & 1] = UCOD_MFMA32(vf, pb[I >> 2][(I >> 1) & 1], o[I & 1]);
+      };
+      issue(IntC<0>{});
+      issue(IntC<1>{});
+      product(IntC<0>{}); product(IntC<1>{}); product(IntC<2>{}); product(IntC<3>{});
+      product(IntC<4>{}); product(IntC<5>{}); product(IntC<6>{}); product(IntC<7>{});
     }
     if (t < nt) {
       const char* kb = kring + (t & 1) * KV_BYTES;
