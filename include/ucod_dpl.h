@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define UCOD_ABI_VERSION 1
+/* 2 (round 3): ucod_vit_desc gained resid16 (shifts ucod_vit_train_desc), epilogues 9 / 10, ucod_resid16_overflow_*, ucod_gemm_reload_tuning;
+ * the experiment variants of ucod_gemm_bf16 / ucod_attention_fwd left the product library.  native.load() refuses any other version. */
+#define UCOD_ABI_VERSION 2
 int ucod_abi_version(void);
 /* 1 when a gfx950 device is visible to this process (hipGetDeviceProperties().gcnArchName) */
 int ucod_device_is_gfx950(void);
@@ -68,22 +70,32 @@ enum {
   /* backbone-backward mode (row B9), ucod_gemm_bf16_train only: */
   UCOD_EPI_GELU_BWD_BF16 = 6,        /* out bf16[M,N] = C * gelu'(aux[m][n]), aux = saved fc1 pre-activation (fc2 dgrad) */
   UCOD_EPI_BIAS_GELU_SAVE_BF16 = 7,  /* out bf16 = gelu_erf(C + bias[n]) and out2 bf16 = C + bias[n] (training-mode fc1) */
-  UCOD_EPI_BIAS_SCALE_RESID_H16 = 9, /* as UCOD_EPI_BIAS_SCALE_RESID_F32 with the residual stream kept in IEEE fp16: out f16[M,N] = resid f16 +
-                                        scale[n]*(C+bias[n]) (ucod_vit_desc.resid16); large-tile kernel only */
-  UCOD_EPI_PATCH_TOKENS_H16 = 10,    /* as UCOD_EPI_PATCH_TOKENS_F32 with f16 token rows */
+  UCOD_EPI_BIAS_SCALE_RESID_H16 = 9, /* as UCOD_EPI_BIAS_SCALE_RESID_F32 with the residual stream kept in IEEE fp16: out f16[M,N] = sat(resid f16 +
+                                        scale[n]*(C+bias[n])) (ucod_vit_desc.resid16; `resid` / `out` point at f16 rows).  sat = clamp to
+                                        +-65504 (never inf); every clamp is counted: ucod_resid16_overflow_fetch.  Any shape. */
+  UCOD_EPI_PATCH_TOKENS_H16 = 10,    /* as UCOD_EPI_PATCH_TOKENS_F32 with f16 token rows (same saturation) */
   UCOD_EPI_QKV_FP8 = 8               /* QKV projection of the fp8 attention path (BASELINE configs[4]): out = e4m3 bytes
                                         [3 (q|k|v)][Bimg*heads][Npad][64], Npad = tokens rounded up to 64, value = clamp((C + bias[n]) *
                                         scale[n], +-448); N = 3*heads*64, M = Bimg*tokens_per_image; large-tile kernel only */
 };
-/* variant: 0 = auto, 1 = 128x128 register staging, 2 = 128x128 LDS-DMA, 3/4 = 256x256 / 256x192 large tile,
- * 5/6 = 3/4 with staggered wave groups, 7/8 = persistent forms of 5/6, 9/10 = 5/6 with two (instead of four) barrier
- * phases per K-tile (what auto picks for large shapes), 12 = 64x64 tile with LDS-DMA (what auto picks when there are fewer
- * 128x128 tiles than CUs: batch-1 passes).  Large-tile variants need N % 4 == 0 (N % 8 == 0 for bf16 output).
- * K % 64 == 0.  For UCOD_EPI_BIAS_BF16 a non-NULL `scale` [N] multiplies
+/* variant: 0 = auto, 1 = 128x128 register staging, 2 = 128x128 LDS-DMA, 12 = 64x64 tile with LDS-DMA (what auto picks when there are
+ * fewer 128x128 tiles than CUs: batch-1 passes), 9 / 10 = 256x256 / 256x192 large tile (LDS-DMA in flight across barriers, staggered
+ * wave groups, two barrier intervals per K-tile, leftover tiles as patches: what auto picks for one- and two-round launches),
+ * 13 / 14 = the same loop with mixed-height tiles (whole rounds: what auto picks for three and more rounds).  3-8 (four intervals,
+ * no stagger, persistent form) are laboratory variants: ucod_gemm_bf16_lab of libucod_dpl_variants.so (`make variants`), refused here.
+ * Large-tile variants need N % 4 == 0 (N % 8 == 0 for bf16 output).  K % 64 == 0.  For UCOD_EPI_BIAS_BF16 a non-NULL `scale` [N] multiplies
  * (C + bias) per column before the bf16 rounding (used to fold the softmax scale into Q). */
 int ucod_gemm_bf16(int epilogue, const void* A_bf16, const void* B_bf16, void* out, int M, int N, int K,
                    const float* bias, const float* scale, const float* resid, const float* pos,
                    int tokens_per_image, int variant, void* stream);
+/* The UCOD_GEMM_* tuning variables (csrc/gemm_bf16_plan.h) are read once per process; this re-reads them (tests, sweep tools). */
+void ucod_gemm_reload_tuning(void);
+
+/* Saturation counter of the f16 residual stream (one word per device): how many wave-lanes had to clamp a value of x to +-65504 since the
+ * last reset.  fetch = asynchronous 4-byte copy into (pinned) host memory on `stream`; the caller orders its own read behind it (event /
+ * stream sync).  A non-zero count means the f16 stream cannot hold this checkpoint's activations: use resid16 = 0 (ViTEngine(resid="f32")). */
+int ucod_resid16_overflow_fetch(unsigned* host_dst, void* stream);
+int ucod_resid16_overflow_reset(void* stream);
 
 /* nn.LayerNorm over the last dim (modeling_dinov2.py:348,353,365,373,441; dino.py:127,131,184):
  * x f32 [rows,D] -> y bf16 [rows,D] (or f32 when out_f32 != 0).  D % 128 == 0. */
@@ -94,12 +106,12 @@ int ucod_layernorm_h16(const void* x_f16, const float* gamma, const float* beta,
 
 /* softmax(Q K^T * scale) V per (image, head), head_dim 64 (modeling_dinov2.py:153-179; dino.py:113-117).
  * qkv bf16 [B*tok, 3*heads*64] rows = [q | k | v], heads contiguous; out bf16 [B*tok, heads*64].
- * variant: 0 = V consumed through ds_read_b64_tr_b16, 1 = V transposed while staging.
- * scale == 0 selects the VALU-lean kernels and declares that Q already carries head_dim^-0.5 * log2(e) (ucod_fill_qscale + the
- * QKV epilogue scale do that inside ucod_vit_forward when attn_variant == 2).  With scale == 0, variant 0 / 2 / 5 = K/V staged by
- * buffer loads to LDS, compile-time LDS offsets, softmax denominator as packed f32 adds (the default); 6 = the same arithmetic
- * with per-tile address computation (previous default); 3 / 4 = denominator on the matrix pipe with K/V staged through
- * registers / by LDS-DMA. */
+ * scale != 0: the generic kernel (Q as the reference holds it, the scale applied inside the softmax, running max per tile).
+ * scale == 0 declares that Q already carries head_dim^-0.5 * log2(e) (ucod_fill_qscale + the QKV epilogue scale do that inside
+ * ucod_vit_forward) and selects the product kernel: K/V by buffer loads to LDS, -m as the score accumulator's initial value, deferred
+ * max, probabilities fed back as MFMA operands from registers, f32 row sums, 16-byte output stores; query rows and 32-key blocks past
+ * the last token are not computed.  variant: 0 or 2 (the same kernels); every other number is a laboratory variant
+ * (ucod_attention_fwd_lab of libucod_dpl_variants.so) and is refused.  tok * heads * 384 must fit 32 bits. */
 int ucod_attention_fwd(const void* qkv_bf16, void* out_bf16, int B, int tok, int heads, float scale, int variant,
                        void* stream);
 
@@ -222,12 +234,17 @@ typedef struct {
   int Kpad;               /* padded C*P*P */
   float eps;              /* LayerNorm eps (1e-6 for DINOv2 / DINO) */
   int full_last_layer;
-  int gemm_variant, attn_variant;
-  int resid16;            /* 1: the residual stream x lives in IEEE fp16 instead of f32 (11 significand bits: finer than the bf16 GEMM operands
-                             it feeds, so the bf16 build's accuracy is unchanged to its own rounding; values must stay below 65504).  Halves
-                             the bytes of LayerNorm's read and of the out-proj / fc2 read-modify-write epilogues.  0: f32 (exact
-                             accumulation).  Logit max-abs vs the f32 reference at full size: bf16 operands 3.2e-3 either way; fp16 operands
-                             3.8e-4 (f32 stream) / 6.4e-4 (fp16 stream). */
+  int gemm_variant;       /* ucod_gemm_bf16's variant for every GEMM of the pass (0 = auto) */
+  int attn_variant;       /* 0 (auto) / 2: pre-scaled-Q product kernel; 1: generic-scale kernel; 8: the fp8 path of BASELINE configs[4];
+                             anything else is refused (UCOD_EINVAL) */
+  int resid16;            /* 1: the residual stream x lives in IEEE fp16 instead of f32 (11 significand bits: 8x finer than the bf16 GEMM
+                             operands it feeds, so the bf16 build's accuracy is unchanged to its own rounding).  Halves the bytes of
+                             LayerNorm's read and of the out-proj / fc2 read-modify-write epilogues.  Values saturate at +-65504 and every
+                             saturation is counted (ucod_resid16_overflow_fetch): a checkpoint whose residual stream exceeds fp16's range
+                             is reported, never silently turned into inf / NaN.  0: f32 (exact accumulation; what the reference holds).
+                             Logit max-abs vs the f32 reference at full size, random-init weights: bf16 operands 3.2e-3 either way; fp16
+                             operands 3.8e-4 (f32 stream) / 6.4e-4 (fp16 stream).  Works for any batch size (small passes take the
+                             128 x 128 / 64 x 64 kernels with the same epilogue). */
 } ucod_vit_desc;
 size_t ucod_vit_workspace_bytes(const ucod_vit_desc* d);
 int ucod_vit_forward(const ucod_vit_desc* d, const void* const* table_host, const float* img, float* key_out,

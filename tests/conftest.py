@@ -13,6 +13,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "variants: laboratory kernels of ucod_dpl_amd/csrc/variants (need `make -C ucod_dpl_amd/csrc variants`; "
+                                       "skipped otherwise).  Run them alone with -m \"gpu and variants\"")
 
 
 def load_golden(name):

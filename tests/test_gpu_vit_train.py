@@ -152,7 +152,7 @@ def _gelu_grad(x):
     return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
 
 
-@pytest.mark.parametrize("variant", [0, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 9, 10])
 @pytest.mark.parametrize("M,Nn,K", [(300, 512, 128), (2740, 3072, 768)])
 def test_gemm_train_epilogues(variant, M, Nn, K):
     g = torch.Generator().manual_seed(M + Nn)

@@ -75,6 +75,12 @@ __device__ __forceinline__ void unpack_f16x2(unsigned w, float& lo, float& hi) {
   lo = (float)v[0];
   hi = (float)v[1];
 }
+// The f16 residual stream saturates instead of overflowing (an inf in x turns every later LayerNorm of the row into NaN with no error):
+// values are clamped to +-65504 before the conversion, and the number of saturated (or NaN) elements is added to a device counter the
+// host polls (ucod_resid16_overflow_*, include/ucod_dpl.h).
+constexpr float F16_MAX = 65504.f;
+__device__ __forceinline__ float clamp_f16(float x) { return __builtin_amdgcn_fmed3f(x, -F16_MAX, F16_MAX); }
+__device__ __forceinline__ bool beyond_f16(float x) { return !(__builtin_fabsf(x) <= F16_MAX); }     // true for NaN too
 // the two values of a packed register as f32
 __device__ __forceinline__ void unpack_h2(unsigned w, float& lo, float& hi) {
 #ifdef UCOD_HALF_F16
@@ -136,6 +142,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// device address of the f16-residual-stream saturation counter of the current device (vit_misc.hip)
+unsigned* resid16_overflow_counter();
 
 // op classes for the optional event profiler (prof.hip); the first six follow the UCOD_EPI_* numbering
 enum ProfClass {

@@ -1,0 +1,534 @@
+// Shared device code of the bf16 MFMA GEMM (product: gemm_bf16.hip; experiment variants: variants/gemm_bf16_lab.hip):
+// the argument block, the XCD-aware tile order, the LDS swizzle, exact-erf GELU, and the epilogues -- element / row-major drains of the
+// 128 x 128 kernel and `big_epilogue` of the large-tile kernels (bias as the accumulator's initial value, column scale in the MFMA
+// layout, drain through wave-private LDS into 16-byte buffer stores with no load between two stores, residual / saved pre-activation
+// double-buffered across passes).  Reference arithmetic: transformers modeling_dinov2.py (Dinov2SelfOutput :238-253, Dinov2LayerScale
+// :272-278, Dinov2MLP :281-297, Dinov2PatchEmbeddings :139-149), data/utils/feature_extractor.py:46-47,55-58 (key hook).
+#pragma once
+#include <cstdlib>
+#include "common.h"
+#include "../../include/ucod_dpl.h"
+
+namespace ucod {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+// cache policy of the large-tile epilogue's output stores (aux bits of buffer_store: 0 default, 2 nt, 16 sc1 = write-through, the line
+// is dropped from the XCD's L2 instead of displacing operand panels)
+#ifndef UCOD_ST_AUX
+#define UCOD_ST_AUX 0
+#endif
+
+
+// Cache policy of the operand LDS-DMA loads (experiment builds: make variant NAME=.. DEFS=-DUCOD_LD_AUX_A=2): 0 default, 2 = nt
+#ifndef UCOD_LD_AUX_A
+#define UCOD_LD_AUX_A 0
+#endif
+#ifndef UCOD_LD_AUX_B
+#define UCOD_LD_AUX_B 0
+#endif
+
+struct GemmArgs {
+  unsigned long long* stamps;   // diagnostic builds only (UCOD_GEMM_STAMPS): per-workgroup segment cycle sums, never read by kernels
+  const bf16_raw* A;
+  const bf16_raw* B;
+  void* out;
+  const float* bias;
+  const float* scale;
+  const float* resid;
+  const float* pos;
+  const void* aux;    // GELU_BWD: bf16 [M,N] pre-activation of the forward fc1
+  void* out2;         // BIAS_GELU_SAVE: bf16 [M,N] pre-activation output
+  unsigned* ovf;      // f16 residual-stream epilogues: saturation counter (common.h: resid16_overflow_counter)
+  int M, N, K;
+  int tok;   // tokens per image incl. CLS (PATCH / KEY epilogues)
+  int tiles_m, tiles_n;
+  int main_tiles;      // large-tile kernel, leftover-as-patches mode (see patch_phase): workgroups launched = whole tiles computed; 0 = off
+  int patches_per_wg;  // 16 x 32 patches of the remaining tiles each workgroup computes on the side
+  int group_m;         // large-tile kernels: row-tiles per group of the tile order inside an XCD's chunk (see tile_of)
+  int col_fast;        // 1: column-tile fastest inside a group (one A panel's N-sweep back to back), 0: row-tile fastest
+};
+
+// Tile order of the large-tile kernels inside one XCD's contiguous chunk of the grid: groups of `group_m` row-tiles x all column-tiles.
+// row-tile fastest (col_fast = 0): the 32 workgroups resident on an XCD share group_m A panels and 32/group_m B panels;
+// column-tile fastest (col_fast = 1): they share 32/tiles_n A panels and ALL B panels, which then stay hot in the XCD's L2 while the A
+// panels stream through once -- the better order when the whole weight matrix fits beside the streaming panels (4 MiB L2 per XCD).
+__device__ __forceinline__ void tile_of(const GemmArgs& a, int wg, int& tm, int& tn) {
+  const int gm = a.group_m;
+  const int per_group = gm * a.tiles_n;
+  const int grp = wg / per_group, first_m = grp * gm;
+  const int gsz = (a.tiles_m - first_m) < gm ? (a.tiles_m - first_m) : gm;
+  const int in_grp = wg - grp * per_group;
+  if (a.col_fast) {
+    tm = first_m + in_grp / a.tiles_n;
+    tn = in_grp - (in_grp / a.tiles_n) * a.tiles_n;
+  } else {
+    tm = first_m + in_grp % gsz;
+    tn = in_grp / gsz;
+  }
+}
+
+// 16-byte chunk swizzle inside a 128-byte (64 x bf16) tile row: conflict-free ds_read_b128 for the
+// 16x16x32 fragment pattern (rows l&15, chunk l>>4) under the 64-bank / 16-lane-group rule.
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// exact-erf GELU (transformers ACT2FN["gelu"], modeling_dinov2.py:289), two elements per call so the polynomial runs
+// on v_pk_fma_f32.  With a = |x|:  0.5*erfc(a/sqrt2) = exp2(-(1 + a*(d1 + d2 a + d3 a^2 + d4 a^3 + d5 a^4)))  (weighted
+// minimax fit of -log2 erfc, |erfc err| <= 5e-6 and RELATIVE in the tail), and  gelu(x) = max(x,0) - a * 0.5*erfc(a/sqrt2).
+// Max |gelu err| = 7.1e-7 over [-30,30] in fp32 -- the same as the Abramowitz-Stegun 7.1.26 form it replaces, at one
+// transcendental and ~9 issue slots per element instead of two and ~22 (the fc1 epilogue runs it 134 M times per
+// launch and was VALU-bound: 6.3 k of its 18.1 k cycles per 256x256 tile).  d5 > 0, so large |x| underflows to t = 0.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  const f32x2 a = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+  f32x2 p = a * 4.881021588e-04f + (-7.198718842e-03f);
+  p = p * a + 5.214663086e-02f;
+  p = p * a + 4.595958292e-01f;
+  p = p * a + 1.151000509e+00f;
+  p = p * a + 1.0f;
+  const f32x2 t = {__builtin_amdgcn_exp2f(-p[0]), __builtin_amdgcn_exp2f(-p[1])};
+  const f32x2 pos = {__builtin_fmaxf(x[0], 0.f), __builtin_fmaxf(x[1], 0.f)};
+  return pos - a * t;
+}
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f32x2){x, x})[0]; }
+// d/dx gelu(x) = Phi(x) + x * phi(x), Phi from the same 0.5*erfc fit (backbone-backward mode, fc1 dgrad epilogue)
+__device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
+  const f32x2 a = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+  f32x2 p = a * 4.881021588e-04f + (-7.198718842e-03f);
+  p = p * a + 5.214663086e-02f;
+  p = p * a + 4.595958292e-01f;
+  p = p * a + 1.151000509e+00f;
+  p = p * a + 1.0f;
+  const f32x2 t = {__builtin_amdgcn_exp2f(-p[0]), __builtin_amdgcn_exp2f(-p[1])};          // 0.5 * erfc(|x| / sqrt 2)
+  const f32x2 cdf = {x[0] >= 0.f ? 1.f - t[0] : t[0], x[1] >= 0.f ? 1.f - t[1] : t[1]};
+  const f32x2 xx = x * x * (-0.72134752044448170f);                                         // -x^2/2 * log2(e)
+  const f32x2 pdf = {__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
+  return cdf + x * pdf * 0.39894228040143268f;
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_store(const GemmArgs& a, int m, int n, float v) {
+  if (m >= a.M || n >= a.N) return;
+  if constexpr (EPI == UCOD_EPI_BIAS_BF16) {
+    reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_h((v + a.bias[n]) * (a.scale ? a.scale[n] : 1.f));
+  } else if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) {
+    reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_h(gelu_erf(v + a.bias[n]));
+  } else if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) {
+    const size_t i = (size_t)m * a.N + n;
+    reinterpret_cast<float*>(a.out)[i] = a.resid[i] + a.scale[n] * (v + a.bias[n]);
+  } else if constexpr (EPI == UCOD_EPI_PATCH_TOKENS_F32) {
+    // row m = b*(tok-1)+p  ->  token row b*tok + 1 + p ; + bias + position embedding of token 1+p
+    const int np = a.tok - 1;
+    const int b = m / np, p = m - b * np;
+    reinterpret_cast<float*>(a.out)[((size_t)b * a.tok + 1 + p) * a.N + n] = v + a.bias[n] + a.pos[(size_t)(1 + p) * a.N + n];
+  } else if constexpr (EPI == UCOD_EPI_PATCH_TOKENS_H16) {
+    const int np = a.tok - 1;
+    const int b = m / np, p = m - b * np;
+    const float o = v + a.bias[n] + a.pos[(size_t)(1 + p) * a.N + n];
+    if (beyond_f16(o)) atomicAdd(a.ovf, 1u);
+    reinterpret_cast<unsigned short*>(a.out)[((size_t)b * a.tok + 1 + p) * a.N + n] = __builtin_bit_cast(unsigned short, (_Float16)clamp_f16(o));
+  } else if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_H16) {
+    const size_t i = (size_t)m * a.N + n;
+    const float o = (float)reinterpret_cast<const _Float16*>(a.resid)[i] + a.scale[n] * (v + a.bias[n]);
+    if (beyond_f16(o)) atomicAdd(a.ovf, 1u);
+    reinterpret_cast<unsigned short*>(a.out)[i] = __builtin_bit_cast(unsigned short, (_Float16)clamp_f16(o));
+  } else if constexpr (EPI == UCOD_EPI_KEY_NCHW_F32) {
+    // m = channel, n = global token index; drop CLS, write [B, C, tok-1]
+    const int b = n / a.tok, t = n - b * a.tok;
+    if (t == 0) return;
+    reinterpret_cast<float*>(a.out)[((size_t)b * a.M + m) * (a.tok - 1) + (t - 1)] = v + a.bias[m];
+  } else if constexpr (EPI == UCOD_EPI_BIAS_F32) {
+    reinterpret_cast<float*>(a.out)[(size_t)m * a.N + n] = v + a.bias[n];
+  }
+}
+
+// Four consecutive columns n..n+3 of output row m (n % 4 == 0, N % 4 == 0): vector loads / stores.
+template <int EPI>
+__device__ __forceinline__ void epilogue_store4(const GemmArgs& a, int m, int n, f32x4 v) {
+  if (m >= a.M || n >= a.N) return;
+  if constexpr (EPI == UCOD_EPI_KEY_NCHW_F32) {
+    // four consecutive tokens of one image, none of them CLS: one dword-aligned 16-byte store into [B, C, tok-1] (row starts are
+    // only 4-byte aligned there: tok-1 is odd); groups that touch a CLS token or straddle two images go token by token
+    const int b = n / a.tok, t = n - b * a.tok;
+    if (t >= 1 && t + 3 < a.tok && n + 3 < a.N) {
+      typedef f32x4 f32x4_u __attribute__((aligned(4)));
+      const float bm = a.bias[m];
+      *reinterpret_cast<f32x4_u*>(reinterpret_cast<float*>(a.out) + ((size_t)b * a.M + m) * (a.tok - 1) + (t - 1)) = v + (f32x4){bm, bm, bm, bm};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) epilogue_store<EPI>(a, m, n + e, v[e]);
+    }
+  } else {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
+    if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) {
+      f32x4 o = v + b;
+      if constexpr (EPI == UCOD_EPI_BIAS_BF16) {
+        if (a.scale) o = o * *reinterpret_cast<const f32x4*>(a.scale + n);
+      }
+      if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) {
+        const f32x2 g0 = gelu_erf2((f32x2){o[0], o[1]}), g1 = gelu_erf2((f32x2){o[2], o[3]});
+        o = (f32x4){g0[0], g0[1], g1[0], g1[1]};
+      }
+      u32x2 w;
+      w[0] = pack_h2(o[0], o[1]);
+      w[1] = pack_h2(o[2], o[3]);
+      *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_raw*>(a.out) + (size_t)m * a.N + n) = w;
+    } else if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) {
+      const size_t i = (size_t)m * a.N + n;
+      const f32x4 r = *reinterpret_cast<const f32x4*>(a.resid + i);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + i) = r + sc * (v + b);
+    } else if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_H16) {
+      const size_t i = (size_t)m * a.N + n;
+      const u32x2 rw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(a.resid) + i);
+      float r0, r1, r2, r3;
+      unpack_f16x2(rw[0], r0, r1);
+      unpack_f16x2(rw[1], r2, r3);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+      const f32x4 o = (f32x4){r0, r1, r2, r3} + sc * (v + b);
+      if (beyond_f16(o[0]) || beyond_f16(o[1]) || beyond_f16(o[2]) || beyond_f16(o[3])) atomicAdd(a.ovf, 1u);
+      u32x2 w;
+      w[0] = pack_f16x2(clamp_f16(o[0]), clamp_f16(o[1]));
+      w[1] = pack_f16x2(clamp_f16(o[2]), clamp_f16(o[3]));
+      *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(a.out) + i) = w;
+    } else if constexpr (EPI == UCOD_EPI_PATCH_TOKENS_F32 || EPI == UCOD_EPI_PATCH_TOKENS_H16) {
+      const int np = a.tok - 1;
+      const int bi = m / np, p = m - bi * np;
+      const f32x4 ps = *reinterpret_cast<const f32x4*>(a.pos + (size_t)(1 + p) * a.N + n);
+      const f32x4 o = v + b + ps;
+      if constexpr (EPI == UCOD_EPI_PATCH_TOKENS_H16) {
+        if (beyond_f16(o[0]) || beyond_f16(o[1]) || beyond_f16(o[2]) || beyond_f16(o[3])) atomicAdd(a.ovf, 1u);
+        u32x2 w;
+        w[0] = pack_f16x2(clamp_f16(o[0]), clamp_f16(o[1]));
+        w[1] = pack_f16x2(clamp_f16(o[2]), clamp_f16(o[3]));
+        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(a.out) + ((size_t)bi * a.tok + 1 + p) * a.N + n) = w;
+      } else {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + ((size_t)bi * a.tok + 1 + p) * a.N + n) = o;
+      }
+    } else {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.N + n) = v + b;
+    }
+  }
+}
+
+// Eight consecutive columns of a bf16-output row: ONE 16-byte store per lane.  The per-CU store path is issue-bound
+// (~7 B/clk/CU with 8-byte stores; measured 12 us to drain a 256x256 bf16 tile): halving the instruction count at equal
+// bytes halves the drain time.
+template <int EPI>
+__device__ __forceinline__ void epilogue_store8_bf16(const GemmArgs& a, int m, int n, f32x4 v0, f32x4 v1) {
+  if (m >= a.M || n >= a.N) return;
+  f32x4 o0 = v0 + *reinterpret_cast<const f32x4*>(a.bias + n);
+  f32x4 o1 = v1 + *reinterpret_cast<const f32x4*>(a.bias + n + 4);
+  if constexpr (EPI == UCOD_EPI_BIAS_BF16) {
+    if (a.scale) {
+      o0 = o0 * *reinterpret_cast<const f32x4*>(a.scale + n);
+      o1 = o1 * *reinterpret_cast<const f32x4*>(a.scale + n + 4);
+    }
+  } else {
+    const f32x2 g0 = gelu_erf2((f32x2){o0[0], o0[1]}), g1 = gelu_erf2((f32x2){o0[2], o0[3]});
+    const f32x2 g2 = gelu_erf2((f32x2){o1[0], o1[1]}), g3 = gelu_erf2((f32x2){o1[2], o1[3]});
+    o0 = (f32x4){g0[0], g0[1], g1[0], g1[1]};
+    o1 = (f32x4){g2[0], g2[1], g3[0], g3[1]};
+  }
+  u32x4 w;
+  w[0] = pack_h2(o0[0], o0[1]);
+  w[1] = pack_h2(o0[2], o0[3]);
+  w[2] = pack_h2(o1[0], o1[1]);
+  w[3] = pack_h2(o1[2], o1[3]);
+  *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_raw*>(a.out) + (size_t)m * a.N + n) = w;
+}
+
+// Epilogue of one wave's RxWCOLS f32 sub-tile through a wave-private LDS region: accumulators are written with the
+// MFMA C layout (lane -> column), read back row-major 16/32 B per lane, so global traffic is whole row segments moved
+// by 16-byte-per-lane instructions (4-8x fewer, wider instructions than storing straight from the accumulator layout).
+template <int EPI, int WCOLS, int ROWS>
+__device__ __forceinline__ void drain_rows(const GemmArgs& a, const char* wbase, int m_first, int n_first, int lane) {
+  constexpr bool BF16_OUT = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16);
+  if constexpr (BF16_OUT && (WCOLS % 8) == 0 && (ROWS * (WCOLS / 8)) % 64 == 0) {
+    constexpr int CH = WCOLS / 8;                     // 32-byte (8 x f32) chunks per row -> 16-byte bf16 stores
+    if ((a.N & 7) == 0) {
+#pragma unroll
+      for (int it = 0; it < ROWS * CH / 64; ++it) {
+        const int idx = it * 64 + lane, r = idx / CH, c = idx - r * CH;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(wbase + r * (WCOLS * 4) + c * 32);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(wbase + r * (WCOLS * 4) + c * 32 + 16);
+        epilogue_store8_bf16<EPI>(a, m_first + r, n_first + c * 8, v0, v1);
+      }
+      return;
+    }
+  }
+  constexpr int CH = WCOLS / 4;                       // 16-byte chunks per row
+  static_assert((ROWS * CH) % 64 == 0, "whole wave instructions");
+#pragma unroll
+  for (int it = 0; it < ROWS * CH / 64; ++it) {
+    const int idx = it * 64 + lane, r = idx / CH, c = idx - r * CH;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + r * (WCOLS * 4) + c * 16);
+    epilogue_store4<EPI>(a, m_first + r, n_first + c * 4, v);
+  }
+}
+
+// ---- large-tile epilogue (one-shot and persistent kernels) ------------------------------------------------------
+// s_memtime stamps (tools/gemm_stamps.py) showed the old epilogue costing 12 k (bf16 out) to 40 k (f32 residual) cycles per
+// 256-wide tile INDEPENDENT of how many CUs were active: not bandwidth, but a latency chain -- every 16-byte store was
+// preceded by bias / scale / residual loads whose `s_waitcnt vmcnt(0)` also drained the stores issued just before (vmcnt
+// counts stores on gfx9), i.e. one ~700-cycle store round trip per store instruction.  So, for the three hot epilogues:
+//   * the bias is the accumulator's INITIAL value and the per-column scale (Q pre-scale, LayerScale gamma) is applied in the
+//     MFMA C layout, where a lane owns one column per 16-wide tile: NT + NT registers, loaded once per output tile;
+//   * GELU runs in the C layout too, so the row-major drain of a bf16 tile is ds_read -> cvt -> 16-byte store, no loads;
+//   * the f32 residual is double buffered: the loads of pass p+1 are issued BEFORE the stores of pass p, and vmcnt retires
+//     in order, so the wait for them leaves pass p's stores in flight.  (out may alias resid: passes touch disjoint rows.)
+template <int EPI>
+constexpr bool kColFused = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 ||
+                            EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16 ||
+                            EPI == UCOD_EPI_QKV_FP8 || EPI == UCOD_EPI_BIAS_SCALE_RESID_H16);
+template <int EPI>
+constexpr bool kF32Out = (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_BIAS_F32);
+
+template <int EPI, int NT>
+__device__ __forceinline__ void load_col_consts(const GemmArgs& a, int ncol0, float (&cb)[NT], float (&cs)[NT]) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    cb[j] = 0.f;
+    cs[j] = 1.f;
+    if constexpr (kColFused<EPI>) {
+      int n = ncol0 + j * 16;
+      n = n < a.N ? n : a.N - 1;
+      if constexpr (EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8) {
+        cb[j] = (a.bias ? a.bias : reinterpret_cast<const float*>(a.B))[n];   // NULL bias = plain product (dgrad GEMMs): selected in finish_col_consts
+      } else if constexpr (EPI != UCOD_EPI_GELU_BWD_BF16) {
+        cb[j] = a.bias[n];
+      }
+      if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_BIAS_SCALE_RESID_H16) cs[j] = a.scale[n];
+      // optional scale: unconditional load now (a branch here costs a vmcnt(0) at the join, ahead of the operand DMAs),
+      // select at the point of use (finish_col_consts) so nothing waits on the load before the DMAs are out
+      if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8) cs[j] = (a.scale ? a.scale : reinterpret_cast<const float*>(a.B))[n];
+    }
+  }
+}
+
+template <int EPI, int NT>
+__device__ __forceinline__ void finish_col_consts(const GemmArgs& a, float (&cb)[NT], float (&cs)[NT]) {
+  if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) cs[j] = a.scale ? cs[j] : 1.f;
+  }
+  if constexpr (EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) cb[j] = a.bias ? cb[j] : 0.f;
+  }
+}
+
+// acc: the wave's 128 x 16*NT tile (8 row-tiles x NT column-tiles, C layout col = lane&15, row = (lane>>4)*4 + reg), bias
+// already inside for the fused epilogues; cs = per-column scale.  wbase: wave-private 32 x WCOLS f32 staging area.  Four passes of 32 rows.
+template <int EPI, int NT, int NI = 8, int AUX = UCOD_ST_AUX>
+__device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI][NT], const float (&cs)[NT], char* wbase,
+                                             int m_first, int n_first, int lane) {
+  constexpr int WCOLS = 16 * NT, PR = 32;
+  constexpr int NP = (NI + 1) / 2;                    // passes of 32 rows; with NI odd the last pass holds 16 rows (rows 16..31 masked off)
+  static_assert(NI == 8 || kColFused<EPI>, "odd row-tile counts only in the column-fused epilogues");
+  auto rows_in = [&](int pass) { return (NI - 2 * pass) >= 2 ? 32 : 16; };
+  auto stage = [&](int pass) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (pass * 2 + i >= NI) continue;
+        f32x4 v = acc[pass * 2 + i < NI ? pass * 2 + i : 0][j];
+        if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_QKV_FP8 ||
+                      EPI == UCOD_EPI_BIAS_SCALE_RESID_H16) v = v * cs[j];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * (WCOLS * 4) + (j * 16 + (lane & 15)) * 4) = v[rg];
+      }
+  };
+  if constexpr (!kColFused<EPI>) {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      stage(pass);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      drain_rows<EPI, WCOLS, PR>(a, wbase, m_first + pass * PR, n_first, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  } else {
+    // Row / column guards without branches (a branch per access makes hipcc fall back to vmcnt(0) before every store):
+    // buffer descriptors over [first row of this wave's tile, end of the matrix) -- rows past M fail the range check and
+    // are dropped (loads return 0) -- and columns past N get an offset beyond any descriptor.
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    constexpr int ELT = kF32Out<EPI> ? 4 : 2;
+    const long rows_left = (long)a.M - m_first;
+    const unsigned long left = rows_left > 0 ? (unsigned long)rows_left * a.N * ELT : 0ul;
+    const unsigned records = left > 0xFFFFFFFFul ? 0xFFFFFFFFu : (unsigned)left;
+    const size_t base = (size_t)(m_first < a.M ? m_first : 0) * a.N * ELT;
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + base, 0, records, 0x00020000);
+    const unsigned row_bytes = (unsigned)a.N * ELT;
+    const unsigned pass_bytes = PR * row_bytes;
+    if constexpr (EPI == UCOD_EPI_QKV_FP8) {
+      // The wave's 64 columns are one head of q, k or v (n_first is a multiple of 64): e4m3 rows of 64 bytes into
+      // [q|k|v][image * heads + head][Npad][64].  Lane -> (row, 16-column chunk): one 16-byte store per 16 outputs.
+      static_assert(NT == 4, "one head per wave");
+      const int Dm = a.N / 3, heads = Dm >> 6, tok = a.tok, npad = ((tok + 63) >> 6) << 6;
+      const int region = n_first / Dm, head = (n_first - region * Dm) >> 6;
+      const size_t npairs = (size_t)(a.M / tok) * heads;
+      char* dst0 = reinterpret_cast<char*>(a.out) + (size_t)region * npairs * npad * 64;
+#pragma unroll
+      for (int pass = 0; pass < NP; ++pass) {
+        stage(pass);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int idx = it * 64 + lane, r = idx >> 2, c = idx & 3;
+          const int m = m_first + pass * PR + r;
+          u32x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + r * (WCOLS * 4) + c * 64 + e * 16);
+            int p = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[0], -448.f), 448.f), fminf(fmaxf(v[1], -448.f), 448.f), 0, false);
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[2], -448.f), 448.f), fminf(fmaxf(v[3], -448.f), 448.f), p, true);
+            w[e] = (unsigned)p;
+          }
+          if (m < a.M && r < rows_in(pass) && n_first < a.N) {
+            const int bimg = m / tok, t = m - bimg * tok;
+            *reinterpret_cast<u32x4*>(dst0 + (((size_t)bimg * heads + head) * npad + t) * 64 + c * 16) = w;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    } else if constexpr (kF32Out<EPI>) {
+      constexpr bool RESID = (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32);
+      constexpr int CH = WCOLS / 4, ITS = PR * CH / 64;          // 16-byte chunks per row; wave instructions per pass
+      static_assert((PR * CH) % 64 == 0, "whole wave instructions");
+      const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(RESID ? (const void*)a.resid : (const void*)a.out)) + base, 0, RESID ? records : 0u, 0x00020000);
+      unsigned off[ITS];                                          // byte offset of (row, chunk) of pass 0; + pass * 32 rows
+      int lrow[ITS], lchk[ITS];
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) {
+        const int idx = it * 64 + lane;
+        lrow[it] = idx / CH;
+        lchk[it] = idx - lrow[it] * CH;
+        const int n = n_first + lchk[it] * 4;
+        off[it] = n < a.N ? (unsigned)lrow[it] * row_bytes + (unsigned)n * 4u : OOB;
+      }
+      // (the pass offset goes into the VGPR offset, not soffset: the range check covers only voffset + inst_offset)
+      auto at = [&](int it, int pass) { return (off[it] == OOB || lrow[it] >= rows_in(pass)) ? OOB : off[it] + (unsigned)pass * pass_bytes; };
+      u32x4 rb[2][ITS];
+      if constexpr (RESID) {
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) rb[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off[it], 0, 0);
+      }
+#pragma unroll
+      for (int pass = 0; pass < NP; ++pass) {
+        stage(pass);
+        if constexpr (RESID) {
+          if (pass + 1 < NP) {
+#pragma unroll
+            for (int it = 0; it < ITS; ++it)
+              rb[(pass + 1) & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, at(it, pass + 1), 0, 0);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          f32x4 o = *reinterpret_cast<const f32x4*>(wbase + lrow[it] * (WCOLS * 4) + lchk[it] * 16);
+          if constexpr (RESID) o = o + __builtin_bit_cast(f32x4, rb[pass & 1][it]);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, at(it, pass), 0, AUX);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    } else {                                                      // bf16 out: 16-byte stores (launch() guarantees N % 8 == 0)
+      constexpr bool GBWD = (EPI == UCOD_EPI_GELU_BWD_BF16), SAVE = (EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
+      constexpr bool RH16 = (EPI == UCOD_EPI_BIAS_SCALE_RESID_H16);   // second matrix = the f16 residual stream (may alias out)
+      constexpr int CH = WCOLS / 8, ITS = PR * CH / 64;
+      static_assert((PR * CH) % 64 == 0, "whole wave instructions");
+      // second bf16 [M,N] matrix with the same geometry: the saved pre-activation, read (GELU_BWD) or written (GELU_SAVE)
+      const void* second = GBWD ? a.aux : (SAVE ? (const void*)a.out2 : (RH16 ? (const void*)a.resid : (const void*)a.out));
+      const auto rs_2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(second)) + base, 0,
+                                                          (GBWD || SAVE || RH16) ? records : 0u, 0x00020000);
+      // (row, chunk) of wave instruction `it`: recomputed where needed -- index arrays cost registers the persistent kernel lacks
+      auto lrow = [&](int it) { return (it * 64 + lane) / CH; };
+      auto lchk = [&](int it) { return (it * 64 + lane) - lrow(it) * CH; };
+      auto at = [&](int it, int pass) {
+        const int n = n_first + lchk(it) * 8;
+        return (n < a.N && lrow(it) < rows_in(pass)) ? (unsigned)(pass * PR + lrow(it)) * row_bytes + (unsigned)n * 2u : OOB;
+      };
+      float amax = 0.f;                                             // RH16: largest |x_new| this lane produced (saturation test after the stores)
+      u32x4 pre[2][ITS];
+      if constexpr (GBWD || RH16) {
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) pre[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_2, at(it, 0), 0, 0);
+      }
+#pragma unroll
+      for (int pass = 0; pass < NP; ++pass) {
+        stage(pass);
+        if constexpr (GBWD || RH16) {
+          if (pass + 1 < NP) {
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) pre[(pass + 1) & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_2, at(it, pass + 1), 0, 0);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          f32x4 v0 = *reinterpret_cast<const f32x4*>(wbase + lrow(it) * (WCOLS * 4) + lchk(it) * 32);
+          f32x4 v1 = *reinterpret_cast<const f32x4*>(wbase + lrow(it) * (WCOLS * 4) + lchk(it) * 32 + 16);
+          if constexpr (SAVE) {                                   // pre-activation out first
+            u32x4 w;
+            w[0] = pack_h2(v0[0], v0[1]);
+            w[1] = pack_h2(v0[2], v0[3]);
+            w[2] = pack_h2(v1[0], v1[1]);
+            w[3] = pack_h2(v1[2], v1[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs_2, at(it, pass), 0, 0);
+          }
+          if constexpr (SAVE || EPI == UCOD_EPI_BIAS_GELU_BF16) {  // GELU in the row-major layout (fewer live registers than in the C layout)
+            const f32x2 g0 = gelu_erf2((f32x2){v0[0], v0[1]}), g1 = gelu_erf2((f32x2){v0[2], v0[3]});
+            const f32x2 g2 = gelu_erf2((f32x2){v1[0], v1[1]}), g3 = gelu_erf2((f32x2){v1[2], v1[3]});
+            v0 = (f32x4){g0[0], g0[1], g1[0], g1[1]};
+            v1 = (f32x4){g2[0], g2[1], g3[0], g3[1]};
+          }
+          if constexpr (GBWD) {
+            const u32x4 pw = pre[pass & 1][it];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              f32x2 x;
+              {
+                float x0, x1;
+                unpack_h2(pw[e], x0, x1);
+                x = (f32x2){x0, x1};
+              }
+              const f32x2 g = gelu_grad2(x);
+              if (e < 2) { v0[2 * e] *= g[0]; v0[2 * e + 1] *= g[1]; }
+              else { v1[2 * (e - 2)] *= g[0]; v1[2 * (e - 2) + 1] *= g[1]; }
+            }
+          }
+          u32x4 w;
+          if constexpr (RH16) {                                   // x_new = x_old + lambda (acc + b), all in IEEE fp16 storage
+            const u32x4 pw = pre[pass & 1][it];
+            float r[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) unpack_f16x2(pw[e], r[2 * e], r[2 * e + 1]);
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = v0[e] + r[e]; x[4 + e] = v1[e] + r[4 + e]; }
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x[e]), __builtin_fabsf(x[e + 1])));   // (v_max3 with |.| modifiers)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = pack_f16x2(clamp_f16(x[2 * e]), clamp_f16(x[2 * e + 1]));
+          } else {
+            w[0] = pack_h2(v0[0], v0[1]);
+            w[1] = pack_h2(v0[2], v0[3]);
+            w[2] = pack_h2(v1[0], v1[1]);
+            w[3] = pack_h2(v1[2], v1[3]);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, at(it, pass), 0, AUX);
+          __builtin_amdgcn_sched_barrier(0);                      // keep chunks in order: hoisting every ds_read/cvt of a pass spills in the persistent kernel
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      if constexpr (RH16) {                                         // after the last store: nothing waits on this
+        if (amax > F16_MAX) atomicAdd(a.ovf, 1u);
+      }
+    }
+  }
+}
+
+
+}  // namespace ucod

@@ -1,0 +1,283 @@
+// LABORATORY FILE -- not part of the product library.  Built only by `make -C ucod_dpl_amd/csrc variants` into
+// ../_native/libucod_dpl_variants.so (entry: ucod_gemm_bf16_lab), loaded only by tools/ and by tests marked `variants`.
+// Forms of the large-tile bf16 GEMM measured in rounds 1-2 and not adopted, kept runnable for A/B runs against
+// the product kernels of ../gemm_bf16.hip:
+//   3 / 4   256 x 256 / 256 x 192, four barrier intervals per K-tile, wave groups in lockstep
+//   5 / 6   the same with staggered wave groups
+//   7 / 8   persistent form (next tile's first K-tile under the epilogue), one workgroup per CU
+// Same template (gemm_bf16_tiles.h), same epilogues (gemm_bf16_epilogue.h), same plans (gemm_bf16_plan.h) as the product.
+#include "../gemm_bf16_tiles.h"
+#include "../gemm_bf16_plan.h"
+
+namespace ucod {
+
+// =====================================================================================================
+// Persistent form of the large-tile kernel: one workgroup per CU walks tiles vt = blockIdx.x, +gridDim.x, ...
+// What it buys: the first K-tile of the NEXT output tile (A0|A1|B, 9-11 LDS-DMAs per thread) is issued BEFORE the epilogue of
+// the current tile, into the K-tile buffer the main loop has just vacated, so the ~3 us of first-tile HBM/L2 latency that every
+// tile of the one-shot kernel pays up front (13 % of a K=768 tile) hides under the epilogue's stores.  The epilogue stages
+// through the OTHER buffer (4 passes of 32 rows, 8 KB per wave) so the two never touch the same LDS bytes.
+// Hazards on top of the one-shot kernel's:
+//   * next-tile DMAs target buffer free_buf = (last K-tile's buffer)^1, last read during K-tile nt-2: dead long before;
+//   * epilogue staging lives in last_buf, whose operand reads all retired before the stagger-out barrier;
+//   * after the epilogue: every wave `vmcnt(0)` (its DMAs landed; also its stores) -> barrier -> only then may B(1) of the next
+//     tile be DMA'd into last_buf (it overlaps other waves' staging areas) and the next main loop read free_buf.
+// =====================================================================================================
+template <int EPI, int NT>
+__global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
+  using Cfg = BigCfg<NT>;
+  __shared__ __attribute__((aligned(16))) char smem[2 * Cfg::BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntiles = a.tiles_m * a.tiles_n;
+  const int K = a.K, nt = K / BK;
+  constexpr int WCOLS = 16 * NT;
+
+  auto decode = [&](int vt, int& m0, int& n0) {
+    const int q = ntiles >> 3, r8 = ntiles & 7, xcd = vt & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (vt >> 3);
+    int tm, tn;
+    tile_of(a, wg, tm, tn);
+    m0 = tm * 256;
+    n0 = tn * Cfg::BN_;
+  };
+  // DMA source rows as 32-bit element offsets from the tile's first A / B row (64-bit per-tile bases stay in SGPRs): the
+  // persistent kernel keeps the next tile's sources live across the epilogue, and 64-bit pointers there spilled VGPRs.
+  unsigned srcA[2][2], srcB[Cfg::NB];
+  const bf16_raw *baseA, *baseB;
+  auto set_src = [&](int m0, int n0) {
+    baseA = a.A + (size_t)m0 * K;
+    baseB = a.B + (size_t)n0 * K;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = (i * 8 + wave) * 8 + (lane >> 3);
+        int lr = h * 128 + r;
+        lr = (m0 + lr) < a.M ? lr : a.M - 1 - m0;
+        srcA[h][i] = (unsigned)lr * (unsigned)K + swz(r, lane & 7) * 8;
+      }
+#pragma unroll
+    for (int i = 0; i < Cfg::NB; ++i) {
+      const int r = (i * 8 + wave) * 8 + (lane >> 3);
+      int lr = (n0 + r) < a.N ? r : a.N - 1 - n0;
+      srcB[i] = (unsigned)lr * (unsigned)K + swz(r, lane & 7) * 8;
+    }
+  };
+  auto dma = [&](const bf16_raw* src, char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto stageA = [&](int t, int h, int pb) {
+    char* slot = smem + ((t + pb) & 1) * Cfg::BUF + h * SLOT_A;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma(baseA + t * BK + srcA[h][i], slot + (i * 8 + wave) * 1024);
+  };
+  auto stageB = [&](int t, int i0, int i1, int pb) {
+    char* slot = smem + ((t + pb) & 1) * Cfg::BUF + 2 * SLOT_A;
+#pragma unroll
+    for (int i = 0; i < Cfg::NB; ++i)
+      if (i >= i0 && i < i1) dma(baseB + t * BK + srcB[i], slot + (i * 8 + wave) * 1024);
+  };
+  constexpr int B_SPLIT = Cfg::NB >= 2 ? 2 : 1;
+
+#ifdef UCOD_GEMM_STAMPS
+  unsigned long long st_loop = 0, st_epi = 0, st_wait = 0, st_tiles = 0, t0s, t1s, t2s, t3s;
+#define STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#else
+#define STAMP(v)
+#endif
+  int vt = blockIdx.x, pb = 0, m0, n0;
+  decode(vt, m0, n0);
+  float cb[NT], cs[NT];
+  load_col_consts<EPI, NT>(a, n0 + wn * WCOLS + (lane & 15), cb, cs);
+  set_src(m0, n0);
+  stageA(0, 0, pb);
+  stageA(0, 1, pb);
+  stageB(0, 0, Cfg::NB, pb);
+  if (nt > 1) {
+    stageB(1, 0, Cfg::NB, pb);
+    wait_vmcnt<Cfg::NB>();
+  } else {
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+
+  while (true) {
+    finish_col_consts<EPI, NT>(a, cb, cs);
+    f32x4 acc[8][NT];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){cb[j], cb[j], cb[j], cb[j]};
+    STAMP(t0s);
+    if (wm == 1) __builtin_amdgcn_s_barrier();               // stagger in (see the one-shot kernel)
+
+    for (int t = 0; t < nt; ++t) {
+      const char* bufA = smem + ((t + pb) & 1) * Cfg::BUF + wm * SLOT_A;
+      const char* bufB = smem + ((t + pb) & 1) * Cfg::BUF + 2 * SLOT_A;
+      const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+      hx8 fb[NT][2];
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        if (ph == 0 && more1) stageA(t + 1, 0, pb);
+        if (ph == 1 && more1) stageA(t + 1, 1, pb);
+        if (ph == 2 && more2) stageB(t + 2, 0, B_SPLIT, pb);
+        if (ph == 3 && more2) stageB(t + 2, B_SPLIT, Cfg::NB, pb);
+        if (ph == 0) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const int r = wn * 16 * NT + j * 16 + (lane & 15);
+              fb[j][ks] = *reinterpret_cast<const hx8*>(bufB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+            }
+        }
+        hx8 fa[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int r = ph * 32 + i * 16 + (lane & 15);
+            fa[i][ks] = *reinterpret_cast<const hx8*>(bufA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+          }
+        if (ph == 3) {
+          if (more2) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[ph * 2 + i][j] = UCOD_MFMA16(fa[i][ks], fb[j][ks], acc[ph * 2 + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();               // stagger out: every wave is past its last LDS operand read
+    STAMP(t1s);
+
+    const int last_buf = (nt - 1 + pb) & 1, free_buf = last_buf ^ 1;
+    const int vnext = vt + gridDim.x;
+    const bool has_next = vnext < ntiles;
+    const int em0 = m0, en0 = n0;
+    if (has_next) {                                           // first K-tile of the next tile, in flight under the epilogue
+      decode(vnext, m0, n0);
+      set_src(m0, n0);
+      stageA(0, 0, free_buf);
+      stageA(0, 1, free_buf);
+      stageB(0, 0, Cfg::NB, free_buf);
+    }
+    big_epilogue<EPI, NT>(a, acc, cs, smem + last_buf * Cfg::BUF + wave * (32 * WCOLS * 4), em0 + wm * 128, en0 + wn * WCOLS, lane);
+    if (has_next) load_col_consts<EPI, NT>(a, n0 + wn * WCOLS + (lane & 15), cb, cs);   // retired by the vmcnt(0) below, with the stores
+    STAMP(t2s);
+#ifdef UCOD_GEMM_STAMPS
+    wait_vmcnt<0>();
+    STAMP(t3s);
+    st_loop += t1s - t0s; st_epi += t2s - t1s; st_wait += t3s - t2s; st_tiles += 1;
+    if (!has_next) {
+      if (tid == 0 && a.stamps) { a.stamps[blockIdx.x * 4 + 0] = st_loop; a.stamps[blockIdx.x * 4 + 1] = st_epi; a.stamps[blockIdx.x * 4 + 2] = st_wait; a.stamps[blockIdx.x * 4 + 3] = st_tiles; }
+      break;
+    }
+#else
+    if (!has_next) break;
+    wait_vmcnt<0>();
+#endif
+    __builtin_amdgcn_s_barrier();
+    vt = vnext;
+    pb = free_buf;
+    if (nt > 1) stageB(1, 0, Cfg::NB, pb);
+  }
+}
+
+
+template <int EPI>
+static int launch_lab(GemmArgs a, int variant, hipStream_t s) {
+  if (variant < 3 || variant > 8 || (a.N & 3) != 0 || a.K < 128) return UCOD_EINVAL;
+  constexpr bool kBf16Out = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16);
+  if (kBf16Out && (a.N & 7) != 0) return UCOD_EINVAL;
+  const bool wide = (variant == 3 || variant == 5 || variant == 7);
+  a.tiles_m = cdiv(a.M, 256);
+  a.tiles_n = cdiv(a.N, wide ? 256 : 192);
+  a.col_fast = a.tiles_n <= 4;
+  dim3 grid(a.tiles_m * a.tiles_n), block(512);
+  if (variant != 7 && variant != 8) {
+    const BigPlan pl = big_plan(a.M, a.N, a.K, wide ? 256 : 192, true);
+    if (pl.patches) {
+      a.main_tiles = pl.rounds * device_cus();
+      a.patches_per_wg = cdiv((long)pl.left * pl.ppt, a.main_tiles);
+      grid.x = a.main_tiles;
+    }
+  }
+  switch (variant) {
+    case 3: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4, false>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3, false>), grid, block, 0, s, a); break;
+    case 5: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4, true>), grid, block, 0, s, a); break;
+    case 6: hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3, true>), grid, block, 0, s, a); break;
+    default: {                                             // 7, 8: persistent, one workgroup per CU
+      const int n_cu = device_cus();
+      const int ntiles = a.tiles_m * a.tiles_n;
+      dim3 pgrid(ntiles < n_cu ? ntiles : n_cu);
+#ifdef UCOD_GEMM_STAMPS
+      if (const char* g = getenv("UCOD_PERS_GRID")) pgrid.x = atoi(g) < ntiles ? atoi(g) : ntiles;   // diagnostic: fewer active CUs
+#endif
+      if (variant == 7) hipLaunchKernelGGL((gemm_bf16_pers_kernel<EPI, 4>), pgrid, block, 0, s, a);
+      else hipLaunchKernelGGL((gemm_bf16_pers_kernel<EPI, 3>), pgrid, block, 0, s, a);
+    }
+  }
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+}  // namespace ucod
+
+// Same argument meaning as ucod_gemm_bf16 (include/ucod_dpl.h); epilogues 0..5 only.
+extern "C" int ucod_gemm_bf16_lab(int epilogue, const void* A, const void* B, void* out, int M, int N, int K, const float* bias,
+                                  const float* scale, const float* resid, const float* pos, int tokens_per_image, int variant,
+                                  void* stream) {
+  using namespace ucod;
+  if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0) return UCOD_EINVAL;
+  GemmArgs a;
+  a.aux = nullptr;
+  a.out2 = nullptr;
+  a.ovf = nullptr;
+  a.stamps = nullptr;
+#ifdef UCOD_GEMM_STAMPS
+  a.stamps = (unsigned long long*)pos;   // diagnostic build: the (otherwise unused here) `pos` argument carries the stamp buffer
+#endif
+  a.A = (const bf16_raw*)A;
+  a.B = (const bf16_raw*)B;
+  a.out = out;
+  a.bias = bias;
+  a.scale = scale;
+  a.resid = resid;
+  a.pos = pos;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.tok = tokens_per_image;
+  a.tiles_m = cdiv(M, BM);
+  a.tiles_n = cdiv(N, BN);
+  a.main_tiles = 0;
+  a.patches_per_wg = 0;
+  a.group_m = 8;
+  a.col_fast = 0;
+  hipStream_t s = (hipStream_t)stream;
+  switch (epilogue) {
+    case UCOD_EPI_BIAS_BF16: return launch_lab<UCOD_EPI_BIAS_BF16>(a, variant, s);
+    case UCOD_EPI_BIAS_GELU_BF16: if (!bias) return UCOD_EINVAL; return launch_lab<UCOD_EPI_BIAS_GELU_BF16>(a, variant, s);
+    case UCOD_EPI_BIAS_SCALE_RESID_F32: if (!bias || !scale || !resid) return UCOD_EINVAL; return launch_lab<UCOD_EPI_BIAS_SCALE_RESID_F32>(a, variant, s);
+    case UCOD_EPI_PATCH_TOKENS_F32: if (!bias || !pos || tokens_per_image < 2) return UCOD_EINVAL; return launch_lab<UCOD_EPI_PATCH_TOKENS_F32>(a, variant, s);
+    case UCOD_EPI_KEY_NCHW_F32: if (!bias || tokens_per_image < 2) return UCOD_EINVAL; return launch_lab<UCOD_EPI_KEY_NCHW_F32>(a, variant, s);
+    case UCOD_EPI_BIAS_F32: return launch_lab<UCOD_EPI_BIAS_F32>(a, variant, s);
+    default: return UCOD_EINVAL;
+  }
+}

@@ -34,10 +34,16 @@ Plan make_plan(const ucod_vit_desc* d) {
   return p;
 }
 
+// attn_variant of the pass: 0 (auto) and 2 = the pre-scaled-Q product kernel, 1 = the generic-scale kernel (Q as the reference holds it,
+// the scale applied inside the softmax), 8 = the fp8 path of BASELINE configs[4].  Laboratory variants (variants/attention_lab.hip) are
+// not reachable from the ViT driver: bench / tools that want to time one call ucod_attention_fwd_lab directly.
+inline bool attn_variant_known(int av) { return av == 0 || av == 1 || av == 2 || av == 8; }
+inline bool attn_variant_takes_prescaled_q(int av) { return av == 0 || av == 2 || av == 8; }
+
 bool valid(const ucod_vit_desc* d) {
   return d && d->B > 0 && d->C > 0 && d->P > 0 && d->H > 0 && d->W > 0 && d->H % d->P == 0 && d->W % d->P == 0 && d->D > 0 &&
          d->heads > 0 && d->D == d->heads * 64 && d->D % 128 == 0 && d->F % 128 == 0 && d->L >= 1 && d->Kpad % 64 == 0 &&
-         d->Kpad >= d->C * d->P * d->P && (d->resid16 == 0 || d->resid16 == 1);
+         d->Kpad >= d->C * d->P * d->P && (d->resid16 == 0 || d->resid16 == 1) && attn_variant_known(d->attn_variant);
 }
 
 }  // namespace
@@ -65,9 +71,9 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
   void* patches = ws + p.off_patch;
   const int M = p.M, tok = p.tok, D = d->D, F = d->F, gv = d->gemm_variant, av = d->attn_variant;
   const float scale = 0.125f;  // head_dim^-0.5, head_dim = 64
-  // attn_variant 2: fold head_dim^-0.5 * log2(e) into the Q third of the QKV epilogue (before its bf16 rounding)
+  // attn_variant 0 / 2: fold head_dim^-0.5 * log2(e) into the Q third of the QKV epilogue (before its 16-bit rounding)
   // attn_variant 8: the fp8 (e4m3, block-scaled MFMA) attention path of BASELINE configs[4]; same pre-scaled Q
-  const bool prescale = (av == 2 || av == 8 || av == 7 || av == 9 || av == 12 || av == 13);   // every kernel that takes Q pre-scaled by hd^-1/2 log2 e
+  const bool prescale = attn_variant_takes_prescaled_q(av);
   float* qscale = (float*)(ws + p.off_qscale);
   if (prescale) RUN(ucod_fill_qscale(qscale, D, scale * 1.4426950408889634f, stream));
   // fp8 path: the QKV epilogue writes e4m3 Q8 | K8 | V8 itself; its column scales carry 2^q_exp (times the pre-scale), 2^k_exp, 2^v_exp
@@ -107,7 +113,7 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
       RUN(ucod_attention_fwd_fp8_fused(ws + p.off_f8, a, d->B, tok, d->heads, QE, KE, VE, stream));
     } else {
       RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_BF16, h, W[2], qkv, M, 3 * D, D, (const float*)W[3], prescale ? qscale : nullptr, nullptr, nullptr, tok, gv, stream));
-      RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, prescale ? 0.f : scale, av, stream));
+      RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, prescale ? 0.f : scale, 0, stream));
     }
     RUN(ucod_gemm_bf16(epi_resid, a, W[4], x, M, D, D, (const float*)W[5], (const float*)W[6], x, nullptr, tok, gv, stream));
     RUN(layernorm((const float*)W[7], (const float*)W[8]));

@@ -336,18 +336,49 @@ __global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__
 }
 
 __global__ void cls_rows_h16_kernel(unsigned short* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos, int B,
-                                    int tok, int D) {
+                                    int tok, int D, unsigned* __restrict__ ovf) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * D) return;
   const int b = i / D, j = i - b * D;
-  x[(size_t)b * tok * D + j] = __builtin_bit_cast(unsigned short, (_Float16)(cls[j] + pos[j]));
+  const float o = cls[j] + pos[j];
+  if (beyond_f16(o)) atomicAdd(ovf, 1u);
+  x[(size_t)b * tok * D + j] = __builtin_bit_cast(unsigned short, (_Float16)clamp_f16(o));
 }
+
+// Saturation counter of the f16 residual stream: every kernel that rounds the stream to fp16 (patch / out-proj / fc2 epilogues, CLS rows)
+// clamps to +-65504 and adds the number of wave-lanes that had to.  One word per device, polled by the host (ucod_resid16_overflow_*).
+__device__ unsigned g_resid16_overflow = 0;
 
 __global__ void cast_kernel(const float* __restrict__ s, bf16_raw* __restrict__ d, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = f32_to_h(s[i]);
 }
 
+unsigned* resid16_overflow_counter() {
+  static unsigned* table[64] = {};                                   // one address per device of this process
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev = dev < 0 || dev >= 64 ? 0 : dev;
+  if (!table[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_resid16_overflow)) != hipSuccess) return nullptr;
+    table[dev] = (unsigned*)p;
+  }
+  return table[dev];
+}
+
 }  // namespace ucod
+
+extern "C" int ucod_resid16_overflow_fetch(unsigned* host_dst, void* stream) {
+  unsigned* c = ucod::resid16_overflow_counter();
+  if (!host_dst || !c) return UCOD_EINVAL;
+  return (int)hipMemcpyAsync(host_dst, c, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream);
+}
+
+extern "C" int ucod_resid16_overflow_reset(void* stream) {
+  unsigned* c = ucod::resid16_overflow_counter();
+  if (!c) return UCOD_EINVAL;
+  return (int)hipMemsetAsync(c, 0, sizeof(unsigned), (hipStream_t)stream);
+}
 
 extern "C" int ucod_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int D, float eps,
                               int out_f32, void* stream) {
@@ -398,7 +429,7 @@ extern "C" int ucod_layernorm_h16(const void* x, const float* gamma, const float
 extern "C" int ucod_cls_rows_h16(void* x, const float* cls, const float* pos, int B, int tok, int D, void* stream) {
   if (!x || !cls || !pos || B <= 0 || tok <= 0 || D <= 0) return UCOD_EINVAL;
   UCOD_PROF(ucod::PROF_CLS, stream);
-  hipLaunchKernelGGL(ucod::cls_rows_h16_kernel, dim3(ucod::cdiv((long)B * D, 256)), dim3(256), 0, (hipStream_t)stream, (unsigned short*)x, cls, pos, B, tok, D);
+  hipLaunchKernelGGL(ucod::cls_rows_h16_kernel, dim3(ucod::cdiv((long)B * D, 256)), dim3(256), 0, (hipStream_t)stream, (unsigned short*)x, cls, pos, B, tok, D, ucod::resid16_overflow_counter());
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }

@@ -9,7 +9,12 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("UCOD_DPL_LIB") or os.path.join(_HERE, "_native", "libucod_dpl.so")   # the override selects an experiment build (tools/)
+LIB_PATH = os.path.join(_HERE, "_native", "libucod_dpl.so")
+# Experiment builds (`make -C ucod_dpl_amd/csrc variant ...`) are selected by tools/ with UCOD_DPL_EXPERIMENT_LIB; the variable is honoured
+# only together with UCOD_DPL_ALLOW_EXPERIMENT=1, so that a stray environment variable cannot swap the product library.
+if os.environ.get("UCOD_DPL_EXPERIMENT_LIB") and os.environ.get("UCOD_DPL_ALLOW_EXPERIMENT") == "1":
+    LIB_PATH = os.environ["UCOD_DPL_EXPERIMENT_LIB"]
+ABI_VERSION = 2                                            # include/ucod_dpl.h: UCOD_ABI_VERSION
 
 EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_SCALE_RESID_F32, EPI_PATCH_TOKENS_F32, EPI_KEY_NCHW_F32, EPI_BIAS_F32 = range(6)
 EPI_GELU_BWD_BF16, EPI_BIAS_GELU_SAVE_BF16 = 6, 7          # ucod_gemm_bf16_train only (backbone-backward mode)
@@ -54,6 +59,9 @@ SIGNATURES = {
     "ucod_prof_class_name": (C.c_char_p, [ci]),
     "ucod_prof_collect": (ci, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ucod_gemm_bf16": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
+    "ucod_gemm_reload_tuning": (None, []),
+    "ucod_resid16_overflow_fetch": (ci, [vp, vp]),
+    "ucod_resid16_overflow_reset": (ci, [vp]),
     "ucod_layernorm": (ci, [vp, vp, vp, vp, ci, ci, cf, ci, vp]),
     "ucod_layernorm_h16": (ci, [vp, vp, vp, vp, ci, ci, cf, vp]),
     "ucod_attention_fwd": (ci, [vp, vp, ci, ci, ci, cf, ci, vp]),
@@ -145,10 +153,41 @@ def load(half="bf16"):
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.ucod_abi_version() != ABI_VERSION:
+            raise ImportError(f"{path} has ABI version {lib.ucod_abi_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                              f"(`make -C ucod_dpl_amd/csrc`)")
         if lib.ucod_half_name().decode() != half:
             raise ImportError(f"{path} was built for {lib.ucod_half_name().decode()} operands, expected {half}")
         _libs[half] = lib
     return _libs[half]
+
+
+# ---- the laboratory library (csrc/variants/*.hip, `make -C ucod_dpl_amd/csrc variants`): never loaded by the product path
+LIB_PATH_LAB = os.path.join(_HERE, "_native", "libucod_dpl_variants.so")
+LAB_SIGNATURES = {
+    "ucod_attention_fwd_lab": (ci, [vp, vp, ci, ci, ci, cf, ci, vp]),
+    "ucod_gemm_bf16_lab": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
+}
+ATTN_PRODUCT_VARIANTS = (0, 2)
+GEMM_PRODUCT_VARIANTS = (0, 1, 2, 9, 10, 12, 13, 14)
+
+
+def have_lab():
+    return os.path.exists(LIB_PATH_LAB)
+
+
+def load_lab():
+    """The experiment variants of rounds 1-2 (tools/, tests marked `variants`).  Raises if `make variants` has not been run."""
+    if "lab" not in _libs:
+        if not have_lab():
+            raise ImportError(f"{LIB_PATH_LAB} is missing: build it with `make -C ucod_dpl_amd/csrc variants` (laboratory kernels; "
+                              f"the product path never needs it)")
+        lib = C.CDLL(LIB_PATH_LAB)
+        for name, (res, args) in LAB_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _libs["lab"] = lib
+    return _libs["lab"]
 
 
 def ptr(t):

@@ -25,8 +25,12 @@ def _bf16(t):
 
 # ----------------------------------------------------------------------------- backbone pieces
 def gemm_bf16(epilogue, A, Bm, out, M, Nn, K, bias=None, scale=None, resid=None, pos=None, tok=0, variant=0):
-    check(N.load().ucod_gemm_bf16(epilogue, ptr(_bf16(A)), ptr(_bf16(Bm)), ptr(out), M, Nn, K, ptr(bias), ptr(scale), ptr(resid),
-                                  ptr(pos), tok, variant, stream()), "ucod_gemm_bf16")
+    """``variant`` outside the product set (native.GEMM_PRODUCT_VARIANTS) goes to the laboratory library (`make variants`)."""
+    if variant in N.GEMM_PRODUCT_VARIANTS:
+        fn, what = N.load().ucod_gemm_bf16, "ucod_gemm_bf16"
+    else:
+        fn, what = N.load_lab().ucod_gemm_bf16_lab, "ucod_gemm_bf16_lab"
+    check(fn(epilogue, ptr(_bf16(A)), ptr(_bf16(Bm)), ptr(out), M, Nn, K, ptr(bias), ptr(scale), ptr(resid), ptr(pos), tok, variant, stream()), what)
     return out
 
 
@@ -53,8 +57,13 @@ def layernorm(x, gamma, beta, eps, out_f32=False):
 
 
 def attention(qkv, B, tok, heads, scale=0.125, variant=0):
+    """``scale`` != 0: generic kernel; ``scale`` == 0: Q pre-scaled by hd^-1/2 log2 e (the product kernel).  ``variant`` outside
+    native.ATTN_PRODUCT_VARIANTS selects a laboratory kernel of libucod_dpl_variants.so (`make variants`)."""
     out = torch.empty(B * tok, heads * 64, dtype=torch.bfloat16, device=qkv.device)
-    check(N.load().ucod_attention_fwd(ptr(_bf16(qkv)), ptr(out), B, tok, heads, float(scale), variant, stream()), "ucod_attention_fwd")
+    if variant in N.ATTN_PRODUCT_VARIANTS:
+        check(N.load().ucod_attention_fwd(ptr(_bf16(qkv)), ptr(out), B, tok, heads, float(scale), variant, stream()), "ucod_attention_fwd")
+    else:
+        check(N.load_lab().ucod_attention_fwd_lab(ptr(_bf16(qkv)), ptr(out), B, tok, heads, float(scale), variant, stream()), "ucod_attention_fwd_lab")
     return out
 
 

@@ -10,6 +10,7 @@ Only what the key hook needs is computed by default (feature_extractor.py:46-47,
 """
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -102,18 +103,30 @@ class ViTEngine:
     def __init__(self, state_dict, heads, eps=1e-6, device="cuda", full_last_layer=False, gemm_variant=0, attn_variant=0, half="bf16",
                  resid="auto"):
         """``half``: 16-bit type of the GEMM / attention operands -- "bf16" (default; BASELINE configs[1]) or "f16" (IEEE fp16, what
-        the reference's fp16-autocast launcher computes in: 8x finer rounding, logits within 1e-3 of the f32 reference at full
-        depth; same speed).  Each choice is its own build of the same kernels (native.load)."""
+        the reference's fp16-autocast launcher multiplies in: 8x finer rounding, logits within 1e-3 of the f32 reference at full
+        depth).  Each choice is its own build of the same kernels (native.load).
+        ``attn_variant``: 0 / 2 the product attention kernel, 1 the generic-scale kernel, 8 the fp8 path of BASELINE configs[4].
+        ``resid``: type of the residual stream x between the GEMM epilogues and LayerNorm -- "f32" (what the reference holds), "f16"
+        (IEEE fp16: half the bytes of LayerNorm's read and of the out-proj / fc2 read-modify-write) or "auto".  "auto" is a property of
+        the ENGINE, never of the batch size (an image's key map does not depend on how many images travel with it):
+          * bf16 operands -> fp16 stream: its 11 significand bits are 8x finer than the bf16 operands every value is rounded to before
+            it is used, so it never sets the error level (logit max-abs vs the f32 oracle 3.2e-3 with either stream);
+          * fp16 operands -> f32 stream: the configuration that meets the 1e-3 logit bar keeps its whole margin (3.8e-4; 6.4e-4 with
+            the fp16 stream -- opt in with resid="f16").
+        The fp16 stream SATURATES at +-65504 and counts every saturation on the device; ``check_overflow`` (polled by every later
+        ``forward``, synchronously with UCOD_CHECK_RESID=1) raises FloatingPointError when the count is non-zero: a checkpoint whose
+        activations do not fit fp16 is reported instead of producing inf -> NaN key maps."""
         self.half = half
         self.lib = N.load(half)
-        # Residual stream x between the GEMM epilogues and LayerNorm: "f32", "f16" (IEEE fp16: 11 significand bits, finer than the bf16
-        # operands it is rounded to anyway; half the bytes of LayerNorm's read and of the out-proj / fc2 read-modify-write), or "auto":
-        # f16 on passes of at least 4096 token rows (the large-tile GEMM regime; a batch-1 Look-Twice pass keeps the small-tile f32
-        # path).  Full-size parity (tools/parity_matrix.py, profiles/r02_parity_matrix.txt), logit max-abs vs the f32 oracle: bf16
-        # operands 3.2e-3 with either stream; fp16 operands 3.8e-4 with the f32 stream, 6.4e-4 with the fp16 stream (bar: 1e-3).
         if resid not in ("auto", "f32", "f16"):
             raise ValueError(f"resid must be 'auto', 'f32' or 'f16', got {resid!r}")
+        if resid == "f16" and not self._allow_resid16:
+            raise ValueError("the backbone-backward engine keeps the f32 residual stream (its backward kernels read it): resid='f16' is not available")
         self.resid = resid
+        self.resid16 = bool(resid == "f16" or (resid == "auto" and half == "bf16" and self._allow_resid16))
+        self._ovf_host, self._ovf_events = None, []
+        if attn_variant not in (0, 1, 2, 8):
+            raise ValueError(f"attn_variant must be 0, 1, 2 or 8 (laboratory kernels are reached through ops.attention(variant=...)), got {attn_variant}")
         c = normalize_state_dict(state_dict)
         self.kind = c["kind"]
         self.device = torch.device(device)
@@ -169,11 +182,42 @@ class ViTEngine:
         d.eps = self.eps
         d.full_last_layer = int(self.full_last_layer)
         d.gemm_variant, d.attn_variant = self.gemm_variant, self.attn_variant
-        rows = B * ((H // self.P) * (W // self.P) + 1)
-        d.resid16 = int(self.resid == "f16" or (self.resid == "auto" and rows >= 4096 and self._allow_resid16))
+        d.resid16 = int(self.resid16)
         return d
 
+    # ---- fp16 residual stream: saturation guard --------------------------------------------------------------------------------
+    def _arm_overflow_check(self, stream):
+        """Enqueue an asynchronous copy of the device's saturation counter behind the pass just launched on ``stream``."""
+        if not self.resid16:
+            return
+        if self._ovf_host is None:
+            self._ovf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        N.check(self.lib.ucod_resid16_overflow_fetch(self._ovf_host.data_ptr(), stream.cuda_stream), "ucod_resid16_overflow_fetch")
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._ovf_events.append(ev)
+        del self._ovf_events[:-8]                                # (only the latest copies matter: the counter never decreases)
+
+    def check_overflow(self, wait=False):
+        """Raise FloatingPointError if any finished pass saturated the fp16 residual stream.  ``wait``: block until every pass enqueued so far
+        has finished (otherwise only passes that already have)."""
+        if not self.resid16 or self._ovf_host is None:
+            return
+        if wait:
+            for ev in self._ovf_events:
+                ev.synchronize()
+            self._ovf_events = []
+        elif not any(ev.query() for ev in self._ovf_events):
+            return
+        n = int(self._ovf_host[0])
+        if n > 0:
+            N.check(self.lib.ucod_resid16_overflow_reset(N.stream()), "ucod_resid16_overflow_reset")
+            self._ovf_host.zero_()
+            raise FloatingPointError(f"the fp16 residual stream saturated at +-65504 in {n} wave-lane(s): this checkpoint's activations do not fit "
+                                     f"fp16; build the engine with resid='f32'")
+
     _allow_resid16 = True                                      # the backbone-backward engine keeps the f32 stream (its kernels read it)
+    _sync_check = os.environ.get("UCOD_CHECK_RESID") == "1"    # debug: check the saturation counter synchronously after every pass
 
     def forward(self, img, out=None, _async=False, n_layers=None):
         """``n_layers``: stop after that many encoder layers and return THAT layer's key map (diagnostics: the per-layer error
@@ -192,6 +236,7 @@ class ViTEngine:
             ptrs += l
         table = (C.c_void_p * len(ptrs))(*[t.data_ptr() for t in ptrs])
         key = out if out is not None else torch.empty(B, self.D, gh, gw, dtype=torch.float32, device=self.device)
+        self.check_overflow()                                      # (non-blocking) passes that have finished since the last call
         ns = max(1, min(int(getattr(self, "streams", 1)), B))
         if ns == 1 and not _async:
             d = self._desc(B, H, W, n_layers)
@@ -202,6 +247,9 @@ class ViTEngine:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             N.check(lib.ucod_vit_forward(C.byref(d), table, N.ptr(img), N.ptr(key), N.ptr(self._ws), self._ws.numel(), N.stream()),
                     "ucod_vit_forward")
+            self._arm_overflow_check(torch.cuda.current_stream(self.device))
+            if self._sync_check:
+                self.check_overflow(wait=True)
             return key
         # Image-parallel sub-batches on independent HIP streams: every kernel of the pass is per-image, so the halves are
         # independent and the tail of one stream's GEMM (a partial last round of 256-row tiles leaves most CUs idle) is filled by
@@ -210,7 +258,6 @@ class ViTEngine:
             # Normal priority.  High-priority side streams (UCOD_SIDE_PRIORITY=-1) were measured: nothing on the pipelined frozen-backbone
             # step (10.16 vs 10.19 ms) and MINUS 17 % in backbone-backward mode (585 vs 702 images/s: the EMA teacher's pass on these
             # streams then starves the student's forward / backward on the training streams).
-            import os
             prio = int(os.environ.get("UCOD_SIDE_PRIORITY", "0"))
             self._side = [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(ns)]
             self._side_ws = [None] * ns
@@ -234,6 +281,7 @@ class ViTEngine:
             with torch.cuda.stream(st):
                 N.check(lib.ucod_vit_forward(C.byref(d), table, N.ptr(img[b0:b1]), N.ptr(key[b0:b1]), N.ptr(self._side_ws[i]),
                                              self._side_ws[i].numel(), N.stream()), "ucod_vit_forward")
+                self._arm_overflow_check(st)
                 done = torch.cuda.Event()
                 done.record(st)
             events.append(done)
@@ -241,6 +289,8 @@ class ViTEngine:
             return key, events
         for done in events:
             cur.wait_event(done)
+        if self._sync_check:
+            self.check_overflow(wait=True)
         return key
 
     def forward_with_cls_attention(self, img):
