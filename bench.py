@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=4)
     ap.add_argument("--gemm-variant", type=int, default=0)
-    ap.add_argument("--attn-variant", type=int, default=2)
+    ap.add_argument("--attn-variant", type=int, default=2, choices=[0, 1, 2, 8], help="0 / 2 product kernel, 1 generic-scale kernel, 8 fp8 path (BASELINE configs[4])")
+    ap.add_argument("--resid", default=os.environ.get("UCOD_RESID", "auto"), choices=["auto", "f32", "f16"],
+                    help="residual-stream type of the backbone (auto: fp16 for bf16 operands, f32 for fp16 operands)")
     ap.add_argument("--streams", type=int, default=2, help="image-parallel sub-batches of the backbone pass on independent HIP streams")
     ap.add_argument("--no-pipeline", action="store_true", help="serial order: backbone pass, then decoder step, on one stream")
     ap.add_argument("--half", default="bf16", choices=["bf16", "f16"], help="16-bit operand type of the backbone (bf16 = BASELINE configs[1])")
@@ -119,6 +121,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path is HIP-only)")
     from ucod_dpl_amd import parallel
+    host_threads = parallel.cap_host_threads(world)           # cores // world intra-op threads per rank (the ranks share one host)
     local_rank = parallel.device_index()                      # = LOCAL_RANK (UCOD_SINGLE_DEVICE=1: test rigs with one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -135,10 +138,10 @@ def main():
     runner = StandardRunner(cfg)                              # initialises the RCCL process group when WORLD_SIZE > 1
     loop = TrainLoop(cfg, runner)
     bb = backbone.random_init(a.arch, seed=0, image_size=a.image, device=dev, full_last_layer=a.full_last_layer,
-                              gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half=a.half, resid=os.environ.get("UCOD_RESID", "auto"))
+                              gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half=a.half, resid=a.resid)
     bb.engine.streams = a.streams
     B = a.batch
-    resid16 = bool(bb.engine._desc(B, a.image, a.image).resid16)      # fp16 residual stream on this pass (ViTEngine resid="auto")
+    resid16 = bool(bb.engine.resid16)                         # fp16 residual stream (ViTEngine resid="auto": a property of the engine)
     g = torch.Generator().manual_seed(1234 + rank)
     images = torch.randn(B, 3, a.image, a.image, generator=g).to(dev)
     pl = (torch.rand(B, 1, 16, 16, generator=g) > 0.7).float().to(dev)
@@ -174,12 +177,16 @@ def main():
         loop.global_step += 1
     barrier()
     t0 = time.perf_counter()
+    host_enqueue = 0.0                                        # host time inside the step calls = first to last launch of a step (nothing in them syncs)
     for _ in range(a.steps):
+        h0 = time.perf_counter()
         loss = step()
+        host_enqueue += time.perf_counter() - h0
         loop.global_step += 1
     barrier()
     dt = time.perf_counter() - t0
     final_loss = float(loss.item())
+    bb.engine.check_overflow(wait=True)                       # a saturated fp16 residual stream is an error of the run, never a green line
 
     # Roofline pass: the SAME step in serial order on one stream, so that every launch has the chip to itself and the
     # HIP-event duration of a kernel class is its exclusive duration (with overlapping streams it is not).
@@ -274,12 +281,31 @@ def main():
             tdt = torch.tensor([dt2], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
             dt2 = tdt.item()
-        top = sorted(((lib.ucod_prof_class_name(i).decode(), tot2[i] / a.lora_steps) for i in range(ncls) if cnt2[i]), key=lambda r: -r[1])[:6]
+        # per-class EXCLUSIVE durations: the same step in serial order (one stream for student, teacher and both chunks), so that no two
+        # launches overlap and an event pair brackets one kernel alone; never part of `value`
+        eng.train_streams, loop.lora_engine_ema.train_streams, loop.serial_schedule = 1, 1, True
+        loop._process_batch_full(images, pl)
+        loop.global_step += 1
+        barrier()
+        lib.ucod_prof_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            loop._process_batch_full(images, pl)
+            loop.global_step += 1
+        barrier()
+        dt2s = (time.perf_counter() - t0) / 2
+        lib.ucod_prof_enable(0)
+        tot3, cnt3 = (C.c_double * ncls)(), (C.c_longlong * ncls)()
+        lib.ucod_prof_collect(tot3, cnt3)
+        loop.serial_schedule = False
+        top = sorted(((lib.ucod_prof_class_name(i).decode(), tot3[i] / 2) for i in range(ncls) if cnt3[i]), key=lambda r: -r[1])[:8]
         lora_mode = {"value": round(world * B * a.lora_steps / dt2, 2), "unit": "images/s", "ms_per_step": round(dt2 / a.lora_steps * 1e3, 3),
                      "steps": a.lora_steps, "final_loss": round(float(l2.item()), 6),
                      "what": "LoRA r=2, alpha=4, dropout 0.05 on q/k/v of all layers: student fwd (saved activations) + EMA-teacher fwd + decoder step + backbone "
                              "backward (dgrad only) + LoRA/decoder all-reduce + 2 fused AdamW/EMA",
-                     "top_kernels_ms_per_step": {n: round(t, 3) for n, t in top}}
+                     "serial_ms_per_step": round(dt2s * 1e3, 3),
+                     "top_kernels_exclusive_ms_per_step": {n: round(t, 3) for n, t in top},
+                     "top_kernels_measured_in": "separate serial single-stream pass of the same step (exclusive launch durations, HIP events)"}
     if rank != 0:
         return
 
@@ -343,15 +369,33 @@ def main():
         if r.returncode != 0 or not line:
             raise SystemExit("bench.py: the fp16-operand child run failed:\n" + r.stderr[-2000:])
         c = json.loads(line[-1])
-        f16_option = {"value": c["value"], "unit": "images/s", "ms_per_step": c["ms_per_step"],
+        f16_option = {"value": c["value"], "unit": "images/s", "ms_per_step": c["ms_per_step"], "residual_stream": c["config"]["residual_stream"],
                       "what": "the timed step with fp16 backbone operands (libucod_dpl_f16.so), same schedule, own process (python bench.py --half f16)"}
 
+    # North-star parity bar (mask logits within 1e-3 of the f32 reference), at the top level of the line: for the dtype the line is
+    # quoted on, and -- next to it -- the configuration that meets the bar with its own throughput.
+    BAR = 1e-3
+    par = (cpu or {}).get("parity_full_size") or {}
+    own = par if a.half == "bf16" else par.get("f16_operands") or {}
+    logit_max_abs = own.get("logit_max_abs")
+    bar_meeting = None
+    if par.get("f16_operands") and (f16_option or a.half == "f16"):
+        pf = par["f16_operands"]
+        bar_meeting = {"dtype": "f16", "residual_stream": (f16_option or {}).get("residual_stream", "fp16" if resid16 else "f32"),
+                       "value": (f16_option or {}).get("value", round(world * B * a.steps / dt, 2)), "unit": "images/s",
+                       "logit_max_abs": pf["logit_max_abs"], "key_rel_l2": pf["key_rel_l2"], "mask_flipped_fraction": pf["mask_flipped_fraction"],
+                       "bar": BAR, "bar_met": bool(pf["logit_max_abs"] <= BAR),
+                       "what": "ViTEngine(half='f16') = libucod_dpl_f16.so: IEEE fp16 GEMM / attention operands (what the reference's fp16-autocast launcher "
+                               "multiplies in, scripts/launch_train_first_stage.sh:20), same kernels, same schedule, own process"}
     ips = world * B * a.steps / dt
     out = {
         "metric": "training images/sec at 3x518x518, DINOv2-B (frozen backbone fwd + DBA/APM/discriminator train step)",
         "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.half, "data": "synthetic",
+        "logit_max_abs": logit_max_abs, "bar": BAR, "bar_met": (None if logit_max_abs is None else bool(logit_max_abs <= BAR)),
+        "bar_meeting_config": bar_meeting,
+        "host_enqueue_ms_per_step": round(host_enqueue / a.steps * 1e3, 3), "host_threads": host_threads,
         "config": {"workload": f"{which_config(a.arch, a.image, B, a.attn_variant)}: {a.arch} @{a.image}x{a.image}, batch {B}/GPU, full APM+DBA+discriminator step, "
                                f"decoder path f32 (1x1 conv as a three-way bf16 split on the matrix pipe: f32-equivalent), backbone {a.half} MFMA", "global_batch": B * world, "parallelism": f"dp{world}",
                    "backbone_last_layer": "full (as reference)" if a.full_last_layer else "key-minimal (identical key output; 279.6 of 303.1 GFLOP/img)",

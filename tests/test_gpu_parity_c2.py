@@ -1,0 +1,172 @@
+"""GPU: the configuration that has to meet the north-star bar, pinned at FULL size, and the range behaviour of the fp16 residual stream.
+
+* BASELINE configs[1] geometry (DINOv2 ViT-B/14, 518 x 518, 1370 tokens, 12 layers), two images, against the f32 CPU oracle
+  (oracle/vit.py: the transformers 5.15 Dinov2 arithmetic of data/utils/feature_extractor.py:49-59, pinned by G8) followed by the f32
+  decoder (oracle/decoder.py: models/modules/DBA.py:31-59, pinned by G1/G2): mask logits of the fp16-operand build within 1e-3
+  (the north-star tolerance, written here) with either residual-stream type; the bf16 build asserted at its measured level so that
+  a regression shows.
+* Residual magnitudes of 1e3 and 3e4 (DINOv2 checkpoints are known for a few massive-activation channels): the fp16 stream must follow
+  the f32 stream to the operand type's own rounding, must never emit inf / NaN, and must REPORT values it cannot hold (saturation
+  counter -> FloatingPointError) instead of passing them on.
+* resid="auto" is a property of the engine, not of the batch: an image's key map at batch 1 equals its key map inside a batch.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from ucod_dpl_amd import ops  # noqa: E402
+from ucod_dpl_amd.vit_engine import ViTEngine  # noqa: E402
+from ucod_dpl_amd.data.utils.feature_extractor import random_state_dict, ARCHS  # noqa: E402
+from oracle import decoder as OD, vit as OV  # noqa: E402
+from oracle.resize import torch_bilinear  # noqa: E402
+
+DEV = "cuda"
+BAR = 1e-3                                                     # BASELINE.json north_star: mask logits within 1e-3 of the reference
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def record(name, values):
+    """Measured values of this run, for DESIGN.md / profiles (gpurun_out/ is merged back from the GPU box)."""
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_c2_measured.jsonl"), "a") as f:
+        f.write(json.dumps({"test": name, **values}) + "\n")
+
+
+def device_logits(key_dev, dec, n, D):
+    """The f32 device decoder on a device key map: 1x1 conv on the native grid, bilinear 37 -> 68, pixel-axis norms, fg head."""
+    emb = dec["learnable_embedding"].reshape(128).to(DEV)
+    hw = torch.cat((dec["conv_out_fg.weight"].reshape(64), dec["conv_out_bg.weight"].reshape(64))).to(DEV)
+    hb = torch.cat((dec["conv_out_fg.bias"], dec["conv_out_bg.bias"])).to(DEV)
+    w, b = dec["decoupling.weight"].reshape(128, D).to(DEV), dec["decoupling.bias"].to(DEV)
+    d = ops.bilinear_resize(ops.dba_project(key_dev, w, b).view(n, 128, *key_dev.shape[-2:]), 68, 68).view(n, 128, 68 * 68)
+    return ops.dba_heads(d, 0, emb, ops.dba_colnorm(d, 0, emb), hw, hb, want_bg=False)[0].view(n, 1, 68, 68).cpu()
+
+
+@pytest.fixture(scope="module")
+def c2():
+    """Two images of BASELINE configs[1] through the f32 oracle (about 2 s of CPU per image on the GPU box's host)."""
+    arch, n = "dinov2_vitb14", 2
+    D, heads, L, P, _, _ = ARCHS[arch]
+    sd = random_state_dict(arch, 0, 518)
+    img = torch.randn(n, 3, 518, 518, generator=torch.Generator().manual_seed(2024))
+    with torch.no_grad():
+        _, key = OV.dinov2_forward(img, sd, heads=heads, patch=P, eps=1e-6, full_last_layer=False)
+        dec = OD.init_params(D, torch.Generator().manual_seed(42))
+        fg, _, _ = OD.rev_decoder_forward(torch_bilinear(key, 68, 68), dec, orth="gram")
+    return dict(sd=sd, img=img, key=key, fg=fg, dec=dec, heads=heads, D=D, n=n)
+
+
+@pytest.mark.parametrize("half,resid,logit_tol,key_tol", [
+    ("f16", "auto", BAR, 1.5e-3),        # the bar-meeting configuration as shipped: fp16 operands, f32 residual stream (measured 3.8e-4 / 6.9e-4)
+    ("f16", "f16", BAR, 2.5e-3),         # the same with the fp16 residual stream (measured 6.4e-4 / 1.2e-3)
+    ("bf16", "auto", 5e-3, 8e-3),        # BASELINE configs[1] dtype: asserted at its measured level (3.2e-3 / 5.5e-3), not at the bar
+    ("bf16", "f32", 5e-3, 8e-3),
+])
+def test_c2_full_size_logits_against_the_oracle(c2, half, resid, logit_tol, key_tol):
+    eng = ViTEngine(c2["sd"], heads=c2["heads"], eps=1e-6, device=DEV, half=half, resid=resid)
+    assert eng.resid16 == {("f16", "auto"): False, ("f16", "f16"): True, ("bf16", "auto"): True, ("bf16", "f32"): False}[(half, resid)]
+    key_dev = eng(c2["img"].to(DEV))
+    eng.check_overflow(wait=True)
+    fd = device_logits(key_dev, c2["dec"], c2["n"], c2["D"])
+    key_rel, logit_abs = rel_l2(key_dev.cpu(), c2["key"]), float((fd - c2["fg"]).abs().max())
+    flipped = float(((fd > 0) != (c2["fg"] > 0)).float().mean())
+    record("c2_full_size", dict(half=half, resid=resid, stream="f16" if eng.resid16 else "f32", key_rel_l2=key_rel, logit_max_abs=logit_abs,
+                                logit_rel_l2=rel_l2(fd, c2["fg"]), mask_flipped_fraction=flipped))
+    assert logit_abs <= logit_tol, (half, resid, logit_abs)
+    assert key_rel <= key_tol, (half, resid, key_rel)
+    assert flipped <= (0.0 if half == "f16" else 2e-4), flipped          # Delta-MAE of the thresholded masks
+
+
+def test_c2_key_map_does_not_depend_on_the_batch(c2):
+    """resid="auto" picks the stream type from the engine, never from the batch size: image 0 alone (small-tile kernels) and image 0 inside a
+    batch of 6 (large-tile kernels) go through the same arithmetic types.  The two passes differ only in the f32 summation order of the two
+    tile shapes; twelve layers of re-rounding to the 16-bit operand type turn those last-bit differences into the operand type's own
+    noise level (bf16: measured 4.0e-3, the same size as the bf16 engine's distance from the oracle; fp16: 8x finer), never more."""
+    img = torch.cat((c2["img"], torch.randn(4, 3, 518, 518, generator=torch.Generator().manual_seed(5))), 0).to(DEV)
+    for half in ("bf16", "f16"):
+        eng = ViTEngine(c2["sd"], heads=c2["heads"], eps=1e-6, device=DEV, half=half)
+        assert eng._desc(1, 518, 518).resid16 == eng._desc(6, 518, 518).resid16 == int(half == "bf16")
+        k6 = eng(img).clone()
+        k1 = eng(img[:1].contiguous())
+        r = rel_l2(k1, k6[:1])
+        record("batch_independence", dict(half=half, rel_l2_batch1_vs_batch6=r))
+        assert r < (8e-3 if half == "bf16" else 1.5e-3), (half, r)
+        eng.check_overflow(wait=True)
+
+
+# ------------------------------------------------------------------------------------------------ residual magnitudes of 1e3 .. 3e4
+def _massive_state_dict(mag, seed=3):
+    """A small DINOv2-shaped model (D = 256, 4 heads, 6 layers, 224 x 224 -> 257 tokens) with "massive activations": the position embedding
+    puts `mag` into two channels of the CLS token and of a few patch tokens, and LayerScale = 1 lets every layer add O(1) on top -- the
+    residual stream then carries values of magnitude `mag` from the first layer to the last, as DINOv2 checkpoints do."""
+    ARCHS["massive_vit"] = (256, 4, 6, 14, 224, True)
+    sd = random_state_dict("massive_vit", seed=seed)
+    pos = sd["embeddings.position_embeddings"]
+    for t in (0, 17, 100, 256):
+        pos[0, t, 5] = mag
+        pos[0, t, 200] = -0.75 * mag
+    return sd
+
+
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+@pytest.mark.parametrize("mag", [1.0e3, 3.0e4])
+def test_fp16_stream_follows_the_f32_stream_at_large_residuals(half, mag):
+    sd = _massive_state_dict(mag)
+    img = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        _, ref = OV.dinov2_forward(img, sd, heads=4, patch=14, eps=1e-6, full_last_layer=False)
+    e32 = ViTEngine(sd, heads=4, eps=1e-6, device=DEV, half=half, resid="f32")
+    e16 = ViTEngine(sd, heads=4, eps=1e-6, device=DEV, half=half, resid="f16")
+    k32, k16 = e32(img.to(DEV)).cpu(), e16(img.to(DEV)).cpu()
+    e16.check_overflow(wait=True)                               # in range: nothing saturated
+    assert bool(torch.isfinite(k16).all()) and bool(torch.isfinite(k32).all())
+    d32, d16, between = rel_l2(k32, ref), rel_l2(k16, ref), rel_l2(k16, k32)
+    record("massive_residual", dict(half=half, mag=mag, f32_stream_vs_oracle=d32, f16_stream_vs_oracle=d16, f16_vs_f32_stream=between))
+    # the fp16 stream may not cost more than the operand type's own rounding already does: within 1.5x of the f32-stream engine's distance
+    # from the oracle (plus the fp16 rounding of one layer's update), and the two engines agree to that level
+    floor = 2.0 ** -11
+    assert d16 <= 1.5 * d32 + 2 * floor, (half, mag, d16, d32)
+    assert between <= 1.5 * d32 + 2 * floor, (half, mag, between, d32)
+
+
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+def test_fp16_stream_saturates_and_reports(half):
+    """A residual value fp16 cannot hold (1e5): the stream clamps to +-65504 (no inf, no NaN key map) and the engine raises."""
+    sd = _massive_state_dict(1.0e5)
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(10))
+    e16 = ViTEngine(sd, heads=4, eps=1e-6, device=DEV, half=half, resid="f16")
+    k16 = e16(img.to(DEV))
+    assert bool(torch.isfinite(k16).all())
+    with pytest.raises(FloatingPointError):
+        e16.check_overflow(wait=True)
+    e16.check_overflow(wait=True)                               # the counter was reset by the report
+    k_again = e16(img.to(DEV))
+    with pytest.raises(FloatingPointError):                     # the NEXT pass (non-blocking poll inside forward, then the explicit wait) reports again
+        e16.check_overflow(wait=True)
+    assert torch.equal(k_again, k16)
+    # the f32 stream holds the same model without complaint
+    e32 = ViTEngine(sd, heads=4, eps=1e-6, device=DEV, half=half, resid="f32")
+    assert bool(torch.isfinite(e32(img.to(DEV))).all())
+
+
+def test_backward_engine_refuses_the_fp16_stream():
+    from ucod_dpl_amd.vit_engine import ViTLoRAEngine
+    ARCHS["tiny_vit"] = (128, 2, 2, 14, 70, True)
+    eng = ViTLoRAEngine(random_state_dict("tiny_vit", seed=1), heads=2, device=DEV)
+    assert eng.resid16 is False and eng._desc(64, 70, 70).resid16 == 0
+    with pytest.raises(ValueError):
+        ViTEngine.__init__(ViTLoRAEngine.__new__(ViTLoRAEngine), random_state_dict("tiny_vit", seed=1), heads=2, device=DEV, resid="f16")

@@ -420,7 +420,9 @@ __global__ __launch_bounds__(256, FORM == 4 ? 4 : 2) void attn_fwd_v5_kernel(con
   // o[dt][4g .. 4g+3] = columns dt*32 + 8g + 4*h5 .. +3 of row q.  For each register pair (g, g+1) one half exchange leaves lanes 0..31
   // with columns 8g .. 8g+7 ([own g | upper's g]) and lanes 32..63 with 8(g+1) .. 8(g+1)+7 ([lower's g+1 | own g+1]): one 16-byte store each.
   const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(out + ((size_t)b * N) * D, 0, (unsigned)N * (unsigned)D * 2u, 0x00020000);
-  const unsigned row_off = q < N ? ((unsigned)q * (unsigned)D + (unsigned)(head * HD + 8 * h5)) * 2u : 0xFFFFFFF0u;   // rows past N: dropped by the range check
+  // rows past N: an offset that stays beyond the buffer after the per-store constants are added (records = N * D * 2 < 2^31), so the
+  // range check drops the store -- 0xFFFFFFF0 would WRAP to the image's first row
+  const unsigned row_off = q < N ? ((unsigned)q * (unsigned)D + (unsigned)(head * HD + 8 * h5)) * 2u : 0x80000000u;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
 
 template <int EPI>
 static int launch_lab(GemmArgs a, int variant, hipStream_t s) {
-  if (variant < 3 || variant > 8 || (a.N & 3) != 0 || a.K < 128) return UCOD_EINVAL;
+  if (variant < 3 || variant > 8 || (a.N & 3) != 0) return UCOD_EINVAL;
   constexpr bool kBf16Out = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16);
   if (kBf16Out && (a.N & 7) != 0) return UCOD_EINVAL;
   const bool wide = (variant == 3 || variant == 5 || variant == 7);

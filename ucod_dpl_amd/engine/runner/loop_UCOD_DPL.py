@@ -305,12 +305,13 @@ class TrainLoop(BaseLoop):
         cur = torch.cuda.current_stream(dev)
         ev0 = torch.cuda.Event()
         ev0.record(cur)
-        self._teacher_stream.wait_event(ev0)
-        images.record_stream(self._teacher_stream)
-        with torch.cuda.stream(self._teacher_stream):
+        tstream = cur if getattr(self, "serial_schedule", False) else self._teacher_stream     # serial_schedule: measurement passes (exclusive kernel times)
+        tstream.wait_event(ev0)
+        images.record_stream(tstream)
+        with torch.cuda.stream(tstream):
             feat_t = eng_t.forward_train(images)
             ev1 = torch.cuda.Event()
-            ev1.record(self._teacher_stream)
+            ev1.record(tstream)
         feat_s = eng.forward_train(images)                                   # [B,C,h,w]; activations kept for backward
         cur.wait_event(ev1)
         feat_t.record_stream(cur)                                            # allocated on the teacher's stream, consumed on this one

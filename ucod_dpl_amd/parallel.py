@@ -31,12 +31,41 @@ def device_index():
     return 0 if os.environ.get("UCOD_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init_from_env(backend="nccl"):
-    """Initialise the default process group from torchrun's environment (no-op for world_size 1)."""
+def cap_host_threads(world=None):
+    """One process per GPU on one host: every rank otherwise inherits torch's default intra-op pool (= all cores: 8 ranks x 128 threads
+    on the MI355X boxes), and the host side of this path is a single-threaded launch loop.  cores // world threads per rank (at least
+    one); UCOD_RANK_THREADS overrides.  Returns the count in force."""
+    world = world if world is not None else env_world()[2]
+    if world > 1 or os.environ.get("UCOD_RANK_THREADS"):
+        n = int(os.environ.get("UCOD_RANK_THREADS") or max(1, (os.cpu_count() or 1) // world))
+        torch.set_num_threads(n)
+    return torch.get_num_threads()
+
+
+def init_from_env(backend="nccl", timeout_s=None):
+    """Initialise the default process group from torchrun's environment (no-op for world_size 1).  A rendezvous that does not complete
+    within ``timeout_s`` (default 300 s, UCOD_DIST_TIMEOUT_S) raises with the addresses it was waiting on instead of hanging: the usual
+    causes are a MASTER_ADDR that does not resolve inside the container (use 127.0.0.1 on one node) or fewer ranks started than
+    WORLD_SIZE announces.  HSA_ENABLE_IPC_MODE_LEGACY=0 is required for RCCL between processes on this driver (dmabuf IPC)."""
+    import datetime
     rank, local_rank, world = env_world()
     backend = os.environ.get("UCOD_DIST_BACKEND", backend)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        cap_host_threads(world)
+        timeout_s = float(os.environ.get("UCOD_DIST_TIMEOUT_S", timeout_s or 300))
+        if backend == "nccl":
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if not torch.cuda.is_available():
+                raise RuntimeError("backend nccl (= RCCL) needs a GPU per rank; set UCOD_DIST_BACKEND=gloo for CPU / single-GPU rigs")
+            if torch.cuda.device_count() <= device_index():
+                raise RuntimeError(f"rank {rank}: LOCAL_RANK {local_rank} but this node exposes {torch.cuda.device_count()} GPU(s) "
+                                   f"(one process per GPU: launch with --nproc-per-node <= the GPU count)")
+        where = f"{os.environ.get('MASTER_ADDR', '?')}:{os.environ.get('MASTER_PORT', '?')}"
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+        except Exception as e:                                  # noqa: BLE001 -- re-raised with the rendezvous it was waiting on
+            raise RuntimeError(f"rank {rank}/{world}: torch.distributed ({backend}) did not initialise against {where} within {timeout_s:.0f} s: "
+                               f"{type(e).__name__}: {e}") from e
     return rank, local_rank, world
 
 
