@@ -358,19 +358,26 @@ def main():
     if not a.no_cpu_baseline and world == 1:                  # rank 0 at N = 1 only (the contract); the N > 1 lines carry null
         cpu = cpu_baseline(a, D, heads, L, P)
 
+    f16_children = []
     if run_f16_child:
+        # Two fp16-operand configurations, each in its own process: the engine's default (resid="auto" -> f32 residual stream: the
+        # whole margin under the bar) and the fp16 residual stream (the faster one; still under the bar, with less margin).
         import subprocess
         torch.cuda.synchronize()
-        cmd = [sys.executable, os.path.abspath(__file__), "--half", "f16", "--steps", str(a.steps), "--warmup", str(a.warmup), "--batch", str(B),
-               "--arch", a.arch, "--image", str(a.image), "--streams", str(a.streams), "--attn-variant", str(a.attn_variant), "--lora-steps", "-1",
-               "--no-cpu-baseline"] + (["--no-pipeline"] if a.no_pipeline else []) + (["--full-last-layer"] if a.full_last_layer else [])
-        r = subprocess.run(cmd, env=dict(os.environ, UCOD_BENCH_CHILD="1"), capture_output=True, text=True)
-        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        if r.returncode != 0 or not line:
-            raise SystemExit("bench.py: the fp16-operand child run failed:\n" + r.stderr[-2000:])
-        c = json.loads(line[-1])
-        f16_option = {"value": c["value"], "unit": "images/s", "ms_per_step": c["ms_per_step"], "residual_stream": c["config"]["residual_stream"],
-                      "what": "the timed step with fp16 backbone operands (libucod_dpl_f16.so), same schedule, own process (python bench.py --half f16)"}
+        for resid in ("auto", "f16"):
+            cmd = [sys.executable, os.path.abspath(__file__), "--half", "f16", "--resid", resid, "--steps", str(a.steps), "--warmup", str(a.warmup),
+                   "--batch", str(B), "--arch", a.arch, "--image", str(a.image), "--streams", str(a.streams), "--attn-variant", str(a.attn_variant),
+                   "--lora-steps", "-1", "--no-cpu-baseline"] + (["--no-pipeline"] if a.no_pipeline else []) + (["--full-last-layer"] if a.full_last_layer else [])
+            r = subprocess.run(cmd, env=dict(os.environ, UCOD_BENCH_CHILD="1"), capture_output=True, text=True)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                raise SystemExit("bench.py: the fp16-operand child run failed:\n" + r.stderr[-2000:])
+            c = json.loads(line[-1])
+            f16_children.append({"resid": resid, "value": c["value"], "unit": "images/s", "ms_per_step": c["ms_per_step"],
+                                 "residual_stream": c["config"]["residual_stream"], "serial_ms_per_step": c["roofline"]["serial_ms_per_step_without_events"],
+                                 "kernels_avg_us": {k: v["avg_us"] for k, v in c["kernels"].items()}})
+        f16_option = {k: v for k, v in f16_children[0].items() if k != "kernels_avg_us"}
+        f16_option["what"] = "the timed step with fp16 backbone operands (libucod_dpl_f16.so), same schedule, own process (python bench.py --half f16)"
 
     # North-star parity bar (mask logits within 1e-3 of the f32 reference), at the top level of the line: for the dtype the line is
     # quoted on, and -- next to it -- the configuration that meets the bar with its own throughput.
@@ -378,15 +385,31 @@ def main():
     par = (cpu or {}).get("parity_full_size") or {}
     own = par if a.half == "bf16" else par.get("f16_operands") or {}
     logit_max_abs = own.get("logit_max_abs")
-    bar_meeting = None
-    if par.get("f16_operands") and (f16_option or a.half == "f16"):
-        pf = par["f16_operands"]
-        bar_meeting = {"dtype": "f16", "residual_stream": (f16_option or {}).get("residual_stream", "fp16" if resid16 else "f32"),
-                       "value": (f16_option or {}).get("value", round(world * B * a.steps / dt, 2)), "unit": "images/s",
-                       "logit_max_abs": pf["logit_max_abs"], "key_rel_l2": pf["key_rel_l2"], "mask_flipped_fraction": pf["mask_flipped_fraction"],
-                       "bar": BAR, "bar_met": bool(pf["logit_max_abs"] <= BAR),
-                       "what": "ViTEngine(half='f16') = libucod_dpl_f16.so: IEEE fp16 GEMM / attention operands (what the reference's fp16-autocast launcher "
-                               "multiplies in, scripts/launch_train_first_stage.sh:20), same kernels, same schedule, own process"}
+    bar_meeting, f16_vs_bf16 = None, None
+    if par.get("f16_operands") and f16_children:
+        cands = []
+        for ch in f16_children:
+            pf = par["f16_operands"] if ch["residual_stream"] == "f32" else par.get("f16_operands_f16_stream") or {}
+            if not pf:
+                continue
+            cands.append({"dtype": "f16", "residual_stream": ch["residual_stream"], "value": ch["value"], "unit": "images/s", "ms_per_step": ch["ms_per_step"],
+                          "logit_max_abs": pf["logit_max_abs"], "key_rel_l2": pf["key_rel_l2"], "mask_flipped_fraction": pf["mask_flipped_fraction"],
+                          "bar": BAR, "bar_met": bool(pf["logit_max_abs"] <= BAR), "margin": round(BAR / max(pf["logit_max_abs"], 1e-12), 2),
+                          "engine": f"ViTEngine(half='f16', resid='{ch['resid']}')"})
+        met = [c_ for c_ in cands if c_["bar_met"]]
+        if met:
+            bar_meeting = dict(max(met, key=lambda c_: c_["value"]))       # the fastest configuration under the bar
+            bar_meeting["what"] = ("libucod_dpl_f16.so: IEEE fp16 GEMM / attention operands (what the reference's fp16-autocast launcher multiplies in, "
+                                   "scripts/launch_train_first_stage.sh:20), same kernels, same schedule, own process")
+            bar_meeting["all_f16_configurations"] = cands
+        # why the fp16-operand build is slower than the bf16 one: per kernel class, same serial pass, own processes on this box
+        ch = next((c_ for c_ in f16_children if c_["residual_stream"] == ("fp16" if resid16 else "f32")), f16_children[-1])
+        f16_vs_bf16 = {"residual_stream_of_both": ch["residual_stream"],
+                       "avg_us_bf16_vs_f16": {k: [kernels[k]["avg_us"], ch["kernels_avg_us"].get(k)] for k in kernels if k in ch["kernels_avg_us"]
+                                              and kernels[k]["ms_per_step"] > 0.05},
+                       "what": "same step, same residual-stream type, serial pass with HIP events: the fp16 MFMA kernels run longer at equal cycles (the chip "
+                               "holds a lower clock on fp16 operands: profiles/r03_f16_vs_bf16_*), the f32 residual stream costs the out-proj / fc2 "
+                               "epilogues and LayerNorm their extra bytes"}
     ips = world * B * a.steps / dt
     out = {
         "metric": "training images/sec at 3x518x518, DINOv2-B (frozen backbone fwd + DBA/APM/discriminator train step)",
@@ -394,7 +417,7 @@ def main():
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.half, "data": "synthetic",
         "logit_max_abs": logit_max_abs, "bar": BAR, "bar_met": (None if logit_max_abs is None else bool(logit_max_abs <= BAR)),
-        "bar_meeting_config": bar_meeting,
+        "bar_meeting_config": bar_meeting, "f16_vs_bf16_per_kernel": f16_vs_bf16,
         "host_enqueue_ms_per_step": round(host_enqueue / a.steps * 1e3, 3), "host_threads": host_threads,
         "config": {"workload": f"{which_config(a.arch, a.image, B, a.attn_variant)}: {a.arch} @{a.image}x{a.image}, batch {B}/GPU, full APM+DBA+discriminator step, "
                                f"decoder path f32 (1x1 conv as a three-way bf16 split on the matrix pipe: f32-equivalent), backbone {a.half} MFMA", "global_batch": B * world, "parallelism": f"dp{world}",
@@ -449,15 +472,17 @@ def cpu_baseline(a, D, heads, L, P):
         d = ops.bilinear_resize(ops.dba_project(key_dev, dec["decoupling.weight"].reshape(128, D).to(dev), dec["decoupling.bias"].to(dev)).view(n, 128, *key_dev.shape[-2:]), 68, 68).view(n, 128, 68 * 68)
         return ops.dba_heads(d, 0, emb, ops.dba_colnorm(d, 0, emb), hw, hb, want_bg=False)[0].view(n, 1, 68, 68).cpu()
 
-    def parity(half):
-        eng = ViTEngine(sd, heads=heads, eps=1e-6, device=dev, attn_variant=a.attn_variant, half=half)
+    def parity(half, resid="auto"):
+        eng = ViTEngine(sd, heads=heads, eps=1e-6, device=dev, attn_variant=a.attn_variant, half=half, resid=resid)
         key_dev = eng(img.to(dev))
         kd, fd = key_dev.cpu(), device_logits(key_dev)
         per_layer = []
         for li in range(1, L + 1):                              # error budget: key map after li layers vs the oracle's
             kl = eng.forward(img.to(dev), n_layers=li).cpu()
             per_layer.append(round(float((kl - layer_ref[li - 1]).norm() / layer_ref[li - 1].norm()), 6))
-        return {"key_rel_l2": round(float((kd - key).norm() / key.norm()), 6), "key_max_abs": round(float((kd - key).abs().max()), 5),
+        eng.check_overflow(wait=True)
+        return {"residual_stream": "fp16" if eng.resid16 else "f32",
+                "key_rel_l2": round(float((kd - key).norm() / key.norm()), 6), "key_max_abs": round(float((kd - key).abs().max()), 5),
                 "logit_max_abs": round(float((fd - fg_ref).abs().max()), 6), "logit_rel_l2": round(float((fd - fg_ref).norm() / fg_ref.norm()), 6),
                 "mask_flipped_fraction": round(float(((fd > 0) != (fg_ref > 0)).float().mean()), 6),
                 "key_rel_l2_after_layer": per_layer}
@@ -466,7 +491,8 @@ def cpu_baseline(a, D, heads, L, P):
         "what": f"{n} images at {a.image}x{a.image}, {a.arch}: device backbone + f32 device decoder vs the f32 oracle (same random-init weights); "
                 f"north-star bar: logit max-abs <= 1e-3",
         **parity("bf16"),
-        "f16_operands": parity("f16")}
+        "f16_operands": parity("f16"),                            # engine default for fp16 operands: f32 residual stream
+        "f16_operands_f16_stream": parity("f16", "f16")}
     return out
 
 

@@ -447,6 +447,16 @@ int ucod_dwconv7_maskdec(const float* x_tokens, const float* dw_tapmajor, const 
 int ucod_window_scatter(const float* windows, const int* coords, const int* win_img, float* out, int n, int B, int H, int W, int ws,
                         void* stream);
 
+/* SparseRefiner.cal_ex_loss, training mode (models/UDLR.py:52-75): the IoU-weighted window loss.  window_preds f32 [n,1,H,W] (logits of
+ * the selected windows), h_targets f32 [B*ws*ws,1,H,W] (per-window high-resolution targets, all windows), win_flat int32 [n] = b*ws*ws + j of
+ * each selected window (raster order, as mask.flatten() selects), l_up f32 [B,1,ws*H,ws*W] = the first-stage logits resized bilinearly.
+ * Per window: l = sigmoid(l_up block) > 0.5; iou of (targets > 0.5 -- after a sigmoid when targets_are_logits, binary_iou's "max > 1"
+ * heuristic which the caller evaluates over all selected targets) with l; w = clamp(1.5 iou, 0, 1);
+ * part[i] = sum_pixels w BCEWithLogits(x, t) + (1 - w) BCEWithLogits(x, l);  loss_out[0] = sum(part) / (2 n H W) (f64 sum, fixed order).
+ * iou_out [n] optional. */
+int ucod_window_loss(const float* window_preds, const float* h_targets, const int* win_flat, const float* l_up, int targets_are_logits,
+                     float* part, float* iou_out, float* loss_out, int n, int B, int H, int W, int ws, void* stream);
+
 /* GatedEnsembler (models/modules/GE_pix_level.py:16-25) after the bilinear resize of l1: 19x19 zero-padded average of
  * sigmoid(l1), its entropy normalised by the maximum over the WHOLE batch, gate = ((1 - en/en_max) + mean sigmoid(l1))/2,
  * y = l1*gate + l2*(1-gate), out = fuser(y) (1x1 conv 1->64, ReLU, 1x1 conv 64->1).  All maps f32 [B,1,h,w]. */

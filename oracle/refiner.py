@@ -111,3 +111,35 @@ def sparse_refiner_forward(input_features, h_inputs, preds, sd, window_size=3, t
     h_preds = concat_windows(window_preds, coords, counts, window_size)
     outputs, ge_w = gated_ensembler(preds, h_preds, sd)
     return outputs, dict(mask=mask, entropy=entropy, h_preds=h_preds, window_preds=window_preds, GE_w=ge_w, preds=preds, coords_list=coords)
+
+
+def binary_iou(preds, targets, threshold=0.5):
+    """UDLR.py:26-42."""
+    if preds.ndim == 4:
+        preds = preds.squeeze(1)
+    if targets.ndim == 4:
+        targets = targets.squeeze(1)
+    if preds.dtype.is_floating_point:
+        preds = torch.sigmoid(preds) if preds.max() > 1 else preds
+        preds = (preds > threshold).int()
+    targets = targets.int()
+    inter = (preds & targets).sum(dim=(1, 2)).float()
+    union = (preds | targets).sum(dim=(1, 2)).float()
+    return inter / (union + 1e-6)
+
+
+def cal_ex_loss(preds, window_preds, mask, h_targets, window_size):
+    """UDLR.py:52-75 in TRAINING mode -> (loss, window_targets, ious): the IoU-weighted window loss.  ``preds`` [B,1,ph,pw] first-stage
+    logits, ``window_preds`` [n,1,h,w], ``mask`` bool [B,1,ws,ws], ``h_targets`` [B*ws*ws,1,h,w]."""
+    if mask.sum() == 0:
+        return torch.zeros(()), None, None
+    _, _, h, w = window_preds.shape
+    ws = window_size
+    l = F.interpolate(preds, size=(h * ws, w * ws), mode="bilinear").sigmoid() > 0.5
+    l = F.unfold(l.float(), kernel_size=(h, w), stride=(h, w)).reshape(-1, 1, h, w, ws ** 2).permute(0, 4, 1, 2, 3).flatten(0, 1)
+    l = l[mask.flatten()]
+    t = h_targets[mask.flatten()]
+    ious = (binary_iou(t, l).view(-1, 1, 1, 1) * 1.5).clamp(0, 1)
+    bce = torch.nn.BCEWithLogitsLoss(reduction="none")
+    loss = (ious * bce(window_preds, t) + (1 - ious) * bce(window_preds, l)).mean() / 2
+    return loss, t, ious.view(-1)

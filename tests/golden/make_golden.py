@@ -431,6 +431,30 @@ def g9():
     save("g9_refiner", **out)
 
 
+def g9b():
+    """G9b: the REAL SparseRefiner in .train() mode with h_targets (models/UDLR.py:52-86): the training-mode forward (identical arithmetic:
+    every dropout is 0) and cal_ex_loss's IoU-weighted window loss, for soft targets in [0,1] and for logit targets (binary_iou's
+    "max > 1" branch), full and partial window selections."""
+    from models.UDLR import SparseRefiner
+    sys.path.insert(0, OUT)
+    import refiner_init as RI
+    torch.manual_seed(RI.SEED)
+    m = RI.perturb_(SparseRefiner.from_config(CfgNode(dict(window_size=3, threshold=0.0015, dim=768)))).train()
+    out = {}
+    for tag, partial in (("full", False), ("partial", True)):
+        l, h, preds = RI.make_inputs(partial)
+        for kind in ("prob", "logit"):
+            ht = RI.make_h_targets(kind)
+            with torch.no_grad():
+                outputs, ex, opt = m(l, h, preds, ht)
+            k = f"{tag}.{kind}."
+            out[k + "ex_loss"] = torch.as_tensor(ex).double()
+            out[k + "window_targets"] = opt["window_targets"]
+            out[k + "outputs"] = outputs
+            out[k + "window_preds"] = opt["window_preds"]
+    save("g9b_refiner_train", **out)
+
+
 # ----------------------------------------------------------------------------- G12: backbone backward (LoRA mode, row B9)
 class _LoRALinear(nn.Module):
     """What peft's LoRA wrapper computes for the LoraConfig of models/modules/full_model.py:47-72 (r, lora_alpha, bias='none';
@@ -823,6 +847,6 @@ def g17():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g9b", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     for w in which:
         globals()[w]()

@@ -32,6 +32,15 @@ def make_inputs(partial):
     return l, h, preds
 
 
+def make_h_targets(kind, B=2, ws=3, H=6):
+    """Per-window high-resolution targets [B*ws*ws, 1, H, H] for the training-mode fixture (G9b): soft masks in [0, 1] ("prob") or logits
+    ("logit": values beyond 1, so that binary_iou applies its sigmoid)."""
+    g = torch.Generator().manual_seed(95 + (kind == "logit"))
+    t = torch.rand(B * ws * ws, 1, H, H, generator=g)
+    t[::2, :, :3] = (t[::2, :, :3] > 0.4).float()            # a mix of hard and soft pixels
+    return t if kind == "prob" else (t - 0.5) * 9.0
+
+
 def coral_inputs():
     """Seeded inputs of the CORAL validation-loop vectors (G15): l [1,768,5,5], m [1,4,768,36,36] (the 2x2 overlapping crops of a
     54x54 map, lr_dataset.py:155-166), h [1,9,768,5,5]."""

@@ -83,8 +83,16 @@ def test_two_rank_gradient_allreduce_equals_global_batch_with_per_rank_bn(tmp_pa
     got = torch.load(out)
     g = load_golden("g5_process_batch")
     dec, ema, disc = sub(g, "model0.decoder."), sub(g, "model0.decoder_ema."), sub(g, "disc0.")
-    ref = sum(_rank_grads(dec, ema, {k: v.clone() for k, v in disc.items()}, g["features0"][r * 2:r * 2 + 2], g["pl0"][r * 2:r * 2 + 2], 0.5)
-              for r in range(2))
+    # the ranks run with cores // world intra-op threads (parallel.cap_host_threads): the same thread count here, so that the CPU
+    # oracle's f32 reductions are summed in the same order and the comparison stays at round-off of the all-reduce alone
+    from ucod_dpl_amd import parallel
+    before = torch.get_num_threads()
+    torch.set_num_threads(max(1, (os.cpu_count() or 1) // 2))
+    try:
+        ref = sum(_rank_grads(dec, ema, {k: v.clone() for k, v in disc.items()}, g["features0"][r * 2:r * 2 + 2], g["pl0"][r * 2:r * 2 + 2], 0.5)
+                  for r in range(2))
+    finally:
+        torch.set_num_threads(before)
     assert torch.allclose(got, ref, rtol=0, atol=1e-9)
     assert got.abs().max() > 1e-4
 

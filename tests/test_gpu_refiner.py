@@ -231,3 +231,52 @@ def test_local_refine_runner_from_the_coral_config(tmp_path):
     assert sorted(saved) == sorted(ref_refiner.state_dict())
     with pytest.raises(NotImplementedError):
         runner.launch_train()
+
+
+@pytest.mark.parametrize("tag", ["full", "partial"])
+@pytest.mark.parametrize("kind", ["prob", "logit"])
+def test_sparse_refiner_training_mode_matches_reference(tag, kind):
+    """models/UDLR.py:52-86 with the module in .train() and h_targets given -- G9b = the REAL reference module run that way: the forward is
+    the eval forward (every dropout is 0), cal_ex_loss is the IoU-weighted window loss.  The loss is checked twice: end to end against the
+    reference's value (its window_preds are f32, ours come through bf16 projections -> 2e-2 relative), and -- the kernel alone -- on the
+    reference's own window_preds against the reference's value (f32 arithmetic: 2e-6 relative)."""
+    g, g9 = load_golden("g9b_refiner_train"), load_golden("g9_refiner")
+    k = f"{tag}.{kind}."
+    torch.manual_seed(RI.SEED)
+    m = RI.perturb_(SparseRefiner.from_config(CfgNode(dict(window_size=3, threshold=0.0015)))).train().cuda()
+    l, h, preds = RI.make_inputs(tag == "partial")
+    ht = RI.make_h_targets(kind)
+    with torch.no_grad():
+        out, ex, opt = m(l.cuda(), h.cuda(), preds.cuda(), ht.cuda())
+    ref = float(g[k + "ex_loss"])
+    assert torch.equal(opt["window_targets"].cpu(), g[k + "window_targets"])
+    assert abs(float(ex) - ref) < 2e-2 * ref, (float(ex), ref)
+    assert rel_l2(out, g[k + "outputs"]) < 2e-2 and rel_l2(out, g9[tag + ".outputs"]) < 2e-2
+    # the loss kernel on the reference's own window logits
+    mask = g9[tag + ".mask"].bool()
+    win_flat = torch.nonzero(mask.flatten()).flatten().to(torch.int32).cuda()
+    wp = g[k + "window_preds"].cuda().contiguous()
+    n, hh, ww = wp.shape[0], wp.shape[-2], wp.shape[-1]
+    l_up = ops.bilinear_resize(preds.cuda(), hh * 3, ww * 3)
+    htd = ht.cuda().contiguous()
+    part, ious, loss = (torch.empty(n, device="cuda"), torch.empty(n, device="cuda"), torch.empty(1, device="cuda"))
+    N.check(N.load().ucod_window_loss(N.ptr(wp), N.ptr(htd), N.ptr(win_flat), N.ptr(l_up), int(kind == "logit"), N.ptr(part), N.ptr(ious), N.ptr(loss),
+                                      n, 2, hh, ww, 3, N.stream()), "ucod_window_loss")
+    assert abs(float(loss[0]) - ref) < 2e-6 * max(1.0, abs(ref)), (float(loss[0]), ref)
+    o_loss, o_t, o_iou = OR.cal_ex_loss(preds, g[k + "window_preds"], mask, ht, 3)
+    assert maxdiff(ious.cpu() * 1.5, (o_iou).cpu().clamp(0, 1)) < 1e-6 or maxdiff((ious.cpu() * 1.5).clamp(0, 1), o_iou) < 1e-6
+
+
+def test_sparse_refiner_training_mode_edge_cases():
+    """No window selected -> ex_loss is the reference's python 0; eval mode ignores h_targets; training mode without h_targets raises."""
+    torch.manual_seed(RI.SEED)
+    m = RI.perturb_(SparseRefiner.from_config(CfgNode(dict(window_size=3, threshold=0.0015)))).train().cuda()
+    l, h, preds = RI.make_inputs(False)
+    confident = torch.full_like(preds, 14.0)                      # zero entropy everywhere: no window passes the threshold
+    out, ex, opt = m(l.cuda(), h.cuda(), confident.cuda(), RI.make_h_targets("prob").cuda())
+    assert ex == 0 and int(opt["mask"].sum()) == 0 and "window_targets" not in opt
+    with pytest.raises(ValueError):
+        m(l.cuda(), h.cuda(), preds.cuda())
+    m.eval()
+    out, ex, opt = m(l.cuda(), h.cuda(), preds.cuda(), RI.make_h_targets("prob").cuda())
+    assert ex == 0

@@ -188,6 +188,23 @@ def test_g9_sparse_refiner(tag):
     assert maxdiff(out, g[tag + ".outputs"]) < 2e-4
 
 
+@pytest.mark.parametrize("tag", ["full", "partial"])
+@pytest.mark.parametrize("kind", ["prob", "logit"])
+def test_g9b_refiner_training_mode_loss(tag, kind):
+    """G9b = the real SparseRefiner in .train() with h_targets (models/UDLR.py:52-86): the oracle's cal_ex_loss reproduces the reference's
+    IoU-weighted window loss and window_targets on the reference's own window logits, for probability and logit targets."""
+    import refiner_init as RI
+    from oracle import refiner as OR
+    g, g9 = load_golden("g9b_refiner_train"), load_golden("g9_refiner")
+    k = f"{tag}.{kind}."
+    _, _, preds = RI.make_inputs(tag == "partial")
+    loss, t, ious = OR.cal_ex_loss(preds, g[k + "window_preds"], g9[tag + ".mask"].bool(), RI.make_h_targets(kind), 3)
+    assert torch.equal(t, g[k + "window_targets"])
+    assert abs(float(loss) - float(g[k + "ex_loss"])) < 1e-7
+    assert maxdiff(g[k + "outputs"], g9[tag + ".outputs"]) == 0     # training-mode forward == eval forward (every dropout is 0)
+    assert float(ious.min()) >= 0 and float(ious.max()) <= 1
+
+
 def test_g12_lora_backbone_grads():
     """Row B9: oracle forward with the LoRA branch + autograd == HF Dinov2Model with LoRA-wrapped q/k/v (the reference's
     full_model.py is unimportable; SURVEY.md 8c pins this row on HF autograd)."""

@@ -143,6 +143,62 @@ __global__ __launch_bounds__(256) void ge_fuse_kernel(const float* __restrict__ 
   wout[i] = wt;
 }
 
+
+// SparseRefiner.cal_ex_loss (models/UDLR.py:52-75), training mode: per selected window i (one workgroup each)
+//   l = (sigmoid(l_up) > 0.5) of that window  (l_up = the first-stage logits, bilinear-resized to [B,1,ws*H,ws*W]; a window is the
+//       (wy, wx) = (j / ws, j % ws) block of image b, j = the window's raster index: the unfold of UDLR.py:67),
+//   t = h_targets[win_flat[i]]  (the window's own high-resolution target),
+//   iou = |bin(t) & l| / (|bin(t) | l| + 1e-6), bin(t) = (t' > 0.5) with t' = sigmoid(t) if `targets_are_logits` (binary_iou's
+//       "preds.max() > 1" heuristic, decided by the caller over ALL selected targets) else t;  w = clamp(1.5 * iou, 0, 1)
+//   part[i] = sum_pixels  w * BCEWithLogits(x, t) + (1 - w) * BCEWithLogits(x, l),   x = window_preds[i]
+// and the caller divides the sum of part by (2 * n * H * W)  (the reference's .mean() / 2).  Fixed reduction trees: deterministic.
+__global__ __launch_bounds__(256) void window_loss_kernel(const float* __restrict__ win_preds, const float* __restrict__ h_targets,
+                                                          const int* __restrict__ win_flat, const float* __restrict__ l_up, int targets_are_logits,
+                                                          float* __restrict__ part, float* __restrict__ iou_out, int H, int W, int ws) {
+  __shared__ float red[16];
+  const int i = blockIdx.x, HW = H * W;
+  const int flat = win_flat[i], b = flat / (ws * ws), j = flat - b * (ws * ws);
+  const int wy = j / ws, wx = j - wy * ws;
+  const float* x = win_preds + (size_t)i * HW;
+  const float* t = h_targets + (size_t)flat * HW;
+  const float* l = l_up + ((size_t)b * ws * H + (size_t)wy * H) * (ws * W) + (size_t)wx * W;
+  float inter = 0.f, uni = 0.f;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const int y = p / W, xx = p - y * W;
+    const float tv = t[p];
+    const bool tb = (targets_are_logits ? sigmoid_acc(tv) : tv) > 0.5f;
+    const bool lb = sigmoid_acc(l[(size_t)y * (ws * W) + xx]) > 0.5f;
+    inter += (tb && lb) ? 1.f : 0.f;
+    uni += (tb || lb) ? 1.f : 0.f;
+  }
+  inter = block_sum(inter, red);
+  uni = block_sum(uni, red);
+  const float iou = inter / (uni + 1e-6f);
+  const float w = fminf(fmaxf(iou * 1.5f, 0.f), 1.f);
+  float acc = 0.f;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const int y = p / W, xx = p - y * W;
+    const float xv = x[p], tv = t[p];
+    const float lv = sigmoid_acc(l[(size_t)y * (ws * W) + xx]) > 0.5f ? 1.f : 0.f;
+    // BCEWithLogits(x, z) = max(x, 0) - x z + log1p(exp(-|x|))   (ATen's stable form)
+    const float sp = fmaxf(xv, 0.f) + log1pf(expf(-fabsf(xv)));
+    acc += w * (sp - xv * tv) + (1.f - w) * (sp - xv * lv);
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    part[i] = acc;
+    if (iou_out) iou_out[i] = iou;
+  }
+}
+
+// loss = (sum_i part[i]) * scale, summed in f64 in a fixed order (one wave)
+__global__ void window_loss_finish_kernel(const float* __restrict__ part, float* __restrict__ loss, int n, double scale) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) acc += (double)part[i];
+  acc = wave_sum_d(acc);
+  if (threadIdx.x == 0) loss[0] = (float)(acc * scale);
+}
+
 }  // namespace ucod
 
 using namespace ucod;
@@ -198,3 +254,13 @@ extern "C" int ucod_gated_ensemble(const float* l1_up, const float* l2, const fl
 }
 
 extern "C" size_t ucod_gated_ensemble_workspace_bytes(int B, int h, int w) { return ((size_t)B * h * w + B + 1) * sizeof(float); }
+
+extern "C" int ucod_window_loss(const float* window_preds, const float* h_targets, const int* win_flat, const float* l_up, int targets_are_logits,
+                                float* part, float* iou_out, float* loss_out, int n, int B, int H, int W, int ws, void* stream) {
+  if (!window_preds || !h_targets || !win_flat || !l_up || !part || !loss_out || n <= 0 || B <= 0 || H <= 0 || W <= 0 || ws <= 0) return UCOD_EINVAL;
+  hipLaunchKernelGGL(ucod::window_loss_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, window_preds, h_targets, win_flat, l_up, targets_are_logits,
+                     part, iou_out, H, W, ws);
+  hipLaunchKernelGGL(ucod::window_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, loss_out, n, 1.0 / (2.0 * n * H * W));
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}

@@ -1,4 +1,4 @@
-"""CORAL second-stage refiner -- host-side mirror of models/UDLR.py::SparseRefiner (inference path).
+"""CORAL second-stage refiner -- host-side mirror of models/UDLR.py::SparseRefiner (eval and training-mode forward).
 
 Same constructor / ``from_config`` (reads ``config.window_size``, ``config.threshold``), same sub-module tree and therefore
 the same state-dict names as the reference (``HRE.CSF.attn.{norm_q,norm_kv,attn.in_proj_*,attn.out_proj,mlp.0,mlp.2,norm_mlp}``,
@@ -8,8 +8,11 @@ the same state-dict names as the reference (``HRE.CSF.attn.{norm_q,norm_kv,attn.
 the reference's); the arithmetic is HIP: window gather + NCHW->token transpose, LayerNorm, bf16 MFMA projections, the
 head_dim-96 cross-attention kernel, fused depthwise-7x7 + mask head, window scatter, gated ensembling.
 
-Only inference is released by the reference (its second-stage train loop is ``pass``, engine/runner/loop_CORAL.py:38-39):
-``forward`` in training mode raises.  ``ex_loss`` is 0 in eval mode exactly as ``cal_ex_loss`` returns (UDLR.py:52-55).
+``ex_loss`` is 0 in eval mode exactly as ``cal_ex_loss`` returns (UDLR.py:52-55).  In training mode (``.train()``) the forward is the same
+arithmetic (every dropout of the module is 0, there is no BatchNorm) and ``cal_ex_loss`` adds the IoU-weighted window loss of
+UDLR.py:56-75 from ``h_targets`` (HIP: ``ucod_window_loss``), with ``opt['window_targets']`` as the reference sets it.  The loss VALUE is
+what the reference defines; it ships no second-stage training loop (``LocalRefineTrainLoop: pass``, engine/runner/loop_CORAL.py:38-39), so
+no backward of the refiner exists to mirror and the returned loss carries no autograd graph.
 """
 import math
 
@@ -136,9 +139,36 @@ class SparseRefiner(nn.Module):
                 "ucod_dwconv7_maskdec")
         return win
 
+    def cal_ex_loss(self, opt, win_flat=None):
+        """UDLR.py:52-75.  Eval mode / no selected window: 0 (python int, as the reference returns).  Training mode: a 0-d f32 tensor."""
+        loss = 0
+        if not self.training:
+            return loss, opt
+        window_preds, preds, h_targets = opt["window_preds"], opt["preds"], opt["h_targets"]
+        n = int(window_preds.shape[0])
+        if n == 0:                                                          # mask.sum() == 0
+            return loss, opt
+        if h_targets is None:
+            raise ValueError("SparseRefiner in training mode needs h_targets [B*ws*ws, 1, h, w] (models/UDLR.py:62)")
+        lib, dev, ws = N.load(), window_preds.device, self.window_size
+        h, w = window_preds.shape[-2:]
+        B = preds.shape[0]
+        h_targets = h_targets.to(dev, torch.float32).contiguous()
+        if tuple(h_targets.shape) not in ((B * ws * ws, 1, h, w), (B * ws * ws, h, w)):
+            raise ValueError(f"h_targets shape {tuple(h_targets.shape)} != {(B * ws * ws, 1, h, w)}")
+        sel = h_targets.view(B * ws * ws, 1, h, w).index_select(0, win_flat.long())
+        opt["window_targets"] = sel                                        # UDLR.py:71
+        logits = int(sel.max().item() > 1)                                  # binary_iou's "already a probability?" test (one host sync)
+        l_up = ops.bilinear_resize(preds, h * ws, w * ws)
+        part = torch.empty(n, dtype=torch.float32, device=dev)
+        ious = torch.empty(n, dtype=torch.float32, device=dev)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        N.check(lib.ucod_window_loss(N.ptr(window_preds), N.ptr(h_targets), N.ptr(win_flat), N.ptr(l_up), logits, N.ptr(part), N.ptr(ious), N.ptr(out),
+                                     n, B, h, w, ws, N.stream()), "ucod_window_loss")
+        opt["window_ious"] = ious
+        return out[0], opt
+
     def forward(self, input_features, h_inputs, preds, h_targets=None):
-        if self.training:
-            raise NotImplementedError("SparseRefiner training is not released by the reference (loop_CORAL.py:38-39); call .eval()")
         if not input_features.is_cuda:
             raise RuntimeError("SparseRefiner runs on the HIP path only: move the module and its inputs to 'cuda'")
         lib = N.load()
@@ -171,6 +201,7 @@ class SparseRefiner(nn.Module):
             cd = coords_list.to(torch.int32).contiguous()
         else:
             l_idx = torch.zeros(0, dtype=torch.int32, device=dev)
+            h_idx = torch.zeros(0, dtype=torch.int32, device=dev)
             window_preds = torch.zeros(0, 1, hH, hW, dtype=torch.float32, device=dev)
             cd = torch.zeros(0, 2, dtype=torch.int32, device=dev)
         h_preds = torch.empty(B, 1, ws * hH, ws * hW, dtype=torch.float32, device=dev)
@@ -186,4 +217,5 @@ class SparseRefiner(nn.Module):
                                         N.ptr(ge_w), N.ptr(wsb), B, h2, w2, st), "ucod_gated_ensemble")
         opt = {"mask": mask, "entropy": entropy, "h_preds": h_preds, "window_preds": window_preds, "GE_w": ge_w, "preds": preds,
                "coords_list": coords_list, "h_targets": h_targets}
-        return outputs, 0, opt
+        ex_loss, opt = self.cal_ex_loss(opt, h_idx)
+        return outputs, ex_loss, opt

@@ -126,6 +126,7 @@ SIGNATURES = {
     "ucod_entropy_scores": (ci, [vp, ci, vp, vp, ci, ci, ci, ci, vp]),
     "ucod_dwconv7_maskdec": (ci, [vp, vp, vp, vp, cf, vp, ci, ci, ci, ci, vp]),
     "ucod_window_scatter": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ucod_window_loss": (ci, [vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ucod_gated_ensemble_workspace_bytes": (sz, [ci, ci, ci]),
     "ucod_gated_ensemble": (ci, [vp, vp, vp, vp, vp, cf, vp, vp, vp, ci, ci, ci, vp]),
     "ucod_adamw_ema": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, ci, cf, vp]),
