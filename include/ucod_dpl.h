@@ -372,8 +372,9 @@ int ucod_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, siz
 /* ------------------------------------------------------------------ Look-Twice (rows L1-L3) */
 
 /* 8-connected component labelling of a HOST uint8 [H,W] mask (non-zero = foreground) into HOST int32 labels
- * (0 = background, k = k-th component in raster order of its first pixel); returns the number of labels INCLUDING
- * the background, like cv2.connectedComponents(connectivity=8) (engine/runner/loop_UCOD_DPL.py:366).  < 0 on error. */
+ * (0 = background, k = k-th component in OpenCV's numbering: raster order of the components' first 2 x 2 blocks -- the order in which
+ * the block-based labelling of cv2.connectedComponents(connectivity=8) creates and flattens its labels); returns the number of labels
+ * INCLUDING the background, like cv2.connectedComponents (engine/runner/loop_UCOD_DPL.py:366).  < 0 on error. */
 int ucod_ccl8_host(const uint8_t* mask_host, int H, int W, int32_t* labels_host);
 
 /* Pillow Image.resize on an 8-bit single-channel HOST image: antialiased separable resample with 22-bit fixed-point
@@ -398,9 +399,10 @@ int ucod_bkg_seg(const float* att, const float* key_map, float th_bkg, float eps
 
 /* GPU Look-Twice tail.
  * ucod_ccl8_components: 8-connected components of a DEVICE uint8 [H,W] mask (non-zero = foreground) -> a DEVICE table of
- * `*count` rows {root, area, xmin, xmax, ymin, ymax} (int32; at most `capacity` rows are written, *count may exceed it),
- * in arbitrary order.  root = linear index of the component's first pixel in raster order, so sorting rows by root yields
- * cv2.connectedComponents' label order (labels 1..n) -- loop_UCOD_DPL.py:366-384 needs only area and bounding box per label. */
+ * `*count` rows {root, area, xmin, xmax, ymin, ymax, order} (7 x int32; at most `capacity` rows are written, *count may exceed it),
+ * in arbitrary order.  root = linear index of the component's first pixel in raster order; order = raster index of its first 2 x 2
+ * block: sorting rows by `order` yields cv2.connectedComponents' label order (labels 1..n, see ucod_ccl8_host) --
+ * loop_UCOD_DPL.py:366-384 needs only area and bounding box per label. */
 size_t ucod_ccl8_workspace_bytes(int H, int W);
 int ucod_ccl8_components(const uint8_t* mask_dev, int H, int W, int32_t* table_dev, int capacity, int32_t* count_dev, void* workspace,
                          size_t workspace_bytes, void* stream);

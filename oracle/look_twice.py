@@ -7,8 +7,11 @@ reference bit-for-bit *including its quirks* (SURVEY.md section 7 / Appendix A):
   * ``br = (h*y)/(H*W)`` (:404) and ``sqrt(1 - br/fr + 1)`` raising ValueError when br/fr > 2 (:405);
   * ``int()`` truncation toward zero (:392-395,417) and a possibly negative new_x/new_y (:412-416).
 cv2 is not installed here (nor vendored by the reference): ``connected_components`` restates
-8-connected raster labelling (label k = k-th component in raster order of its first pixel,
-label 0 = background) and ``bounding_rect`` restates cv2.boundingRect -> (x, y, w, h).
+8-connected labelling with OpenCV's NUMBERING (label k = k-th component in raster order of its first
+2 x 2 block: cv2 labels 2 x 2 blocks in raster order -- Grana's BBDT / Bolelli's Spaghetti,
+modules/imgproc/src/connectedcomponents.cpp -- unions keep the smaller provisional label and flattenL
+renumbers roots in increasing order; label 0 = background) and ``bounding_rect`` restates
+cv2.boundingRect -> (x, y, w, h).
 """
 import math
 import numpy as np
@@ -56,14 +59,19 @@ def connected_components(img):
                 for r in roots:
                     parent[r] = m
     remap = {}
+    for by in range(0, H, 2):                              # OpenCV's numbering: first 2 x 2 block in raster order
+        for bx in range(0, W, 2):
+            for y in range(by, min(by + 2, H)):
+                for x in range(bx, min(bx + 2, W)):
+                    if labels[y, x]:
+                        r = find(labels[y, x])
+                        if r not in remap:
+                            remap[r] = len(remap) + 1
     out = np.zeros_like(labels)
     for y in range(H):
         for x in range(W):
             if labels[y, x]:
-                r = find(labels[y, x])
-                if r not in remap:
-                    remap[r] = len(remap) + 1
-                out[y, x] = remap[r]
+                out[y, x] = remap[find(labels[y, x])]
     return len(remap) + 1, out
 
 

@@ -54,7 +54,20 @@ mod("timm.models.registry", register_model=lambda f: f)
 
 
 def connectedComponents(img, connectivity=8):
+    """Stand-in for cv2.connectedComponents (OpenCV is not installed here): scipy's 8-connected partition, renumbered the way OpenCV numbers
+    labels -- raster order of each component's first 2 x 2 block (cv2 labels 2 x 2 blocks in raster order, a block that touches nothing
+    labelled yet takes the next provisional label, unions keep the smaller one, flattenL renumbers roots in increasing order)."""
     lab, n = ndimage.label(img > 0, structure=np.ones((3, 3)))
+    if n:
+        H, W = lab.shape
+        ys, xs = np.nonzero(lab)
+        key = (ys >> 1) * ((W + 1) >> 1) + (xs >> 1)
+        first = np.full(n + 1, np.iinfo(np.int64).max, np.int64)
+        np.minimum.at(first, lab[ys, xs], key)
+        order = np.argsort(first[1:], kind="stable")            # component ids (0-based) in OpenCV's order
+        remap = np.zeros(n + 1, np.int32)
+        remap[order + 1] = np.arange(1, n + 1, dtype=np.int32)
+        lab = remap[lab]
     return n + 1, lab.astype(np.int32)
 
 
@@ -329,6 +342,18 @@ def g7():
             m[rng.integers(0, H, 40), rng.integers(0, W, 40)] = 1                                             # speckle
             blob(m, rng.integers(8, 56), rng.integers(8, 56), rng.integers(4, 8), rng.integers(4, 8))
         cases.append(m)
+    # Label-ORDER cases (appended, so the 240 masks above keep their indices): equal rectangles -> equal box areas -> process_preds' stable
+    # sort keeps the labelling's order (:382).  Placed so that OpenCV's order (first 2 x 2 block in raster order) differs from the order of
+    # first pixels: the rectangle on the left starts on the ODD row of a block row, the one on the right on its even row.
+    for (ya, xa, yb, xb, hh, ww) in ((1, 2, 0, 40, 8, 8), (11, 4, 10, 30, 7, 9), (21, 0, 20, 50, 10, 6), (3, 20, 2, 44, 8, 8), (31, 6, 30, 36, 9, 9),
+                                     (41, 10, 40, 48, 8, 10), (1, 30, 0, 50, 8, 8), (51, 2, 50, 34, 8, 8)):
+        mm = np.zeros((H, W), np.uint8)
+        mm[ya:ya + hh, xa:xa + ww] = 1
+        mm[yb:yb + hh, xb:xb + ww] = 1
+        cases.append(mm)
+        mm2 = mm.copy()
+        mm2[(ya + 24) % 50:(ya + 24) % 50 + hh, 22:22 + ww] = 1       # a third equal rectangle elsewhere
+        cases.append(mm2)
     fake = SimpleNamespace(img_size=(H, W), cfg=SimpleNamespace(val_cfg=SimpleNamespace(look_twice_th=0.15, expand_type="dynamic")))
     fake.expand_bbox = lambda *a, **k: V.expand_bbox(fake, *a, **k)
     recs = []

@@ -1,5 +1,5 @@
 // Look-Twice support (engine/runner/loop_UCOD_DPL.py:326-384):
-//   * ucod_ccl8_host        -- 8-connected component labelling (cv2.connectedComponents, :366) on the host, raster-order labels;
+//   * ucod_ccl8_host        -- 8-connected component labelling (cv2.connectedComponents, :366) on the host, labels numbered as OpenCV numbers them;
 //   * ucod_pil_resize_u8_host -- Pillow's 8-bit antialiased resample (Image.resize on the 'L' mask, :350) on the host;
 //   * ucod_crop_resize_norm -- batched GPU crop + Pillow-BILINEAR resize to the network input + /255 + ImageNet normalise
 //                              (PIL crop + torchvision Resize/ToTensor/Normalize, :282-286,341-342), one launch pair for all boxes.
@@ -145,14 +145,26 @@ extern "C" int ucod_ccl8_host(const uint8_t* mask, int H, int W, int32_t* labels
       if (!best) { parent.push_back((int)parent.size()); best = (int)parent.size() - 1; }
       L = best;
     }
+  // Final numbering = OpenCV's.  cv2.connectedComponents(connectivity=8) labels 2 x 2 BLOCKS in raster order (Grana's BBDT before 4.5.2,
+  // Bolelli's Spaghetti since: modules/imgproc/src/connectedcomponents.cpp), a block that touches nothing labelled so far takes the next
+  // provisional label, unions keep the smaller label as root and flattenL() renumbers the roots in increasing order -- so component k is
+  // the k-th component in raster order of its first 2 x 2 block (all foreground pixels of a block are mutually 8-adjacent: one component
+  // per block).  That differs from the raster order of first PIXELS exactly when a component starts on the odd row of a block row to the
+  // left of one that starts on the even row; it decides the order of equal-area boxes in process_preds' stable sort (:382) and with it the
+  // paste order of look_twice (:346-352).
   std::vector<int> remap(parent.size(), 0);
   int next = 0;
+  for (int by = 0; by < H; by += 2)
+    for (int bx = 0; bx < W; bx += 2)
+      for (int dy = 0; dy < 2 && by + dy < H; ++dy)
+        for (int dx = 0; dx < 2 && bx + dx < W; ++dx) {
+          const int l = labels[(size_t)(by + dy) * W + bx + dx];
+          if (!l) continue;
+          const int r = find(l);
+          if (!remap[r]) remap[r] = ++next;
+        }
   for (size_t i = 0; i < (size_t)H * W; ++i)
-    if (labels[i]) {
-      const int r = find(labels[i]);
-      if (!remap[r]) remap[r] = ++next;                      // raster order of each component's first pixel
-      labels[i] = remap[r];
-    }
+    if (labels[i]) labels[i] = remap[find(labels[i])];
   return next + 1;                                           // cv2 convention: background counts as label 0
 }
 

@@ -1,8 +1,8 @@
 // GPU Look-Twice tail (engine/runner/loop_UCOD_DPL.py:362-384 and :346-352):
 //   * ucod_ccl8_components  -- 8-connected component labelling ON THE DEVICE (union-find with the smaller linear index as the
-//                              root, so a component's root is its first pixel in raster order: the order in which
-//                              cv2.connectedComponents numbers labels) and a compact table of components
-//                              (root, area, xmin, xmax, ymin, ymax); only that table (a few dozen ints) goes to the host,
+//                              root) and a compact table of components (root, area, xmin, xmax, ymin, ymax, order): `order` = the raster
+//                              index of the component's first 2 x 2 block, i.e. the key by which cv2.connectedComponents numbers labels
+//                              (look_twice.hip: ucod_ccl8_host); only that table (a few dozen ints) goes to the host,
 //                              where the reference's float box arithmetic runs unchanged.  Replaces a 268 KB mask D2H + host CCL.
 //   * ucod_paste_resized_u8 -- for every box: Pillow-BICUBIC (8-bit, 22-bit fixed point, horizontal then vertical pass with
 //                              the intermediate rounded to uint8) resize of a small refined mask to the box size, pasted into
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned char* __r
   }
 }
 
-// stats[root] = {area, xmin, xmax, ymin, ymax}: the LAST pixel of every run adds the whole run
+// stats[root] = {area, xmin, xmax, ymin, ymax, first 2 x 2 block}: the LAST pixel of every run adds the whole run
 __global__ __launch_bounds__(256) void ccl_stats_kernel(const unsigned char* __restrict__ mask, int* __restrict__ parent, int* __restrict__ stats, int H,
                                                         int W) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -94,23 +94,25 @@ __global__ __launch_bounds__(256) void ccl_stats_kernel(const unsigned char* __r
   const bool is_start = x == 0 || !mask[i - 1];
   const int start = is_start ? i : parent[i];             // non-start pixels keep pointing at their run start for ever
   const int r = uf_find(parent, start);
-  int* s = stats + (size_t)r * 5;
+  int* s = stats + (size_t)r * 6;
   atomicAdd(&s[0], i - start + 1);
   atomicMin(&s[1], start - y * W);
   atomicMax(&s[2], x);
   atomicMin(&s[3], y);
   atomicMax(&s[4], y);
+  atomicMin(&s[5], (y >> 1) * ((W + 1) >> 1) + ((start - y * W) >> 1));       // the run's first block, in block-raster order
 }
 
 __global__ __launch_bounds__(256) void ccl_stats_init_kernel(const int* __restrict__ parent, int* __restrict__ stats, int n, int W, int H) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n || parent[i] != i) return;                         // only roots own a stats row (parent is final after merge)
-  int* s = stats + (size_t)i * 5;
+  int* s = stats + (size_t)i * 6;
   s[0] = 0;
   s[1] = W;
   s[2] = -1;
   s[3] = H;
   s[4] = -1;
+  s[5] = 0x7FFFFFFF;
 }
 
 __global__ __launch_bounds__(256) void ccl_compact_kernel(const int* __restrict__ parent, const int* __restrict__ stats, int n, int* __restrict__ count,
@@ -119,10 +121,10 @@ __global__ __launch_bounds__(256) void ccl_compact_kernel(const int* __restrict_
   if (i >= n || parent[i] != i) return;
   const int slot = atomicAdd(count, 1);
   if (slot >= cap) return;
-  int* t = table + (size_t)slot * 6;
+  int* t = table + (size_t)slot * 7;
   t[0] = i;
 #pragma unroll
-  for (int k = 0; k < 5; ++k) t[1 + k] = stats[(size_t)i * 5 + k];
+  for (int k = 0; k < 6; ++k) t[1 + k] = stats[(size_t)i * 6 + k];
 }
 
 // ----------------------------------------------------------------------------------------------- Pillow resample (as look_twice.hip)
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void paste_box_kernel(const unsigned char* __r
 
 using namespace ucod;
 
-extern "C" size_t ucod_ccl8_workspace_bytes(int H, int W) { return H > 0 && W > 0 ? (size_t)H * W * 6 * sizeof(int) + 256 : 0; }
+extern "C" size_t ucod_ccl8_workspace_bytes(int H, int W) { return H > 0 && W > 0 ? (size_t)H * W * 7 * sizeof(int) + 256 : 0; }
 
 extern "C" int ucod_ccl8_components(const uint8_t* mask, int H, int W, int32_t* table, int capacity, int32_t* count, void* workspace,
                                     size_t workspace_bytes, void* stream) {

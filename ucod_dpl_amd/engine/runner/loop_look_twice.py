@@ -141,7 +141,7 @@ class ValLoop_Look_Twice(BaseLoop):
         return None
 
     def components_gpu(self, mask_u8_dev):
-        """Device CCL -> host list of (area, x, y, w, h) per component in cv2's label order (raster order of the first pixel)."""
+        """Device CCL -> host list of (area, x, y, w, h) per component in cv2's label order (raster order of the first 2 x 2 block)."""
         Hh, Ww = mask_u8_dev.shape
         lib = N.load()
         need = lib.ucod_ccl8_workspace_bytes(Hh, Ww)
@@ -149,7 +149,7 @@ class ValLoop_Look_Twice(BaseLoop):
             self._ccl_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         cap = 4096
         while True:
-            table = torch.empty(cap, 6, dtype=torch.int32, device=self.device)
+            table = torch.empty(cap, 7, dtype=torch.int32, device=self.device)
             count = torch.zeros(1, dtype=torch.int32, device=self.device)
             N.check(lib.ucod_ccl8_components(N.ptr(mask_u8_dev), Hh, Ww, N.ptr(table), cap, N.ptr(count), N.ptr(self._ccl_ws), self._ccl_ws.numel(),
                                              N.stream()), "ucod_ccl8_components")
@@ -158,7 +158,7 @@ class ValLoop_Look_Twice(BaseLoop):
                 break
             cap = n
         rows = table[:n].cpu().numpy()
-        rows = rows[np.argsort(rows[:, 0], kind="stable")]
+        rows = rows[np.argsort(rows[:, 6], kind="stable")]
         return [(int(r[1]), int(r[2]), int(r[4]), int(r[3] - r[2] + 1), int(r[5] - r[4] + 1)) for r in rows]
 
     def boxes_from_mask_gpu(self, mask_u8_dev):
