@@ -116,6 +116,26 @@ def _nccl_worker(rank, world, port, out):
     loop._process_batch((g["pl0"][rank * 2:rank * 2 + 2], g["features0"][rank * 2:rank * 2 + 2]))
     torch.cuda.synchronize()
     torch.save((runner.arena.g.cpu(), runner.arena.p.cpu()), out + str(rank))
+    # every OTHER collective of the product path, so that one two-rank run (RCCL on a 2-GPU lease, gloo on this box) has exercised them all:
+    # (a) the discriminator phase: all-reduce of the discriminator's gradient arena, fused AdamW on the reduced arena
+    loop._discriminator_batch((g["pl0"][rank * 2:rank * 2 + 2], g["features0"][rank * 2:rank * 2 + 2]))
+    torch.cuda.synchronize()
+    disc = (runner.disc_arena.g.cpu().clone(), runner.disc_arena.p.cpu().clone())
+    # (b) backbone-backward mode: broadcast of the LoRA matrices at attach time, the decoder arena's all-reduce issued BEFORE the backbone
+    #     backward, the LoRA arena's after it, both fused optimisers (TrainLoop._process_batch_full)
+    from ucod_dpl_amd.vit_engine import ViTLoRAEngine
+    from ucod_dpl_amd.data.utils.feature_extractor import random_state_dict, ARCHS
+    ARCHS["mr_vit"] = (384, 6, 2, 14, 70, True)
+    eng = ViTLoRAEngine(random_state_dict("mr_vit", seed=4), heads=6, r=2, lora_alpha=4, device=dev, generator=torch.Generator().manual_seed(100 + rank),
+                        lora_dropout=0.0, seed=5)                # different LoRA init per rank: the broadcast must overwrite rank 1's
+    loop.attach_lora_backbone(eng)
+    gi = torch.Generator().manual_seed(77)
+    images = torch.randn(4, 3, 70, 70, generator=gi)[rank * 2:rank * 2 + 2].to(dev)
+    loss = loop._process_batch_full(images, g["pl0"][rank * 2:rank * 2 + 2])
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    torch.save((disc, (eng.lora_grad.cpu().clone(), eng.lora.cpu().clone(), loop.lora_engine_ema.lora.cpu().clone(), runner.arena.p.cpu().clone())),
+               out + "x" + str(rank))
     torch.distributed.destroy_process_group()
 
 
@@ -129,9 +149,19 @@ def test_two_ranks_over_rccl_match_the_global_batch(tmp_path):
     assert torch.equal(g0, g1) and torch.equal(p0, p1)           # the all-reduce leaves every rank with the same arena -> same step
     runner, _ = build(g)
     _check_against_reference(g0, ref, runner.arena)
+    _check_other_collectives(out)
 
 
 # ------------------------------------------------------------------------------------------------ two ranks on ONE GPU (gloo)
+def _check_other_collectives(out):
+    """Discriminator phase and backbone-backward mode: after the collectives every rank holds the same reduced gradients and the same
+    parameters, and the reduced gradients are not trivially zero."""
+    (d0, l0), (d1, l1) = torch.load(out + "x0"), torch.load(out + "x1")
+    for a, b in zip(d0 + l0, d1 + l1):
+        assert torch.equal(a, b)
+    assert d0[0].abs().max() > 0 and l0[0].abs().max() > 0 and torch.isfinite(l0[1]).all() and torch.isfinite(l0[3]).all()
+
+
 def _gloo_worker(rank, world, port, out):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       UCOD_SINGLE_DEVICE="1", UCOD_DIST_BACKEND="gloo")
@@ -150,6 +180,7 @@ def test_two_ranks_on_one_gpu_over_gloo_match_the_global_batch(tmp_path):
     assert torch.equal(g0, g1) and torch.equal(p0, p1)
     runner, _ = build(g)
     _check_against_reference(g0, ref, runner.arena)
+    _check_other_collectives(out)
 
 
 def test_bench_launches_two_ranks_itself(tmp_path):
