@@ -178,6 +178,9 @@ typedef struct {
 /* y_aug bf16 [rows, D+64] = [ LayerNorm(x) | dropout_q(LN(x)) A_q^T, dropout_k(LN(x)) A_k^T, dropout_v(LN(x)) A_v^T (3r values) | 0 ] */
 int ucod_layernorm_lora(const float* x, const float* gamma, const float* beta, const float* lora_layer, int r, void* y_aug_bf16,
                         int rows, int D, float eps, const ucod_lora_dropout* dropout, void* stream);
+/* the same from an IEEE fp16 residual stream (the no-grad LoRA pass with vit.resid16) */
+int ucod_layernorm_lora_h16(const void* x_f16, const float* gamma, const float* beta, const float* lora_layer, int r, void* y_aug_bf16,
+                            int rows, int D, float eps, const ucod_lora_dropout* dropout, void* stream);
 
 /* LayerNorm backward w.r.t. its input (frozen gamma/beta), fused with the residual add and the next GEMM's A operand:
  * dx f32 [rows,D] = dres (nullable) + dLN(dy; x, gamma);  s bf16 [rows,D] = next_scale (nullable: ones) * dx.
@@ -272,6 +275,12 @@ int ucod_vit_forward_train(const ucod_vit_train_desc* t, const void* const* tabl
                            const float* img, float* key_out, void* workspace, size_t workspace_bytes, void* stream);
 int ucod_vit_backward(const ucod_vit_train_desc* t, const void* const* table_host, const void* const* train_table_host,
                       const float* dkey, void* workspace, size_t workspace_bytes, void* stream);
+/* No-grad pass of the LoRA backbone -- the EMA teacher of models/modules/full_model.py:84,108-111 (backbone_ema under torch.no_grad()):
+ * the arithmetic of ucod_vit_forward_train (LoRA as aug columns, the same dropout masks for the same seed) with nothing saved for a
+ * backward; t->vit.resid16 may be 1 (fp16 residual stream, as ucod_vit_forward).  Own, inference-sized workspace. */
+size_t ucod_vit_lora_infer_workspace_bytes(const ucod_vit_train_desc* t);
+int ucod_vit_forward_lora_infer(const ucod_vit_train_desc* t, const void* const* table_host, const void* const* train_table_host,
+                                const float* img, float* key_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ decoder / APM path (rows A1-A8) */
 

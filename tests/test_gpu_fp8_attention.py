@@ -83,8 +83,10 @@ def test_fp8_attention_matches_f32_softmax_attention(B, N, heads):
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/fp8_attention_measured.jsonl", "a") as f:
         f.write(json.dumps(dict(B=B, N=N, heads=heads, rel_l2=rel, max_abs_over_max=maxdiff(out, ref) / ref.abs().max().item())) + "\n")
-    assert rel < 1e-1, rel
-    assert maxdiff(out, ref) < 0.35 * ref.abs().max().item()
+    # what e4m3 gives on unit-Gaussian q, k, v (measured on MI355X, round 3: relative L2 5.8e-2 .. 7.2e-2, max-abs 6.3e-2 .. 1.16e-1 of the
+    # largest output; the error of a 64-term e4m3 score in the exponent): asserted just above the measured range
+    assert rel < 8.5e-2, rel
+    assert maxdiff(out, ref) < 0.16 * ref.abs().max().item()
     # and close to the bf16 kernel on the same inputs (the two paths differ by the fp8 rounding only)
     qkv = torch.cat((q * C, k, v), -1).reshape(B * N, 3 * D).to(torch.bfloat16).to(DEV)
     bf = ops.attention(qkv, B, N, heads, scale=0.0, variant=2).float().cpu().reshape(B, N, D)

@@ -125,12 +125,12 @@ def _nccl_worker(rank, world, port, out):
     #     backward, the LoRA arena's after it, both fused optimisers (TrainLoop._process_batch_full)
     from ucod_dpl_amd.vit_engine import ViTLoRAEngine
     from ucod_dpl_amd.data.utils.feature_extractor import random_state_dict, ARCHS
-    ARCHS["mr_vit"] = (384, 6, 2, 14, 70, True)
+    ARCHS["mr_vit"] = (384, 6, 2, 14, 126, True)                  # 9 x 9 key map -> 28 x 28 features (the resize adjoint takes up to ~3.5x)
     eng = ViTLoRAEngine(random_state_dict("mr_vit", seed=4), heads=6, r=2, lora_alpha=4, device=dev, generator=torch.Generator().manual_seed(100 + rank),
                         lora_dropout=0.0, seed=5)                # different LoRA init per rank: the broadcast must overwrite rank 1's
     loop.attach_lora_backbone(eng)
     gi = torch.Generator().manual_seed(77)
-    images = torch.randn(4, 3, 70, 70, generator=gi)[rank * 2:rank * 2 + 2].to(dev)
+    images = torch.randn(4, 3, 126, 126, generator=gi)[rank * 2:rank * 2 + 2].to(dev)
     loss = loop._process_batch_full(images, g["pl0"][rank * 2:rank * 2 + 2])
     torch.cuda.synchronize()
     assert torch.isfinite(loss)

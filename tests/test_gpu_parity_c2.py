@@ -107,9 +107,13 @@ def test_c5_fp8_attention_path_full_depth_against_the_oracle(c2):
              bf16_mask_flipped_fraction=float(((fb > 0) != (c2["fg"] > 0)).float().mean()))
     record("c5_fp8_full_depth", m)
     assert bool(torch.isfinite(k8).all())
-    assert m["fp8_key_rel_l2"] < 0.2, m                        # PLACEHOLDER bounds until the first measurement (gpurun_out/parity_c2_measured.jsonl)
-    assert m["fp8_logit_max_abs"] < 0.2, m
-    assert m["fp8_mask_flipped_fraction"] < 5e-2, m
+    # Measured (MI355X, round 3, profiles/r03_parity_measured.jsonl): key relative L2 5.74e-3 against the bf16 engine's 5.55e-3, logit max-abs
+    # 2.95e-3 against 2.99e-3, no mask pixel flipped.  With random-init weights the attention rows are nearly flat (scores of a few
+    # tenths), so the e4m3 rounding of the scores averages out over 1370 keys; a trained checkpoint's peaked rows sit closer to the
+    # kernel-level figure (7 % on unit-Gaussian q, k: tests/test_gpu_fp8_attention.py).  Asserted at 2x the measurement.
+    assert m["fp8_key_rel_l2"] < 1.2e-2, m
+    assert m["fp8_logit_max_abs"] < 6e-3, m
+    assert m["fp8_mask_flipped_fraction"] < 1e-3, m
 
 
 def test_c2_key_map_does_not_depend_on_the_batch(c2):

@@ -271,6 +271,35 @@ def test_forward_train_matches_inference_forward():
     assert maxdiff(k1.cpu(), g["key"]) < 3e-2 * max(1.0, g["key"].abs().max().item())
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.3])
+def test_forward_nograd_is_the_training_forward_without_the_saved_activations(dropout):
+    """ViTLoRAEngine.forward_nograd (ucod_vit_forward_lora_infer: the EMA teacher's pass, models/modules/full_model.py:84,108-111) against
+    forward_train on the same engine state: non-zero LoRA B matrices, the same dropout masks (same seed and step), f32 residual stream ->
+    same arithmetic up to the GEMM tile shapes; fp16 residual stream -> within the bf16 operands' own noise; against the reference's key
+    map (G8, LoRA off) at the inference engine's tolerance."""
+    g = load_golden("g8_dinov2_native")
+    base = sub(g, "sd.")
+    x = g["x"].to(DEV)
+
+    def engine():
+        e = ViTLoRAEngine(base, heads=2, device=DEV, lora_dropout=dropout, seed=11, generator=torch.Generator().manual_seed(3))
+        gen = torch.Generator().manual_seed(4)
+        rD = e.r * e.D
+        for p in range(3):                                        # B matrices away from zero so that the LoRA branch matters
+            e.lora[:, p * 2 * rD + rD:(p + 1) * 2 * rD] = (torch.randn(e.L, rD, generator=gen) * 0.05).to(DEV)
+        e.repack()
+        return e
+
+    k_train = engine().forward_train(x)
+    k_f32 = engine().forward_nograd(x, resid16=False)
+    k_f16 = engine().forward_nograd(x, resid16=True)
+    assert k_f32.shape == k_train.shape and bool(torch.isfinite(k_f16).all())
+    assert rel_l2(k_f32, k_train) < 2e-3, rel_l2(k_f32, k_train)
+    assert rel_l2(k_f16, k_train) < 4e-3, rel_l2(k_f16, k_train)
+    e0 = ViTLoRAEngine(base, heads=2, device=DEV)                 # B = 0: the LoRA branch vanishes -> the reference's key map
+    assert maxdiff(e0.forward_nograd(x).cpu(), g["key"]) < 3e-2 * max(1.0, g["key"].abs().max().item())
+
+
 def test_medium_model_lora_gradients_vs_oracle_autograd():
     """D=256, 4 heads, 4 layers, 9x9 patches (82 tokens), batch 3: HIP passes vs oracle/vit.py + torch autograd (CPU, f32)."""
     from transformers import Dinov2Config, Dinov2Model

@@ -65,6 +65,26 @@ __device__ __forceinline__ bf16x8 tr_take(TrFrag& f) {
   return (bf16x8){f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
 }
 
+// Row-per-lane epilogue: lanes l and l+32 hold adjacent 4-column groups of one output row (columns 8g + 4*h5 .. +3 of each 8-column
+// group g); one v_permlane32_swap per register pair leaves lanes 0..31 with columns 8g .. 8g+7 and lanes 32..63 with 8(g+1) .. 8(g+1)+7:
+// one 16-byte store instead of two 8-byte ones (the store tail of such kernels is issue-bound per instruction).  `off` = byte offset of
+// the row's 64-column head block + 16 * h5 (rows that must not be written: an offset past the buffer), `scale` applied before rounding.
+__device__ __forceinline__ void store_rows64(const f32x16 (&acc)[2], float scale, __amdgpu_buffer_rsrc_t rs, unsigned off) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      const int g = 2 * gp;
+      const unsigned a0 = pack_bf16x2(acc[dt][4 * g + 0] * scale, acc[dt][4 * g + 1] * scale), a1 = pack_bf16x2(acc[dt][4 * g + 2] * scale, acc[dt][4 * g + 3] * scale);
+      const unsigned b0 = pack_bf16x2(acc[dt][4 * g + 4] * scale, acc[dt][4 * g + 5] * scale), b1 = pack_bf16x2(acc[dt][4 * g + 6] * scale, acc[dt][4 * g + 7] * scale);
+      const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+      const u32x4 w = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+      __builtin_amdgcn_raw_buffer_store_b128(w, rs, off + (unsigned)(dt * 32 + 16 * gp) * 2u, 0, 0);
+    }
+}
+constexpr unsigned ROW_DROPPED = 0x80000000u;          // (+ the per-store constants stays beyond any buffer of < 2 GiB; 0xFFFFFFF0 would wrap)
+
 struct Map {            // XCD-aware 1-D grid -> (image, head, row block): all blocks of one (image, head) on one XCD
   int b, head, blk;
   bool ok;
@@ -107,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_raw* __r
   if (!mp.ok) return;
   const int D = heads * HD, ld = 3 * D;
   const int q0 = mp.blk * WT + wave * 32;
+  const bool live = q0 < N;                              // (wave-uniform) a wave whose 32 queries all lie past the last token only stages and keeps the barriers
   const bf16_raw* base = qkv + (size_t)mp.b * N * ld + mp.head * HD;
   const int q = q0 + l31, qc = q < N ? q : N - 1;
 
@@ -177,9 +198,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_raw* __r
     constexpr bool TAIL = decltype(tailc)::value != 0;
     dma_landed_barrier();                                  // this wave's LDS-DMA pieces of tile t, then everyone's
     if (t + 1 < nt) stage(IntC<BUF ^ 1>{});
+    if (!live) return;
     const char* kb = smem + BUF * STAGE;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
+      if (TAIL && kt == 1 && t * ST + 32 >= N) break;      // (wave-uniform, last tile only) no real key in the second 32-key block: P = 0 there
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = -L; dp[i] = -dl; }
@@ -225,18 +248,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_raw* __r
       tile(t, IntC<0>{}, IntC<1>{});
     }
   }
-  if (q < N) {
-    bf16_raw* op = dqkv + ((size_t)mp.b * N + q) * ldd + mp.head * HD + 4 * h5;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 w;
-        w[0] = pack_bf16x2(acc[dt][4 * g + 0] * qscale, acc[dt][4 * g + 1] * qscale);
-        w[1] = pack_bf16x2(acc[dt][4 * g + 2] * qscale, acc[dt][4 * g + 3] * qscale);
-        *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
-      }
-  }
+  if (!live) return;
+  const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(dqkv + (size_t)mp.b * N * ldd, 0, (unsigned)N * (unsigned)ldd * 2u, 0x00020000);
+  store_rows64(acc, qscale, rs_o, q < N ? ((unsigned)q * (unsigned)ldd + (unsigned)(mp.head * HD + 8 * h5)) * 2u : ROW_DROPPED);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -257,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_raw* __
   if (!mp.ok) return;
   const int D = heads * HD, ld = 3 * D;
   const int k0 = mp.blk * WT + wave * 32;
+  const bool live = k0 < N;                              // (wave-uniform) see the dQ kernel
   const bf16_raw* base = qkv + (size_t)mp.b * N * ld + mp.head * HD;
   const int key = k0 + l31, kc = key < N ? key : N - 1;
 
@@ -325,13 +340,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_raw* __
     }
   }
 
-  auto tile = [&](int t, auto bufc) {
+  // LAST (compile time): the last query tile, whose second 32-query block may lie entirely past the last token -- its Q', dO, L and delta
+  // are all zero there, so it contributes nothing and is skipped; the main-loop body carries no test for it.
+  auto tile = [&](int t, auto bufc, auto lastc) {
     constexpr int BUF = decltype(bufc)::value;
+    constexpr bool LAST = decltype(lastc)::value != 0;
     dma_landed_barrier();                                  // this wave's LDS-DMA pieces of tile t, then everyone's
-    if (t + 1 < nt) stage(IntC<BUF ^ 1>{});
+    if (!LAST) stage(IntC<BUF ^ 1>{});
+    if (!live) return;
     const char* sb = smem + BUF * STAGE;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
+      if (LAST && qt == 1 && t * ST + 32 >= N) break;      // (wave-uniform)
       // accumulator rows r <-> query qt*32 + 4*h5 + (r&3) + 8*(r>>2): initial values L[q], delta[q] (four float4 each)
       f32x16 s, dp;
 #pragma unroll
@@ -367,26 +387,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_raw* __
     }
   };
   stage(IntC<0>{});
-  for (int t = 0; t < nt; t += 2) {
-    tile(t, IntC<0>{});
-    if (t + 1 < nt) tile(t + 1, IntC<1>{});
+  {
+    const int nmain = nt - 1;
+    for (int t = 0; t < nmain; t += 2) {
+      tile(t, IntC<0>{}, IntC<0>{});
+      if (t + 1 < nmain) tile(t + 1, IntC<1>{}, IntC<0>{});
+    }
+    if (nmain & 1) tile(nmain, IntC<1>{}, IntC<1>{});
+    else tile(nmain, IntC<0>{}, IntC<1>{});
   }
-  if (key < N) {
-    bf16_raw* op = dqkv + ((size_t)mp.b * N + key) * ldd + D + mp.head * HD + 4 * h5;
-    constexpr float NLN2 = -0.69314718055994531f;                        // dk holds -dS^T Q'
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 w;
-        w[0] = pack_bf16x2(dk[dt][4 * g + 0] * NLN2, dk[dt][4 * g + 1] * NLN2);
-        w[1] = pack_bf16x2(dk[dt][4 * g + 2] * NLN2, dk[dt][4 * g + 3] * NLN2);
-        *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * g) = w;
-        w[0] = pack_bf16x2(dv[dt][4 * g + 0], dv[dt][4 * g + 1]);
-        w[1] = pack_bf16x2(dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
-        *reinterpret_cast<u32x2*>(op + D + dt * 32 + 8 * g) = w;
-      }
-  }
+  if (!live) return;
+  constexpr float NLN2 = -0.69314718055994531f;                          // dk holds -dS^T Q'
+  const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(dqkv + (size_t)mp.b * N * ldd, 0, (unsigned)N * (unsigned)ldd * 2u, 0x00020000);
+  const unsigned off = key < N ? ((unsigned)key * (unsigned)ldd + (unsigned)(D + mp.head * HD + 8 * h5)) * 2u : ROW_DROPPED;
+  store_rows64(dk, NLN2, rs_o, off);
+  store_rows64(dv, 1.f, rs_o, off + (unsigned)D * 2u);
 }
 #undef LDS_DMA16
 
@@ -396,8 +411,9 @@ extern "C" int ucod_attention_bwd(const void* qkv, const void* out, const void* 
                                   int ld_dqkv, int B, int tok, int heads, void* stream) {
   UCOD_BF16_ONLY();
   using namespace ucod;
-  if (!qkv || !out || !dout || !lse || !delta || !dqkv || B <= 0 || tok <= 0 || heads <= 0 || ld_dqkv < 3 * heads * HD || (ld_dqkv & 3))
+  if (!qkv || !out || !dout || !lse || !delta || !dqkv || B <= 0 || tok <= 0 || heads <= 0 || ld_dqkv < 3 * heads * HD || (ld_dqkv & 7))
     return UCOD_EINVAL;
+  if ((size_t)tok * ld_dqkv * 2 >= (1ull << 31)) return UCOD_EINVAL;     // per-image output rows are addressed with 32-bit byte offsets (16-byte stores)
   UCOD_PROF(PROF_ATTN_BWD, stream);
   const int npairs = B * heads, nb = cdiv(tok, WT);
   dim3 grid(cdiv(npairs, 8) * 8 * nb), block(256);

@@ -166,6 +166,12 @@ struct MixCfg {
   static_assert(NI % NPH == 0, "whole phases");
 };
 
+#ifndef UCOD_GEMM_EARLY_A
+#define UCOD_GEMM_EARLY_A 1
+#endif
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <int EPI, int NT, int XT, int AUX>
 __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0, int n0, int wave, int lane) {
   using Cfg = MixCfg<NT, XT>;
@@ -216,8 +222,22 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
   stageA(0, 0);
   stageA(0, 1);
   stageB(0);
-  if (nt > 1) stageB(1);
-  if (nt > 1) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
+  // EARLY_A: the A tiles of K-tile 1 are requested here too (buffer 1 is idle until K-tile 1), not during K-tile 0.  At K = 768 a tile is
+  // only 12 K-tiles long and every workgroup of a round starts at the same moment: requested one K-tile (~1.2 us) ahead, the first A
+  // panels arrive late behind that synchronised burst and the loop stalls at K-tile 1; requested here they have the whole prologue wait
+  // and K-tile 0 to land.  The counted wait below leaves all of K-tile 1's requests in flight.
+  constexpr bool EARLY_A = UCOD_GEMM_EARLY_A != 0;
+  if (nt > 1) {
+    if constexpr (EARLY_A) { stageA(1, 0); stageA(1, 1); }
+    stageB(1);
+    if constexpr (EARLY_A) {
+      if (XT == 1 && wave < 2) wait_vmcnt_n<Cfg::NB + 6>(); else wait_vmcnt_n<Cfg::NB + 4>();   // (waves 0 / 1 of a tall tile issue one more piece per A slot)
+    } else {
+      wait_vmcnt<Cfg::NB>();
+    }
+  } else {
+    wait_vmcnt<0>();
+  }
   finish_col_consts<EPI, NT>(a, cb, cs);
   f32x4 acc[NI][NT];
 #pragma unroll
@@ -231,15 +251,16 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
     const char* bufA = smem + (t & 1) * Cfg::BUF + wm * Cfg::SLOT;
     const char* bufB = smem + (t & 1) * Cfg::BUF + 2 * Cfg::SLOT;
     const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+    const bool stage_a = more1 && (!EARLY_A || t > 0);   // K-tile 1's A tiles were requested in the prologue
     hx8 fb[NT][2];
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
       if constexpr (NPH == 2) {
-        if (ph == 0 && more1) { stageA(t + 1, 0); stageA(t + 1, 1); }
+        if (ph == 0 && stage_a) { stageA(t + 1, 0); stageA(t + 1, 1); }
         if (ph == 1 && more2) stageB(t + 2);
       } else {
-        if (ph == 0 && more1) stageA(t + 1, 0);
-        if (ph == 1 && more1) stageA(t + 1, 1);
+        if (ph == 0 && stage_a) stageA(t + 1, 0);
+        if (ph == 1 && stage_a) stageA(t + 1, 1);
         if (ph == 2 && more2) stageB(t + 2);
       }
       if (ph == 0) {

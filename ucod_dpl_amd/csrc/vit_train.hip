@@ -57,8 +57,9 @@ static Drop make_drop(const ucod_lora_dropout* dd) {
 // ---------------------------------------------------------------------------------------------------------------------
 // LayerNorm forward + LoRA down-projection.  One wave per row, D = 128*NCH, row in registers (as layernorm_kernel).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NCH>
-__global__ __launch_bounds__(256) void ln_lora_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+// XH16: the residual stream is IEEE fp16 (the no-grad pass of the EMA teacher, ucod_vit_forward_lora_infer with resid16) instead of f32
+template <int NCH, bool XH16 = false>
+__global__ __launch_bounds__(256) void ln_lora_kernel(const void* __restrict__ x_, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ lora,
                                                       int r, bf16_raw* __restrict__ y, int rows, int D, float eps, Drop drop) {
   // the 3r LoRA A rows live in LDS for the whole block (they were re-read from L2 for every row: 92 us against 33 us for the plain
@@ -78,9 +79,15 @@ __global__ __launch_bounds__(256) void ln_lora_kernel(const float* __restrict__ 
 #pragma unroll
     for (int q = 0; q < R; ++q) {
       const int row = (row0 + q) < rows ? (row0 + q) : rows - 1;
-      const float2* xr = reinterpret_cast<const float2*>(x + (size_t)row * D);
+      if constexpr (XH16) {
+        const unsigned* xr = reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(x_) + (size_t)row * D);
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) v[q][i] = xr[lane + 64 * i];
+        for (int i = 0; i < NCH; ++i) unpack_f16x2(xr[lane + 64 * i], v[q][i].x, v[q][i].y);
+      } else {
+        const float2* xr = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(x_) + (size_t)row * D);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) v[q][i] = xr[lane + 64 * i];
+      }
     }
 #pragma unroll
     for (int q = 0; q < R; ++q) {
@@ -452,9 +459,8 @@ constexpr int LORA_GRAD_BLOCKS = 512;
 
 using namespace ucod;
 
-extern "C" int ucod_layernorm_lora(const float* x, const float* gamma, const float* beta, const float* lora, int r, void* y_aug, int rows,
-                                   int D, float eps, const ucod_lora_dropout* dropout, void* stream) {
-  UCOD_BF16_ONLY();
+static int launch_ln_lora(const void* x, bool x_h16, const float* gamma, const float* beta, const float* lora, int r, void* y_aug, int rows, int D, float eps,
+                          const ucod_lora_dropout* dropout, void* stream) {
   if (!x || !gamma || !beta || !lora || !y_aug || rows <= 0 || D <= 0 || (D % 128) != 0 || r < 1 || 3 * r > AUG) return UCOD_EINVAL;
   if (dropout && (dropout->p < 0.f || dropout->p >= 1.f)) return UCOD_EINVAL;
   UCOD_PROF(PROF_LN, stream);
@@ -464,13 +470,29 @@ extern "C" int ucod_layernorm_lora(const float* x, const float* gamma, const flo
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)3 * r * D * sizeof(float);
   switch (D / 128) {
-#define C(n) case n: hipLaunchKernelGGL((ln_lora_kernel<n>), grid, block, lds, s, x, gamma, beta, lora, r, (bf16_raw*)y_aug, rows, D, eps, drop); break;
+#define C(n)                                                                                                                                         \
+  case n:                                                                                                                                            \
+    if (x_h16) hipLaunchKernelGGL((ln_lora_kernel<n, true>), grid, block, lds, s, x, gamma, beta, lora, r, (bf16_raw*)y_aug, rows, D, eps, drop);      \
+    else hipLaunchKernelGGL((ln_lora_kernel<n, false>), grid, block, lds, s, x, gamma, beta, lora, r, (bf16_raw*)y_aug, rows, D, eps, drop);           \
+    break;
     C(1) C(2) C(3) C(4) C(5) C(6) C(8) C(10) C(12)
 #undef C
     default: return UCOD_EINVAL;
   }
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
+}
+
+extern "C" int ucod_layernorm_lora(const float* x, const float* gamma, const float* beta, const float* lora, int r, void* y_aug, int rows,
+                                   int D, float eps, const ucod_lora_dropout* dropout, void* stream) {
+  UCOD_BF16_ONLY();
+  return launch_ln_lora(x, false, gamma, beta, lora, r, y_aug, rows, D, eps, dropout, stream);
+}
+
+extern "C" int ucod_layernorm_lora_h16(const void* x_f16, const float* gamma, const float* beta, const float* lora, int r, void* y_aug, int rows,
+                                       int D, float eps, const ucod_lora_dropout* dropout, void* stream) {
+  UCOD_BF16_ONLY();
+  return launch_ln_lora(x_f16, true, gamma, beta, lora, r, y_aug, rows, D, eps, dropout, stream);
 }
 
 static int launch_ln_bwd(const float* dy, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx, void* s_bf16,

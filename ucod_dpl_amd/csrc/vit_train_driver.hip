@@ -129,6 +129,95 @@ extern "C" int ucod_vit_forward_train(const ucod_vit_train_desc* t, const void* 
   return UCOD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// No-grad pass of the LoRA backbone: what the EMA teacher of models/modules/full_model.py:84,108-111 runs (backbone_ema under
+// torch.no_grad()).  Same arithmetic as ucod_vit_forward_train -- LoRA as 64 extra K columns of the QKV / key GEMMs, dropout masks
+// from the same counter hash -- but nothing is saved: one residual buffer updated in place, plain GELU epilogue, no log-sum-exp, and
+// the residual stream may be IEEE fp16 (vit.resid16) like the frozen-backbone pass.  Workspace ~ the inference pass's.
+namespace {
+struct IPlan {
+  size_t x, h_aug, h2, qkv, a, g, patch, qscale, total;
+  int M, tok;
+};
+bool valid_infer(const ucod_vit_train_desc* t) {
+  if (!t) return false;
+  const ucod_vit_desc* d = &t->vit;
+  return d->B > 0 && d->C > 0 && d->P > 0 && d->H > 0 && d->W > 0 && d->H % d->P == 0 && d->W % d->P == 0 && d->D > 0 && d->heads > 0 &&
+         d->D == d->heads * 64 && d->D % 128 == 0 && d->F % 128 == 0 && d->L >= 1 && d->Kpad % 64 == 0 && d->Kpad >= d->C * d->P * d->P &&
+         t->lora_r >= 1 && 3 * t->lora_r <= UCOD_LORA_AUG && t->lora_dropout >= 0.f && t->lora_dropout < 1.f && (d->resid16 == 0 || d->resid16 == 1);
+}
+IPlan make_iplan(const ucod_vit_train_desc* t) {
+  const ucod_vit_desc* d = &t->vit;
+  IPlan p;
+  const int gh = d->H / d->P, gw = d->W / d->P;
+  p.tok = gh * gw + 1;
+  p.M = d->B * p.tok;
+  const size_t M = p.M, D = d->D, F = d->F;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += up(bytes); return r; };
+  p.x = take(M * D * (d->resid16 ? 2 : 4));
+  p.h_aug = take(M * (D + UCOD_LORA_AUG) * 2);
+  p.h2 = take(M * D * 2);
+  p.qkv = take(M * 3 * D * 2);
+  p.a = take(M * D * 2);
+  p.g = take(M * F * 2);
+  p.patch = take((size_t)d->B * gh * gw * d->Kpad * 2);
+  p.qscale = take(3 * D * 4);
+  p.total = o;
+  return p;
+}
+}  // namespace
+
+extern "C" size_t ucod_vit_lora_infer_workspace_bytes(const ucod_vit_train_desc* t) { return valid_infer(t) ? make_iplan(t).total : 0; }
+
+extern "C" int ucod_vit_forward_lora_infer(const ucod_vit_train_desc* t, const void* const* T, const void* const* TT, const float* img,
+                                           float* key_out, void* workspace, size_t workspace_bytes, void* stream) {
+  UCOD_BF16_ONLY();
+  if (!valid_infer(t) || !T || !TT || !img || !key_out || !workspace) return UCOD_EINVAL;
+  const ucod_vit_desc* d = &t->vit;
+  const IPlan p = make_iplan(t);
+  if (workspace_bytes < p.total) return UCOD_ENOMEM;
+  char* ws = (char*)workspace;
+  const int M = p.M, tok = p.tok, D = d->D, F = d->F, gv = d->gemm_variant, KA = D + UCOD_LORA_AUG;
+  const bool r16 = d->resid16 != 0;
+  float* x = (float*)(ws + p.x);
+  void* h_aug = ws + p.h_aug;
+  void* h2 = ws + p.h2;
+  void* qkv = ws + p.qkv;
+  void* a = ws + p.a;
+  void* g = ws + p.g;
+  void* patches = ws + p.patch;
+  float* qscale = (float*)(ws + p.qscale);
+  const int epi_patch = r16 ? UCOD_EPI_PATCH_TOKENS_H16 : UCOD_EPI_PATCH_TOKENS_F32;
+  const int epi_resid = r16 ? UCOD_EPI_BIAS_SCALE_RESID_H16 : UCOD_EPI_BIAS_SCALE_RESID_F32;
+  RUN(ucod_fill_qscale(qscale, D, 0.125f * 1.4426950408889634f, stream));
+  RUN(ucod_patch_im2col(img, patches, d->B, d->C, d->H, d->W, d->P, d->Kpad, stream));
+  RUN(ucod_gemm_bf16(epi_patch, patches, T[0], x, d->B * (tok - 1), D, d->Kpad, (const float*)T[1], nullptr, nullptr, (const float*)T[3], tok, gv, stream));
+  if (r16) RUN(ucod_cls_rows_h16(x, (const float*)T[2], (const float*)T[3], d->B, tok, D, stream));
+  else RUN(ucod_cls_rows(x, (const float*)T[2], (const float*)T[3], d->B, tok, D, stream));
+  for (int l = 0; l < d->L; ++l) {
+    const void* const* W = T + 4 + UCOD_VIT_LAYER_STRIDE * l;
+    const void* const* X = TT + UCOD_VIT_TRAIN_STRIDE * l;
+    const ucod_lora_dropout drop{t->lora_dropout, t->seed, l};
+    const ucod_lora_dropout* dp = t->lora_dropout > 0.f ? &drop : nullptr;
+    if (r16) RUN(ucod_layernorm_lora_h16(x, (const float*)W[0], (const float*)W[1], (const float*)X[5], t->lora_r, h_aug, M, D, d->eps, dp, stream));
+    else RUN(ucod_layernorm_lora(x, (const float*)W[0], (const float*)W[1], (const float*)X[5], t->lora_r, h_aug, M, D, d->eps, dp, stream));
+    if (l == d->L - 1) {
+      const char* wk = (const char*)X[0] + (size_t)D * KA * 2;
+      RUN(ucod_gemm_bf16(UCOD_EPI_KEY_NCHW_F32, wk, h_aug, key_out, D, M, KA, (const float*)W[3] + D, nullptr, nullptr, nullptr, tok, gv, stream));
+      break;
+    }
+    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_BF16, h_aug, X[0], qkv, M, 3 * D, KA, (const float*)W[3], qscale, nullptr, nullptr, tok, gv, stream));
+    RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, 0.f, 0, stream));
+    RUN(ucod_gemm_bf16(epi_resid, a, W[4], x, M, D, D, (const float*)W[5], (const float*)W[6], x, nullptr, tok, gv, stream));
+    if (r16) RUN(ucod_layernorm_h16(x, (const float*)W[7], (const float*)W[8], h2, M, D, d->eps, stream));
+    else RUN(ucod_layernorm(x, (const float*)W[7], (const float*)W[8], h2, M, D, d->eps, 0, stream));
+    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_GELU_BF16, h2, W[9], g, M, F, D, (const float*)W[10], nullptr, nullptr, nullptr, tok, gv, stream));
+    RUN(ucod_gemm_bf16(epi_resid, g, W[11], x, M, D, F, (const float*)W[12], (const float*)W[13], x, nullptr, tok, gv, stream));
+  }
+  return UCOD_OK;
+}
+
 extern "C" int ucod_vit_backward(const ucod_vit_train_desc* t, const void* const* T, const void* const* TT, const float* dkey,
                                  void* workspace, size_t workspace_bytes, void* stream) {
   UCOD_BF16_ONLY();

@@ -309,7 +309,7 @@ class TrainLoop(BaseLoop):
         tstream.wait_event(ev0)
         images.record_stream(tstream)
         with torch.cuda.stream(tstream):
-            feat_t = eng_t.forward_train(images)
+            feat_t = eng_t.forward_nograd(images)                               # EMA teacher: no backward -> nothing saved, fp16 residual stream
             ev1 = torch.cuda.Event()
             ev1.record(tstream)
         feat_s = eng.forward_train(images)                                   # [B,C,h,w]; activations kept for backward

@@ -80,8 +80,11 @@ SIGNATURES = {
     "ucod_vit_train_workspace_bytes": (sz, [C.POINTER(VitTrainDesc)]),
     "ucod_vit_forward_train": (ci, [C.POINTER(VitTrainDesc), C.POINTER(vp), C.POINTER(vp), vp, vp, vp, sz, vp]),
     "ucod_vit_backward": (ci, [C.POINTER(VitTrainDesc), C.POINTER(vp), C.POINTER(vp), vp, vp, sz, vp]),
+    "ucod_vit_lora_infer_workspace_bytes": (sz, [C.POINTER(VitTrainDesc)]),
+    "ucod_vit_forward_lora_infer": (ci, [C.POINTER(VitTrainDesc), C.POINTER(vp), C.POINTER(vp), vp, vp, vp, sz, vp]),
     "ucod_gemm_bf16_train": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, ci, vp]),
     "ucod_layernorm_lora": (ci, [vp, vp, vp, vp, ci, vp, ci, ci, cf, C.POINTER(LoraDropout), vp]),
+    "ucod_layernorm_lora_h16": (ci, [vp, vp, vp, vp, ci, vp, ci, ci, cf, C.POINTER(LoraDropout), vp]),
     "ucod_layernorm_bwd_lora": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp, vp, ci, C.POINTER(LoraDropout), vp]),
     "ucod_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp]),
     "ucod_attention_fwd_lse": (ci, [vp, vp, vp, ci, ci, ci, vp]),

@@ -499,6 +499,42 @@ class ViTLoRAEngine(ViTEngine):
         self._saved_for = (B, H, W)
         return key
 
+    def forward_nograd(self, img, out=None, resid16=True):
+        """The pass of a LoRA backbone that needs no backward -- the EMA teacher (models/modules/full_model.py:84,108-111: backbone_ema under
+        torch.no_grad()): same arithmetic as ``forward_train`` (LoRA aug columns, dropout masks of this engine's own seed stream when in
+        train mode) with nothing saved, an inference-sized workspace and, by default, the fp16 residual stream of the frozen-backbone pass
+        (bf16 operands: the stream's rounding is 8x finer than theirs).  Image-parallel chunks on the training side streams."""
+        if not img.is_cuda:
+            raise RuntimeError("ViTLoRAEngine needs a CUDA(ROCm) tensor; there is no CPU path")
+        img = img.to(torch.float32).contiguous()
+        B, _, H, W = img.shape
+        gh, gw = H // self.P, W // self.P
+        lib = N.load()
+        key = out if out is not None else torch.empty(B, self.D, gh, gw, dtype=torch.float32, device=self.device)
+        self._bounds = self._chunks(B)
+        self._step += 1
+        self._step_seed = (self._seed * 0x9E3779B97F4A7C15 + self._step) & 0xFFFFFFFFFFFFFFFF
+        if int(self._drop_p() > 0.0) != getattr(self, "_packed_zero_a", 0):
+            self.repack()
+        if getattr(self, "_iside_ws", None) is None or len(self._iside_ws) != len(self._tside):
+            self._iside_ws = [None] * len(self._tside)
+
+        def run(i, b0, b1):
+            t = self._train_desc(b1 - b0, H, W)
+            t.vit.resid16 = int(bool(resid16))
+            t.seed = (self._step_seed + 0x51ED270B * (i + 1) * int(b0 > 0)) & 0xFFFFFFFFFFFFFFFF
+            need = lib.ucod_vit_lora_infer_workspace_bytes(C.byref(t))
+            if need == 0:
+                raise ValueError("unsupported ViT geometry")
+            if self._iside_ws[i] is None or self._iside_ws[i].numel() < need:
+                self._iside_ws[i] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            T, TT, keep = self._tables(gh, gw, self._tside_grad[i])
+            N.check(lib.ucod_vit_forward_lora_infer(C.byref(t), T, TT, N.ptr(img[b0:b1]), N.ptr(key[b0:b1]), N.ptr(self._iside_ws[i]),
+                                                    self._iside_ws[i].numel(), N.stream()), "ucod_vit_forward_lora_infer")
+
+        self._fan_out(run, (img, key))
+        return key
+
     def backward(self, dkey):
         """dkey [B, D, H/P, W/P] -> self.lora_grad (overwritten), returned as the flat [L, 6*r*D] tensor."""
         if self._saved_for is None:
