@@ -236,18 +236,7 @@ __device__ __forceinline__ float xhalf_max(float v) {
 // Epilogue: lanes l and l+32 hold adjacent 4-column groups of one output row; one v_permlane32_swap per register pair turns two
 // 8-byte stores at a 1.5 KB row stride into one 16-byte store (the store tail of such kernels is issue-bound per instruction).
 // =====================================================================================================
-enum TileKind { TILE_MAIN = 0, TILE_LAST = 1 };
-// FORM (how the last, partial tile is handled; measured forms, tools/attn_ab.py, profiles/r03_attention_forms.txt):
-//   1  one tile body, key mask behind a run-time test of the tile index (the round-2 kernel + dead-wave skip + wide stores)
-//   2  as 1, and the last tile's second 32-key block is skipped when it holds no real key (a wave-uniform break between the blocks)
-//   3  the last tile has its own body (mask + block skip), the main-loop body has neither
-//   4  as 3 at four waves per SIMD by __launch_bounds__
-#ifndef UCOD_ATTN_FORM
-#define UCOD_ATTN_FORM 2
-#endif
-
-template <int FORM>
-__global__ __launch_bounds__(256, FORM == 4 ? 4 : 2) void attn_fwd_v5_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N, int heads,
+__global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N, int heads,
                                                               int npairs, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_BYTES];       // [buffer][K | V]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -316,11 +305,10 @@ __global__ __launch_bounds__(256, FORM == 4 ? 4 : 2) void attn_fwd_v5_kernel(con
   const int nt = (N + KT - 1) / KT, nfull = nt - 1;
   const bool half_dead = nfull * KT + 32 >= N;           // (uniform) the keys of the last tile's second 32-key block all lie past the last token
 
-  auto tile = [&](int t, auto bufc, auto kindc) {
+  auto tile = [&](int t, auto bufc) {
     constexpr int BUF = decltype(bufc)::value;
-    constexpr int KIND = decltype(kindc)::value;
     dma_landed_barrier();                                // this wave's DMAs of tile t have landed; everyone is done reading tile t-1
-    if (FORM >= 3 ? KIND == TILE_MAIN : t + 1 < nt) stage(IntC<BUF ^ 1>{});
+    if (t + 1 < nt) stage(IntC<BUF ^ 1>{});
     if (!live) return;                                   // (wave-uniform) nothing to compute for rows past the last token
     const char* kb = smem + BUF * (2 * KV_BYTES);
 
@@ -328,7 +316,7 @@ __global__ __launch_bounds__(256, FORM == 4 ? 4 : 2) void attn_fwd_v5_kernel(con
     const float neg_m = -m_run;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      if (FORM >= 2 && (FORM >= 3 ? KIND == TILE_LAST : t == nfull) && kt == 1 && half_dead) break;   // (wave-uniform; last tile only) no real key in the second 32-key block
+      if (t == nfull && kt == 1 && half_dead) break;     // (wave-uniform; last tile only) no real key in the second 32-key block
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[kt][i] = neg_m;
 #pragma unroll
@@ -337,7 +325,7 @@ __global__ __launch_bounds__(256, FORM == 4 ? 4 : 2) void attn_fwd_v5_kernel(con
         s[kt] = UCOD_MFMA32(kf, qf[sd], s[kt]);
       }
     }
-    if (FORM >= 3 ? KIND != TILE_MAIN : (t == nfull && (N & (KT - 1)) != 0)) {
+    if (t == nfull && (N & (KT - 1)) != 0) {
       const int kbase = t * KT + 4 * h5;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
@@ -349,7 +337,7 @@ __global__ __launch_bounds__(256, FORM == 4 ? 4 : 2) void attn_fwd_v5_kernel(con
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      if (FORM >= 2 && (FORM >= 3 ? KIND == TILE_LAST : t == nfull) && kt == 1 && half_dead) break;
+      if (t == nfull && kt == 1 && half_dead) break;
       // v_maximum3_f32 (IEEE maximum: no operand canonicalisation), two scores per instruction.  The lane's 16 keys are enough
       // for the wave-wide "does any score run away" test; the other half's keys are fetched only when the rescale fires.
       float mloc = __builtin_elementwise_maximum(s[kt][0], s[kt][1]);
@@ -395,20 +383,11 @@ __global__ __launch_bounds__(256, FORM == 4 ? 4 : 2) void attn_fwd_v5_kernel(con
     }
   };
 
-  // tiles 0 .. nt-2 through the main body (two per iteration: compile-time LDS buffer), then the last tile through the masked body
+  // two tiles per iteration: the LDS buffer index is a compile-time constant
   stage(IntC<0>{});
-  if constexpr (FORM >= 3) {
-    for (int t = 0; t < nfull; t += 2) {
-      tile(t, IntC<0>{}, IntC<TILE_MAIN>{});
-      if (t + 1 < nfull) tile(t + 1, IntC<1>{}, IntC<TILE_MAIN>{});
-    }
-    if (nfull & 1) tile(nfull, IntC<1>{}, IntC<TILE_LAST>{});
-    else tile(nfull, IntC<0>{}, IntC<TILE_LAST>{});
-  } else {
-    for (int t = 0; t < nt; t += 2) {
-      tile(t, IntC<0>{}, IntC<TILE_MAIN>{});
-      if (t + 1 < nt) tile(t + 1, IntC<1>{}, IntC<TILE_MAIN>{});
-    }
+  for (int t = 0; t < nt; t += 2) {
+    tile(t, IntC<0>{});
+    if (t + 1 < nt) tile(t + 1, IntC<1>{});
   }
   if (!live) return;
 
@@ -617,25 +596,12 @@ __global__ __launch_bounds__(256, 2) void attn_cross96_kernel(const bf16_raw* __
 extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, int heads, float scale, int variant, void* stream) {
   using namespace ucod;
   if (!qkv || !out || B <= 0 || tok <= 0 || heads <= 0) return UCOD_EINVAL;
-#ifdef UCOD_ATTN_LAB_FORMS
-  if (scale == 0.f && variant >= 21 && variant <= 24) {     // experiment build (make variant FILE=attention DEFS=-DUCOD_ATTN_LAB_FORMS): every form in one library
-    const int npairs = B * heads, nq = cdiv(tok, QT);
-    dim3 g1(cdiv(npairs, 8) * 8 * nq), blk(256);
-    UCOD_PROF(PROF_ATTN, stream);
-    if (variant == 21) hipLaunchKernelGGL(attn_fwd_v5_kernel<1>, g1, blk, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
-    if (variant == 22) hipLaunchKernelGGL(attn_fwd_v5_kernel<2>, g1, blk, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
-    if (variant == 23) hipLaunchKernelGGL(attn_fwd_v5_kernel<3>, g1, blk, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
-    if (variant == 24) hipLaunchKernelGGL(attn_fwd_v5_kernel<4>, g1, blk, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
-    UCOD_CHECK_LAUNCH();
-    return UCOD_OK;
-  }
-#endif
   if (variant != 0 && variant != 2) return UCOD_EINVAL;
   if ((size_t)tok * heads * HD * 3 * 2 >= (1ull << 32)) return UCOD_EINVAL;       // per-image qkv rows are addressed with 32-bit byte offsets
   UCOD_PROF(PROF_ATTN, stream);
   if (scale == 0.f) {   // Q pre-scaled by head_dim^-0.5 * log2(e)
     const int npairs = B * heads, nq = cdiv(tok, QT);
-    hipLaunchKernelGGL(attn_fwd_v5_kernel<UCOD_ATTN_FORM>, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads,
+    hipLaunchKernelGGL(attn_fwd_v5_kernel, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads,
                        npairs, (float*)nullptr);
   } else {
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(tok, QT), heads, B), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads,
@@ -663,7 +629,7 @@ extern "C" int ucod_attention_fwd_lse(const void* qkv, void* out, float* lse, in
   if ((size_t)tok * heads * HD * 3 * 2 >= (1ull << 32)) return UCOD_EINVAL;
   UCOD_PROF(PROF_ATTN, stream);
   const int npairs = B * heads, nq = cdiv(tok, QT);
-  hipLaunchKernelGGL(attn_fwd_v5_kernel<UCOD_ATTN_FORM>, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs,
+  hipLaunchKernelGGL(attn_fwd_v5_kernel, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs,
                      lse);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;

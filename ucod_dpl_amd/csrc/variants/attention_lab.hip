@@ -1349,6 +1349,283 @@ __global__ __launch_bounds__(128) void attn_fwd_w64_kernel(const bf16_raw* __res
 }
 
 
+
+// =====================================================================================================
+// r3: the ROUND-3 product kernel (dead-wave / dead-block skip, 16-byte stores) with three more experiment flags, all measured SLOWER than
+// the plain form (profiles/r03_attention_onescol_msum.txt, r03_attention_seq_occupancy.txt; variants 30 = plain, 31 ONESCOL, 32 MSUM, 33 both,
+// 34 SEQ at five waves per SIMD, 35 SEQ at four):
+// Two ways of moving softmax bookkeeping from the vector issue stream (the kernel's bound: ~9.7 vector instructions per MFMA, matrix pipe
+// 0.54 busy; profiles/r03_attention_pmc.txt) onto the matrix pipe, measured as template flags (tools/attn_ab.py, variants 31-33 of the
+// experiment build):
+//   ONESCOL  S' = S - m as a FIFTH k-step of the score product instead of 16 v_mov per 32-key block: A fragment = a constant column of
+//            ones (k = 0 of the step), B fragment = -m of the lane's query in that k (m kept representable in the 16-bit operand type so
+//            that the subtraction is exact); the first k-step then starts from the inline constant 0.
+//   MSUM     the softmax denominator as one more MFMA per 16 keys (all-ones A fragment times the P fragment that feeds P V: the row
+//            sums of the ROUNDED probabilities) instead of 32 v_add_f32 per tile.
+//   SEQ      one 32-key block at a time (scores, softmax, P V, then the next block): one live score tile -> 96 registers -> five waves per SIMD
+template <bool ONESCOL, bool MSUM, int SEQ = 0>
+__global__ __launch_bounds__(256, SEQ == 1 ? 5 : 2) void attn_fwd_r3_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N, int heads,
+                                                              int npairs, float* __restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * KV_BYTES];       // [buffer][K | V]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h5 = lane >> 5, l31 = lane & 31;
+  const int nq = (N + QT - 1) / QT;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pair = (slot / nq) * 8 + xcd, qt = slot - (slot / nq) * nq;
+  if (pair >= npairs) return;
+  const int head = pair % heads, b = pair / heads;
+  const int D = heads * HD, ld = 3 * D;
+  const int q0 = qt * QT + wave * 32;
+  const bool live = q0 < N;                              // wave-uniform: this wave owns at least one real query row
+  const bf16_raw* base = qkv + (size_t)b * N * ld + head * HD;
+
+  hx8 qf[4];
+  {
+    int qr = q0 + l31;
+    qr = qr < N ? qr : N - 1;
+    const bf16_raw* qp = base + (size_t)qr * ld + 8 * h5;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const hx8*>(qp + 16 * s);
+  }
+
+  // this image's qkv rows as one buffer: byte offsets fit 32 bits, a key row >= N is out of range and reads as zero
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(qkv + (size_t)b * N * ld), 0, (unsigned)N * (unsigned)ld * 2u, 0x00020000);
+  unsigned sk[2], sv[2];                                 // loop-carried source offsets of this lane's four DMA chunks
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = i * 32 + wave * 8 + (lane >> 3), ch = lane & 7;
+    sk[i] = (unsigned)(row * ld + D + head * HD + swz_k(row, ch) * 8) * 2u;
+    sv[i] = (unsigned)(row * ld + 2 * D + head * HD + swz_v(row, ch) * 8) * 2u;
+  }
+  const unsigned tile_step = (unsigned)(KT * ld) * 2u;
+  auto stage = [&](auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      char* dst = smem + BUF * (2 * KV_BYTES) + (i * 32 + wave * 8) * 128;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, sk[i], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + KV_BYTES), 16, sv[i], 0, 0, 0);
+      sk[i] += tile_step;
+      sv[i] += tile_step;
+    }
+  };
+
+  // loop-invariant LDS byte offsets: K fragment chunk per 16-wide d step, V fragment per 32-wide d half
+  int koff[4], voff[2];
+#pragma unroll
+  for (int sd = 0; sd < 4; ++sd) koff[sd] = l31 * 128 + swz_k(l31, 2 * sd + h5) * 16;      // +4096 per 32 keys keeps the swizzle
+  {
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    const int key = 4 * h5 + (i16 >> 2);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int dst = dt * 32 + g1 * 16 + 4 * (i16 & 3);
+      voff[dt] = KV_BYTES + key * 128 + swz_v(key, dst >> 3) * 16 + (dst & 7) * 2;          // +8/16/32 keys keep the swizzle
+    }
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m_run = 0.f;
+  f32x2_t lsum = {0.f, 0.f};
+  f32x16 osum;                                           // MSUM: every row of this tile = the lane's denominator
+#pragma unroll
+  for (int i = 0; i < 16; ++i) osum[i] = 0.f;
+  // ONESCOL operands: element (half 0, j = 0) <-> k = 0 of the extra k-step.  kone = 1 there, qm = -m there, zeros elsewhere.
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  const unsigned one_h = (unsigned)__builtin_bit_cast(unsigned short, (half_t)1.0f);
+  const hx8 kone = __builtin_bit_cast(hx8, (u32x4_t){h5 == 0 ? one_h : 0u, 0u, 0u, 0u});
+  const hx8 ones = __builtin_bit_cast(hx8, (u32x4_t){one_h * 0x10001u, one_h * 0x10001u, one_h * 0x10001u, one_h * 0x10001u});
+  hx8 qm = __builtin_bit_cast(hx8, (u32x4_t){0u, 0u, 0u, 0u});
+  const int nt = (N + KT - 1) / KT, nfull = nt - 1;
+  const bool half_dead = nfull * KT + 32 >= N;           // (uniform) the keys of the last tile's second 32-key block all lie past the last token
+
+  auto tile = [&](int t, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    dma_landed_barrier();                                // this wave's DMAs of tile t have landed; everyone is done reading tile t-1
+    if (t + 1 < nt) stage(IntC<BUF ^ 1>{});
+    if (!live) return;                                   // (wave-uniform) nothing to compute for rows past the last token
+    const char* kb = smem + BUF * (2 * KV_BYTES);
+
+    if constexpr (SEQ != 0) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        if (t == nfull && kt == 1 && half_dead) break;
+        f32x16 sc;
+        const float neg_m = -m_run;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[i] = neg_m;
+#pragma unroll
+        for (int sd = 0; sd < 4; ++sd) {
+          const hx8 kf = *reinterpret_cast<const hx8*>(kb + kt * 4096 + koff[sd]);
+          sc = UCOD_MFMA32(kf, qf[sd], sc);
+        }
+        if (t == nfull && (N & (KT - 1)) != 0) {
+          const int kbase = t * KT + 4 * h5 + kt * 32;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kbase + (r & 3) + 8 * (r >> 2) >= N) sc[r] = -1e30f;
+        }
+        float mloc = __builtin_elementwise_maximum(sc[0], sc[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, sc[r]), sc[r + 1]);
+        const bool first = (t == 0 && kt == 0);
+        if (first || __any(mloc > DEFER_THR)) {
+          mloc = xhalf_max(mloc);
+          const float delta = first ? mloc : fmaxf(mloc, 0.f);
+          const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+          m_run += delta;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            sc[i] -= delta;
+            o[0][i] *= alpha;
+            o[1][i] *= alpha;
+          }
+          lsum *= alpha;
+        }
+        hx8 pb[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          u32x4 w;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const f32x2_t e = {__builtin_amdgcn_exp2f(sc[8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(sc[8 * ks + 2 * jj + 1])};
+            sum_pair(lsum, e);
+            w[jj] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_t));
+          }
+          pb[ks] = __builtin_bit_cast(hx8, w);
+        }
+        __builtin_amdgcn_sched_barrier(0);                 // the score tile dies here: the next block's Q K^T must not start above this point
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const char* p0 = kb + (kt * 32 + ks * 16) * 128 + voff[dt];
+            const hx4 lo = UCOD_TR16(p0);
+            const hx4 hi = UCOD_TR16(p0 + 8 * 128);
+            const hx8 vf = (hx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[dt] = UCOD_MFMA32(vf, pb[ks], o[dt]);
+          }
+      }
+      return;
+    }
+    f32x16 s[2];
+    const float neg_m = -m_run;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      if (t == nfull && kt == 1 && half_dead) break;     // (wave-uniform; last tile only) no real key in the second 32-key block
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kt][i] = ONESCOL ? 0.f : neg_m;
+#pragma unroll
+      for (int sd = 0; sd < 4; ++sd) {
+        const hx8 kf = *reinterpret_cast<const hx8*>(kb + kt * 4096 + koff[sd]);
+        s[kt] = UCOD_MFMA32(kf, qf[sd], s[kt]);
+      }
+      if constexpr (ONESCOL) s[kt] = UCOD_MFMA32(kone, qm, s[kt]);
+    }
+    if (t == nfull && (N & (KT - 1)) != 0) {
+      const int kbase = t * KT + 4 * h5;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + kt * 32 + (r & 3) + 8 * (r >> 2);
+          if (key >= N) s[kt][r] = -1e30f;
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      if (t == nfull && kt == 1 && half_dead) break;
+      // v_maximum3_f32 (IEEE maximum: no operand canonicalisation), two scores per instruction.  The lane's 16 keys are enough
+      // for the wave-wide "does any score run away" test; the other half's keys are fetched only when the rescale fires.
+      float mloc = __builtin_elementwise_maximum(s[kt][0], s[kt][1]);
+#pragma unroll
+      for (int r = 2; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[kt][r]), s[kt][r + 1]);
+      const bool first = (t == 0 && kt == 0);
+      if (first || __any(mloc > DEFER_THR)) {
+        mloc = xhalf_max(mloc);
+        float delta = first ? mloc : fmaxf(mloc, 0.f);
+        if constexpr (ONESCOL) {                           // the new maximum must be exact in the operand type: delta = what m really moves by
+          const float m_new = (float)(half_t)(m_run + delta);
+          delta = m_new - m_run;
+          const unsigned nm = (unsigned)__builtin_bit_cast(unsigned short, (half_t)(-m_new));
+          qm = __builtin_bit_cast(hx8, (u32x4_t){h5 == 0 ? nm : 0u, 0u, 0u, 0u});
+        }
+        const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+        m_run += delta;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          s[kt][i] -= delta;
+          if (kt == 0) s[1][i] -= delta;
+          o[0][i] *= alpha;
+          o[1][i] *= alpha;
+        }
+        lsum *= alpha;
+        if constexpr (MSUM) osum[0] *= alpha;
+      }
+      hx8 pb[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 w;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const f32x2_t e = {__builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj + 1])};
+          if constexpr (!MSUM) sum_pair(lsum, e);
+          w[jj] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_t));
+        }
+        pb[ks] = __builtin_bit_cast(hx8, w);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if constexpr (MSUM) osum = UCOD_MFMA32(ones, pb[ks], osum);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const char* p0 = kb + (kt * 32 + ks * 16) * 128 + voff[dt];
+          const hx4 lo = UCOD_TR16(p0);
+          const hx4 hi = UCOD_TR16(p0 + 8 * 128);
+          const hx8 vf = (hx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[dt] = UCOD_MFMA32(vf, pb[ks], o[dt]);
+        }
+      }
+    }
+  };
+
+  // two tiles per iteration: the LDS buffer index is a compile-time constant
+  stage(IntC<0>{});
+  for (int t = 0; t < nt; t += 2) {
+    tile(t, IntC<0>{});
+    if (t + 1 < nt) tile(t + 1, IntC<1>{});
+  }
+  if (!live) return;
+
+  const float lane_sum = lsum[0] + lsum[1];
+  const float denom = MSUM ? osum[0] : lane_sum + __shfl_xor(lane_sum, 32, 64);   // (the all-ones product already sums both halves' keys)
+  const float inv = 1.0f / denom;
+  const int q = q0 + l31;
+  if (lse && h5 == 0 && q < N) lse[((size_t)b * heads + head) * N + q] = m_run + __builtin_amdgcn_logf(denom);
+  // o[dt][4g .. 4g+3] = columns dt*32 + 8g + 4*h5 .. +3 of row q.  For each register pair (g, g+1) one half exchange leaves lanes 0..31
+  // with columns 8g .. 8g+7 ([own g | upper's g]) and lanes 32..63 with 8(g+1) .. 8(g+1)+7 ([lower's g+1 | own g+1]): one 16-byte store each.
+  const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(out + ((size_t)b * N) * D, 0, (unsigned)N * (unsigned)D * 2u, 0x00020000);
+  // rows past N: an offset that stays beyond the buffer after the per-store constants are added (records = N * D * 2 < 2^31), so the
+  // range check drops the store -- 0xFFFFFFF0 would WRAP to the image's first row
+  const unsigned row_off = q < N ? ((unsigned)q * (unsigned)D + (unsigned)(head * HD + 8 * h5)) * 2u : 0x80000000u;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      const int g = 2 * gp;
+      unsigned a0 = cvt_pk_bf16(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv), a1 = cvt_pk_bf16(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+      unsigned b0 = cvt_pk_bf16(o[dt][4 * g + 4] * inv, o[dt][4 * g + 5] * inv), b1 = cvt_pk_bf16(o[dt][4 * g + 6] * inv, o[dt][4 * g + 7] * inv);
+      const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+      const u32x4 w = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+      __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, row_off + (unsigned)(dt * 32 + 16 * gp) * 2u, 0, 0);
+    }
+}
+
+
 }  // namespace ucod
 
 extern "C" int ucod_attention_fwd_lab(const void* qkv, void* out, int B, int tok, int heads, float scale, int variant, void* stream) {
@@ -1361,7 +1638,15 @@ extern "C" int ucod_attention_fwd_lab(const void* qkv, void* out, int B, int tok
     dim3 grid1(cdiv(npairs, 8) * 8 * nq);
     // variant 3: K/V staged through registers, 4: LDS-DMA, both with the denominator on the matrix pipe (all-ones MFMA);
     // 6: LDS-DMA + denominator as f32 adds of the unrounded probabilities (4 % faster than 4 at 4 waves per SIMD)
-    if (variant == 4)
+    if (variant >= 30 && variant <= 35) {
+      const float* nol = nullptr;
+      if (variant == 30) hipLaunchKernelGGL((attn_fwd_r3_kernel<false, false, 0>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nol);
+      if (variant == 31) hipLaunchKernelGGL((attn_fwd_r3_kernel<true, false, 0>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nol);
+      if (variant == 32) hipLaunchKernelGGL((attn_fwd_r3_kernel<false, true, 0>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nol);
+      if (variant == 33) hipLaunchKernelGGL((attn_fwd_r3_kernel<true, true, 0>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nol);
+      if (variant == 34) hipLaunchKernelGGL((attn_fwd_r3_kernel<false, false, 1>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nol);
+      if (variant == 35) hipLaunchKernelGGL((attn_fwd_r3_kernel<false, false, 2>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nol);
+    } else if (variant == 4)
       hipLaunchKernelGGL((attn_fwd_v2_kernel<true, false>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
     else if (variant == 3)
       hipLaunchKernelGGL((attn_fwd_v2_kernel<false>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nullptr);
