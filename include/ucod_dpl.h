@@ -378,6 +378,20 @@ int ucod_binarize(const float* x, float* out, size_t n, int logits, void* stream
 int ucod_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float ema_alpha, void* stream);
 
+/* Discriminator WITH the feature branch (models/discriminator.py:77-95, dis_use_features=True; no shipped config enables it): forward only, from
+ * generic pieces.  A ConvBlock(Cin, Cout, 3, stride, 1) is  ucod_unfold3x3 -> ucod_dba_project(W.reshape(Cout, Cin*9) zero-padded to Kpad columns,
+ * zero bias) -> ucod_bn_lrelu_train.
+ * ucod_unfold3x3: x f32 [B,C,H,W] -> out f32 [B,Kpad,Ho*Wo], row c*9 + ky*3 + kx = the input shifted by (ky-1, kx-1) with zero padding (F.unfold
+ *   order), rows >= C*9 zero; Ho = (H-1)/stride + 1; stride 1 or 2; Kpad % 16 == 0 for the GEMM.
+ * ucod_bn_lrelu_train: y f32 [B,C,HW] in place: training-mode nn.BatchNorm2d (batch statistics, biased variance; running buffers updated with
+ *   `momentum` and the unbiased variance when update_running != 0) followed by LeakyReLU(slope).  Statistics in f64, deterministic.
+ * ucod_linear_sigmoid: out[b] = sigmoid(x[b,:] . w + bias[0]). */
+int ucod_unfold3x3(const float* x, float* out, int B, int C, int H, int W, int stride, int Kpad, void* stream);
+size_t ucod_bn_lrelu_workspace_bytes(int C);
+int ucod_bn_lrelu_train(float* y, const float* gamma, const float* beta, float* running_mean, float* running_var, int B, int C, int HW, float eps,
+                        float momentum, float slope, int update_running, void* workspace, size_t workspace_bytes, void* stream);
+int ucod_linear_sigmoid(const float* x, const float* w, const float* bias, float* out, int B, int K, void* stream);
+
 /* ------------------------------------------------------------------ Look-Twice (rows L1-L3) */
 
 /* 8-connected component labelling of a HOST uint8 [H,W] mask (non-zero = foreground) into HOST int32 labels

@@ -67,3 +67,15 @@ def discriminator_forward(mask, sd, update_running=True):
     h = h.flatten(1)
     z = h @ sd["linear.weight"].t() + sd["linear.bias"]
     return torch.sigmoid(z)
+
+
+def discriminator_forward_with_features(mask, feature, sd, update_running=True):
+    """discriminator.py:86-95 with ``dis_use_features=True`` (:77-83): featureConv (dim -> dim) on the feature map, concatenated behind the
+    mask branch, two stride-2 ConvBlocks on (dim + 32) and (dim + 32) // 2 channels, Linear on (dim + 32) // 4 * ((fs + 3) // 4)**2."""
+    h = conv_block(mask, sd, "maskConv", 1, update_running)
+    f = conv_block(feature, sd, "featureConv", 1, update_running)
+    h = torch.cat((h, f), 1)
+    h = conv_block(h, sd, "convs.0", 2, update_running)
+    h = conv_block(h, sd, "convs.1", 2, update_running)
+    z = h.flatten(1) @ sd["linear.weight"].t() + sd["linear.bias"]
+    return torch.sigmoid(z)

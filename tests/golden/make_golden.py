@@ -197,6 +197,29 @@ def g3():
     save("g3_discriminator", **out)
 
 
+def g3b():
+    """G3b: the REAL Discriminator with dis_use_features=True (models/discriminator.py:77-95): two forward calls (train-mode BatchNorm: running
+    buffers keep moving) on seeded masks and feature maps; dim 32, feature_size 20 (-> 64 / 32 / 16 channels, Linear on 16 * 5 * 5)."""
+    torch.manual_seed(33)
+    d = Discriminator(CfgNode(dict(dim=32, feature_size=20, ema_weight=0.99, dis_use_features=True)))
+    with torch.no_grad():                                   # non-trivial BatchNorm affine terms
+        for n, p in d.named_parameters():
+            if ".layers.1." in n:
+                p.add_(0.2 * torch.randn_like(p))
+    out = dict(sd_flat("sd0.", d))
+    mask = (torch.rand(3, 1, 20, 20) > 0.6).float()
+    feat = torch.randn(3, 32, 20, 20)
+    with torch.no_grad():
+        out["mask"], out["feature"], out["prob"] = mask, feat, d(mask, feat)
+        out.update(sd_flat("sd1.", d))
+        mask2 = torch.zeros(3, 1, 20, 20)
+        mask2[:, :, 4:15, 2:12] = 1.0
+        feat2 = torch.randn(3, 32, 20, 20) * 2 + 0.3
+        out["mask2"], out["feature2"], out["prob2"] = mask2, feat2, d(mask2, feat2)
+        out.update(sd_flat("sd2.", d))
+    save("g3b_discriminator_features", **out)
+
+
 # ----------------------------------------------------------------------------- fake runner for the loops
 class NullLogger:
     def log(self, *a, **k):
@@ -872,6 +895,6 @@ def g17():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g9b", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3b", "g4", "g5", "g6", "g7", "g8", "g9", "g9b", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     for w in which:
         globals()[w]()

@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 if not torch.cuda.is_available():
     pytest.skip("needs a GPU", allow_module_level=True)
 
+from ucod_dpl_amd import native as N  # noqa: E402
 from ucod_dpl_amd.engine.config import CfgNode  # noqa: E402
 from ucod_dpl_amd.engine.runner import StandardRunner, TrainLoop  # noqa: E402
 
@@ -219,3 +220,50 @@ def test_shipped_checkpoint_on_the_hip_decoder(ver, tmp_path):
     t2, _, _ = ops.dba_heads(d, 128, emb_t, ops.dba_colnorm(d, 128, emb_t), hw_t, hb_t, want_bg=False)
     assert maxdiff(fg2.view(1, 1, 10, 10).cpu(), g["fg"]) < 1e-4 and maxdiff(bg2.view(1, 1, 10, 10).cpu(), g["bg"]) < 1e-4
     assert maxdiff(t2.view(1, 1, 10, 10).cpu(), g["teacher"]) < 1e-4
+
+
+def test_discriminator_with_the_feature_branch_matches_reference():
+    """models/discriminator.py:77-95 with dis_use_features=True (no shipped config enables it): the mirror module's forward through the generic
+    HIP pieces (unfold + exact-f32 MFMA GEMM + train-mode BatchNorm/LeakyReLU + linear head) against the REAL module's two calls (G3b):
+    probabilities to 1e-5, running buffers of all four BatchNorms after each call; and the generic pieces one by one against torch."""
+    import torch.nn.functional as F
+    from ucod_dpl_amd.models.discriminator import Discriminator
+    g = load_golden("g3b_discriminator_features")
+    m = Discriminator(CfgNode(dict(dim=32, feature_size=20, ema_weight=0.99, dis_use_features=True)))
+    m.load_state_dict(sub(g, "sd0."), strict=True)
+    m = m.cuda()
+    for tag, mk, fk, after in (("prob", "mask", "feature", "sd1."), ("prob2", "mask2", "feature2", "sd2.")):
+        p = m(g[mk].cuda(), g[fk].cuda())
+        assert p.shape == (3, 1)
+        assert maxdiff(p.cpu(), g[tag]) < 1e-5, maxdiff(p.cpu(), g[tag])
+        sd = m.state_dict()
+        for k, v in sub(g, after).items():
+            if "running" in k or "num_batches" in k:
+                assert maxdiff(sd[k].cpu(), v) < 1e-5 * max(1.0, float(v.double().abs().max())), k
+    with pytest.raises(ValueError):
+        m(g["mask"].cuda())
+    # the pieces: im2col == F.unfold (both strides, odd size), BatchNorm + LeakyReLU == torch in training mode
+    lib = N.load()
+    gen = torch.Generator().manual_seed(1)
+    for (B, C, H, W, stride) in ((2, 5, 9, 7, 1), (2, 5, 9, 7, 2), (1, 3, 20, 20, 2)):
+        x = torch.randn(B, C, H, W, generator=gen)
+        Kpad = (C * 9 + 15) // 16 * 16
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        out = torch.full((B, Kpad, Ho * Wo), 7.0, device="cuda")
+        xd = x.cuda()
+        N.check(lib.ucod_unfold3x3(N.ptr(xd), N.ptr(out), B, C, H, W, stride, Kpad, N.stream()), "unfold")
+        ref = F.unfold(x, 3, padding=1, stride=stride)
+        assert torch.equal(out[:, :C * 9].cpu(), ref) and float(out[:, C * 9:].abs().max()) == 0
+    bn = torch.nn.BatchNorm2d(6)
+    with torch.no_grad():
+        bn.weight.add_(0.3 * torch.randn(6, generator=gen))
+        bn.bias.add_(0.3 * torch.randn(6, generator=gen))
+    y = torch.randn(4, 6, 11, 13, generator=gen) * 2 + 0.5
+    ref = F.leaky_relu(bn(y), 0.1)
+    yd = y.cuda().reshape(4, 6, 143).contiguous()
+    rm, rv = torch.zeros(6, device="cuda"), torch.ones(6, device="cuda")
+    ws = torch.empty(lib.ucod_bn_lrelu_workspace_bytes(6), dtype=torch.uint8, device="cuda")
+    gw, gb = bn.weight.detach().cuda(), bn.bias.detach().cuda()
+    N.check(lib.ucod_bn_lrelu_train(N.ptr(yd), N.ptr(gw), N.ptr(gb), N.ptr(rm), N.ptr(rv), 4, 6, 143, 1e-5, 0.1, 0.1, 1, N.ptr(ws), ws.numel(), N.stream()), "bn")
+    assert maxdiff(yd.cpu().view(4, 6, 11, 13), ref.detach()) < 1e-5
+    assert maxdiff(rm.cpu(), bn.running_mean) < 1e-6 and maxdiff(rv.cpu(), bn.running_var) < 1e-5

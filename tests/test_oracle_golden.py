@@ -188,6 +188,25 @@ def test_g9_sparse_refiner(tag):
     assert maxdiff(out, g[tag + ".outputs"]) < 2e-4
 
 
+def test_g3b_discriminator_with_the_feature_branch():
+    """G3b = the real Discriminator with dis_use_features=True (models/discriminator.py:77-95), two calls: the oracle reproduces both
+    probabilities and the BatchNorm running buffers after each; the mirror module has the reference's parameter names and shapes."""
+    from oracle import discriminator as ODISC
+    from ucod_dpl_amd.models.discriminator import Discriminator
+    from ucod_dpl_amd.engine.config import CfgNode
+    g = load_golden("g3b_discriminator_features")
+    sd = {k: v.clone() for k, v in sub(g, "sd0.").items()}
+    for tag, mk, fk, after in (("prob", "mask", "feature", "sd1."), ("prob2", "mask2", "feature2", "sd2.")):
+        p = ODISC.discriminator_forward_with_features(g[mk], g[fk], sd)
+        assert maxdiff(p, g[tag]) < 1e-6
+        for k, v in sub(g, after).items():
+            if "running" in k:
+                assert maxdiff(sd[k], v) < 1e-5 * max(1.0, float(v.abs().max())), k
+    m = Discriminator(CfgNode(dict(dim=32, feature_size=20, ema_weight=0.99, dis_use_features=True)))
+    m.load_state_dict(sub(g, "sd0."), strict=True)
+    assert all(not p.requires_grad for p in m.parameters())
+
+
 @pytest.mark.parametrize("tag", ["full", "partial"])
 @pytest.mark.parametrize("kind", ["prob", "logit"])
 def test_g9b_refiner_training_mode_loss(tag, kind):

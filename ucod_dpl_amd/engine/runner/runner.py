@@ -60,6 +60,9 @@ class StandardRunner:
     # ------------------------------------------------------------------ builders (runner.py:266-308)
     def _build_model(self):
         self.model = baseline(self.config.model_cfg)
+        if self.config.model_cfg.get("dis_use_features", False):
+            raise NotImplementedError("the fused first-stage step is built for dis_use_features=False (every shipped config, configs/uscod/*.py); "
+                                      "the feature-branch discriminator exists as a module (ucod_dpl_amd.models.discriminator, forward only)")
         self.discriminator = Discriminator(self.config.model_cfg)
         ckpt = self.config.train_cfg.get("checkpoint", None)
         if ckpt:

@@ -110,6 +110,10 @@ SIGNATURES = {
     "ucod_disc_fwd": (ci, [vp, C.POINTER(DiscParams), vp, vp, ci, ci, ci, vp]),
     "ucod_disc_bwd_workspace_bytes": (sz, [ci, ci]),
     "ucod_disc_bwd": (ci, [vp, C.POINTER(DiscParams), vp, vp, C.POINTER(DiscGrads), ci, vp, ci, ci, vp]),
+    "ucod_unfold3x3": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "ucod_bn_lrelu_workspace_bytes": (sz, [ci]),
+    "ucod_bn_lrelu_train": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cf, cf, ci, vp, sz, vp]),
+    "ucod_linear_sigmoid": (ci, [vp, vp, vp, vp, ci, ci, vp]),
     "ucod_apm_bce": (ci, [vp, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, ci, ci, vp]),
     "ucod_binarize": (ci, [vp, vp, sz, ci, vp]),
     "ucod_ccl8_host": (ci, [vp, ci, ci, vp]),
