@@ -114,7 +114,14 @@ def _val_worker(rank, world, port, out):
     empty = statistics()                                     # a rank with no image at all must not hang or crash
     if rank == 0:
         empty._records = [rec[:3]]
-    empty.gather_records()
+    empty.gather_records(device="cpu")
+    # parallel.shard: an unsharded loader is dealt round-robin (no duplicates, union = the whole set); a pre-sharded one is left alone
+    mine = list(parallel.shard(list(range(7))))
+    assert mine == list(range(7))[rank::world]
+
+    class _Pre(list):
+        sampler = type("S", (), {"num_replicas": world})()
+    assert list(parallel.shard(_Pre([1, 2, 3]))) == [1, 2, 3]
     torch.save((res, st.per_image(), empty.per_image()), out + str(rank))
     torch.distributed.destroy_process_group()
 

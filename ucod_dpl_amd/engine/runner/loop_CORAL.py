@@ -12,7 +12,7 @@ features and the 2x2 overlapping crops of the 54x54 key map, with every backbone
 import numpy as np
 import torch
 
-from ... import ops
+from ... import ops, parallel
 from .loop_UCOD_DPL import BaseLoop
 from .loop_look_twice import MAEStatistics  # noqa: F401  (re-exported)
 from ..utils.metrics import statistics
@@ -142,9 +142,9 @@ class LocalRefineValidationLoop(BaseLoop):
     def run(self):
         stats = statistics()                                  # the nine COD measures on the device (engine/utils/metrics/metric.py:19-74)
         self.runner.refiner.eval()
-        for batch in self.runner.val_dataloader:
+        for batch in parallel.shard(self.runner.val_dataloader):
             self._process_validation_batch(batch, stats)
-        stats.gather_records()
+        stats.gather_records(device=self.device)
         result = stats.get_result()
         self.runner.logger.log_table({k: [round(v, 4)] for k, v in result.items()})
         return result

@@ -18,7 +18,7 @@ import os
 import numpy as np
 import torch
 
-from ... import native as N, ops
+from ... import native as N, ops, parallel
 from .loop_UCOD_DPL import BaseLoop
 from ..utils.metrics import statistics
 
@@ -262,7 +262,7 @@ class ValLoop_Look_Twice(BaseLoop):
         fs = self.cfg.model_cfg.feature_size
         # Multi-rank: every rank walks ITS shard of the validation set (the reference's accelerator.prepare shards the loader) with no
         # per-image collective; the per-image records meet once, before get_result (the role of gather_for_metrics, :310).
-        for batch in self.runner.val_dataloader:
+        for batch in parallel.shard(self.runner.val_dataloader):
             _, label_tensor, features, img_path = batch.values()
             features = ops.bilinear_resize(features.to(self.device, torch.float32), fs, fs)
             with torch.no_grad():
@@ -272,7 +272,7 @@ class ValLoop_Look_Twice(BaseLoop):
                 preds_up = self.look_twice(img_path[0], bboxes, preds_up).to(self.device)
             out = ops.bilinear_resize(preds_up.reshape(1, 1, *preds_up.shape[-2:]).to(self.device), label_tensor.shape[-2], label_tensor.shape[-1])
             stats.step(label_tensor.to(self.device), (out.reshape(1, *out.shape[-2:]) > 0.5))
-        stats.gather_records()
+        stats.gather_records(device=self.device)
         result = stats.get_result()
         self.runner.logger.log_table({k: [round(v, 4)] for k, v in result.items()})
         return result

@@ -46,11 +46,13 @@ class statistics:
         """f64 [images, 1032] on the device (layout: include/ucod_dpl.h)."""
         return torch.cat(self._records, dim=0)
 
-    def gather_records(self):
+    def gather_records(self, device=None):
         """Multi-rank validation (what ``accelerator.gather_for_metrics`` is for in the reference, loop_UCOD_DPL.py:310): every rank
         has stepped over ITS shard of the validation set; collect all ranks' per-image records so that ``get_result`` is the
         measure over the whole set and identical on every rank.  Two collectives per validation run (counts, then the records
-        padded to the longest shard), none per image; ranks may hold different numbers of images, including none."""
+        padded to the longest shard), none per image; ranks may hold different numbers of images, including none.  ``device``: where a
+        rank WITHOUT records builds its empty contribution (default: the current GPU under nccl, the CPU under gloo) -- it must be the
+        device the other ranks' records live on."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
@@ -58,7 +60,7 @@ class statistics:
         if self._records:
             mine = self.per_image()
         else:
-            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu")
             mine = torch.zeros(0, 1032, dtype=torch.float64, device=dev)
         counts = [torch.zeros(1, dtype=torch.int64, device=mine.device) for _ in range(world)]
         dist.all_gather(counts, torch.tensor([mine.shape[0]], dtype=torch.int64, device=mine.device))

@@ -116,3 +116,17 @@ def max_over_ranks(value, device):
 def barrier():
     if world_size() > 1:
         dist.barrier()
+
+
+def shard(loader):
+    """This rank's share of a validation loader: batches rank, rank + world, rank + 2 world, ... -- unless the loader is already sharded
+    (its sampler carries ``num_replicas``, i.e. a DistributedSampler: what accelerator.prepare makes of it in the reference,
+    engine/runner/runner.py:372), in which case it is walked as it is.  With world_size 1 the loader itself.  Interleaved shards hold no
+    duplicates, so the gathered records are exactly one per image (a pre-sharded DistributedSampler pads its last batches with repeats
+    unless built with drop_last; the reference's gather_for_metrics drops those -- build such a sampler with drop_last or let this shard)."""
+    import itertools
+    world = world_size()
+    if world == 1 or getattr(getattr(loader, "sampler", None), "num_replicas", None) is not None:
+        return loader
+    rank = dist.get_rank()
+    return itertools.islice(loader, rank, None, world)
