@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--arch", default="dinov2_vitb14")
     ap.add_argument("--image", type=int, default=518)
@@ -337,7 +337,7 @@ def main():
     dom = max((n for n in kernels if "tflops" in kernels[n] and n.startswith(("gemm_bf16", "attention"))),
               key=lambda n: kernels[n]["ms_per_step"])
     traffic = None                                            # HBM-side bytes per launch from committed PMC passes (see the file's "source")
-    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if os.path.exists(tpath) and a.arch == "dinov2_vitb14" and B == 32 and a.image == 518:
         traffic = json.load(open(tpath)).get("kernels", {}).get(dom, {}).get("traffic_bytes")
     roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

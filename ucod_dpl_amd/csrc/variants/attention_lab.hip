@@ -1363,8 +1363,8 @@ __global__ __launch_bounds__(128) void attn_fwd_w64_kernel(const bf16_raw* __res
 //   MSUM     the softmax denominator as one more MFMA per 16 keys (all-ones A fragment times the P fragment that feeds P V: the row
 //            sums of the ROUNDED probabilities) instead of 32 v_add_f32 per tile.
 //   SEQ      one 32-key block at a time (scores, softmax, P V, then the next block): one live score tile -> 96 registers -> five waves per SIMD
-template <bool ONESCOL, bool MSUM, int SEQ = 0>
-__global__ __launch_bounds__(256, SEQ == 1 ? 5 : 2) void attn_fwd_r3_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N, int heads,
+template <bool ONESCOL, bool MSUM, int SEQ = 0, int ABL = 0, int SCHED = 0>
+__global__ __launch_bounds__(256, SEQ == 1 ? 5 : (SCHED >= 3 ? 4 : 2)) void attn_fwd_r3_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N, int heads,
                                                               int npairs, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_BYTES];       // [buffer][K | V]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1442,10 +1442,29 @@ __global__ __launch_bounds__(256, SEQ == 1 ? 5 : 2) void attn_fwd_r3_kernel(cons
   const int nt = (N + KT - 1) / KT, nfull = nt - 1;
   const bool half_dead = nfull * KT + 32 >= N;           // (uniform) the keys of the last tile's second 32-key block all lie past the last token
 
+  // ABL (timing only, results are wrong): 1 = no MFMA (operands and accumulator kept alive, accumulator opaque), 2 = no softmax vector
+  // work (max / exp / sum / convert), 4 = no LDS fragment reads, 8 = no K/V staging and no barrier
+  // SCHED 5 / 6 / 7 (bit 0 of SCHED - 4: NEGM, bit 1: DOT2) -- vector instructions taken OUT of the tile body:
+  //   NEGM  a persistent 16-register block holding -m (rewritten only inside the rare rescale branch) as the C operand of each block's first
+  //         MFMA, instead of 16 v_mov per tile re-creating that splat;
+  //   DOT2  the denominator as one v_dot2c_f32_bf16 (pair of ROUNDED probabilities times (1, 1)) per pair instead of two v_add_f32.
+  constexpr bool NEGM = SCHED >= 5 && ((SCHED - 4) & 1), DOT2 = SCHED >= 5 && ((SCHED - 4) & 2);
+  f32x16 negm;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) negm[i] = 0.f;
+  if constexpr (NEGM) asm volatile("" : "+v"(negm));     // opaque: the compiler must not know it is a splat (it would re-materialise it per tile)
+  auto MF = [&](const hx8& a, const hx8& bq, f32x16 c) -> f32x16 {
+    if constexpr (ABL & 1) {
+      asm volatile("" : "+v"(c) : "v"(a), "v"(bq));
+      return c;
+    } else return UCOD_MFMA32(a, bq, c);
+  };
   auto tile = [&](int t, auto bufc) {
     constexpr int BUF = decltype(bufc)::value;
-    dma_landed_barrier();                                // this wave's DMAs of tile t have landed; everyone is done reading tile t-1
-    if (t + 1 < nt) stage(IntC<BUF ^ 1>{});
+    if constexpr (!(ABL & 8)) {
+      dma_landed_barrier();                              // this wave's DMAs of tile t have landed; everyone is done reading tile t-1
+      if (t + 1 < nt) stage(IntC<BUF ^ 1>{});
+    }
     if (!live) return;                                   // (wave-uniform) nothing to compute for rows past the last token
     const char* kb = smem + BUF * (2 * KV_BYTES);
 
@@ -1511,20 +1530,116 @@ __global__ __launch_bounds__(256, SEQ == 1 ? 5 : 2) void attn_fwd_r3_kernel(cons
       }
       return;
     }
+    if constexpr (SCHED == 3 || SCHED == 4) {
+      // max / rescale test of the first 32-key block BEFORE the second block's Q K^T, so that the first block's exponentials, converts and
+      // sums share a basic block with those four MFMAs; the second block's max shares one with the first block's P V.
+      const bool do1 = !(t == nfull && half_dead);
+      const bool masked = t == nfull && (N & (KT - 1)) != 0;
+      f32x16 s0, s1;
+      auto qk = [&](f32x16& sc, int kt) {
+        const float nm = -m_run;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[i] = nm;
+#pragma unroll
+        for (int sd = 0; sd < 4; ++sd) {
+          const hx8 kf = *reinterpret_cast<const hx8*>(kb + kt * 4096 + koff[sd]);
+          sc = UCOD_MFMA32(kf, qf[sd], sc);
+        }
+      };
+      auto mask = [&](f32x16& sc, int kt) {
+        const int kbase = t * KT + 4 * h5 + kt * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kbase + (r & 3) + 8 * (r >> 2) >= N) sc[r] = -1e30f;
+      };
+      auto maxfix = [&](f32x16& sc, bool first) {
+        float mloc = __builtin_elementwise_maximum(sc[0], sc[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, sc[r]), sc[r + 1]);
+        if (first || __any(mloc > DEFER_THR)) {
+          mloc = xhalf_max(mloc);
+          const float delta = first ? mloc : fmaxf(mloc, 0.f);
+          const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+          m_run += delta;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            sc[i] -= delta;
+            o[0][i] *= alpha;
+            o[1][i] *= alpha;
+          }
+          lsum *= alpha;
+        }
+      };
+      auto probs = [&](const f32x16& sc, hx8 (&pb)[2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          u32x4 w;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const f32x2_t e = {__builtin_amdgcn_exp2f(sc[8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(sc[8 * ks + 2 * jj + 1])};
+            sum_pair(lsum, e);
+            w[jj] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_t));
+          }
+          pb[ks] = __builtin_bit_cast(hx8, w);
+        }
+      };
+      auto pv = [&](const hx8 (&pb)[2], int kt) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const char* p0 = kb + (kt * 32 + ks * 16) * 128 + voff[dt];
+            const hx4 lo = UCOD_TR16(p0);
+            const hx4 hi = UCOD_TR16(p0 + 8 * 128);
+            const hx8 vf = (hx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[dt] = UCOD_MFMA32(vf, pb[ks], o[dt]);
+          }
+      };
+      hx8 p0[2], p1[2];
+      qk(s0, 0);
+      if (masked) mask(s0, 0);
+      maxfix(s0, t == 0);
+      if (do1) {
+        qk(s1, 1);                                         // four MFMAs ...
+        probs(s0, p0);                                     // ... beside 16 exp + 8 convert + 16 add of the first block
+        if constexpr (SCHED == 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+          }
+        }
+        if (masked) mask(s1, 1);
+        pv(p0, 0);
+        maxfix(s1, false);
+        probs(s1, p1);
+        pv(p1, 1);
+      } else {
+        probs(s0, p0);
+        pv(p0, 0);
+      }
+      return;
+    }
     f32x16 s[2];
     const float neg_m = -m_run;
+    if constexpr (SCHED == 1) __builtin_amdgcn_s_setprio(1);
+    if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       if (t == nfull && kt == 1 && half_dead) break;     // (wave-uniform; last tile only) no real key in the second 32-key block
+      if constexpr (!NEGM) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[kt][i] = ONESCOL ? 0.f : neg_m;
+        for (int i = 0; i < 16; ++i) s[kt][i] = ONESCOL ? 0.f : neg_m;
+      }
 #pragma unroll
       for (int sd = 0; sd < 4; ++sd) {
-        const hx8 kf = *reinterpret_cast<const hx8*>(kb + kt * 4096 + koff[sd]);
-        s[kt] = UCOD_MFMA32(kf, qf[sd], s[kt]);
+        const hx8 kf = (ABL & 4) ? qf[(sd + 1) & 3] : *reinterpret_cast<const hx8*>(kb + kt * 4096 + koff[sd]);
+        s[kt] = MF(kf, qf[sd], (NEGM && sd == 0) ? negm : s[kt]);
       }
       if constexpr (ONESCOL) s[kt] = UCOD_MFMA32(kone, qm, s[kt]);
     }
+    if constexpr (SCHED == 1) __builtin_amdgcn_s_setprio(0);
+    if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(1);
     if (t == nfull && (N & (KT - 1)) != 0) {
       const int kbase = t * KT + 4 * h5;
 #pragma unroll
@@ -1541,10 +1656,12 @@ __global__ __launch_bounds__(256, SEQ == 1 ? 5 : 2) void attn_fwd_r3_kernel(cons
       // v_maximum3_f32 (IEEE maximum: no operand canonicalisation), two scores per instruction.  The lane's 16 keys are enough
       // for the wave-wide "does any score run away" test; the other half's keys are fetched only when the rescale fires.
       float mloc = __builtin_elementwise_maximum(s[kt][0], s[kt][1]);
+      if constexpr (!(ABL & 2)) {
 #pragma unroll
-      for (int r = 2; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[kt][r]), s[kt][r + 1]);
+        for (int r = 2; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[kt][r]), s[kt][r + 1]);
+      }
       const bool first = (t == 0 && kt == 0);
-      if (first || __any(mloc > DEFER_THR)) {
+      if (!(ABL & 2) && (first || __any(mloc > DEFER_THR))) {
         mloc = xhalf_max(mloc);
         float delta = first ? mloc : fmaxf(mloc, 0.f);
         if constexpr (ONESCOL) {                           // the new maximum must be exact in the operand type: delta = what m really moves by
@@ -1564,6 +1681,12 @@ __global__ __launch_bounds__(256, SEQ == 1 ? 5 : 2) void attn_fwd_r3_kernel(cons
         }
         lsum *= alpha;
         if constexpr (MSUM) osum[0] *= alpha;
+        if constexpr (NEGM) {
+          const float nm = -m_run;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) negm[i] = nm;
+          asm volatile("" : "+v"(negm));
+        }
       }
       hx8 pb[2];
 #pragma unroll
@@ -1571,9 +1694,20 @@ __global__ __launch_bounds__(256, SEQ == 1 ? 5 : 2) void attn_fwd_r3_kernel(cons
         u32x4 w;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
+          if constexpr (ABL & 2) {                         // no exp / sum / convert: the raw score bits feed the second product
+            w[jj] = (__builtin_bit_cast(unsigned, s[kt][8 * ks + 2 * jj]) >> 16) | (__builtin_bit_cast(unsigned, s[kt][8 * ks + 2 * jj + 1]) & 0xffff0000u);
+          } else {
           const f32x2_t e = {__builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj + 1])};
-          if constexpr (!MSUM) sum_pair(lsum, e);
+          if constexpr (!MSUM && !DOT2) sum_pair(lsum, e);
           w[jj] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_t));
+          if constexpr (DOT2) {
+#ifdef UCOD_HALF_F16
+            lsum[jj & 1] = __builtin_amdgcn_fdot2(__builtin_bit_cast(hx2, w[jj]), __builtin_bit_cast(hx2, 0x3c003c00u), lsum[jj & 1], false);
+#else
+            lsum[jj & 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hx2, w[jj]), __builtin_bit_cast(hx2, 0x3f803f80u), lsum[jj & 1], false);
+#endif
+          }
+          }
         }
         pb[ks] = __builtin_bit_cast(hx8, w);
       }
@@ -1583,10 +1717,14 @@ __global__ __launch_bounds__(256, SEQ == 1 ? 5 : 2) void attn_fwd_r3_kernel(cons
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const char* p0 = kb + (kt * 32 + ks * 16) * 128 + voff[dt];
-          const hx4 lo = UCOD_TR16(p0);
-          const hx4 hi = UCOD_TR16(p0 + 8 * 128);
-          const hx8 vf = (hx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          o[dt] = UCOD_MFMA32(vf, pb[ks], o[dt]);
+          hx8 vf;
+          if constexpr (ABL & 4) vf = qf[(2 * ks + dt) & 3];
+          else {
+            const hx4 lo = UCOD_TR16(p0);
+            const hx4 hi = UCOD_TR16(p0 + 8 * 128);
+            vf = (hx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+          o[dt] = MF(vf, pb[ks], o[dt]);
         }
       }
     }
@@ -1638,8 +1776,14 @@ extern "C" int ucod_attention_fwd_lab(const void* qkv, void* out, int B, int tok
     dim3 grid1(cdiv(npairs, 8) * 8 * nq);
     // variant 3: K/V staged through registers, 4: LDS-DMA, both with the denominator on the matrix pipe (all-ones MFMA);
     // 6: LDS-DMA + denominator as f32 adds of the unrounded probabilities (4 % faster than 4 at 4 waves per SIMD)
-    if (variant >= 30 && variant <= 35) {
+    if (variant >= 30 && variant <= 59) {
       const float* nol = nullptr;
+#define UCOD_ABL_CASE(V, A) if (variant == V) hipLaunchKernelGGL((attn_fwd_r3_kernel<false, false, 0, A>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nol);
+      UCOD_ABL_CASE(40, 1) UCOD_ABL_CASE(41, 2) UCOD_ABL_CASE(42, 4) UCOD_ABL_CASE(43, 8) UCOD_ABL_CASE(44, 14) UCOD_ABL_CASE(45, 13) UCOD_ABL_CASE(46, 12) UCOD_ABL_CASE(47, 6)
+#undef UCOD_ABL_CASE
+#define UCOD_SCHED_CASE(V, S) if (variant == V) hipLaunchKernelGGL((attn_fwd_r3_kernel<false, false, 0, 0, S>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nol);
+      UCOD_SCHED_CASE(50, 1) UCOD_SCHED_CASE(51, 2) UCOD_SCHED_CASE(52, 3) UCOD_SCHED_CASE(53, 4) UCOD_SCHED_CASE(54, 5) UCOD_SCHED_CASE(55, 6) UCOD_SCHED_CASE(56, 7)
+#undef UCOD_SCHED_CASE
       if (variant == 30) hipLaunchKernelGGL((attn_fwd_r3_kernel<false, false, 0>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nol);
       if (variant == 31) hipLaunchKernelGGL((attn_fwd_r3_kernel<true, false, 0>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nol);
       if (variant == 32) hipLaunchKernelGGL((attn_fwd_r3_kernel<false, true, 0>), grid1, block, 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs, (float*)nol);
