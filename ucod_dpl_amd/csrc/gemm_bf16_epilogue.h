@@ -79,14 +79,24 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 // launch and was VALU-bound: 6.3 k of its 18.1 k cycles per 256x256 tile).  d5 > 0, so large |x| underflows to t = 0.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+#ifdef UCOD_GELU_FMAXF
   const f32x2 a = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+#else
+  // IEEE maximum (v_maximum3_f32): fmaxf would put a canonicalising v_max x, x, x in front of every max; |x| = 2 max(x, 0) - x (exact) is one
+  // packed FMA per pair instead of two v_and.  11 instead of 14 vector instructions per pair: the fc1 epilogue is bound by exactly these
+  // (profiles/r03_fc1_gelu_epilogue.txt)
+  const f32x2 pos = {__builtin_elementwise_maximum(x[0], 0.f), __builtin_elementwise_maximum(x[1], 0.f)};
+  const f32x2 a = pos * 2.0f - x;
+#endif
   f32x2 p = a * 4.881021588e-04f + (-7.198718842e-03f);
   p = p * a + 5.214663086e-02f;
   p = p * a + 4.595958292e-01f;
   p = p * a + 1.151000509e+00f;
   p = p * a + 1.0f;
   const f32x2 t = {__builtin_amdgcn_exp2f(-p[0]), __builtin_amdgcn_exp2f(-p[1])};
+#ifdef UCOD_GELU_FMAXF
   const f32x2 pos = {__builtin_fmaxf(x[0], 0.f), __builtin_fmaxf(x[1], 0.f)};
+#endif
   return pos - a * t;
 }
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f32x2){x, x})[0]; }
@@ -441,14 +451,30 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
       static_assert((PR * CH) % 64 == 0, "whole wave instructions");
       // second bf16 [M,N] matrix with the same geometry: the saved pre-activation, read (GELU_BWD) or written (GELU_SAVE)
       const void* second = GBWD ? a.aux : (SAVE ? (const void*)a.out2 : (RH16 ? (const void*)a.resid : (const void*)a.out));
+      // 64-column waves (CH == 8): wave instruction `it` covers rows it*8 + lane/8, chunk lane%8, so the lane's byte offset is ONE register
+      // (its pass-0 / it-0 offset, or DROP when its columns lie past N) plus a wave-uniform term: one v_add per store instead of the ~11
+      // vector instructions (one of them v_mul_lo_u32) of the generic (row, chunk) arithmetic -- the drain of fc1 is bound by its vector
+      // work (profiles/r03_fc1_gelu_epilogue.txt).  DROP + any tile-relative offset stays >= 2^31 and the descriptors end below that.
+      constexpr bool FAST = (CH == 8);
+      constexpr unsigned DROP = 0x80000000u;
+      const unsigned rec16 = FAST ? (records > 0x7FFFFFF0u ? 0x7FFFFFF0u : records) : records;
+      const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + base, 0, rec16, 0x00020000);
       const auto rs_2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(second)) + base, 0,
-                                                          (GBWD || SAVE || RH16) ? records : 0u, 0x00020000);
+                                                          (GBWD || SAVE || RH16) ? rec16 : 0u, 0x00020000);
       // (row, chunk) of wave instruction `it`: recomputed where needed -- index arrays cost registers the persistent kernel lacks
       auto lrow = [&](int it) { return (it * 64 + lane) / CH; };
       auto lchk = [&](int it) { return (it * 64 + lane) - lrow(it) * CH; };
-      auto at = [&](int it, int pass) {
+      const unsigned off0 = (n_first + (lane & 7) * 8 < a.N) ? (unsigned)(lane >> 3) * row_bytes + (unsigned)(n_first + (lane & 7) * 8) * 2u : DROP;
+      const char* lds0 = wbase + (lane >> 3) * (WCOLS * 4) + (lane & 7) * 32;
+      auto live = [&](int it, int pass) { return !FAST || it * 8 < rows_in(pass); };   // (compile-time after unrolling) rows 16..31 of a 16-row last pass
+      auto at = [&](int it, int pass) -> unsigned {
+        if constexpr (FAST) return off0 + (unsigned)(pass * PR + it * 8) * row_bytes;
         const int n = n_first + lchk(it) * 8;
         return (n < a.N && lrow(it) < rows_in(pass)) ? (unsigned)(pass * PR + lrow(it)) * row_bytes + (unsigned)n * 2u : OOB;
+      };
+      auto lds_at = [&](int it) -> const char* {
+        if constexpr (FAST) return lds0 + it * 8 * (WCOLS * 4);
+        return wbase + lrow(it) * (WCOLS * 4) + lchk(it) * 32;
       };
       float amax = 0.f;                                             // RH16: largest |x_new| this lane produced (saturation test after the stores)
       u32x4 pre[2][ITS];
@@ -462,14 +488,18 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
         if constexpr (GBWD || RH16) {
           if (pass + 1 < NP) {
 #pragma unroll
-            for (int it = 0; it < ITS; ++it) pre[(pass + 1) & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_2, at(it, pass + 1), 0, 0);
+            for (int it = 0; it < ITS; ++it) {
+              if (!live(it, pass + 1)) continue;
+              pre[(pass + 1) & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_2, at(it, pass + 1), 0, 0);
+            }
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
-          f32x4 v0 = *reinterpret_cast<const f32x4*>(wbase + lrow(it) * (WCOLS * 4) + lchk(it) * 32);
-          f32x4 v1 = *reinterpret_cast<const f32x4*>(wbase + lrow(it) * (WCOLS * 4) + lchk(it) * 32 + 16);
+          if (!live(it, pass)) continue;
+          f32x4 v0 = *reinterpret_cast<const f32x4*>(lds_at(it));
+          f32x4 v1 = *reinterpret_cast<const f32x4*>(lds_at(it) + 16);
           if constexpr (SAVE) {                                   // pre-activation out first
             u32x4 w;
             w[0] = pack_h2(v0[0], v0[1]);
@@ -518,7 +548,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
             w[2] = pack_h2(v1[0], v1[1]);
             w[3] = pack_h2(v1[2], v1[3]);
           }
-          __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, at(it, pass), 0, AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(w, rs_o, at(it, pass), 0, AUX);
           __builtin_amdgcn_sched_barrier(0);                      // keep chunks in order: hoisting every ds_read/cvt of a pass spills in the persistent kernel
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
