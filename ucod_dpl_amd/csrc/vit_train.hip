@@ -150,79 +150,85 @@ __global__ __launch_bounds__(256) void ln_lora_kernel(const void* __restrict__ x
 // ---------------------------------------------------------------------------------------------------------------------
 // LORA: dy additionally receives the dropout-masked LoRA branch  sum_p mask_p/keep * (t_p A_p)  (t = aug columns of dqkv_aug); with
 // dropout off that term rides on the dgrad GEMM instead (A^T columns of WqkvT_aug) and this kernel is launched with LORA = false.
-template <int NCH, bool LORA>
+// One wave per row; a lane owns NCH chunks of VW consecutive floats (VW = 4: 16-byte accesses, rows of a multiple of 256 floats; VW = 2 for
+// the other widths).  Everything the row needs from memory -- x, dy, the residual cotangent -- is requested before the first reduction, so
+// that one latency covers all three streams (round 3: 103 -> see profiles/r03_ln_bwd.txt).
+template <int NCH, int VW, bool LORA>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      const float* __restrict__ scale, float* __restrict__ dx,
                                                      bf16_raw* __restrict__ sout, int rows, int D, float eps,
                                                      const bf16_raw* __restrict__ tq, int ldt, const float* __restrict__ lora, int r, Drop drop) {
+  typedef float vecf __attribute__((ext_vector_type(VW)));
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float2* xr = reinterpret_cast<const float2*>(x + (size_t)row * D);
-  const float2* dyr = reinterpret_cast<const float2*>(dy + (size_t)row * D);
-  const float2* g2 = reinterpret_cast<const float2*>(gamma);
-  float2 v[NCH], g[NCH];
+  const vecf* xr = reinterpret_cast<const vecf*>(x + (size_t)row * D);
+  const vecf* dyr = reinterpret_cast<const vecf*>(dy + (size_t)row * D);
+  const vecf* rr = dres ? reinterpret_cast<const vecf*>(dres + (size_t)row * D) : nullptr;
+  const vecf* g2 = reinterpret_cast<const vecf*>(gamma);
+  vecf v[NCH], g[NCH], res[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) v[i] = xr[lane + 64 * i];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) g[i] = dyr[lane + 64 * i];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) res[i] = rr ? rr[lane + 64 * i] : (vecf)(0.f);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    v[i] = xr[lane + 64 * i];
-    float2 d = dyr[lane + 64 * i];
+    vecf d = g[i];
     if constexpr (LORA) {
-      const unsigned idx = (unsigned)row * (unsigned)D + 2u * (unsigned)(lane + 64 * i);
+      const unsigned idx = (unsigned)row * (unsigned)D + (unsigned)VW * (unsigned)(lane + 64 * i);
       for (int p = 0; p < 3; ++p) {
-        float a0 = 0.f, a1 = 0.f;
+        vecf acc = (vecf)(0.f);
         for (int jr = 0; jr < r; ++jr) {
           const float t = bf16_to_f32(tq[(size_t)row * ldt + p * r + jr]);
-          const float2 av = reinterpret_cast<const float2*>(lora + (size_t)p * 2 * r * D + (size_t)jr * D)[lane + 64 * i];
-          a0 += t * av.x;
-          a1 += t * av.y;
+          const vecf av = reinterpret_cast<const vecf*>(lora + (size_t)p * 2 * r * D + (size_t)jr * D)[lane + 64 * i];
+          acc += t * av;
         }
-        d.x += a0 * drop_scale(drop, p, idx);
-        d.y += a1 * drop_scale(drop, p, idx + 1u);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) d[e] += acc[e] * drop_scale(drop, p, idx + (unsigned)e);
       }
     }
-    const float2 gm = g2[lane + 64 * i];
-    g[i] = make_float2(d.x * gm.x, d.y * gm.y);
-    s += v[i].x + v[i].y;
+    g[i] = d * g2[lane + 64 * i];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) s += v[i][e];
   }
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    v[i].x -= mean;
-    v[i].y -= mean;
-    q += v[i].x * v[i].x + v[i].y * v[i].y;
+    v[i] -= mean;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) q += v[i][e] * v[i][e];
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
   float sg = 0.f, sgx = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    v[i].x *= rstd;
-    v[i].y *= rstd;
-    sg += g[i].x + g[i].y;
-    sgx += g[i].x * v[i].x + g[i].y * v[i].y;
+    v[i] *= rstd;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      sg += g[i][e];
+      sgx += g[i][e] * v[i][e];
+    }
   }
   const float mg = wave_sum(sg) / (float)D, mgx = wave_sum(sgx) / (float)D;
-  const float2* rr = dres ? reinterpret_cast<const float2*>(dres + (size_t)row * D) : nullptr;
-  const float2* sc2 = scale ? reinterpret_cast<const float2*>(scale) : nullptr;
+  const vecf* sc2 = scale ? reinterpret_cast<const vecf*>(scale) : nullptr;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    float o0 = rstd * (g[i].x - mg - v[i].x * mgx), o1 = rstd * (g[i].y - mg - v[i].y * mgx);
-    if (rr) {
-      const float2 r = rr[lane + 64 * i];
-      o0 += r.x;
-      o1 += r.y;
-    }
-    if (dx) reinterpret_cast<float2*>(dx + (size_t)row * D)[lane + 64 * i] = make_float2(o0, o1);
+    vecf o;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) o[e] = rstd * (g[i][e] - mg - v[i][e] * mgx) + res[i][e];
+    if (dx) reinterpret_cast<vecf*>(dx + (size_t)row * D)[lane + 64 * i] = o;
     if (sout) {
-      float c0 = 1.f, c1 = 1.f;
-      if (sc2) {
-        const float2 c = sc2[lane + 64 * i];
-        c0 = c.x;
-        c1 = c.y;
-      }
-      reinterpret_cast<unsigned*>(sout + (size_t)row * D)[lane + 64 * i] = pack_bf16x2(o0 * c0, o1 * c1);
+      const vecf c = sc2 ? sc2[lane + 64 * i] : (vecf)(1.f);
+      typedef unsigned vecu __attribute__((ext_vector_type(VW / 2)));
+      vecu w;
+#pragma unroll
+      for (int e = 0; e < VW / 2; ++e) w[e] = pack_bf16x2(o[2 * e] * c[2 * e], o[2 * e + 1] * c[2 * e + 1]);
+      reinterpret_cast<vecu*>(sout + (size_t)row * D)[lane + 64 * i] = w;
     }
   }
 }
@@ -499,16 +505,23 @@ static int launch_ln_bwd(const float* dy, const float* x, const float* gamma, co
                          int rows, int D, float eps, const bf16_raw* tq, int ldt, const float* lora, int r, const Drop& drop, hipStream_t s) {
   dim3 grid(cdiv(rows, 4)), block(256);
   const bool lo = tq != nullptr;
-  switch (D / 128) {
-#define C(n)                                                                                                                                   \
+#define C(n, vw)                                                                                                                               \
   case n:                                                                                                                                      \
-    if (lo) hipLaunchKernelGGL((ln_bwd_kernel<n, true>), grid, block, 0, s, dy, x, gamma, dres, next_scale, dx, (bf16_raw*)s_bf16, rows, D, eps, tq, ldt, lora, r, drop); \
-    else hipLaunchKernelGGL((ln_bwd_kernel<n, false>), grid, block, 0, s, dy, x, gamma, dres, next_scale, dx, (bf16_raw*)s_bf16, rows, D, eps, tq, ldt, lora, r, drop); \
+    if (lo) hipLaunchKernelGGL((ln_bwd_kernel<n, vw, true>), grid, block, 0, s, dy, x, gamma, dres, next_scale, dx, (bf16_raw*)s_bf16, rows, D, eps, tq, ldt, lora, r, drop); \
+    else hipLaunchKernelGGL((ln_bwd_kernel<n, vw, false>), grid, block, 0, s, dy, x, gamma, dres, next_scale, dx, (bf16_raw*)s_bf16, rows, D, eps, tq, ldt, lora, r, drop); \
     break;
-    C(1) C(2) C(3) C(4) C(5) C(6) C(8) C(10) C(12)
-#undef C
-    default: return UCOD_EINVAL;
+  if (D % 256 == 0) {                                      // 16-byte accesses
+    switch (D / 256) {
+      C(1, 4) C(2, 4) C(3, 4) C(4, 4) C(5, 4) C(6, 4)
+      default: return UCOD_EINVAL;
+    }
+  } else {
+    switch (D / 128) {
+      C(1, 2) C(3, 2) C(5, 2) C(7, 2) C(9, 2) C(11, 2)
+      default: return UCOD_EINVAL;
+    }
   }
+#undef C
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }
