@@ -39,21 +39,34 @@ __device__ __forceinline__ float bn_lrelu(float y, float mean, float rstd, float
 }
 
 // in: [B,CIN,IH,IW] (pre-BN output of the previous block, or the raw mask when !BN_IN); out: [B,COUT,OH,OW] pre-BN
-template <int CIN, int COUT, int STRIDE, bool BN_IN>
+template <int CIN, int COUT, int STRIDE, bool BN_IN, int CPT = COUT>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                       const float* __restrict__ in_stats, const float* __restrict__ in_g,
                                                       const float* __restrict__ in_b, float* __restrict__ out,
                                                       double* __restrict__ gacc /* [2*COUT]: sum, sum of squares */, int B, int IH,
                                                       int OH) {
-  __shared__ __attribute__((aligned(16))) float ws[CIN * 9 * COUT];  // [ci][tap][co]
+  // Round 3.  Weights: with CIN >= 16 they are read straight from `w` with wave-uniform indices (scalar loads, the FMA takes the SGPR
+  // operand); they used to be transposed into LDS and re-read per FMA -- 4 608 LDS reads per thread in the 32 -> 16 layer, 63.7 us for
+  // 341 MFLOP.  The single-input-channel layer keeps its 288 weights in LDS (they do not fit the scalar registers at once).  Taps: the nine
+  // clamped offsets and validity flags are computed once, not per input channel.  The accumulation order per output channel -- (ci, tap)
+  // lexicographic -- is unchanged, so results are bitwise the same as before.
+  // CPT output channels per thread (blockIdx.y selects the group): the 32 -> 16 layer has 145 workgroups' worth of pixels at batch 32, not
+  // one wave per SIMD, and every input-channel step is a load latency followed by its FMAs; four channel groups put four times the waves
+  // on the chip.  (The statistics partial of a workgroup is then summed over 256 / CPT instead of 256 / COUT threads per channel.)
+  static_assert(COUT % CPT == 0 && 256 % CPT == 0, "channel groups");
+  const int c0 = blockIdx.y * CPT;
+  constexpr bool SW = CIN >= 16 || CIN * CPT * 9 <= 96;   // (scalar weights: a step's CPT x 9, or all of them, fit the scalar registers)
+  __shared__ __attribute__((aligned(16))) float ws[SW ? 1 : CIN * 9 * COUT];  // [ci][tap][co]
   __shared__ float sc[CIN > 1 ? CIN : 1], sh[CIN > 1 ? CIN : 1];
-  constexpr int PARTS = 256 / COUT;                     // threads cooperating on one channel in the statistics pass
-  __shared__ float red[256 * (COUT + 1)];
-  __shared__ float psum[PARTS][COUT], psq[PARTS][COUT];
+  constexpr int PARTS = 256 / CPT;                      // threads cooperating on one channel in the statistics pass
+  __shared__ float red[256 * (CPT + 1)];
+  __shared__ float psum[PARTS][CPT], psq[PARTS][CPT];
   const int tid = threadIdx.x;
-  for (int i = tid; i < CIN * 9 * COUT; i += 256) {
-    const int co = i % COUT, rest = i / COUT, tap = rest % 9, ci = rest / 9;
-    ws[i] = w[(co * CIN + ci) * 9 + tap];
+  if constexpr (!SW) {
+    for (int i = tid; i < CIN * 9 * COUT; i += 256) {
+      const int co = i % COUT, rest = i / COUT, tap = rest % 9, ci = rest / 9;
+      ws[i] = w[(co * CIN + ci) * 9 + tap];
+    }
   }
   if (BN_IN && tid < CIN) {
     const float mean = in_stats[tid], rstd = in_stats[CIN + tid];
@@ -66,50 +79,65 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
   const bool valid = idx0 < total;
   const long idx = valid ? idx0 : total - 1;
   const int ox = (int)(idx % OH), oy = (int)((idx / OH) % OH), b = (int)(idx / ((long)OH * OH));
-  float acc[COUT];
+  float acc[CPT];
 #pragma unroll
-  for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+  for (int co = 0; co < CPT; ++co) acc[co] = 0.f;
+  int off[9];
+  bool ok[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy * STRIDE - 1 + ky, ix = ox * STRIDE - 1 + kx;
+      ok[ky * 3 + kx] = iy >= 0 && iy < IH && ix >= 0 && ix < IH;
+      const int cy = iy < 0 ? 0 : (iy >= IH ? IH - 1 : iy), cx = ix < 0 ? 0 : (ix >= IH ? IH - 1 : ix);
+      off[ky * 3 + kx] = cy * IH + cx;
+    }
   const float* ib = in + (long)b * CIN * IH * IH;
   for (int ci = 0; ci < CIN; ++ci) {
     float v[9];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int iy = oy * STRIDE - 1 + ky, ix = ox * STRIDE - 1 + kx;
-        float t = 0.f;
-        if (iy >= 0 && iy < IH && ix >= 0 && ix < IH) {
-          t = ib[((long)ci * IH + iy) * IH + ix];
-          if (BN_IN) {
-            t = fmaf(t, sc[ci], sh[ci]);
-            t = t >= 0.f ? t : t * LRELU;
-          }
-        }
-        v[ky * 3 + kx] = t;
+    for (int k = 0; k < 9; ++k) {
+      float t = ib[off[k]];                                       // (clamped: always in range)
+      if (BN_IN) {
+        t = fmaf(t, sc[ci], sh[ci]);
+        t = t >= 0.f ? t : t * LRELU;
       }
+      v[k] = ok[k] ? t : 0.f;
+    }
+    ib += IH * IH;
+    if constexpr (SW) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const float* wr = &ws[(ci * 9 + tap) * COUT];
+      for (int co = 0; co < CPT; ++co) {
+        const float* wr = w + ((c0 + co) * CIN + ci) * 9;         // (uniform address: scalar loads)
 #pragma unroll
-      for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wr[co], v[tap], acc[co]);
+        for (int tap = 0; tap < 9; ++tap) acc[co] = fmaf(wr[tap], v[tap], acc[co]);
+      }
+    } else {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float* wr = &ws[(ci * 9 + tap) * COUT + c0];
+#pragma unroll
+        for (int co = 0; co < CPT; ++co) acc[co] = fmaf(wr[co], v[tap], acc[co]);
+      }
     }
   }
-  float* ob = out + (long)b * COUT * OH * OH + (long)oy * OH + ox;
+  float* ob = out + ((long)b * COUT + c0) * OH * OH + (long)oy * OH + ox;
   // pre-BN output + this workgroup's share of the batch statistics: transpose through LDS (thread-major -> channel-major),
   // PARTS threads per channel sum 256/PARTS pixels each, then one f64 atomic per channel per workgroup.
 #pragma unroll
-  for (int co = 0; co < COUT; ++co) {
+  for (int co = 0; co < CPT; ++co) {
     const float v = valid ? acc[co] : 0.f;
     if (valid) ob[(long)co * OH * OH] = v;
-    red[tid * (COUT + 1) + co] = v;
+    red[tid * (CPT + 1) + co] = v;
   }
   __syncthreads();
   {
-    const int ch = tid % COUT, part = tid / COUT;
+    const int ch = tid % CPT, part = tid / CPT;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll 8
     for (int r = part; r < 256; r += PARTS) {
-      const float v = red[r * (COUT + 1) + ch];
+      const float v = red[r * (CPT + 1) + ch];
       s1 += v;
       s2 = fmaf(v, v, s2);
     }
@@ -117,12 +145,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     psq[part][ch] = s2;
   }
   __syncthreads();
-  if (tid < COUT) {
+  if (tid < CPT) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int q = 0; q < PARTS; ++q) { s1 += psum[q][tid]; s2 += psq[q][tid]; }
-    atomicAdd(&gacc[tid], (double)s1);
-    atomicAdd(&gacc[COUT + tid], (double)s2);
+    atomicAdd(&gacc[c0 + tid], (double)s1);
+    atomicAdd(&gacc[COUT + c0 + tid], (double)s2);
   }
 }
 
@@ -185,11 +213,11 @@ extern "C" int ucod_disc_fwd(const float* mask, const ucod_disc_params* p, float
   double* ac3 = ac2 + 32;
   hipError_t e = hipMemsetAsync(ac1, 0, 112 * sizeof(double), s);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv3x3_kernel<1, 32, 1, false>), dim3(cdiv((long)B * d.s1 * d.s1, 256)), dim3(256), 0, s, mask, p->w1, nullptr, nullptr, nullptr, y1, ac1, B, fs, d.s1);
+  hipLaunchKernelGGL((conv3x3_kernel<1, 32, 1, false, 8>), dim3(cdiv((long)B * d.s1 * d.s1, 256), 4), dim3(256), 0, s, mask, p->w1, nullptr, nullptr, nullptr, y1, ac1, B, fs, d.s1);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, ac1, 32, (double)B * d.s1 * d.s1, st1, p->rm1, p->rv1, update_running);
-  hipLaunchKernelGGL((conv3x3_kernel<32, 16, 2, true>), dim3(cdiv((long)B * d.s2 * d.s2, 256)), dim3(256), 0, s, y1, p->w2, st1, p->g1, p->b1, y2, ac2, B, d.s1, d.s2);
+  hipLaunchKernelGGL((conv3x3_kernel<32, 16, 2, true, 4>), dim3(cdiv((long)B * d.s2 * d.s2, 256), 4), dim3(256), 0, s, y1, p->w2, st1, p->g1, p->b1, y2, ac2, B, d.s1, d.s2);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, ac2, 16, (double)B * d.s2 * d.s2, st2, p->rm2, p->rv2, update_running);
-  hipLaunchKernelGGL((conv3x3_kernel<16, 8, 2, true>), dim3(cdiv((long)B * d.s3 * d.s3, 256)), dim3(256), 0, s, y2, p->w3, st2, p->g2, p->b2, y3, ac3, B, d.s2, d.s3);
+  hipLaunchKernelGGL((conv3x3_kernel<16, 8, 2, true, 2>), dim3(cdiv((long)B * d.s3 * d.s3, 256), 4), dim3(256), 0, s, y2, p->w3, st2, p->g2, p->b2, y3, ac3, B, d.s2, d.s3);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, ac3, 8, (double)B * d.s3 * d.s3, st3, p->rm3, p->rv3, update_running);
   hipLaunchKernelGGL(disc_head_kernel, dim3(B), dim3(256), 0, s, y3, st3, p->g3, p->b3, p->lin_w, p->lin_b, prob, d.s3 * d.s3);
   UCOD_CHECK_LAUNCH();
