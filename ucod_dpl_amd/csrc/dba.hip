@@ -69,36 +69,37 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------- Gram matrices (f32 MFMA)
 // grid (S pixel chunks, B); partial[b][s][branch][64][64] = sum over the chunk of f f^T.
 constexpr int GCH = 512;   // pixels per workgroup
-constexpr int GK = 16;     // pixels per K-tile
-constexpr int GLD = 129;
+constexpr int GK = 64;     // pixels per K-tile: a wave instruction of the staging loads reads 256 contiguous bytes of ONE channel row
+constexpr int GLD = 129;   // (round 3; was 16 pixels = four 64-byte pieces of four rows per instruction: 78 us for 76 MB.  The MFMAs consume
+                           //  the same (k, k+1) pixel pairs in the same order, so the partial sums are bitwise what they were.)
 __global__ __launch_bounds__(256, 2) void gram_partial_kernel(const float* __restrict__ d, int ld_c, int c0,
                                                            const float* __restrict__ emb, const float* __restrict__ norm,
                                                            float* __restrict__ partial, int HW, int S) {
   __shared__ float Fs[2][GK * GLD];
-  __shared__ float kf[128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, ps = blockIdx.x * GCH, pe = min(ps + GCH, HW);
-  if (tid < 128) kf[tid] = emb[tid] / norm[b * 128 + tid];
-  __syncthreads();
   const float* dbase = d + ((long)b * ld_c + c0) * HW;
-  const int sk = tid & 15, srow = tid >> 4;  // staging: 16 lanes = 64 contiguous bytes of one channel row
+  const int sk = tid & 63, srow = tid >> 6;  // staging: a wave = 64 consecutive pixels of one channel row, 4 rows per pass
   const int br = wave >> 1, rt = wave & 1;   // wave -> (branch, row tile); both column tiles
+  float kf[32];                              // emb / norm of this thread's 32 rows
+#pragma unroll
+  for (int i = 0; i < 32; ++i) kf[i] = emb[srow + 4 * i] / norm[b * 128 + srow + 4 * i];
   f32x16 acc[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
 
-  float r[8];
+  float r[32];
   auto gload = [&](int k0) {
     const int k = k0 + sk;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = srow + 16 * i;
-      r[i] = (k < pe) ? dbase[(long)row * HW + k] * kf[row] : 0.f;
+    for (int i = 0; i < 32; ++i) {
+      const int row = srow + 4 * i;
+      r[i] = (k < pe) ? dbase[(long)row * HW + k] * kf[i] : 0.f;
     }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) Fs[buf][sk * GLD + srow + 16 * i] = r[i];
+    for (int i = 0; i < 32; ++i) Fs[buf][sk * GLD + srow + 4 * i] = r[i];
   };
   const int nt = (pe - ps + GK - 1) / GK;
   gload(ps);
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void gram_partial_kernel(const float* __res
     const bool more = t + 1 < nt;
     if (more) gload(ps + (t + 1) * GK);
     const float* fs = Fs[t & 1];
-#pragma unroll
+#pragma unroll 8
     for (int kk = 0; kk < GK; kk += 2) {
       const int k = kk + (lane >> 5);
       const float a = fs[k * GLD + br * 64 + rt * 32 + (lane & 31)];
@@ -130,32 +131,33 @@ __global__ __launch_bounds__(256, 2) void gram_partial_kernel(const float* __res
     }
 }
 
-// grid (B): gram[b] = sum_s partial[b][s]; trace[b] = sum_ij G1_ij G2_ij (= tr(G1 G2), both symmetric)
+// grid (B, FIN_Y): gram[b] = sum_s partial[b][s]; trace[b][y] = this workgroup's share of sum_ij G1_ij G2_ij (= tr(G1 G2), both symmetric)
+constexpr int FIN_Y = E * E / 256;
 __global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restrict__ partial, float* __restrict__ gram,
                                                             float* __restrict__ trace, int S) {
   __shared__ float red[16];
-  const int b = blockIdx.x;
-  float tr = 0.f;
-  for (int i = threadIdx.x; i < E * E; i += 256) {
-    float g1 = 0.f, g2 = 0.f;
-    for (int s = 0; s < S; ++s) {
-      const float* p = partial + (((long)b * S + s) * 2) * (E * E);
-      g1 += p[i];
-      g2 += p[E * E + i];
-    }
-    gram[((long)b * 2 + 0) * (E * E) + i] = g1;
-    gram[((long)b * 2 + 1) * (E * E) + i] = g2;
-    tr = fmaf(g1, g2, tr);
+  const int b = blockIdx.x, i = blockIdx.y * 256 + threadIdx.x;
+  float g1 = 0.f, g2 = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float* p = partial + (((long)b * S + s) * 2) * (E * E);
+    g1 += p[i];
+    g2 += p[E * E + i];
   }
-  tr = block_sum(tr, red);
-  if (threadIdx.x == 0) trace[b] = tr;
+  gram[((long)b * 2 + 0) * (E * E) + i] = g1;
+  gram[((long)b * 2 + 1) * (E * E) + i] = g2;
+  const float tr = block_sum(g1 * g2, red);
+  if (threadIdx.x == 0) trace[b * FIN_Y + blockIdx.y] = tr;
 }
 
 __global__ void orth_loss_kernel(const float* __restrict__ trace, const float* __restrict__ sdiag, float* __restrict__ loss, int B,
                                  double inv_z) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     double t = 0.0;
-    for (int b = 0; b < B; ++b) t += (double)trace[b] - (double)sdiag[b];
+    for (int b = 0; b < B; ++b) {
+      double tb = 0.0;
+      for (int y = 0; y < FIN_Y; ++y) tb += (double)trace[b * FIN_Y + y];
+      t += tb - (double)sdiag[b];
+    }
     loss[0] = (float)(t * inv_z);
   }
 }
@@ -315,7 +317,7 @@ extern "C" int ucod_dba_heads_fwd(const float* d, int ld_c, int c0, const float*
 
 extern "C" size_t ucod_orth_workspace_bytes(int B, int HW) {
   const size_t S = (size_t)cdiv(HW, GCH);
-  return ((size_t)B * S * 2 * E * E + (size_t)B) * sizeof(float);
+  return ((size_t)B * S * 2 * E * E + (size_t)B * FIN_Y) * sizeof(float);
 }
 
 extern "C" int ucod_orth_gram_fwd(const float* d, int ld_c, int c0, const float* emb, const float* norm, const float* sdiag,
@@ -327,7 +329,7 @@ extern "C" int ucod_orth_gram_fwd(const float* d, int ld_c, int c0, const float*
   float* partial = (float*)ws;
   float* trace = partial + (size_t)B * S * 2 * E * E;
   hipLaunchKernelGGL(gram_partial_kernel, dim3(S, B), dim3(256), 0, s, d, ld_c, c0, emb, norm, partial, HW, S);
-  hipLaunchKernelGGL(gram_finalize_kernel, dim3(B), dim3(256), 0, s, partial, gram, trace, S);
+  hipLaunchKernelGGL(gram_finalize_kernel, dim3(B, FIN_Y), dim3(256), 0, s, partial, gram, trace, S);
   const double inv_z = 1.0 / ((double)B * (double)HW * (double)HW);
   hipLaunchKernelGGL(orth_loss_kernel, dim3(1), dim3(64), 0, s, trace, sdiag, loss, B, inv_z);
   UCOD_CHECK_LAUNCH();
