@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void colnorm_kernel(const float* __restrict__ 
   const float e = emb[c];  // emb [2,64] flattened == channel index within this decoder
   const float* row = d + ((long)b * ld_c + c0 + c) * HW;
   float s = 0.f;
+#pragma unroll 8
   for (int p = threadIdx.x; p < HW; p += 256) {
     const float u = row[p] * e;
     s = fmaf(u, u, s);
