@@ -140,6 +140,9 @@ __device__ __forceinline__ T block_sum(T v, T* smem /* >= 16 entries */) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+// the DBA gate's sigmoid (128 per pixel in heads_fwd / dba_bwd, which were bound by expf + the IEEE division of sigmoid_acc): v_exp_f32 of
+// the scaled argument and v_rcp_f32 -- 1 ulp each plus |x| * 6e-8 from the argument's rounding, against the 5e-5 the step is pinned to
+__device__ __forceinline__ float sigmoid_gate(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

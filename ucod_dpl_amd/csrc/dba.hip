@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
     for (int c = 0; c < E; ++c) {
       const float d1 = dp[(long)c * HW], d2 = dp[(long)(c + E) * HW];
       const float f1 = d1 * kf[c], f2 = d2 * kf[c + E];
-      accf = fmaf(hw[c], sigmoid_acc(f1 * d1) + d1, accf);
-      accb = fmaf(hw[c + E], sigmoid_acc(f2 * d2) + d2, accb);
+      accf = fmaf(hw[c], sigmoid_gate(f1 * d1) + d1, accf);
+      accb = fmaf(hw[c + E], sigmoid_gate(f2 * d2) + d2, accb);
       s = fmaf(f1, f2, s);
     }
     fg[(long)b * HW + p] = accf;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void dba_bwd_a_kernel(const float* __restri
         const int c = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h5;
         const float d1 = dp[(long)c * HW + px[ct]], d2 = dp[(long)(c + E) * HW + px[ct]];
         const float f1 = d1 * kf[c], f2 = d2 * kf[c + E];
-        const float s1 = sigmoid_acc(f1 * d1), s2 = sigmoid_acc(f2 * d2);
+        const float s1 = sigmoid_gate(f1 * d1), s2 = sigmoid_gate(f2 * d2);
         if (ok[ct]) {
           gp[(long)c * HW + px[ct]] = coef * (a1[rt][ct][r] - s * f2) + g1 * hw[c] * s1 * (1.f - s1) * d1;
           gp[(long)(c + E) * HW + px[ct]] = coef * (a2[rt][ct][r] - s * f1) + g2 * hw[c + E] * s2 * (1.f - s2) * d2;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void dba_bwd_b_kernel(const float* __restrict_
   float sgd = 0.f, sga = 0.f, sg_up = 0.f;
   for (int p = tid; p < HW; p += 256) {
     const float dv = drow[p], f = dv * k, gf = grow[p], g = gup[p];
-    const float sg = sigmoid_acc(f * dv);
+    const float sg = sigmoid_gate(f * dv);
     const float gu = clamped ? gf / NORM_EPS : (gf - f * r) / n;
     const float o = fmaf(gu, e, g * w * fmaf(sg * (1.f - sg), f, 1.f));
     orow[p] = o;
