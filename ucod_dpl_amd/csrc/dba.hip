@@ -90,13 +90,14 @@ __global__ __launch_bounds__(256, 2) void gram_partial_kernel(const float* __res
   for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
 
   float r[32];
-  auto gload = [&](int k0) {
+  auto gload = [&](int k0) {                 // clamped address + select: a predicated load would be a branch with its own vmcnt(0) per pair
     const int k = k0 + sk;
+    const float* src = dbase + (k < pe ? k : pe - 1);
+    const float live = k < pe ? 1.f : 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int row = srow + 4 * i;
-      r[i] = (k < pe) ? dbase[(long)row * HW + k] * kf[i] : 0.f;
-    }
+    for (int i = 0; i < 32; ++i) r[i] = src[(long)(srow + 4 * i) * HW];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) r[i] *= kf[i] * live;
   };
   auto lstore = [&](int buf) {
 #pragma unroll
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void dba_bwd_a_kernel(const float* __restri
     a2[0][0][i] = a2[0][1][i] = a2[1][0][i] = a2[1][1][i] = 0.f;
   }
   float spart[2] = {0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 8
   for (int kk = 0; kk < E; kk += 2) {
     const int k = kk + h5;
     const float k1 = kf[k], k2 = kf[E + k];
@@ -264,10 +265,12 @@ __global__ __launch_bounds__(256) void dba_bwd_b_kernel(const float* __restrict_
   const float* gup = (c < E ? gfg : gbg) + (long)b * HW;
   float* orow = gd + ((long)b * 128 + c) * HW;
   float r = 0.f;
+#pragma unroll 8
   for (int p = tid; p < HW; p += 256) r = fmaf(drow[p] * k, grow[p], r);
   r = block_sum(r, red);
   const bool clamped = (n <= NORM_EPS);
   float sgd = 0.f, sga = 0.f, sg_up = 0.f;
+#pragma unroll 6
   for (int p = tid; p < HW; p += 256) {
     const float dv = drow[p], f = dv * k, gf = grow[p], g = gup[p];
     const float sg = sigmoid_gate(f * dv);

@@ -256,7 +256,17 @@ __global__ __launch_bounds__(512, 2) void dba_project_b3_kernel(const float* __r
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // C/D map of the 32x32 accumulator: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
+  // the lane's 16 NR bias values in ONE batch of loads (round 3: `acc + bias[n]` inside the store loop was a load, a vmcnt(0) and a store per
+  // element, and the `n < Nout` guard a branch per store -- 96 serialised round trips per thread at the end of every workgroup)
   float* db = d + (long)b * Nout * HW;
+  float bv[NR][16];
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = 32 * (NR * wr + i) + (r & 3) + 8 * (r >> 2) + 4 * h5;
+      bv[i][r] = bias[n];                                         // (Nout == NR * 128: the entry point admits nothing else)
+    }
 #pragma unroll
   for (int cb = 0; cb < 3; ++cb) {
     const int p = p0 + 96 * wc + 32 * cb + l31;
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void dba_project_b3_kernel(const float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = 32 * (NR * wr + i) + (r & 3) + 8 * (r >> 2) + 4 * h5;
-        if (n < Nout) db[(long)n * HW + p] = acc[i][cb][r] + bias[n];
+        db[(long)n * HW + p] = acc[i][cb][r] + bv[i][r];           // no per-element guard: a branch per store is a vmcnt(0) per store
       }
   }
 }
