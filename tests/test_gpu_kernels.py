@@ -321,6 +321,45 @@ def test_patch_embed_matches_conv():
     assert x.view(B, 26, D)[:, 0].abs().max().item() == 0      # CLS rows untouched by the GEMM
 
 
+@pytest.mark.parametrize("variant", [0, 9, 10, 2])
+def test_key_hook_epilogue_on_the_large_tile_kernel(variant):
+    """UCOD_EPI_KEY_NCHW_F32 at a size that takes the 256-wide large-tile kernel (variant 0 = auto, 9 forced): rows = channels, columns = the
+    tokens of 700 images of 50 -- a CLS column every 50 columns, so most 64-column waves hold chunks that straddle an image boundary --
+    written as [B, C, tok - 1] with the per-CHANNEL bias inside the accumulators; 10 / 2: the chunk-by-chunk drains, same values."""
+    g = torch.Generator().manual_seed(41)
+    C, K, tok, Bimg = 512, 128, 50, 700
+    ntok = Bimg * tok
+    Wk = bf(torch.randn(C, K, generator=g) * 0.1)
+    x = bf(torch.randn(ntok, K, generator=g))
+    bias = torch.randn(C, generator=g)
+    out = torch.full((Bimg, C, tok - 1), -7.0, device=DEV)
+    ops.gemm_bf16(N.EPI_KEY_NCHW_F32, Wk.to(DEV), x.to(DEV), out, C, ntok, K, bias=bias.to(DEV), tok=tok, variant=variant)
+    ref = (x.float() @ Wk.float().t() + bias).view(Bimg, tok, C)[:, 1:].transpose(1, 2)
+    assert maxdiff(out.cpu(), ref) < 2e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("variant", [0, 9, 10, 2])
+@pytest.mark.parametrize("h16", [False, True])
+def test_patch_token_epilogues_on_the_large_tile_kernel(variant, h16):
+    """UCOD_EPI_PATCH_TOKENS_F32 / _H16 through the large-tile kernel: 40 images of 64 patches (2560 rows, row tiles straddle images), rows
+    remapped past the CLS rows, + bias + position embedding; CLS rows and the rows past the last image stay untouched."""
+    g = torch.Generator().manual_seed(42)
+    Bimg, npatch, D, K = 40, 64, 256, 640
+    tok = npatch + 1
+    A = bf(torch.randn(Bimg * npatch, K, generator=g))
+    W = bf(torch.randn(D, K, generator=g) * 0.05)
+    b = torch.randn(D, generator=g)
+    pos = torch.randn(tok, D, generator=g)
+    dt = torch.float16 if h16 else torch.float32
+    buf = torch.full((Bimg * tok + 3, D), -5.0, dtype=dt, device=DEV)
+    ops.gemm_bf16(N.EPI_PATCH_TOKENS_H16 if h16 else N.EPI_PATCH_TOKENS_F32, A.to(DEV), W.to(DEV), buf, Bimg * npatch, D, K, bias=b.to(DEV),
+                  pos=pos.to(DEV), tok=tok, variant=variant)
+    ref = (A.float() @ W.float().t() + b).view(Bimg, npatch, D) + pos[1:]
+    got = buf[:Bimg * tok].view(Bimg, tok, D).float().cpu()
+    assert maxdiff(got[:, 1:], ref) < (2e-2 if h16 else 2e-3) * max(1.0, ref.abs().max().item())
+    assert torch.all(got[:, 0] == -5.0) and torch.all(buf[Bimg * tok:].float() == -5.0)
+
+
 # ----------------------------------------------------------------------------------------- ViT end to end
 @pytest.mark.parametrize("name,heads,fn", [("g8_dinov2_native", 2, "dinov2"), ("g8_dinov2_interp", 2, "dinov2"),
                                            ("g8_dinov1_native", 2, "dinov1"), ("g8_dinov1_interp", 2, "dinov1")])

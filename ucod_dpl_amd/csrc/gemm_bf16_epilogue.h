@@ -329,7 +329,18 @@ __device__ __forceinline__ void finish_col_consts(const GemmArgs& a, float (&cb)
 
 // acc: the wave's 128 x 16*NT tile (8 row-tiles x NT column-tiles, C layout col = lane&15, row = (lane>>4)*4 + reg), bias
 // already inside for the fused epilogues; cs = per-column scale.  wbase: wave-private 32 x WCOLS f32 staging area.  Four passes of 32 rows.
-template <int EPI, int NT, int NI = 8, int AUX = UCOD_ST_AUX>
+// kRowMapped: the key hook (rows = channels, columns = tokens written as [B, C, tok-1]) and the patch embedding (rows remapped past the CLS
+// rows, + position embedding).  With 64-column waves the large-tile kernel drains them with the offset scheme of the fused epilogues
+// (FASTRM: what a pass needs from memory -- the per-channel bias rows of the key hook, the position rows of the patch embedding -- is
+// requested before the pass is staged, so no load sits between two stores; round 3: their chunk-by-chunk drain had a bias / position load
+// and a vmcnt(0) in front of every store, one store round trip per store instruction: key hook 106 us, patch embedding 78 us per 32
+// images.  Same order of additions as the chunk-by-chunk drains, (sum + bias) + position: bitwise the same values on every tile path.)
+template <int EPI>
+constexpr bool kRowMapped = (EPI == UCOD_EPI_KEY_NCHW_F32 || EPI == UCOD_EPI_PATCH_TOKENS_F32 || EPI == UCOD_EPI_PATCH_TOKENS_H16);
+template <int EPI, int NT>
+constexpr bool kFastRowMapped = kRowMapped<EPI> && NT == 4;
+
+template <int EPI, int NT, int NI = 8, int AUX = UCOD_ST_AUX, bool FASTRM = false>
 __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI][NT], const float (&cs)[NT], char* wbase,
                                              int m_first, int n_first, int lane) {
   constexpr int WCOLS = 16 * NT, PR = 32;
@@ -350,7 +361,122 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
           *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * (WCOLS * 4) + (j * 16 + (lane & 15)) * 4) = v[rg];
       }
   };
-  if constexpr (!kColFused<EPI>) {
+  if constexpr (FASTRM && EPI == UCOD_EPI_KEY_NCHW_F32) {
+    // out f32 [B, C = M, tok-1]; the lane's four tokens (columns) are the same for every row, so its byte offset is one register plus a
+    // wave-uniform row term.  Four consecutive tokens of one image, none of them CLS: one 16-byte store (rows start 4-byte aligned only:
+    // tok-1 is odd); chunks that hold a CLS token or straddle two images go element by element, in a branch the whole wave takes or skips.
+    static_assert(WCOLS == 64 && NI == 8, "64-column waves");
+    constexpr unsigned DROP = 0x80000000u;
+    const int tok = a.tok, np1 = tok - 1;
+    const unsigned total = (unsigned)(a.N / tok) * (unsigned)a.M * (unsigned)np1 * 4u;         // (launch(): < 2^31)
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out), 0, total, 0x00020000);
+    const unsigned row_bytes = (unsigned)np1 * 4u;
+    const int n = n_first + (lane & 15) * 4;
+    const int lrow = m_first + (lane >> 4);
+    const unsigned lane_row = (unsigned)lrow * row_bytes;
+    const int b = n / tok, t = n - b * tok;
+    const bool clean = n + 3 < a.N && t >= 1 && t + 3 < tok;
+    const unsigned off_w = clean ? ((unsigned)b * (unsigned)a.M * (unsigned)np1 + (unsigned)(t - 1)) * 4u + lane_row : DROP;
+    unsigned off_e[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ne = n + e, be = ne / tok, te = ne - be * tok;
+      off_e[e] = (!clean && ne < a.N && te != 0) ? ((unsigned)be * (unsigned)a.M * (unsigned)np1 + (unsigned)(te - 1)) * 4u + lane_row : DROP;
+    }
+    const bool ragged = __any(!clean && n < a.N);                 // (wave-uniform)
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      float bm[8];                                                // bias of the lane's eight rows of this pass
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int m = lrow + pass * PR + it * 4;
+        bm[it] = a.bias[m < a.M ? m : a.M - 1];
+      }
+      stage(pass);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + (it * 4 + (lane >> 4)) * (WCOLS * 4) + (lane & 15) * 16) + (f32x4){bm[it], bm[it], bm[it], bm[it]};
+        const unsigned rowterm = (unsigned)(pass * PR + it * 4) * row_bytes;
+        const bool row_ok = lrow + pass * PR + it * 4 < a.M;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, row_ok ? off_w + rowterm : DROP, 0, 0);
+        if (ragged) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            unsigned ve = __builtin_bit_cast(u32x4, v)[e];
+            asm volatile("" : "+v"(ve));   // (hipcc 7.2 otherwise stores element 0 four times and reuses the other three registers for the offsets)
+            __builtin_amdgcn_raw_buffer_store_b32(ve, rs, row_ok ? off_e[e] + rowterm : DROP, 0, 0);
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  } else if constexpr (FASTRM && (EPI == UCOD_EPI_PATCH_TOKENS_F32 || EPI == UCOD_EPI_PATCH_TOKENS_H16)) {
+    // row m = image * (tok-1) + p  ->  token row image * tok + 1 + p = m + image + 1, + position embedding of token 1 + p.  The position
+    // rows of a pass are requested before its accumulators are staged; nothing else is loaded, so the wait in front of a pass's stores is
+    // the only one (it also retires the previous pass's stores: four round trips per tile instead of one per store).
+    static_assert(WCOLS == 64 && NI == 8, "64-column waves");
+    constexpr bool H16 = (EPI == UCOD_EPI_PATCH_TOKENS_H16);
+    constexpr unsigned DROP = 0x80000000u;
+    constexpr int EW = H16 ? 8 : 4;                               // columns per lane and store
+    constexpr int CH = WCOLS / EW, RPI = 64 / CH, ITS = PR / RPI; // chunks per row, rows per wave instruction, instructions per pass
+    const int np = a.tok - 1;
+    const unsigned out_bytes = (unsigned)(a.M / np) * (unsigned)a.tok * (unsigned)a.N * (H16 ? 2u : 4u);   // (launch(): < 2^31)
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out), 0, out_bytes, 0x00020000);
+    const auto rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.pos)), 0, (unsigned)a.tok * (unsigned)a.N * 4u, 0x00020000);
+    const int n = n_first + (lane % CH) * EW;
+    const bool col_ok = n < a.N;
+    const int lrow = m_first + lane / CH;
+    f32x4 cbias[H16 ? 2 : 1];                                     // bias of the lane's EW columns
+    {
+      const int nb = col_ok ? n : 0;
+      cbias[0] = *reinterpret_cast<const f32x4*>(a.bias + nb);
+      if constexpr (H16) cbias[1] = *reinterpret_cast<const f32x4*>(a.bias + nb + 4);
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      unsigned o_off[ITS];
+      u32x4 pv[ITS][H16 ? 2 : 1];
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) {
+        const int m = lrow + pass * PR + it * RPI;
+        const int bi = m / np, p = m - bi * np;
+        const bool ok = col_ok && m < a.M;
+        o_off[it] = ok ? ((unsigned)(m + bi + 1) * (unsigned)a.N + (unsigned)n) * (H16 ? 2u : 4u) : DROP;
+        const unsigned p_off = ok ? ((unsigned)(1 + p) * (unsigned)a.N + (unsigned)n) * 4u : DROP;
+        pv[it][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, p_off, 0, 0);
+        if constexpr (H16) pv[it][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, p_off + 16u, 0, 0);
+      }
+      stage(pass);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) {
+        const char* src = wbase + (it * RPI + lane / CH) * (WCOLS * 4) + (lane % CH) * (EW * 4);
+        f32x4 v0 = (*reinterpret_cast<const f32x4*>(src) + cbias[0]) + __builtin_bit_cast(f32x4, pv[it][0]);
+        if constexpr (H16) {
+          const f32x4 v1 = (*reinterpret_cast<const f32x4*>(src + 16) + cbias[H16 ? 1 : 0]) + __builtin_bit_cast(f32x4, pv[it][1]);
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v0[e]), __builtin_fabsf(v0[e + 1])));
+            amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v1[e]), __builtin_fabsf(v1[e + 1])));
+          }
+          u32x4 w;
+          w[0] = pack_f16x2(clamp_f16(v0[0]), clamp_f16(v0[1]));
+          w[1] = pack_f16x2(clamp_f16(v0[2]), clamp_f16(v0[3]));
+          w[2] = pack_f16x2(clamp_f16(v1[0]), clamp_f16(v1[1]));
+          w[3] = pack_f16x2(clamp_f16(v1[2]), clamp_f16(v1[3]));
+          __builtin_amdgcn_raw_buffer_store_b128(w, rs_o, o_off[it], 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rs_o, o_off[it], 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if constexpr (H16) {
+      if (amax > F16_MAX) atomicAdd(a.ovf, 1u);
+    }
+  } else if constexpr (!kColFused<EPI>) {
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       stage(pass);

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   // per-column epilogue constants first (oldest in the vmcnt queue: landed long before the accumulators are initialised)
   float cb[NT], cs[NT];
   load_col_consts<EPI, NT>(a, n0 + wn * 16 * NT + (lane & 15), cb, cs);
+  constexpr bool FASTRM = kFastRowMapped<EPI, NT>;                 // key hook / patch embedding with 64-column waves: see big_epilogue
 
   // prologue: tile 0 complete, B of tile 1 in flight
   stageA(0, 0);
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();
 
   // epilogue through a wave-private LDS region (operand tiles are dead: last barrier passed)
-  big_epilogue<EPI, NT>(a, acc, cs, smem + wave * (32 * 16 * NT * 4), m0 + wm * 128, n0 + wn * 16 * NT, lane);
+  big_epilogue<EPI, NT, 8, UCOD_ST_AUX, FASTRM>(a, acc, cs, smem + wave * (32 * 16 * NT * 4), m0 + wm * 128, n0 + wn * 16 * NT, lane);
 }
 
 }  // namespace ucod
