@@ -13,6 +13,7 @@
 // Parameter layout of one layer in the flat LoRA arena (f32): [A_q (r x D) | B_q (D x r) | A_k | B_k | A_v | B_v].
 // With LoRA dropout on, u is computed from the dropped LN1(x) (one mask per projection), dA from the same dropped input, and the
 // t A term of dLN1 is added -- masked -- by the LayerNorm-1 backward instead of the dgrad GEMM (A^T columns packed as zeros).
+#include <type_traits>
 #include "common.h"
 #include "../../include/ucod_dpl.h"
 
@@ -180,15 +181,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     vecf d = g[i];
     if constexpr (LORA) {
       const unsigned idx = (unsigned)row * (unsigned)D + (unsigned)VW * (unsigned)(lane + 64 * i);
-      for (int p = 0; p < 3; ++p) {
-        vecf acc = (vecf)(0.f);
-        for (int jr = 0; jr < r; ++jr) {
-          const float t = bf16_to_f32(tq[(size_t)row * ldt + p * r + jr]);
-          const vecf av = reinterpret_cast<const vecf*>(lora + (size_t)p * 2 * r * D + (size_t)jr * D)[lane + 64 * i];
-          acc += t * av;
-        }
+      auto branch = [&](auto rc) {                                // rank known at compile time: the 3 r coefficient / A-row loads go out together
+        constexpr int R = decltype(rc)::value;
+        vecf av[3][R];
+        float t[3][R];
 #pragma unroll
-        for (int e = 0; e < VW; ++e) d[e] += acc[e] * drop_scale(drop, p, idx + (unsigned)e);
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int jr = 0; jr < R; ++jr) {
+            t[p][jr] = bf16_to_f32(tq[(size_t)row * ldt + p * R + jr]);
+            av[p][jr] = reinterpret_cast<const vecf*>(lora + (size_t)p * 2 * R * D + (size_t)jr * D)[lane + 64 * i];
+          }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          vecf acc = (vecf)(0.f);
+#pragma unroll
+          for (int jr = 0; jr < R; ++jr) acc += t[p][jr] * av[p][jr];
+#pragma unroll
+          for (int e = 0; e < VW; ++e) d[e] += acc[e] * drop_scale(drop, p, idx + (unsigned)e);
+        }
+      };
+      if (r == 2) branch(std::integral_constant<int, 2>{});
+      else if (r == 4) branch(std::integral_constant<int, 4>{});
+      else if (r == 1) branch(std::integral_constant<int, 1>{});
+      else {
+        for (int p = 0; p < 3; ++p) {
+          vecf acc = (vecf)(0.f);
+          for (int jr = 0; jr < r; ++jr) {
+            const float t = bf16_to_f32(tq[(size_t)row * ldt + p * r + jr]);
+            const vecf av = reinterpret_cast<const vecf*>(lora + (size_t)p * 2 * r * D + (size_t)jr * D)[lane + 64 * i];
+            acc += t * av;
+          }
+#pragma unroll
+          for (int e = 0; e < VW; ++e) d[e] += acc[e] * drop_scale(drop, p, idx + (unsigned)e);
+        }
       }
     }
     g[i] = d * g2[lane + 64 * i];
