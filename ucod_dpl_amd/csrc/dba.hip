@@ -49,13 +49,23 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
   if (p < HW) {
     const float* dp = d + ((long)b * ld_c + c0) * HW + p;
     float accf = head_b[0], accb = head_b[1], s = 0.f;
-#pragma unroll 8
-    for (int c = 0; c < E; ++c) {
-      const float d1 = dp[(long)c * HW], d2 = dp[(long)(c + E) * HW];
-      const float f1 = d1 * kf[c], f2 = d2 * kf[c + E];
-      accf = fmaf(hw[c], sigmoid_gate(f1 * d1) + d1, accf);
-      accb = fmaf(hw[c + E], sigmoid_gate(f2 * d2) + d2, accb);
-      s = fmaf(f1, f2, s);
+    for (int c0 = 0; c0 < E; c0 += 16) {                          // 32 loads out before the first use (hipcc's own schedule of the unrolled
+      float v1[16], v2[16];                                       // loop waited after every pair: two loads in flight per thread)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        v1[j] = dp[(long)(c0 + j) * HW];
+        v2[j] = dp[(long)(c0 + j + E) * HW];
+      }
+      __builtin_amdgcn_sched_barrier(0);                          // (the scheduler would sink the loads back next to their uses)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int c = c0 + j;
+        const float d1 = v1[j], d2 = v2[j];
+        const float f1 = d1 * kf[c], f2 = d2 * kf[c + E];
+        accf = fmaf(hw[c], sigmoid_gate(f1 * d1) + d1, accf);
+        accb = fmaf(hw[c + E], sigmoid_gate(f2 * d2) + d2, accb);
+        s = fmaf(f1, f2, s);
+      }
     }
     fg[(long)b * HW + p] = accf;
     if (bg) bg[(long)b * HW + p] = accb;
@@ -204,25 +214,38 @@ __global__ __launch_bounds__(256, 2) void dba_bwd_a_kernel(const float* __restri
     a2[0][0][i] = a2[0][1][i] = a2[1][0][i] = a2[1][1][i] = 0.f;
   }
   float spart[2] = {0.f, 0.f};
-#pragma unroll 8
-  for (int kk = 0; kk < E; kk += 2) {
-    const int k = kk + h5;
-    const float k1 = kf[k], k2 = kf[E + k];
-    float f1[2], f2[2];
+  for (int kk0 = 0; kk0 < E; kk0 += 16) {                          // the features of eight k-pairs (32 loads) out before the first MFMA
+    float r1[8][2], r2[8][2];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      f1[ct] = dp[(long)k * HW + px[ct]] * k1;
-      f2[ct] = dp[(long)(k + E) * HW + px[ct]] * k2;
-      spart[ct] = fmaf(f1[ct], f2[ct], spart[ct]);
-    }
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const float g2 = G[1][k * E + rt * 32 + l31];
-      const float g1 = G[0][k * E + rt * 32 + l31];
+    for (int j = 0; j < 8; ++j) {
+      const int k = kk0 + 2 * j + h5;
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        a1[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g2, f1[ct], a1[rt][ct], 0, 0, 0);
-        a2[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, f2[ct], a2[rt][ct], 0, 0, 0);
+        r1[j][ct] = dp[(long)k * HW + px[ct]];
+        r2[j][ct] = dp[(long)(k + E) * HW + px[ct]];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                            // (the scheduler would sink the loads back next to their uses)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kk0 + 2 * j + h5;
+      const float k1 = kf[k], k2 = kf[E + k];
+      float f1[2], f2[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        f1[ct] = r1[j][ct] * k1;
+        f2[ct] = r2[j][ct] * k2;
+        spart[ct] = fmaf(f1[ct], f2[ct], spart[ct]);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const float g2 = G[1][k * E + rt * 32 + l31];
+        const float g1 = G[0][k * E + rt * 32 + l31];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          a1[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g2, f1[ct], a1[rt][ct], 0, 0, 0);
+          a2[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, f2[ct], a2[rt][ct], 0, 0, 0);
+        }
       }
     }
   }
@@ -270,16 +293,28 @@ __global__ __launch_bounds__(256) void dba_bwd_b_kernel(const float* __restrict_
   r = block_sum(r, red);
   const bool clamped = (n <= NORM_EPS);
   float sgd = 0.f, sga = 0.f, sg_up = 0.f;
-#pragma unroll 6
-  for (int p = tid; p < HW; p += 256) {
-    const float dv = drow[p], f = dv * k, gf = grow[p], g = gup[p];
-    const float sg = sigmoid_gate(f * dv);
-    const float gu = clamped ? gf / NORM_EPS : (gf - f * r) / n;
-    const float o = fmaf(gu, e, g * w * fmaf(sg * (1.f - sg), f, 1.f));
-    orow[p] = o;
-    sgd += o;
-    sga = fmaf(g, sg + dv, sga);
-    sg_up += g;
+  for (int p0 = tid; p0 < HW; p0 += 256 * 6) {                     // six pixels per thread and trip: 18 loads out before the first use
+    float dv6[6], gf6[6], g6[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int p = p0 + 256 * j, pc = p < HW ? p : HW - 1;
+      dv6[j] = drow[pc];
+      gf6[j] = grow[pc];
+      g6[j] = gup[pc];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int p = p0 + 256 * j;
+      if (p >= HW) break;
+      const float dv = dv6[j], f = dv * k, gf = gf6[j], g = g6[j];
+      const float sg = sigmoid_gate(f * dv);
+      const float gu = clamped ? gf / NORM_EPS : (gf - f * r) / n;
+      const float o = fmaf(gu, e, g * w * fmaf(sg * (1.f - sg), f, 1.f));
+      orow[p] = o;
+      sgd += o;
+      sga = fmaf(g, sg + dv, sga);
+      sg_up += g;
+    }
   }
   sgd = block_sum(sgd, red);
   sga = block_sum(sga, red);
