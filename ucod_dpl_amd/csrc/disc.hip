@@ -317,25 +317,37 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
   float acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-  const long total = (long)(b_hi - b_lo) * OH * OH;
-  for (long idx = tid; idx < total; idx += 256) {
-    const int ox = (int)(idx % OH), oy = (int)((idx / OH) % OH), b = b_lo + (int)(idx / ((long)OH * OH));
-    const float gv = gy[(((long)b * COUT + co) * OH + oy) * OH + ox];
+  // 32-bit pixel index inside one image (the 64-bit div / mod per pixel and the branch around every tap load -- each with its own
+  // vmcnt(0) -- were most of this kernel's time); the pixels of an image are dealt to the threads per image now, so the sums add in a
+  // different (still fixed) order
+  const int npix = OH * OH;
+  for (int b = b_lo; b < b_hi; ++b) {
+    const float* gyb = gy + ((long)b * COUT + co) * npix;
     const float* ib = in + ((long)b * CIN + ci) * IH * IH;
+    for (int p = tid; p < npix; p += 256) {
+      const int oy = p / OH, ox = p - oy * OH;
+      const float gv = gyb[p];
+      float t9[9];
+      bool ok9[9];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int iy = oy * STRIDE - 1 + ky, ix = ox * STRIDE - 1 + kx;
-        if (iy >= 0 && iy < IH && ix >= 0 && ix < IH) {
-          float t = ib[(long)iy * IH + ix];
-          if (BN_IN) {
-            t = fmaf(t, sc, sh);
-            t = t >= 0.f ? t : t * LRELU;
-          }
-          acc[ky * 3 + kx] = fmaf(gv, t, acc[ky * 3 + kx]);
+        for (int kx = 0; kx < 3; ++kx) {
+          const int iy = oy * STRIDE - 1 + ky, ix = ox * STRIDE - 1 + kx;
+          ok9[ky * 3 + kx] = iy >= 0 && iy < IH && ix >= 0 && ix < IH;
+          const int cy = iy < 0 ? 0 : (iy >= IH ? IH - 1 : iy), cx = ix < 0 ? 0 : (ix >= IH ? IH - 1 : ix);
+          t9[ky * 3 + kx] = ib[cy * IH + cx];
         }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        float t = t9[k];
+        if (BN_IN) {
+          t = fmaf(t, sc, sh);
+          t = t >= 0.f ? t : t * LRELU;
+        }
+        if (ok9[k]) acc[k] = fmaf(gv, t, acc[k]);
       }
+    }
   }
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
