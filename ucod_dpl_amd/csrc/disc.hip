@@ -385,20 +385,32 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_kernel(const float* __restr
   float acc[CIN];
 #pragma unroll
   for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.f;
+  // which of the nine taps reach an output pixel, and where, does not depend on the output channel: computed once; the loads are
+  // unconditional (clamped) and the tap is skipped by a wave-level test -- a branch around each load cost a vmcnt(0) per tap
+  int toff[9];
+  bool tok[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ty = iy + 1 - ky, tx = ix + 1 - kx;
+      const int oy = ty / STRIDE, ox = tx / STRIDE;
+      const bool ok = ty >= 0 && tx >= 0 && (ty % STRIDE) == 0 && (tx % STRIDE) == 0 && oy < OH && ox < OH;
+      tok[ky * 3 + kx] = ok;
+      toff[ky * 3 + kx] = ok ? oy * OH + ox : 0;
+    }
+  const float* gyb = gy + (long)b * COUT * OH * OH;
   for (int co = 0; co < COUT; ++co) {
+    float gv[9];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int k = 0; k < 9; ++k) gv[k] = gyb[co * OH * OH + toff[k]];
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ty = iy + 1 - ky, tx = ix + 1 - kx;
-        if (ty < 0 || tx < 0 || (ty % STRIDE) || (tx % STRIDE)) continue;
-        const int oy = ty / STRIDE, ox = tx / STRIDE;
-        if (oy >= OH || ox >= OH) continue;
-        const float gv = gy[(((long)b * COUT + co) * OH + oy) * OH + ox];
-        const float* wr = &ws[(co * 9 + ky * 3 + kx) * CIN];
+    for (int k = 0; k < 9; ++k) {
+      const float g = tok[k] ? gv[k] : 0.f;
+      const float* wr = &ws[(co * 9 + k) * CIN];
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) acc[ci] = fmaf(gv, wr[ci], acc[ci]);
-      }
+      for (int ci = 0; ci < CIN; ++ci) acc[ci] = fmaf(g, wr[ci], acc[ci]);
+    }
   }
 #pragma unroll
   for (int ci = 0; ci < CIN; ++ci) {
