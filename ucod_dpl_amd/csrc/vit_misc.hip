@@ -134,6 +134,25 @@ __global__ __launch_bounds__(256) void layernorm_h16_strip_kernel(const u32x4* _
 #pragma unroll
     for (int e = 0; e < 4; ++e) unpack_f16x2(w[e], v[i][2 * e], v[i][2 * e + 1]);
   }
+  // gamma / beta of the lane's chunks, requested behind the row loads and before the reductions: loaded inside the output loop they sat
+  // between two stores, and the wait for them also waited for the store in front (vmcnt counts stores): one store round trip per chunk
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  float4 ga[NC], gb[NC], ba[NC], bb[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i, col = second[i] ? c - cpr : c;
+    ga[i] = g4[2 * col];
+    gb[i] = g4[2 * col + 1];
+    ba[i] = b4[2 * col];
+    bb[i] = b4[2 * col + 1];
+  }
+  // (LLVM sinks loads into the conditional block that uses them -- the odd-last-row skip below -- unless the values are opaque here)
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    asm volatile("" : "+v"(ga[i].x), "+v"(ga[i].y), "+v"(ga[i].z), "+v"(ga[i].w), "+v"(gb[i].x), "+v"(gb[i].y), "+v"(gb[i].z), "+v"(gb[i].w));
+    asm volatile("" : "+v"(ba[i].x), "+v"(ba[i].y), "+v"(ba[i].z), "+v"(ba[i].w), "+v"(bb[i].x), "+v"(bb[i].y), "+v"(bb[i].z), "+v"(bb[i].w));
+  }
   float s0 = 0.f, s1 = 0.f;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
@@ -158,20 +177,16 @@ __global__ __launch_bounds__(256) void layernorm_h16_strip_kernel(const u32x4* _
   }
   const float rstd0 = rsqrtf(wave_sum(q0) * inv_d + eps), rstd1 = rsqrtf(wave_sum(q1) * inv_d + eps);
   u32x4* ys = y + (size_t)row0 * cpr;
-  const float4* g4 = reinterpret_cast<const float4*>(gamma);
-  const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
     if (second[i] && !two) continue;
-    const int col = second[i] ? c - cpr : c;
     const float rstd = second[i] ? rstd1 : rstd0;
-    const float4 ga = g4[2 * col], gb = g4[2 * col + 1], ba = b4[2 * col], bb = b4[2 * col + 1];
     u32x4 w;
-    w[0] = pack_h2(v[i][0] * rstd * ga.x + ba.x, v[i][1] * rstd * ga.y + ba.y);
-    w[1] = pack_h2(v[i][2] * rstd * ga.z + ba.z, v[i][3] * rstd * ga.w + ba.w);
-    w[2] = pack_h2(v[i][4] * rstd * gb.x + bb.x, v[i][5] * rstd * gb.y + bb.y);
-    w[3] = pack_h2(v[i][6] * rstd * gb.z + bb.z, v[i][7] * rstd * gb.w + bb.w);
+    w[0] = pack_h2(v[i][0] * rstd * ga[i].x + ba[i].x, v[i][1] * rstd * ga[i].y + ba[i].y);
+    w[1] = pack_h2(v[i][2] * rstd * ga[i].z + ba[i].z, v[i][3] * rstd * ga[i].w + ba[i].w);
+    w[2] = pack_h2(v[i][4] * rstd * gb[i].x + bb[i].x, v[i][5] * rstd * gb[i].y + bb[i].y);
+    w[3] = pack_h2(v[i][6] * rstd * gb[i].z + bb[i].z, v[i][7] * rstd * gb[i].w + bb[i].w);
     ys[c] = w;
   }
 }
