@@ -77,14 +77,16 @@ __global__ __launch_bounds__(256, 2) void dba_project_kernel(const float* __rest
   auto load_x = [&](int c0) {
     if constexpr (VEC) {
       const int k = tid >> 4, p = p0 + 4 * (tid & 15);
-      rx = (p < HW) ? *reinterpret_cast<const float4*>(xb + (long)(c0 + k) * HW + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rx = *reinterpret_cast<const float4*>(xb + (long)(c0 + k) * HW + (p < HW ? p : 0));   // (clamped + select: no branch around the load)
+      if (p >= HW) rx = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
       const int p = p0 + (tid & 63);
       float v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = (tid >> 6) + 4 * i;
-        v[i] = (p < HW) ? xb[(long)(c0 + k) * HW + p] : 0.f;
+        const float t = xb[(long)(c0 + k) * HW + (p < HW ? p : HW - 1)];
+        v[i] = (p < HW) ? t : 0.f;
       }
       rx = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -129,6 +131,12 @@ __global__ __launch_bounds__(256, 2) void dba_project_kernel(const float* __rest
   }
   // C/D map of the 32x32 accumulator: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
   float* db = d + (long)b * Nout * HW;
+  float bv[16];                                                  // the lane's 16 bias values in one batch (a load inside the store loop waits for
+#pragma unroll                                                   // the store in front of it as well: vmcnt counts stores)
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    bv[r] = bias[n < Nout ? n : Nout - 1];
+  }
 #pragma unroll
   for (int pt = 0; pt < 2; ++pt) {
     const int p = p0 + pt * 32 + (lane & 31);
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void dba_project_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = n0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (n < Nout) db[(long)n * HW + p] = acc[pt][r] + bias[n];
+      if (n < Nout) db[(long)n * HW + p] = acc[pt][r] + bv[r];
     }
   }
 }
