@@ -91,34 +91,51 @@ __global__ __launch_bounds__(256) void window_scatter_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------ gated ensembling (GE_pix_level.py:16-25)
-// pass 1: p = sigmoid(l1); psum[b] += p; en = -m*log(max(m,1e-5)), m = 19x19 average of p (zero padded, /361); enmax = max en.
-__global__ __launch_bounds__(256) void ge_stats_kernel(const float* __restrict__ l1, float* __restrict__ en, float* __restrict__ psum,
-                                                       unsigned* __restrict__ enmax_bits, int h, int w) {
+// pass 0: p = sigmoid(l1) once per pixel (round 3: the entropy pass evaluated the sigmoid of all 361 neighbours of every pixel), psum[b] += p.
+// pass 1: en = -m*log(max(m,1e-5)), m = 19x19 average of p (zero padded, /361), summed in the same (dy, dx) order as before; enmax = max en.
+__global__ __launch_bounds__(256) void ge_prob_kernel(const float* __restrict__ l1, float* __restrict__ pm, float* __restrict__ psum, int hw) {
   __shared__ float red[16];
   const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-  float pv = 0.f, ev = 0.f;
+  float pv = 0.f;
+  if (p < hw) {
+    pv = sigmoid_acc(l1[(size_t)b * hw + p]);
+    pm[(size_t)b * hw + p] = pv;
+  }
+  const float bs = block_sum(pv, red);
+  if (threadIdx.x == 0) atomicAdd(&psum[b], bs);
+}
+
+__global__ __launch_bounds__(256) void ge_stats_kernel(const float* __restrict__ pm, float* __restrict__ en, unsigned* __restrict__ enmax_bits,
+                                                       int h, int w) {
+  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  float ev = 0.f;
   if (p < h * w) {
     const int y = p / w, x = p - y * w;
-    const float* lb = l1 + (size_t)b * h * w;
-    pv = sigmoid_acc(lb[p]);
+    const float* pb = pm + (size_t)b * h * w;
     float s = 0.f;
     for (int dy = -9; dy <= 9; ++dy) {
       const int yy = y + dy;
-      if (yy < 0 || yy >= h) continue;
+      if (yy < 0 || yy >= h) continue;                            // (wave-uniform only by luck; no load in this branch's condition)
+      const float* prow = pb + yy * w;
+      float t19[19];
+#pragma unroll
       for (int dx = -9; dx <= 9; ++dx) {
         const int xx = x + dx;
-        if (xx >= 0 && xx < w) s += sigmoid_acc(lb[yy * w + xx]);
+        t19[dx + 9] = prow[xx < 0 ? 0 : (xx >= w ? w - 1 : xx)];   // clamped: the 19 loads of a row go out together
+      }
+#pragma unroll
+      for (int dx = -9; dx <= 9; ++dx) {
+        const int xx = x + dx;
+        if (xx >= 0 && xx < w) s += t19[dx + 9];
       }
     }
     const float m = s / 361.0f;
     ev = -m * logf(fmaxf(m, 1e-5f));
     en[(size_t)b * h * w + p] = ev;
   }
-  const float bs = block_sum(pv, red);
   float mx = ev;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  if (threadIdx.x == 0) atomicAdd(&psum[b], bs);
   if ((threadIdx.x & 63) == 0) atomicMax(enmax_bits, __float_as_uint(fmaxf(mx, 0.f)));   // en >= 0: uint order == float order
 }
 
@@ -245,15 +262,17 @@ extern "C" int ucod_gated_ensemble(const float* l1_up, const float* l2, const fl
   float* en = (float*)ws;
   float* psum = en + (size_t)B * h * w;
   unsigned* enmax = (unsigned*)(psum + B);
+  float* pm = psum + B + 1;                                       // sigmoid(l1), B*h*w
   hipError_t e = hipMemsetAsync(psum, 0, sizeof(float) * (B + 1), s);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(ge_stats_kernel, dim3(cdiv(h * w, 256), B), dim3(256), 0, s, l1_up, en, psum, enmax, h, w);
+  hipLaunchKernelGGL(ge_prob_kernel, dim3(cdiv(h * w, 256), B), dim3(256), 0, s, l1_up, pm, psum, h * w);
+  hipLaunchKernelGGL(ge_stats_kernel, dim3(cdiv(h * w, 256), B), dim3(256), 0, s, pm, en, enmax, h, w);
   hipLaunchKernelGGL(ge_fuse_kernel, dim3(cdiv(h * w, 256), B), dim3(256), 0, s, l1_up, l2, en, psum, enmax, f0w, f0b, f2w, f2b, out, weight_out, h, w);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }
 
-extern "C" size_t ucod_gated_ensemble_workspace_bytes(int B, int h, int w) { return ((size_t)B * h * w + B + 1) * sizeof(float); }
+extern "C" size_t ucod_gated_ensemble_workspace_bytes(int B, int h, int w) { return ((size_t)2 * B * h * w + B + 1) * sizeof(float); }
 
 extern "C" int ucod_window_loss(const float* window_preds, const float* h_targets, const int* win_flat, const float* l_up, int targets_are_logits,
                                 float* part, float* iou_out, float* loss_out, int n, int B, int H, int W, int ws, void* stream) {
