@@ -400,7 +400,8 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
       const int tok = a.tok > 1 ? a.tok : 2;
       const unsigned long out_bytes = EPI == UCOD_EPI_KEY_NCHW_F32 ? (unsigned long)(a.N / tok) * a.M * (tok - 1) * 4ul
                                                                    : (unsigned long)(a.M / (tok - 1)) * tok * a.N * (EPI == UCOD_EPI_PATCH_TOKENS_H16 ? 2ul : 4ul);
-      const bool ok = a.tok > 1 && out_bytes < 0x7FFFFFF0ul && (unsigned long)a.tok * a.N * 4ul < 0x7FFFFFF0ul &&
+      const bool whole = EPI == UCOD_EPI_KEY_NCHW_F32 ? (a.N % tok) == 0 : (a.M % (tok - 1)) == 0;   // whole images (the drains size the output from them)
+      const bool ok = a.tok > 1 && whole && out_bytes < 0x7FFFFFF0ul && (unsigned long)a.tok * a.N * 4ul < 0x7FFFFFF0ul &&
                       (EPI != UCOD_EPI_PATCH_TOKENS_H16 || (a.N & 7) == 0);
       if (!ok) variant = 10;                                      // (192-wide tiles keep the chunk-by-chunk drain)
     }
