@@ -94,11 +94,15 @@ class DiscArena:
             p.data = view
             self.grad_views.append(self.g[off:off + n].view(p.shape))
             off += n
-        for b in (disc.maskConv, disc.convs[0], disc.convs[1]):      # buffers to the device too
+        # buffers to the device too; the three num_batches_tracked counters become views of ONE tensor, so that a forward call bumps them
+        # with one launch (discriminator._bump_num_batches) instead of three
+        blocks = (disc.maskConv, disc.convs[0], disc.convs[1])
+        disc._nbt = torch.stack([b.layers[1].num_batches_tracked.data.to(device) for b in blocks])
+        for i, b in enumerate(blocks):
             bn = b.layers[1]
             bn.running_mean.data = bn.running_mean.data.to(device)
             bn.running_var.data = bn.running_var.data.to(device)
-            bn.num_batches_tracked.data = bn.num_batches_tracked.data.to(device)
+            bn.num_batches_tracked.data = disc._nbt[i]
 
 
 class FusedAdamW:

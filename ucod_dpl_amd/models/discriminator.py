@@ -78,6 +78,11 @@ class Discriminator(nn.Module):
         return t
 
     def _bump_num_batches(self):
+        nbt = getattr(self, "_nbt", None)           # set by DiscArena: the three counters as views of one tensor
+        if nbt is not None and all(b.layers[1].num_batches_tracked.data_ptr() == nbt[i].data_ptr()
+                                   for i, b in enumerate((self.maskConv, self.convs[0], self.convs[1]))):
+            nbt += 1
+            return
         for b in (self.maskConv, self.convs[0], self.convs[1]):
             b.layers[1].num_batches_tracked += 1
 
