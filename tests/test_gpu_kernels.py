@@ -321,6 +321,24 @@ def test_patch_embed_matches_conv():
     assert x.view(B, 26, D)[:, 0].abs().max().item() == 0      # CLS rows untouched by the GEMM
 
 
+@pytest.mark.variants
+@pytest.mark.parametrize("M,Nn,K", [(3000, 384, 128), (5000, 2304, 768)])
+def test_parked_tile_persistent_gemm_matches_the_192_wide_kernel(M, Nn, K):
+    """Laboratory variant 20 (persistent 256 x 192 kernel, finished tile parked as packed bf16 and stored under the next tile's main loop;
+    measured slower than the product kernels, kept for the record): same tile width and arithmetic as variant 10, so the outputs must be
+    bitwise equal -- ragged last row / column tiles included."""
+    if not N.have_lab():
+        pytest.skip("laboratory library not built (make -C ucod_dpl_amd/csrc variants)")
+    g = torch.Generator().manual_seed(M)
+    A, W, b = bf(torch.randn(M, K, generator=g)).to(DEV), bf(torch.randn(Nn, K, generator=g) * 0.1).to(DEV), torch.randn(Nn, generator=g).to(DEV)
+    for epi in (N.EPI_BIAS_BF16, N.EPI_BIAS_GELU_BF16):
+        o20 = torch.zeros(M + 2, Nn, dtype=torch.bfloat16, device=DEV)
+        o10 = torch.zeros(M + 2, Nn, dtype=torch.bfloat16, device=DEV)
+        ops.gemm_bf16(epi, A, W, o20, M, Nn, K, bias=b, variant=20)
+        ops.gemm_bf16(epi, A, W, o10, M, Nn, K, bias=b, variant=10)
+        assert torch.equal(o20, o10) and float(o20[M:].float().abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("variant", [0, 9, 10, 2])
 def test_key_hook_epilogue_on_the_large_tile_kernel(variant):
     """UCOD_EPI_KEY_NCHW_F32 at a size that takes the 256-wide large-tile kernel (variant 0 = auto, 9 forced): rows = channels, columns = the

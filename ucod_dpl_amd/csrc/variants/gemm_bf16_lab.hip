@@ -199,8 +199,259 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(const GemmArgs a) {
 }
 
 
+
+// =====================================================================================================
+// Variant 20 (round 3, experiment): persistent 256 x 192 kernel that PARKS the finished tile.  One workgroup per CU walks tiles
+// orig = blockIdx.x, + gridDim.x, ...; the K-tiles of consecutive output tiles run as ONE pipeline (the next tile's K-tile 0 / 1 are
+// requested during the current tile's last two K-tiles); after the last K-tile the accumulators go through a wave-private staging area
+// (48 KB beside the two 56 KB K-tile buffers = 160 KB) into 48 registers of packed bf16 per lane, in the row-major 16-byte chunks the
+// stores want, and those 12 stores are issued one per K-tile of the NEXT tile's main loop.  Nothing of the drain is left in front of the
+// matrix pipe except the conversion.  256-row tiles only (no tall tiles); epilogues: bias (+ column scale) -> bf16, bias + GELU -> bf16.
+// =====================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_park_kernel(const GemmArgs a) {
+  constexpr int NT = 3, IT = 4, NPH = 2, SLOT = 128 * 128, NB = 3, BN_ = 192, WCOLS = 48;
+  constexpr int BUF = 2 * SLOT + BN_ * 128;                      // 57 344 bytes: A0 | A1 | B of one K-tile
+  constexpr int STG = 32 * WCOLS * 4;                            // 6 144 bytes of staging per wave
+  constexpr unsigned DROP = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF + 8 * STG];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int K = a.K, nt = K / BK;                                // (launch: nt even, >= 2)
+  const int ntiles = a.tiles_m * a.tiles_n, G = gridDim.x;
+  char* wstage = smem + 2 * BUF + wave * STG;
+
+  const unsigned long bytesA = (unsigned long)a.M * K * 2ul, bytesB = (unsigned long)a.N * K * 2ul;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(a.A), 0, bytesA > 0xFFFFFFFFul ? 0xFFFFFFFFu : (unsigned)bytesA, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(a.B), 0, bytesB > 0xFFFFFFFFul ? 0xFFFFFFFFu : (unsigned)bytesB, 0x00020000);
+  const auto rsO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out), 0, (unsigned)((unsigned long)a.M * a.N * 2ul), 0x00020000);
+
+  auto tile_xy = [&](int orig, int& m0, int& n0) {
+    const int q = ntiles >> 3, r8 = ntiles & 7, xcd = orig & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    int tm, tn;
+    tile_of(a, wg, tm, tn);
+    m0 = tm * 256;
+    n0 = tn * BN_;
+  };
+  unsigned offA[2][2], offB[NB];
+  auto set_offsets = [&](int m0, int n0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = (i * 8 + wave) * 8 + (lane >> 3);
+        offA[h][i] = ((unsigned)(m0 + h * 128 + r) * (unsigned)K + (unsigned)swz(r, lane & 7) * 8u) * 2u;
+      }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int r = (i * 8 + wave) * 8 + (lane >> 3);
+      offB[i] = ((unsigned)(n0 + r) * (unsigned)K + (unsigned)swz(r, lane & 7) * 8u) * 2u;
+    }
+  };
+  auto stageA = [&](int t, int h) {
+    char* slot = smem + (t & 1) * BUF + h * SLOT;
+    const unsigned kt = (unsigned)t * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(slot + (i * 8 + wave) * 1024), 16, offA[h][i], kt, 0, UCOD_LD_AUX_A);
+  };
+  auto stageB = [&](int t) {
+    char* slot = smem + (t & 1) * BUF + 2 * SLOT;
+    const unsigned kt = (unsigned)t * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(slot + (i * 8 + wave) * 1024), 16, offB[i], kt, 0, UCOD_LD_AUX_B);
+  };
+
+  int orig = blockIdx.x;
+  int m0, n0;
+  tile_xy(orig, m0, n0);
+  set_offsets(m0, n0);
+  float cb[NT], cs[NT];
+  load_col_consts<EPI, NT>(a, n0 + wn * WCOLS + (lane & 15), cb, cs);
+  stageA(0, 0);
+  stageA(0, 1);
+  stageB(0);
+  stageB(1);
+  wait_vmcnt<NB>();                                              // K-tile 0 landed, B(1) in flight
+  finish_col_consts<EPI, NT>(a, cb, cs);
+  f32x4 acc[8][NT];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){cb[j], cb[j], cb[j], cb[j]};
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();                     // staggered wave groups
+
+  u32x4 park[12];                                                // the previous tile, packed bf16: chunk q = pass * 3 + it
+  bool have_parked = false;
+  int pm = 0, pn = 0;                                            // first row / column of the parked wave tile
+  // (row, chunk) of wave instruction `it` inside a 32-row pass: 6 chunks of 8 columns per row
+  auto lrow = [&](int it) { return (it * 64 + lane) / 6; };    // (recomputed: index arrays cost registers this kernel does not have)
+  auto lchk = [&](int it) { return (it * 64 + lane) - lrow(it) * 6; };
+  const unsigned row_bytes = (unsigned)a.N * 2u;
+  auto park_store = [&](int q) {
+    const int pass = q / 3, it = q - pass * 3;
+    const int m = pm + pass * 32 + lrow(it), n = pn + lchk(it) * 8;
+    const unsigned off = (m < a.M && n < a.N) ? (unsigned)m * row_bytes + (unsigned)n * 2u : DROP;
+    __builtin_amdgcn_raw_buffer_store_b128(park[q], rsO, off, 0, UCOD_ST_AUX);
+  };
+  const int spk = (12 + nt - 1) / nt;                            // parked stores per K-tile
+
+  for (;;) {
+    const bool has_next = orig + G < ntiles;
+    int m0n = 0, n0n = 0;
+    float cbn[NT], csn[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { cbn[j] = 0.f; csn[j] = 1.f; }
+    for (int t = 0; t < nt; ++t) {
+      const char* bufA = smem + (t & 1) * BUF + wm * SLOT;
+      const char* bufB = smem + (t & 1) * BUF + 2 * SLOT;
+      const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+      hx8 fb[NT][2];
+#pragma unroll
+      for (int ph = 0; ph < NPH; ++ph) {
+        if (ph == 0) {
+          if (have_parked) {
+            for (int q = t * spk; q < (t + 1) * spk && q < 12; ++q) {
+              switch (q) {                                       // (register array: compile-time indices)
+#define PK(Q) case Q: park_store(Q); break;
+                PK(0) PK(1) PK(2) PK(3) PK(4) PK(5) PK(6) PK(7) PK(8) PK(9) PK(10) PK(11)
+#undef PK
+              }
+            }
+          }
+          if (more1) { stageA(t + 1, 0); stageA(t + 1, 1); }
+          else if (has_next) { stageA(0, 0); stageA(0, 1); }     // (offsets already those of the next tile: switched at K-tile nt-2)
+          if (t == nt - 2 && has_next) {                         // no DMA of this tile is left to issue: switch to the next tile's sources
+            tile_xy(orig + G, m0n, n0n);
+            set_offsets(m0n, n0n);
+            load_col_consts<EPI, NT>(a, n0n + wn * WCOLS + (lane & 15), cbn, csn);
+          }
+        }
+        if (ph == 1) {
+          if (more2) stageB(t + 2);
+          else if (has_next) stageB(t + 2 - nt);
+        }
+        if (ph == 0) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const int r = wn * WCOLS + j * 16 + (lane & 15);
+              fb[j][ks] = *reinterpret_cast<const hx8*>(bufB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+            }
+        }
+        hx8 fa[IT][2];
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int r = ph * (IT * 16) + i * 16 + (lane & 15);
+            fa[i][ks] = *reinterpret_cast<const hx8*>(bufA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+          }
+        if (ph == NPH - 1) {
+          if (more2 || has_next) wait_vmcnt<NB>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < IT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[ph * IT + i][j] = UCOD_MFMA16(fa[i][ks], fb[j][ks], acc[ph * IT + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- conversion: accumulators -> (scale, GELU) -> packed bf16 in the row-major chunk layout, through the wave's staging area
+    if (have_parked) {                                           // (only when nt * spk < 12: never for nt >= 12)
+      for (int q = nt * spk; q < 12; ++q) {
+        switch (q) {
+#define PK(Q) case Q: park_store(Q); break;
+          PK(0) PK(1) PK(2) PK(3) PK(4) PK(5) PK(6) PK(7) PK(8) PK(9) PK(10) PK(11)
+#undef PK
+        }
+      }
+    }
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          f32x4 v = acc[pass * 2 + i][j];
+          if constexpr (EPI == UCOD_EPI_BIAS_BF16) v = v * cs[j];
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+            *reinterpret_cast<float*>(wstage + (i * 16 + (lane >> 4) * 4 + rg) * (WCOLS * 4) + (j * 16 + (lane & 15)) * 4) = v[rg];
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 3; ++it) {
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(wstage + lrow(it) * (WCOLS * 4) + lchk(it) * 32);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(wstage + lrow(it) * (WCOLS * 4) + lchk(it) * 32 + 16);
+        if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) {
+          const f32x2 g0 = gelu_erf2((f32x2){v0[0], v0[1]}), g1 = gelu_erf2((f32x2){v0[2], v0[3]});
+          const f32x2 g2 = gelu_erf2((f32x2){v1[0], v1[1]}), g3 = gelu_erf2((f32x2){v1[2], v1[3]});
+          v0 = (f32x4){g0[0], g0[1], g1[0], g1[1]};
+          v1 = (f32x4){g2[0], g2[1], g3[0], g3[1]};
+        }
+        u32x4 w;
+        w[0] = pack_h2(v0[0], v0[1]);
+        w[1] = pack_h2(v0[2], v0[3]);
+        w[2] = pack_h2(v1[0], v1[1]);
+        w[3] = pack_h2(v1[2], v1[3]);
+        park[pass * 3 + it] = w;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    pm = m0 + wm * 128;
+    pn = n0 + wn * WCOLS;
+    have_parked = true;
+    if (!has_next) break;
+    orig += G;
+    m0 = m0n;
+    n0 = n0n;
+    finish_col_consts<EPI, NT>(a, cbn, csn);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { cb[j] = cbn[j]; cs[j] = csn[j]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){cb[j], cb[j], cb[j], cb[j]};
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int q = 0; q < 12; ++q) park_store(q);
+}
+
 template <int EPI>
 static int launch_lab(GemmArgs a, int variant, hipStream_t s) {
+  if (variant == 20) {                                           // persistent 192-wide kernel with the parked tile (bf16 epilogues only)
+    if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) {
+      const int nt = a.K / BK;
+      if ((a.N & 7) != 0 || nt < 2 || (nt & 1) || !a.bias || (long)a.M * a.N * 2 >= (1L << 31) || (long)a.M * a.K * 2 >= (1L << 32) || (long)a.N * a.K * 2 >= (1L << 32))
+        return UCOD_EINVAL;
+      a.tiles_m = cdiv(a.M, 256);
+      a.tiles_n = cdiv(a.N, 192);
+      a.col_fast = a.tiles_n <= 4;
+      const int n_cu = device_cus(), ntiles = a.tiles_m * a.tiles_n;
+      hipLaunchKernelGGL((gemm_bf16_park_kernel<EPI>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), 0, s, a);
+      UCOD_CHECK_LAUNCH();
+      return UCOD_OK;
+    } else {
+      return UCOD_EINVAL;
+    }
+  }
   if (variant < 3 || variant > 8 || (a.N & 3) != 0) return UCOD_EINVAL;
   constexpr bool kBf16Out = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16);
   if (kBf16Out && (a.N & 7) != 0) return UCOD_EINVAL;
