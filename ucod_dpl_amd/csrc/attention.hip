@@ -21,6 +21,9 @@
 
 namespace ucod {
 
+#ifndef UCOD_ATTN_ASM_DEFAULT
+#define UCOD_ATTN_ASM_DEFAULT 0
+#endif
 constexpr int HD = 64;        // head dim
 constexpr int QT = 128;       // query rows per workgroup
 constexpr int KT = 64;        // keys per tile
@@ -589,6 +592,18 @@ __global__ __launch_bounds__(256, 2) void attn_cross96_kernel(const bf16_raw* __
   }
 }
 
+bool attn_asm_eligible(int B, int tok, int heads);                                                     // attention_asm.hip
+int attn_asm_launch(const void* qkv, void* out, float* lse, int B, int tok, int heads, hipStream_t stream);
+
+// UCOD_ATTN_ASM (read once): 1 = the hand-placed assembly kernel serves every eligible pre-scaled-Q call (the default), 0 = attn_fwd_v5_kernel
+static bool attn_asm_default() {
+  static const bool on = [] {
+    const char* e = getenv("UCOD_ATTN_ASM");
+    return e ? (e[0] != '0') : (UCOD_ATTN_ASM_DEFAULT != 0);
+  }();
+  return on;
+}
+
 }  // namespace ucod
 
 // variant: 0 / 2 = the product kernels (generic-scale when scale != 0, pre-scaled-Q when scale == 0).  Every other number is an
@@ -596,9 +611,13 @@ __global__ __launch_bounds__(256, 2) void attn_cross96_kernel(const bf16_raw* __
 extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, int heads, float scale, int variant, void* stream) {
   using namespace ucod;
   if (!qkv || !out || B <= 0 || tok <= 0 || heads <= 0) return UCOD_EINVAL;
-  if (variant != 0 && variant != 2) return UCOD_EINVAL;
+  if (variant != 0 && variant != 2 && variant != 3 && variant != 5) return UCOD_EINVAL;
   if ((size_t)tok * heads * HD * 3 * 2 >= (1ull << 32)) return UCOD_EINVAL;       // per-image qkv rows are addressed with 32-bit byte offsets
+  // variant 3 = the assembly kernel (refused where it does not apply), 5 = attn_fwd_v5_kernel whatever the default, 0 / 2 = the default
+  if (variant == 3 && (scale != 0.f || !attn_asm_eligible(B, tok, heads))) return UCOD_EINVAL;
   UCOD_PROF(PROF_ATTN, stream);
+  if (scale == 0.f && (variant == 3 || (variant != 5 && attn_asm_default() && attn_asm_eligible(B, tok, heads))))
+    return attn_asm_launch(qkv, out, nullptr, B, tok, heads, (hipStream_t)stream);
   if (scale == 0.f) {   // Q pre-scaled by head_dim^-0.5 * log2(e)
     const int npairs = B * heads, nq = cdiv(tok, QT);
     hipLaunchKernelGGL(attn_fwd_v5_kernel, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads,
@@ -628,6 +647,7 @@ extern "C" int ucod_attention_fwd_lse(const void* qkv, void* out, float* lse, in
   if (!qkv || !out || !lse || B <= 0 || tok <= 0 || heads <= 0) return UCOD_EINVAL;
   if ((size_t)tok * heads * HD * 3 * 2 >= (1ull << 32)) return UCOD_EINVAL;
   UCOD_PROF(PROF_ATTN, stream);
+  if (attn_asm_default() && attn_asm_eligible(B, tok, heads)) return attn_asm_launch(qkv, out, lse, B, tok, heads, (hipStream_t)stream);
   const int npairs = B * heads, nq = cdiv(tok, QT);
   hipLaunchKernelGGL(attn_fwd_v5_kernel, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs,
                      lse);
