@@ -33,10 +33,8 @@ else:
     from .isa import Prog, V, A, S, VCC, M0, F, I, Lit, f32_bits
 
 KERNEL_NAME = "ucod_attn_fwd_pw64"
-LDS_BYTES = 65536
 SLOT = 8192
-V_RING = 32768
-KARG_BYTES = 64
+KARG_BYTES = 72
 
 # ------------------------------------------------------------------------------------------------ register map
 s_karg = S(0, 2)
@@ -82,6 +80,10 @@ s_desc_o_cur = S(56, 4)
 s_desc_l_cur = S(60, 4)
 s_t = [S(64 + k) for k in range(16)]      # scratch
 s_slot_w = S(80)
+s_stamp = [S(82 + 2 * k, 2) for k in range(6)]     # diagnostic build (stamps=True) only
+s_sacc = [S(94 + k) for k in range(6)]
+s_dbg = S(100, 2)
+s_par = S(81)
 
 v_tid = V(0)
 v_lane = V(1)
@@ -122,12 +124,30 @@ a_Qn = [A(112, 16), A(128, 16)]
 a_ones = A(144, 4)
 a_mask = [A(148, 4), A(152, 4)]
 a_onesB = A(156, 4)
-ACC_VGPRS = 160
+a_L = [a_T, A(160, 16)]         # without per-unit detection: the two running denominators (ONES accumulates into them)
+ACC_VGPRS = 176
 
 
 class Gen:
-    def __init__(self, dtype="bf16", thr_exp=None, table=None):
+    def __init__(self, dtype="bf16", thr_exp=None, table=None, abl=(), unit_detect=None, margin=64, dma_gap=4, ring=4):
         self.p = Prog()
+        # K / V rings of `ring` 8-KiB slots each; the stream runs ring - 1 (ring 4) or 4 (ring 8) tiles ahead.  ring 8: one barrier per TWO
+        # tiles (a tile is visible one barrier after its wait, and its slot is rewritten two barriers after its last read)
+        self.ring = ring
+        self.lead = 3 if ring == 4 else 4
+        self.v_ring = ring * SLOT
+        self.lds_bytes = 2 * ring * SLOT
+        # per-unit overflow detection + out-of-line rescale (the only form that is safe for fp16 probabilities); bf16 runs without:
+        # the running max is fixed at item start with a margin (rescale_block)
+        self.unit_detect = (dtype != "bf16") if unit_detect is None else unit_detect
+        self.margin = margin
+        self.dma_gap = dma_gap
+        self.lds_policy = next((a[4:] for a in abl if a.startswith("lds_")), "early")
+        # softmax denominator: "mfma" = an all-ones A operand (ONES products), "valu" = per-lane f32 adds of the unrounded probabilities
+        self.sums = "mfma" if (self.unit_detect or "msum" in abl) else "valu"
+        assert not (self.sums == "valu" and self.unit_detect)
+        self.stamps = "stamps" in abl           # diagnostic: s_memtime at the step boundaries of the steady iteration, sums per wave to a buffer
+        self.abl = set(abl)           # timing-only ablations (wrong results): see tools/attn_asm/bench_variants.py
         self.dtype = dtype
         self.thr_exp = thr_exp if thr_exp is not None else (40 if dtype == "bf16" else 13)
         self.lds_issued = 0           # LDS reads issued since the last lgkmcnt(0)
@@ -144,6 +164,8 @@ class Gen:
             self.p.v_cvt_pk_f16_f32(d, a, b)
 
     def mfma(self, d, a, b, c):
+        if "nomfma" in self.abl:
+            return None
         return self.p.mfma(d, a, b, c, dtype=self.dtype)
 
     def one16(self):
@@ -154,6 +176,8 @@ class Gen:
 
     # LDS read tracking (counted lgkmcnt)
     def lds_read(self, kind, dst, addr, offset, buf):
+        if "nolds" in self.abl:
+            return
         if kind == "b128":
             self.p.ds_read_b128(dst, addr, offset)
         else:
@@ -292,7 +316,15 @@ class Gen:
     def dma_piece(self, which, i):
         """one 1-KiB LDS-DMA piece of the stream's current tile: which = 'k' | 'v', i = 0 | 1 (rows 8w.. / 32+8w..)"""
         p = self.p
-        off = (V_RING if which == "v" else 0) + i * 4096
+        off = (self.v_ring if which == "v" else 0) + i * 4096
+        if "nodma" in self.abl:
+            return lambda: None
+        if "dma2reg" in self.abl:       # timing only: the same loads to registers (+ a 16-byte LDS store of older data)
+            def issue():
+                p.buffer_load_dwordx4(V(216 + 4 * ((2 * (which == "v") + i) % 4), 4), (v_dma_k if which == "k" else v_dma_v)[i], s_desc_kv, s_kcol if which == "k" else s_vcol)
+                if "dswrite" in self.abl:
+                    p.ds_write_b128(v_koffb[0], V(232, 4), 0)
+            return issue
         p.s_add_u32(M0, s_m0base, I(off))
         return lambda: p.buffer_load_lds_dwordx4((v_dma_k if which == "k" else v_dma_v)[i], s_desc_kv, s_kcol if which == "k" else s_vcol)
 
@@ -304,6 +336,10 @@ class Gen:
         p.s_load(S(12, 4), s_karg, 32)          # npairs nqb magic_nqb magic_heads
         p.s_load(S(16, 2), s_karg, 48)          # nt stride
         p.s_load(S(26, 2), s_karg, 56)          # add-one flags of the two divisions
+        if self.stamps:
+            p.s_load(s_dbg, s_karg, 64)
+            for k in range(6):
+                p.s_mov_b32(s_sacc[k], I(0))
         p.s_waitcnt(lgkmcnt=0)
         # ---- lane constants
         p.v_and_b32(v_lane, I(63), v_tid)
@@ -354,7 +390,7 @@ class Gen:
             p.v_and_b32(v_x[7], I(7), v_x[5])
             p.v_lshl_add_u32(v_x[6], v_x[7], I(1), v_x[6])
             p.v_lshl_add_u32(v_voffb[dt], v_x[2], I(7), v_x[6])
-            p.v_add_u32(v_voffb[dt], I(V_RING), v_voffb[dt])
+            p.v_add_u32(v_voffb[dt], I(self.v_ring), v_voffb[dt])
         # DMA source offsets: row = 8 w + (lane >> 3) (+ 32 i), chunk = lane & 7
         p.v_lshrrev_b32(v_x[0], I(3), v_lane)
         p.s_lshl_b32(s_t[0], s_w, 3)
@@ -415,9 +451,13 @@ class Gen:
             p.v_mov_b32(v_S[2][r], I(0))
             p.v_mov_b32(v_S[3][r], I(0))
             p.v_mov_b32(v_VF[1][r], I(0))
+        p.v_mov_b32(v_x[4], F(1.0))
         for qb in range(2):
             p.v_mov_b32(v_l[qb], F(1.0))
+            p.v_mov_b32(v_tmp[qb], I(0))
             p.v_mov_b32(v_m[qb], I(0))
+            for r in range(16):
+                p.v_accvgpr_write_b32(a_L[qb][r], v_x[4])
             for dt in range(2):
                 for r in range(16):
                     p.v_accvgpr_write_b32(a_O[qb][dt][r], v_x[1])
@@ -439,7 +479,7 @@ class Gen:
         self.make_kv_desc(s_jdma)
         p.s_mov_b32(s_slot_r, I(0))
         switches = []
-        for t in range(3):
+        for t in range(self.lead):
             p.s_lshl_b32(s_m0base, s_w, 10)
             p.s_add_u32(s_m0base, s_m0base, I(t * SLOT))
             for which in ("k", "v"):
@@ -448,8 +488,9 @@ class Gen:
                     p.s_nop(0)
                     issue()
             switches.append(self.dma_advance())
-        p.s_waitcnt(vmcnt=4)                    # Q and tiles 0, 1 have landed (tile 2 may still be in flight)
+        p.s_waitcnt(vmcnt=4 if self.ring == 4 else 0)   # Q and tiles 0, 1 have landed (ring 4: tile 2 may still be in flight)
         p.s_barrier()
+        p.s_mov_b32(s_par, I(0))
         for sd in range(4):
             p.ds_read_b128(v_KF[0][4 * sd:4 * sd + 4], v_koffb[sd], 0)          # K(0, kt 0): slot 0
         for sd in range(4):
@@ -463,12 +504,33 @@ class Gen:
         return lab_items
 
     # ------------------------------------------------------------------ pieces of a step
-    def sm_items(self, Sx, Px):
-        """SM(i): 16 exponentials into rolling temporaries, 8 packs; returns a list of (emit, cost)"""
+    def sm_items(self, Sx, Px, qb=None):
+        """SM(i): 16 exponentials into rolling temporaries, 8 packs (+ 16 adds into two per-lane partial sums when the denominator is
+        kept on the vector unit); returns a list of (emit, cost, kind)"""
         p = self.p
         order = []
+        if "nosm" in self.abl:
+            return order
+        if self.sums == "valu":
+            acc = [v_l[qb], v_tmp[qb]]
+
+            def ex(k):
+                return (lambda: p.v_exp_f32(v_E[k % 8], Sx[k]), 2, "exp")
+
+            def ad(k):
+                return (lambda: p.v_add_f32(acc[k & 1], acc[k & 1], v_E[k % 8]), 1, "add")
+
+            def cv(w):
+                return (lambda: self.cvt_pk(Px[w], v_E[(2 * w) % 8], v_E[(2 * w + 1) % 8]), 1, "cvt")
+            order += [ex(0), ex(1), ex(2), ad(0), ex(3), ad(1), cv(0)]
+            for w in range(1, 7):
+                order += [ex(2 * w + 2), ad(2 * w), ex(2 * w + 3), ad(2 * w + 1), cv(w)]
+            order += [ad(14), ad(15), cv(7)]
+            return order
 
         def ex(k):
+            if "exp2mov" in self.abl:
+                return (lambda: p.v_mov_b32(v_E[k % 8], Sx[k]), 1, "exp")
             return (lambda: p.v_exp_f32(v_E[k % 8], Sx[k]), 2, "exp")
 
         def cv(w):
@@ -481,11 +543,16 @@ class Gen:
 
     def rescale_block(self, qb, Sx, Px, Snext, first, back):
         """out-of-line (or, first=True, in-line) rescale of one unit: new running max from Sx; O, l, -m and the next unit's scores follow.
-        Touches only its own temporaries (v_re, v_rs): it runs in the middle of a step whose SM / epilogue fillers are in flight."""
+        Touches only its own temporaries (v_re, v_rs): it runs in the middle of a step whose SM / epilogue fillers are in flight.
+        Without per-unit detection (bf16) only the first form exists: it sets m = max(first 32 keys) + MARGIN, so that every later
+        probability 2^(s - m) stays finite up to MARGIN + 127 above that maximum and exact (a power-of-two scale) below it."""
         p = self.p
         t0, t1, mx, al, acc = v_rs[0], v_rs[1], v_rs[2], v_rs[3], v_rs[4]
-        p.s_nop(15)                     # the Q K^T products of the next unit were issued just before
-        p.s_nop(15)
+        if first == "part2":
+            return self.rescale_part2(qb, Sx, Px, True, None)
+        if not first:
+            p.s_nop(15)                 # the Q K^T products of the next unit were issued just before
+            p.s_nop(15)
         p.v_max3_f32(t0, Sx[0], Sx[1], Sx[2])
         for k in range(3, 15, 2):
             p.v_max3_f32(t0, t0, Sx[k], Sx[k + 1])
@@ -495,6 +562,8 @@ class Gen:
         p.v_permlane32_swap_b32(t0, t1)
         p.s_nop(1)
         p.v_max_f32(mx, t0, t1)
+        if first and not self.unit_detect and self.margin:
+            p.v_add_f32(mx, F(float(self.margin)), mx)
         if not first:
             p.v_max_f32(mx, mx, F(0.0))
             p.v_sub_f32(t0, F(0.0), mx)
@@ -517,34 +586,49 @@ class Gen:
             p.v_sub_f32(t0, F(0.0), mx)
             for r in range(16):
                 p.v_mov_b32(v_negm[qb][r], t0)
+            p.s_nop(1)
+            return                      # item start, part 1: the next unit's Q K^T is issued now, with -m as its C operand
         for r in range(16):
             p.v_sub_f32(Snext[r], Snext[r], mx)
-        # the unit again, against the new maximum (two halves of eight scores)
+        self.rescale_part2(qb, Sx, Px, False, back)
+
+    def rescale_part2(self, qb, Sx, Px, first, back):
+        """the unit again, against the new maximum (two halves of eight scores)"""
+        p = self.p
+        t0, t1, mx, al, acc = v_rs[0], v_rs[1], v_rs[2], v_rs[3], v_rs[4]
+        sums = self.unit_detect or self.sums == "valu"
         for half in range(2):
             for k in range(8):
                 p.v_sub_f32(v_re[k], Sx[8 * half + k], mx)
             for k in range(8):
                 p.v_exp_f32(v_re[k], v_re[k])
-            if half == 0:
-                p.v_add_f32(acc, v_re[0], v_re[1])
+            if sums:
+                if half == 0:
+                    p.v_add_f32(acc, v_re[0], v_re[1])
+                else:
+                    p.v_add_f32(acc, acc, v_re[0])
+                    p.v_add_f32(acc, acc, v_re[1])
+                for k in range(2, 8):
+                    p.v_add_f32(acc, acc, v_re[k])
             else:
-                p.v_add_f32(acc, acc, v_re[0])
-                p.v_add_f32(acc, acc, v_re[1])
-            for k in range(2, 8):
-                p.v_add_f32(acc, acc, v_re[k])
+                p.s_nop(0)
             for w in range(4):
                 self.cvt_pk(Px[4 * half + w], v_re[2 * w], v_re[2 * w + 1])
-        p.v_mov_b32(t1, acc)
-        p.s_nop(1)
-        p.v_permlane32_swap_b32(acc, t1)
-        p.s_nop(1)
-        p.v_add_f32(acc, acc, t1)
-        if first:
-            p.v_mov_b32(v_l[qb], acc)
+        if sums and self.sums == "valu":
+            p.v_mov_b32(v_l[qb], acc)          # per-lane partial sums; the halves meet in the epilogue
+            p.v_mov_b32(v_tmp[qb], I(0))
+        elif sums:
+            p.v_mov_b32(t1, acc)
             p.s_nop(1)
-        else:
-            p.v_add_f32(v_l[qb], v_l[qb], acc)
+            p.v_permlane32_swap_b32(acc, t1)
             p.s_nop(1)
+            p.v_add_f32(acc, acc, t1)
+            if first:
+                p.v_mov_b32(v_l[qb], acc)
+            else:
+                p.v_add_f32(v_l[qb], v_l[qb], acc)
+        p.s_nop(1)
+        if not first:
             p.s_branch(back)
 
     def epilogue_items(self, qb):
@@ -552,8 +636,19 @@ class Gen:
         p = self.p
         inv, lg = v_inv, v_lg
         it = []
-        it.append((lambda: p.v_rcp_f32(inv, v_l[qb]), 2, "ep"))
-        it.append((lambda: p.v_log_f32(lg, v_l[qb]), 2, "ep"))
+        lsrc = v_l[qb]
+        if self.sums == "valu":
+            it.append((lambda: p.v_add_f32(v_l[qb], v_l[qb], v_tmp[qb]), 1, "ep"))
+            it.append((lambda: p.v_mov_b32(v_lg, v_l[qb]), 1, "ep"))
+            it.append((lambda: p.s_nop(1), 1, "ep"))
+            it.append((lambda: p.v_permlane32_swap_b32(v_l[qb], v_lg), 1, "ep"))
+            it.append((lambda: p.s_nop(0), 1, "ep"))
+            it.append((lambda: p.v_add_f32(v_l[qb], v_l[qb], v_lg), 1, "ep"))
+        elif not self.unit_detect:
+            it.append((lambda: p.v_accvgpr_read_b32(v_l[qb], a_L[qb][0]), 1, "ep"))
+            it.append((lambda: p.s_nop(0), 1, "ep"))
+        it.append((lambda: p.v_rcp_f32(inv, lsrc), 2, "ep"))
+        it.append((lambda: p.v_log_f32(lg, lsrc), 2, "ep"))
         it.append((lambda: p.s_nop(0), 1, "ep"))
         it.append((lambda: p.v_add_f32(lg, lg, v_m[qb]), 1, "ep"))
         it.append((lambda: p.buffer_store_dword(lg, v_lseoff, s_desc_l, I(0), offset=128 * qb), 1, "ep"))
@@ -584,8 +679,11 @@ class Gen:
     def step(self, kind, X, slow_sites):
         """kind: 'first' | 'steady' | 'last';  X: 0..3 = a..d.
         a: unit i = U(t-1, 3)   b: U(t, 0)   c: U(t, 1)   d: U(t, 2)        (qb(i) = [1, 0, 1, 0][X])
+        MFMA order: per-unit detection (f16):  ONES(i-1) x2, QK(i+1) x4, [DETECT(i-1)], PV(i-1) x4
+                    none (bf16):               QK(i+1) x4, [item start: rescale], ONES(i-1) x2 (accumulating), PV(i-1) x4
         """
         p = self.p
+        ud = self.unit_detect
         jS = [3, 0, 1, 2][X]                  # S buffer / position of unit i
         qb = jS & 1                           # qb of unit i
         qo = 1 - qb                           # qb of units i - 1 and i + 1
@@ -594,21 +692,30 @@ class Gen:
         kt_next = jNext >> 1
         kbuf = kt_next                        # K fragments: buffer 0 = kt 0 (steps a, b), buffer 1 = kt 1 (steps c, d)
         vbuf = jPrev >> 1                     # V fragments of unit i - 1: kt(i - 1)
-        first_new = kind == "first" and X in (2, 3)          # DETECT position runs the new item's first unit (steps c, d)
+        first_new = kind == "first" and X in (2, 3)          # the mid position runs the new item's first unit (steps c, d)
         no_sm = kind == "first" and X in (1, 2)               # SM of the new item's first units is done by the in-line rescale
-        no_ones = kind == "first" and X in (2, 3)             # P of unit i - 1 does not exist yet
-        czero_qk = kind == "first"                            # the new item's first tile: raw scores, fixed up by the rescale
+        no_ones = (ud and kind == "first" and X in (2, 3)) or "noones" in self.abl or self.sums == "valu"
+        czero_qk = kind == "first" and X in (0, 1)            # the new item's first two units: raw scores (their maximum becomes m)
         czero_pv = kind == "first" and X in (2, 3)            # first products into a fresh O
         masked = kind == "last"
 
-        mf = []          # MFMA emitters, in issue order
-        tags = []
-        # ONES(i-1)
-        if not no_ones:
-            mf.append(lambda: self.mfma(a_T, a_ones, v_P[qo][0:4], I(0)))
-            mf.append(lambda: self.mfma(a_T, a_ones, v_P[qo][4:8], a_T))
-            tags += ["ones", "ones"]
-        # QK(i+1)
+        mf, tags = [], []
+
+        def add_ones():
+            if no_ones:
+                return
+            if ud:
+                mf.append(lambda: self.mfma(a_T, a_ones, v_P[qo][0:4], I(0)))
+                mf.append(lambda: self.mfma(a_T, a_ones, v_P[qo][4:8], a_T))
+            else:
+                c0 = I(0) if first_new else a_L[qo]
+                mf.append(lambda: self.mfma(a_L[qo], a_ones, v_P[qo][0:4], c0))
+                mf.append(lambda: self.mfma(a_L[qo], a_ones, v_P[qo][4:8], a_L[qo]))
+            tags.extend(["ones", "ones"])
+
+        if ud:
+            add_ones()
+        i_qk0 = len(mf)
         Sn = v_S[jNext]
         for sd in range(4):
             c = (I(0) if czero_qk else v_negm[qo]) if sd == 0 else Sn
@@ -617,8 +724,10 @@ class Gen:
         if masked:
             mf.append(lambda: self.mfma(Sn, a_mask[kt_next], a_onesB, Sn))
             tags.append("qk")
-        i_detect = len(mf)           # DETECT sits after the last QK MFMA
-        # PV(i-1)
+        i_mid = len(mf)               # DETECT / the item's first rescale sit after the last QK MFMA
+        if not ud:
+            add_ones()
+        i_pv0 = len(mf)
         for ks in range(2):
             for dt in range(2):
                 c = I(0) if (czero_pv and ks == 0) else a_O[qo][dt]
@@ -627,11 +736,10 @@ class Gen:
         nm = len(mf)
 
         # ---- fillers: queues
-        sm = [] if no_sm else self.sm_items(v_S[jS], v_P[qb])
+        sm = [] if no_sm else self.sm_items(v_S[jS], v_P[qb], qb)
         ep = []
         if kind == "first" and X in (1, 2):
             ep = self.epilogue_items(0 if X == 1 else 1)
-        # LDS reads of this step
         lds = []
         if X in (0, 1):       # K(t, kt 1) -> KF[1] (2 per step), V(t, kt 0) -> VF[0] (4 per step)
             for sd in (2 * X, 2 * X + 1):
@@ -649,22 +757,20 @@ class Gen:
                 for hi in range(2):
                     lds.append(lambda ks=ks, dt=dt, hi=hi: self.lds_read("tr", v_VF[1][8 * ks + 4 * dt + 2 * hi:8 * ks + 4 * dt + 2 * hi + 2], v_va[dt],
                                                                          (1 * 32 + ks * 16) * 128 + hi * 1024, "VF1"))
-        # DMA piece of this step
         which, pi = [("k", 0), ("k", 1), ("v", 0), ("v", 1)][X]
 
         # ---- forced items before given MFMAs
         pre = {k: [] for k in range(nm + 1)}
-        iq0 = 0 if no_ones else 2
         if X == 2:
-            pre[iq0].append(lambda: self.wait_frag("KF1"))
-            pre[i_detect].append(lambda: self.wait_frag("VF0"))
+            pre[i_qk0].append(lambda: self.wait_frag("KF1"))
+            pre[i_pv0].append(lambda: self.wait_frag("VF0"))
         # (steps a, b use KF[0] / VF[1]: complete since the iteration boundary; step d uses KF[1] / VF[0]: waited in step c)
 
         # ---- head of the step (before the first MFMA)
         if X == 0:
             # ring: this iteration reads tile t from slot_r; the stream writes tile t + 3
-            p.s_add_u32(s_slot_w, s_slot_r, I(3 * SLOT))
-            p.s_and_b32(s_slot_w, s_slot_w, I(4 * SLOT - 1))
+            p.s_add_u32(s_slot_w, s_slot_r, I(self.lead * SLOT))
+            p.s_and_b32(s_slot_w, s_slot_w, I(self.ring * SLOT - 1))
             p.s_lshl_b32(s_m0base, s_w, 10)
             p.s_add_u32(s_m0base, s_m0base, s_slot_w)
             for dt in range(2):
@@ -672,24 +778,26 @@ class Gen:
         if X == 2:
             # K reads of steps c, d come from tile t + 1
             p.s_add_u32(s_slot_r, s_slot_r, I(SLOT))
-            p.s_and_b32(s_slot_r, s_slot_r, I(4 * SLOT - 1))
+            p.s_and_b32(s_slot_r, s_slot_r, I(self.ring * SLOT - 1))
             for sd in range(4):
                 p.v_add_u32(v_ka[sd], s_slot_r, v_koffb[sd])
 
         # ---- interleave
-        tab = self.table.get((kind, X)) or self.default_table(kind, X, nm, len(sm), len(lds), len(ep), i_detect)
+        tab = self.table.get((kind, X)) or self.default_table(kind, X, nm, sm, len(lds), ep, tags)
         dma_issue = None
         qs, ql, qe = list(sm), list(lds), list(ep)
-        det_done = False
+        mid_done = False
         for g in range(nm):
             for f in pre[g]:
                 f()
-            if g == i_detect and not det_done:
+            if g == i_qk0 and first_new:
+                self.rescale_block(qo, v_S[jPrev], v_P[qo], v_S[jNext], True, None)      # part 1: m and -m of the new item's block
+            if g == i_mid and not mid_done:
                 self.detect(kind, X, qo, jPrev, jNext, first_new, slow_sites)
-                det_done = True
+                mid_done = True
             mf[g]()
             row = tab[g]
-            texts_before = p.count()
+            before = p.count()
             for what in row:
                 if what == "sm" and qs:
                     qs.pop(0)[0]()
@@ -711,39 +819,57 @@ class Gen:
                     for qb_ in range(2):
                         for sd in range(4):
                             p.buffer_load_dwordx4(a_Qn[qb_][4 * sd:4 * sd + 4], v_qoff[qb_], s_desc_q, s_qcol, offset=32 * sd)
-            self.issue_rows.append((kind, "abcd"[X], g, tags[g], p.count() - texts_before))
+            self.issue_rows.append((kind, "abcd"[X], g, tags[g], " ".join(row)))
         assert not qs and not ql and not qe, (kind, X, len(qs), len(ql), len(qe))
 
-    def default_table(self, kind, X, nm, n_sm, n_lds, n_ep, i_detect):
-        """per gap: the fillers that follow MFMA g.  Even spread; the DMA piece in the middle; tuned tables override this."""
+    COST = {"lds": 1, "m0": 1, "dma": 4}
+
+    def default_table(self, kind, X, nm, sm, n_lds, ep, tags):
+        """per gap: the fillers that follow MFMA g, balanced by issue cost (exp 2 slots, everything else 1, a DMA piece 4).
+        One LDS read per gap from the first gap on (their consumers are a step or more away), the DMA piece in the middle,
+        the exponentials / packs (or the epilogue's instructions) fill every gap up to the common level."""
         rows = [[] for _ in range(nm)]
-        # SM: spread evenly
-        for k in range(n_sm):
-            rows[min(nm - 1, k * nm // max(n_sm, 1))].append("sm")
-        for k in range(n_ep):
-            rows[min(nm - 1, k * nm // max(n_ep, 1))].append("ep")
-        # LDS reads early (their consumers are one or two steps away)
+        cost = [0.0] * nm
+        fixed = {}
         for k in range(n_lds):
-            rows[min(nm - 1, k)].append("lds")
-        rows[min(nm - 1, 6)].append("m0")
-        rows[min(nm - 1, 7)].append("dma")
+            g_l = {"early": k, "front": k // 3, "pairs": 2 * (k // 2) // 2 + (k // 2), "late": nm - 1 - n_lds + k}[self.lds_policy]
+            fixed.setdefault(max(0, min(nm - 1, g_l)), []).append("lds")
+        g_dma = min(nm - 2, self.dma_gap)
+        fixed.setdefault(g_dma, []).append("m0")
+        fixed.setdefault(g_dma + 1, []).append("dma")
         if kind == "last" and X == 3:
-            rows[1].append("qcopy0")
-            rows[nm - 1].append("qcopy1")
+            fixed.setdefault(1, []).append("qcopy0")
+            fixed.setdefault(nm - 1, []).append("qcopy1")
         if kind == "first" and X == 3:
-            rows[nm - 1].append("qload")
+            fixed.setdefault(nm - 1, []).append("qload")
+        for g, lst in fixed.items():
+            for w in lst:
+                rows[g].append(w)
+                cost[g] += self.COST.get(w, 0)
+        queue = [("sm", c) for (_, c, _) in sm] + [("ep", c) for (_, c, _) in ep]
+        total = sum(cost) + sum(c for _, c in queue)
+        level = total / nm
+        g = 0
+        for name, c in queue:
+            while g < nm - 1 and cost[g] + c > level + 0.5:
+                g += 1
+            rows[g].append(name)
+            cost[g] += c
         return rows
 
     def detect(self, kind, X, qo, jPrev, jNext, first_new, slow_sites):
         p = self.p
         if first_new:
-            self.rescale_block(qo, v_S[jPrev], v_P[qo], v_S[jNext], True, None)
+            self.rescale_block(qo, v_S[jPrev], v_P[qo], v_S[jNext], "part2", None)
+            return
+        if not self.unit_detect or "nodetect" in self.abl:
             return
         lab_slow, lab_back = p.newlabel("slow"), p.newlabel("back")
         p.v_accvgpr_read_b32(v_tt, a_T[0])
         p.s_nop(0)
         p.v_cmp("ngt", "f32", s_thr, v_tt)          # not (thr > t): the unit needs a new maximum (or t is NaN)
-        p.s_cbranch("vccnz", lab_slow)
+        if "nobranch" not in self.abl:
+            p.s_cbranch("vccnz", lab_slow)
         p.v_add_f32(v_l[qo], v_l[qo], v_tt)
         p.label(lab_back)
         slow_sites.append((lab_slow, lab_back, qo, jPrev, jNext))
@@ -753,14 +879,37 @@ class Gen:
         p = self.p
         p.comment(f"================ iteration: {kind}")
         sw = None
+        st = self.stamps and kind == "steady"
         for X in range(4):
             p.comment(f"---- step {'abcd'[X]} ({kind})")
+            if st:
+                p.s_memtime(s_stamp[X])
             self.step(kind, X, slow_sites)
         sw = self.dma_advance()
+        if st:
+            p.s_memtime(s_stamp[4])
         nvm = 4 + (10 + 8 if kind == "first" else 0)
+        if "nodma" in self.abl:
+            nvm = 63
         p.s_waitcnt(vmcnt=nvm, lgkmcnt=0)
         self.lds_all_done()
-        p.s_barrier()
+        if "nobar" not in self.abl:
+            if self.ring == 4:
+                p.s_barrier()
+            else:
+                lab = p.newlabel("nobarrier")
+                p.s_add_u32(s_par, s_par, I(1))
+                p.s_and_b32(s_t[0], s_par, I(1))
+                p.s_cbranch("scc1", lab)          # odd count: no barrier this tile
+                p.s_barrier()
+                p.label(lab)
+        if st:
+            p.s_memtime(s_stamp[5])
+            p.s_waitcnt(lgkmcnt=0)
+            for k in range(5):
+                p.s_sub_u32(s_t[0], s_stamp[k + 1][0], s_stamp[k][0])
+                p.s_add_u32(s_sacc[k], s_sacc[k], s_t[0])
+            p.s_add_u32(s_sacc[5], s_sacc[5], I(1))
         return sw
 
     def build(self):
@@ -793,6 +942,24 @@ class Gen:
         p.s_branch(lab_items)
         p.label(lab_done)
         p.s_waitcnt(vmcnt=0)
+        if self.stamps:
+            # record of this wave: 6 sums (steps a..d, wait, barrier .. iterations) + 2 spare, at dbg + (4 wg + w) * 32
+            p.s_lshl_b32(s_t[0], s_wg, 2)
+            p.s_add_u32(s_t[0], s_t[0], s_w)
+            p.s_lshl_b32(s_t[0], s_t[0], 5)
+            p.s_add_u32(s_dbg[0], s_dbg[0], s_t[0])
+            p.s_addc_u32(s_dbg[1], s_dbg[1], I(0))
+            p.v_mov_b32(v_x[0], s_dbg[0])
+            p.v_mov_b32(v_x[1], s_dbg[1])
+            for k in range(6):
+                p.v_mov_b32(v_ep[8 + k], s_sacc[k])
+            p.v_mov_b32(v_ep[14], I(0))
+            p.v_mov_b32(v_ep[15], I(0))
+            p.global_store_dwordx4(v_x[0:2], v_ep[8:12])
+            p.v_add_u32(v_x[0], I(16), v_x[0])
+            p.s_nop(1)
+            p.global_store_dwordx4(v_x[0:2], v_ep[12:16])
+            p.s_waitcnt(vmcnt=0)
         p.s_endpgm()
         # out-of-line blocks
         for sw, dn in switches:
@@ -874,6 +1041,7 @@ amdhsa.kernels:
       - {{.offset: 52, .size: 4, .value_kind: by_value}}
       - {{.offset: 56, .size: 4, .value_kind: by_value}}
       - {{.offset: 60, .size: 4, .value_kind: by_value}}
+      - {{.address_space: global, .offset: 64, .size: 8, .value_kind: global_buffer}}
     .group_segment_fixed_size: {lds}
     .kernarg_segment_align: 8
     .kernarg_segment_size: {kargs}
@@ -902,7 +1070,7 @@ def kernel_text(dtype="bf16", name=None, **kw):
     g = Gen(dtype=dtype, **kw)
     prog = g.build()
     body = prog.text().replace(KERNEL_NAME + ":", name + ":")
-    txt = HEADER.format(name=name) + body + FOOTER.format(name=name, lds=LDS_BYTES, kargs=KARG_BYTES, nvgpr=ARCH_VGPRS + ACC_VGPRS, accum=ARCH_VGPRS,
+    txt = HEADER.format(name=name) + body + FOOTER.format(name=name, lds=g.lds_bytes, kargs=KARG_BYTES, nvgpr=ARCH_VGPRS + ACC_VGPRS, accum=ARCH_VGPRS,
                                                         nagpr=ACC_VGPRS)
     return txt, g
 

@@ -237,6 +237,11 @@ class Prog:
         return self._emit("ds_read_b64_tr_b16", d, (addr,), "ds", mods={"offset": offset},
                           text=f"ds_read_b64_tr_b16 {op_t(d)}, {op_t(addr)}" + (f" offset:{offset}" if offset else ""))
 
+    def ds_write_b128(self, addr, data, offset=0):
+        assert data.n == 4
+        return self._emit("ds_write_b128", None, (addr, data), "dsw", mods={"offset": offset},
+                          text=f"ds_write_b128 {op_t(addr)}, {op_t(data)}" + (f" offset:{offset}" if offset else ""))
+
     # ------------------------------------------------------------------ VMEM (raw buffer, offen)
     def buffer_load_dwordx4(self, d, voff, rsrc, soff, offset=0):
         assert d.n == 4 and rsrc.n == 4 and 0 <= offset < 4096
@@ -284,6 +289,13 @@ class Prog:
     def s_load(self, d, base, offset):
         name = {1: "s_load_dword", 2: "s_load_dwordx2", 4: "s_load_dwordx4", 8: "s_load_dwordx8"}[d.n]
         return self._emit(name, d, (base,), "smem", mods={"offset": offset}, text=f"{name} {op_t(d)}, {op_t(base)}, {hex(offset)}")
+
+    def s_memtime(self, d): return self._emit("s_memtime", d, (), "smem", mods={"offset": 0}, text=f"s_memtime {op_t(d)}")
+    def s_memrealtime(self, d): return self._emit("s_memrealtime", d, (), "smem", mods={"offset": 0}, text=f"s_memrealtime {op_t(d)}")
+
+    def global_store_dwordx4(self, addr, data):
+        assert addr.n == 2 and data.n == 4
+        return self._emit("global_store_dwordx4", None, (addr, data), "vmem", text=f"global_store_dwordx4 {op_t(addr)}, {op_t(data)}, off")
 
     def s_waitcnt(self, vmcnt=None, lgkmcnt=None):
         parts = []

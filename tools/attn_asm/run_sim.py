@@ -12,7 +12,7 @@ def magic(d):
     return (0, 1) if d == 1 else (((1 << 32) + d - 1) // d, 0)
 
 
-def kernargs(qkv, out, lse, N, heads, npairs, stride):
+def kernargs(qkv, out, lse, N, heads, npairs, stride, dbg=0):
     nqb, nt = (N + 255) // 256, (N + 63) // 64
     mq, aq = magic(nqb)
     mh, ah = magic(heads)
@@ -20,6 +20,7 @@ def kernargs(qkv, out, lse, N, heads, npairs, stride):
     for k, ptr in enumerate((qkv, out, lse)):
         ka[2 * k], ka[2 * k + 1] = ptr & 0xFFFFFFFF, ptr >> 32
     ka[6:16] = [N, heads, npairs, nqb, mq, mh, nt, stride, aq, ah]
+    ka[16], ka[17] = dbg & 0xFFFFFFFF, dbg >> 32
     return ka
 
 

@@ -55,7 +55,7 @@ class Wave:
 
 
 class Machine:
-    def __init__(self, prog, nwaves=4, lds_bytes=65536, dtype="bf16"):
+    def __init__(self, prog, nwaves=4, lds_bytes=163840, dtype="bf16"):
         self.items = prog.items
         self.labels = {}
         for i, it in enumerate(self.items):
@@ -187,6 +187,8 @@ class Machine:
             self.exec_mfma(w, ins)
         elif ins.klass == "salu":
             self.exec_salu(w, ins)
+        elif ins.klass == "smem" and n in ("s_memtime", "s_memrealtime"):
+            w.s[d.idx], w.s[d.idx + 1] = w.icount & 0xFFFFFFFF, 0
         elif ins.klass == "smem":
             base = int(w.s[s[0].idx]) | (int(w.s[s[0].idx + 1]) << 32)
             a = base + ins.mods["offset"]
@@ -488,7 +490,7 @@ class Machine:
         elif n == "buffer_load_lds_dwordx4":
             voff, rsrc, soff = s
             addr, ok = self.buf_addr(w, rsrc, self.rd(w, voff), self.rs(w, soff), 0, 16)
-            m0 = int(w.s[M0_IDX]) & 0xFFFF
+            m0 = int(w.s[M0_IDX]) & 0x3FFFF
             data = np.zeros(1024, dtype=np.uint8)
             for l in range(64):
                 if ok[l]:
@@ -505,6 +507,14 @@ class Machine:
                 self.lds_pub_epoch[sl] = self.epoch
                 self.lds_pub_wave[sl] = wid
             w.vm_q.append({"kind": "dma", "apply": apply})
+        elif n == "global_store_dwordx4":
+            addr, data = s
+            lo, hi = self.rd(w, addr[0]).astype(np.int64), self.rd(w, addr[1]).astype(np.int64)
+            blk = self.vblock(w, data)
+            for l in range(64):
+                a = int(lo[l] | (hi[l] << 32))
+                self.mem[a:a + 16] = np.ascontiguousarray(blk[:, l]).view(np.uint8)
+            w.vm_q.append({"kind": "store"})
         elif n in ("buffer_store_dwordx4", "buffer_store_dword"):
             data, voff, rsrc, soff = s
             size = 16 if n.endswith("x4") else 4
