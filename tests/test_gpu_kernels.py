@@ -234,6 +234,51 @@ def test_attention(variant, B, tok, heads):
     assert rel_l2(out, ref) < 1e-2
 
 
+@pytest.mark.parametrize("variant", [64, 32])
+@pytest.mark.parametrize("B,tok,heads", [(1, 200, 3), (2, 1370, 2), (3, 129, 2), (2, 300, 12), (1, 785, 6), (9, 257, 1)])
+def test_attention_assembly_kernels(B, tok, heads, variant):
+    """The hand-placed assembly kernels (variant 64: 4 waves x 64 rows, one wave per SIMD; 32: 8 waves x 32 rows, two per SIMD; generated by
+    tools/attn_asm, simulated on the CPU in tests/test_attn_asm.py): same contract as the product kernel.  Shapes: rows past N in the only
+    item (200), the C2 token count, three tiles exactly (129), several items per workgroup (12 heads x 2 images on 8 groups; 9 images of one
+    head), 785 = ViT-S/8 at 224.  Deterministic (no atomics): a second launch is bitwise equal."""
+    g = torch.Generator().manual_seed(tok * 5 + heads)
+    D = heads * 64
+    qkv = torch.randn(B * tok, 3 * D, generator=g) * 1.5
+    qkv[:, :D] *= 0.125 * math.log2(math.e)
+    qkv = bf(qkv)
+    q, k, v = (qkv.double()[:, i * D:(i + 1) * D].reshape(B, tok, heads, 64).transpose(1, 2) for i in range(3))
+    p = torch.softmax(torch.matmul(q, k.transpose(2, 3)) * math.log(2.0), dim=-1)
+    ref = torch.matmul(p, v).transpose(1, 2).reshape(B * tok, D).float()
+    qd = qkv.to(DEV)
+    out = ops.attention(qd, B, tok, heads, scale=0.0, variant=variant).float().cpu()
+    assert maxdiff(out, ref) < 2.5e-2, maxdiff(out, ref)
+    assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)          # measured 2.0-2.3e-3 (bf16 probabilities)
+    assert torch.equal(out, ops.attention(qd, B, tok, heads, scale=0.0, variant=variant).float().cpu())
+    prod = ops.attention(qd, B, tok, heads, scale=0.0, variant=5).float().cpu()
+    assert maxdiff(out, prod) < 1.6e-2
+
+
+def test_attention_assembly_kernels_refuse_what_they_cannot_do():
+    qkv = torch.zeros(64, 192, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)
+    lib = N.load()
+    for variant in (64, 32):
+        assert lib.ucod_attention_fwd(qkv.data_ptr(), out.data_ptr(), 1, 64, 1, 0.0, variant, None) == -1        # fewer than three key tiles
+        assert lib.ucod_attention_fwd(qkv.data_ptr(), out.data_ptr(), 1, 64, 1, 0.125, variant, None) == -1      # generic scale
+
+
+def test_attention_assembly_lse_path():
+    """UCOD_ATTN_ASM is read once per process: the LSE entry (backbone-backward mode) with the assembly kernel runs in a child process"""
+    import subprocess, sys, os
+    env = dict(os.environ, UCOD_ATTN_ASM="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_asm", "gpu_check.py"), "lse"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("lse path")][-1]
+    out_err, lse_err = float(line.split("out max|err|")[1].split()[0]), float(line.split("lse max|err|")[1].split()[0])
+    assert "rc 0" in line and out_err < 2.5e-2 and lse_err < 1e-3, line
+
+
 @pytest.mark.parametrize("variant", [2] + [lab(v) for v in (3, 4, 6, 7, 9, 12, 13, 14, 15, 102)])
 @pytest.mark.parametrize("B,tok,heads", [(1, 26, 2), (2, 64, 1), (1, 200, 3), (2, 1370, 2), (1, 1, 1), (3, 129, 2)])
 def test_attention_prescaled_q_kernel(B, tok, heads, variant):
@@ -279,7 +324,7 @@ def test_attention_prescaled_deferred_max_branches():
         q, k, v = (x.float()[:, i * D:(i + 1) * D] for i in range(3))
         p = torch.softmax((q @ k.t()) * math.log(2.0), dim=-1)
         ref = p @ v
-        for variant in (2,) + ((6, 7, 9, 12, 13, 14, 15) if N.have_lab() else ()):
+        for variant in (2, 64, 32) + ((6, 7, 9, 12, 13, 14, 15) if N.have_lab() else ()):          # 64 / 32: the assembly kernels
             out = ops.attention(x.to(DEV), 1, tok, 1, scale=0.0, variant=variant).float().cpu()
             assert maxdiff(out, ref) < 3e-2, (variant, maxdiff(out, ref))
 

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from tools.attn_asm.gen_attn import kernel_text, KARG_BYTES  # noqa: E402
+from tools.attn_asm import gen_attn32  # noqa: E402
 from tools.attn_asm.run_sim import kernargs  # noqa: E402
 from ucod_dpl_amd import ops  # noqa: E402
 
@@ -27,8 +28,8 @@ hip = C.CDLL("libamdhip64.so")
 tmp = tempfile.mkdtemp(prefix="attnasm_")
 
 
-def build(name, **kw):
-    txt, g = kernel_text("bf16", name="k_" + name, **kw)
+def build(name, pw32=False, **kw):
+    txt, g = (gen_attn32.kernel_text if pw32 else kernel_text)("bf16", name="k_" + name, **kw)
     s, o, co = (os.path.join(tmp, name + e) for e in (".s", ".o", ".co"))
     open(s, "w").write(txt)
     subprocess.check_call([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", s, "-o", o])
@@ -39,7 +40,7 @@ def build(name, **kw):
     return fn
 
 
-def launcher(fn, qkv, out, lse_ptr=0, dbg_ptr=0):
+def launcher(fn, qkv, out, lse_ptr=0, dbg_ptr=0, threads=256):
     npairs = B * heads
     nqb = (tok + 255) // 256
     stride = min(32, ((npairs + 7) // 8) * nqb)
@@ -50,7 +51,7 @@ def launcher(fn, qkv, out, lse_ptr=0, dbg_ptr=0):
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def go():
-        rc = hip.hipModuleLaunchKernel(fn, 8 * stride, 1, 1, 256, 1, 1, 0, st, None, cfg)
+        rc = hip.hipModuleLaunchKernel(fn, 8 * stride, 1, 1, threads, 1, 1, 0, st, None, cfg)
         assert rc == 0, rc
     go.keep = (buf, size, cfg)
     return go
@@ -62,13 +63,16 @@ def main():
     qkv_f = torch.randn(B * tok, 3 * heads * 64, device="cuda", generator=g)
     qkv_f[:, :heads * 64] *= 0.125 * math.log2(math.e)
     qkv = qkv_f.to(torch.bfloat16)
+    if os.environ.get("ATTN_ZERO"):
+        qkv.zero_()                       # constant operands: the clock the chip holds when the data does not toggle
     ref = ops.attention(qkv, B, tok, heads, scale=0.0, variant=5)
     arms, dbgs = {}, {}
     for sp in specs:
         name, flags = sp.split("=", 1)
         kw = {}
         fl = [f for f in flags.split("+") if f]
-        abl = [f for f in fl if not f.startswith(("thr", "dmagap", "ud", "margin", "ring"))]
+        pw32 = "pw32" in fl
+        abl = [f for f in fl if not f.startswith(("thr", "dmagap", "ud", "margin", "ring", "pw32"))]
         for f in fl:
             if f.startswith("thr"):
                 kw["thr_exp"] = int(f[3:])
@@ -82,9 +86,10 @@ def main():
                 kw["margin"] = int(f[6:])
         out = torch.zeros(B * tok, heads * 64, dtype=torch.bfloat16, device="cuda")
         dbg = torch.zeros(256 * 4 * 8, dtype=torch.int32, device="cuda") if "stamps" in abl else None
-        arms[name] = (launcher(build(name, abl=abl, **kw), qkv, out, dbg_ptr=dbg.data_ptr() if dbg is not None else 0), out, abl)
+        arms[name] = (launcher(build(name, pw32=pw32, abl=abl, **kw), qkv, out, dbg_ptr=dbg.data_ptr() if dbg is not None else 0,
+                               threads=512 if pw32 else 256), out, abl)
         if dbg is not None:
-            dbgs[name] = dbg
+            dbgs[name] = (dbg, pw32)
     arms["v5"] = (lambda: ops.attention(qkv, B, tok, heads, scale=0.0, variant=5), ref, ["ref"])
     for name, (go, out, abl) in arms.items():
         go()
@@ -107,9 +112,16 @@ def main():
         print(f"{name:22s} median {med:7.1f}  min {mn:7.1f}  {fl / (med * 1e-6) / 2.5e15:.3f} of 2.5 PF   max|out - v5| {d:.3g}   [{'+'.join(abl)}]", flush=True)
 
 
-    for name, dbg in dbgs.items():
+    for name, (dbg, pw32) in dbgs.items():
         arms[name][0]()
         torch.cuda.synchronize()
+        if pw32:
+            d = dbg.cpu().view(-1, 4).double()
+            d = d[d[:, 3] > 0]
+            per = d[:, :3] / d[:, 3:4]
+            print(f"stamps {name}: cycles per steady iteration of a live wave, mean over {len(d)} waves: step a {per[:, 0].mean().item():.0f}  step b {per[:, 1].mean().item():.0f}"
+                  f"  wait+barrier {per[:, 2].mean().item():.0f}  total {per.sum(1).mean().item():.0f}")
+            continue
         d = dbg.cpu().view(-1, 8).double()
         d = d[d[:, 5] > 0]
         per = d[:, :5] / d[:, 5:6]

@@ -1,7 +1,7 @@
 """Static wait-state audit of a generated program (isa.Prog).  hipcc pads none of this for hand-written code, and the hardware has no
 interlock for these pairs (cdna_hip_programming.md section 5.7 item 2; LLVM GCNHazardRecognizer for gfx940/gfx950), so the generator's
-output is checked in program order.  Wait states are counted per issued instruction (s_nop N = N + 1); an intervening MFMA counts as one,
-which is conservative.  Rules (producer -> consumer: wait states required between them):
+output is checked in program order.  Wait states are counted per issued instruction (s_nop N = N + 1; an intervening MFMA counts as eight: the matrix pipe takes one 8-pass
+instruction per 8 quad-cycles).  Rules (producer -> consumer: wait states required between them):
 
   R1  VALU write of a VGPR            -> MFMA reading it as A, B or C                          2
   R2  MFMA write of D                 -> any non-MFMA access of D, or an MFMA reading it as A/B 12   (C of the same range as D: 0, the accumulate chain)
@@ -26,12 +26,18 @@ def audit(prog, verbose=False):
     last_mfma_write = {}   # reg id -> (time, ins)
     last_store_read = {}   # reg id -> time
     m0_write = -100
+    last_mfma_issue = -100
     for it in prog.items:
         if not isinstance(it, Ins):
             continue
         ins = it
+        # an s_nop N idles N + 1 wait states; an 8-pass MFMA cannot issue less than 8 quad-cycles after the previous MFMA (one matrix pipe
+        # per SIMD), so everything issued BEFORE it is at least that far behind whatever follows it
         ws = (ins.mods.get("n", 0) + 1) if ins.klass == "nop" else 1
         k = ins.klass
+        if k == "mfma":
+            t = max(t, last_mfma_issue + 8)
+            last_mfma_issue = t
 
         def need(reg, t_prod, gap, rule):
             if t - t_prod - 1 < gap:
@@ -103,7 +109,9 @@ def audit(prog, verbose=False):
 if __name__ == "__main__":
     import sys
     from .gen_attn import Gen
-    g = Gen(dtype=sys.argv[1] if len(sys.argv) > 1 else "bf16")
+    from .gen_attn32 import Gen32
+    dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+    g = (Gen32 if len(sys.argv) > 2 and sys.argv[2] == "pw32" else Gen)(dtype=dt)
     v = audit(g.build())
     for x in v[:50]:
         print(x)

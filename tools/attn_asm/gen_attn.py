@@ -129,7 +129,7 @@ ACC_VGPRS = 176
 
 
 class Gen:
-    def __init__(self, dtype="bf16", thr_exp=None, table=None, abl=(), unit_detect=None, margin=64, dma_gap=4, ring=4):
+    def __init__(self, dtype="bf16", thr_exp=None, table=None, abl=(), unit_detect=None, margin=64, dma_gap=7, ring=4):
         self.p = Prog()
         # K / V rings of `ring` 8-KiB slots each; the stream runs ring - 1 (ring 4) or 4 (ring 8) tiles ahead.  ring 8: one barrier per TWO
         # tiles (a tile is visible one barrier after its wait, and its slot is rewritten two barriers after its last read)
@@ -1003,7 +1003,7 @@ FOOTER = """.Lfunc_end_{name}:
 \t\t.amdhsa_system_sgpr_workgroup_info 0
 \t\t.amdhsa_system_vgpr_workitem_id 0
 \t\t.amdhsa_next_free_vgpr {nvgpr}
-\t\t.amdhsa_next_free_sgpr 96
+\t\t.amdhsa_next_free_sgpr 102
 \t\t.amdhsa_accum_offset {accum}
 \t\t.amdhsa_reserve_vcc 1
 \t\t.amdhsa_float_round_mode_32 0

@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from ucod_dpl_amd import native as N, ops  # noqa: E402
 
 stage = sys.argv[1] if len(sys.argv) > 1 else "small"
+AV = int(os.environ.get("ATTN_VARIANT", "64"))
 DEV = "cuda"
 
 
@@ -37,11 +38,11 @@ if stage == "small":
         qkv[:, :D] *= 0.125 * math.log2(math.e)
         qkv = qkv.to(torch.bfloat16)
         ref, _ = ref_attn(qkv, B, tok, heads)
-        o3 = run(qkv, B, tok, heads, 3)
+        o3 = run(qkv, B, tok, heads, AV)
         o5 = run(qkv, B, tok, heads, 5)
         e3, e5 = (o3.double() - ref).abs().max().item(), (o5.double() - ref).abs().max().item()
         r3 = ((o3.double() - ref).norm() / ref.norm()).item()
-        again = run(qkv, B, tok, heads, 3)
+        again = run(qkv, B, tok, heads, AV)
         print(f"shape {(B, tok, heads)}: asm max|err| {e3:.4g} rel-L2 {r3:.3g}  (v5 {e5:.4g})  repeat-bitwise {torch.equal(o3, again)}  nan {torch.isnan(o3).any().item()}", flush=True)
 elif stage == "branches":
     D, tok = 64, 400
@@ -55,7 +56,7 @@ elif stage == "branches":
         x = x.clone(); x[:, :D] *= c
         x = x.to(torch.bfloat16)
         ref, _ = ref_attn(x, 1, tok, 1)
-        o3 = run(x, 1, tok, 1, 3)
+        o3 = run(x, 1, tok, 1, AV)
         print(f"{name}: asm max|err| {(o3.double() - ref).abs().max().item():.4g} nan {torch.isnan(o3).any().item()}", flush=True)
 elif stage == "lse":
     os.environ["UCOD_ATTN_ASM"] = "1"

@@ -5,6 +5,7 @@ import math
 import sys
 import numpy as np
 from .gen_attn import Gen, KERNEL_NAME, KARG_BYTES
+from . import gen_attn32
 from .sim import Machine, bf16_round, bf16_to_f32, f16_round, f16_to_f32, U32, F32
 
 
@@ -37,8 +38,11 @@ def reference(qkv_f, B, N, heads):
     return o.transpose(0, 2, 1, 3).reshape(B * N, D), lse          # lse [B, heads, N]
 
 
-def simulate(B, heads, N, stride=32, dtype="bf16", seed=0, qkv_f=None, thr_exp=None, with_lse=True, verbose=False):
-    g = Gen(dtype=dtype, thr_exp=thr_exp)
+def simulate(B, heads, N, stride=32, dtype="bf16", seed=0, qkv_f=None, thr_exp=None, with_lse=True, verbose=False, kernel="pw64", **genkw):
+    if kernel == "pw64":
+        g, nwaves, entry = Gen(dtype=dtype, thr_exp=thr_exp, **genkw), 4, KERNEL_NAME
+    else:
+        g, nwaves, entry = gen_attn32.Gen32(dtype=dtype, **genkw), 8, gen_attn32.KERNEL_NAME
     prog = g.build()
     D = heads * 64
     rng = np.random.default_rng(seed)
@@ -48,7 +52,7 @@ def simulate(B, heads, N, stride=32, dtype="bf16", seed=0, qkv_f=None, thr_exp=N
     rnd, back = (bf16_round, bf16_to_f32) if dtype == "bf16" else (f16_round, f16_to_f32)
     bits = rnd(qkv_f.astype(F32).ravel()).astype(np.uint16)
     qkv_q = back(bits.astype(U32)).reshape(B * N, 3 * D)
-    m = Machine(prog, dtype=dtype)
+    m = Machine(prog, dtype=dtype, nwaves=nwaves)
     a_qkv = m.alloc(bits.nbytes + 4096)
     m.write(a_qkv, bits)
     a_out = m.alloc(B * N * D * 2 + 4096)
@@ -59,7 +63,7 @@ def simulate(B, heads, N, stride=32, dtype="bf16", seed=0, qkv_f=None, thr_exp=N
     m.write(a_ka, kernargs(a_qkv, a_out, a_lse, N, heads, npairs, stride))
     total = {"steps": 0, "mfma": 0}
     for wg in range(8 * stride):
-        m.waves = [type(m.waves[0])(w) for w in range(4)]
+        m.waves = [type(m.waves[0])(w) for w in range(nwaves)]
         m.lds[:] = 0xEE
         m.lds_inflight[:] = 0
         m.lds_pub_epoch[:] = -1
@@ -70,7 +74,7 @@ def simulate(B, heads, N, stride=32, dtype="bf16", seed=0, qkv_f=None, thr_exp=N
             w.s[0], w.s[1] = a_ka & 0xFFFFFFFF, a_ka >> 32
             w.s[2] = wg
             w.v[0] = np.arange(64, dtype=U32) + 64 * w.wid
-        total["steps"] += m.run(KERNEL_NAME, setup)
+        total["steps"] += m.run(entry, setup)
     total["mfma"] = m.mfma_count
     out_bits = m.read(a_out, B * N * D * 2).view(np.uint16)
     out = back(out_bits.astype(U32)).reshape(B * N, D)
@@ -88,7 +92,7 @@ if __name__ == "__main__":
     B, heads, N = (int(a[0]), int(a[1]), int(a[2])) if len(a) >= 3 else (1, 1, 200)
     stride = int(a[3]) if len(a) > 3 else 1
     dtype = a[4] if len(a) > 4 else "bf16"
-    r = simulate(B, heads, N, stride=stride, dtype=dtype)
+    r = simulate(B, heads, N, stride=stride, dtype=dtype, kernel=a[5] if len(a) > 5 else "pw64")
     v = r.pop("violations")
     print(r)
     for x in v[:20]:
