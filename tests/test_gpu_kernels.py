@@ -255,7 +255,7 @@ def test_attention_assembly_kernels(B, tok, heads, variant):
     assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)          # measured 2.0-2.3e-3 (bf16 probabilities)
     assert torch.equal(out, ops.attention(qd, B, tok, heads, scale=0.0, variant=variant).float().cpu())
     prod = ops.attention(qd, B, tok, heads, scale=0.0, variant=5).float().cpu()
-    assert maxdiff(out, prod) < 1.6e-2
+    assert maxdiff(out, prod) < 4e-2          # two bf16 roundings of the same value: up to 2 ulp at |out| ~ 4
 
 
 def test_attention_assembly_kernels_refuse_what_they_cannot_do():
