@@ -122,6 +122,35 @@ def _val_worker(rank, world, port, out):
     class _Pre(list):
         sampler = type("S", (), {"num_replicas": world})()
     assert list(parallel.shard(_Pre([1, 2, 3]))) == [1, 2, 3]
+    # a plain DataLoader is REBUILT over this rank's indices: the dataset is asked for them only
+    from torch.utils.data import DataLoader, Dataset
+    from torch.utils.data.distributed import DistributedSampler
+
+    class _DS(Dataset):
+        def __init__(self):
+            self.asked = []
+
+        def __len__(self):
+            return 7
+
+        def __getitem__(self, i):
+            self.asked.append(i)
+            return torch.tensor([i])
+    ds = _DS()
+    got = [int(x) for b in parallel.shard(DataLoader(ds, batch_size=2)) for x in b.view(-1)]
+    assert got == list(range(7))[rank::world] and sorted(ds.asked) == got
+    # a DistributedSampler without drop_last pads 7 images to 8: the repeat (image 0, on rank 1) is dropped by gather_records
+    ds2 = _DS()
+    dl = DataLoader(ds2, batch_size=2, sampler=DistributedSampler(ds2, num_replicas=world, rank=rank, shuffle=False))
+    assert parallel.padded_sampler_len(dl) == 7
+    st2 = statistics()
+    for b in parallel.shard(dl):
+        for i in b.view(-1):
+            st2._records.append(rec[int(i):int(i) + 1])
+    assert len(st2._records) == 4
+    st2.gather_records(dataset_len=parallel.padded_sampler_len(dl))
+    p2 = st2.per_image()
+    assert p2.shape[0] == 7 and torch.equal(p2, torch.cat([rec[0::2], rec[1::2]]))
     torch.save((res, st.per_image(), empty.per_image()), out + str(rank))
     torch.distributed.destroy_process_group()
 

@@ -589,6 +589,49 @@ def test_fp16_residual_stream_kernels():
         assert torch.all(buf[M:] == 7.0)
 
 
+def _resid16_counter():
+    """fetch-and-clear of the device's fp16-stream saturation counter (ucod_resid16_overflow_fetch / _reset)"""
+    lib = N.load()
+    host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    N.check(lib.ucod_resid16_overflow_fetch(host.data_ptr(), N.stream()), "fetch")
+    N.check(lib.ucod_resid16_overflow_reset(N.stream()), "reset")
+    torch.cuda.synchronize()
+    return int(host[0])
+
+
+@pytest.mark.parametrize("M,Nn,K", [(21916, 768, 768), (300, 256, 192)])          # the large-tile drain / the 128 x 128 one
+def test_fp16_stream_epilogues_count_nan_and_saturation(M, Nn, K):
+    """A NaN (or a value past +-65504) in the fp16 residual stream must be COUNTED by every drain: clamp_f16 (v_med3) turns a NaN into
+    -65504, so without the count a NaN activation becomes a finite key map (the large-tile drains' maximum dropped NaN)."""
+    g = torch.Generator().manual_seed(M)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = bf(torch.randn(Nn, K, generator=g) * 0.05).to(DEV)
+    bias, sc = torch.randn(Nn, generator=g).to(DEV), (torch.rand(Nn, generator=g) + 0.5).to(DEV)
+    resid = (torch.randn(M, Nn, generator=g) * 4).to(torch.float16).to(DEV)
+    _resid16_counter()
+    xx = resid.clone()
+    ops.gemm_bf16(N.EPI_BIAS_SCALE_RESID_H16, A, W, xx, M, Nn, K, bias=bias, scale=sc, resid=xx)
+    assert _resid16_counter() == 0                                     # clean inputs: nothing counted
+    for bad in (float("nan"), 1.0e6):
+        A2 = A.clone()
+        A2[M // 2, 5] = bad
+        xx = resid.clone()
+        ops.gemm_bf16(N.EPI_BIAS_SCALE_RESID_H16, A2, W, xx, M, Nn, K, bias=bias, scale=sc, resid=xx)
+        assert bool(torch.isfinite(xx.float()).all())                   # the stream itself saturates, never inf / NaN
+        assert _resid16_counter() > 0, bad
+    # patch-token drain (rows remapped past the CLS rows)
+    Bimg, npatch, D, Kp = 40, 64, 256, 640
+    tok = npatch + 1
+    Ap = bf(torch.randn(Bimg * npatch, Kp, generator=g))
+    Ap[777, 3] = float("nan")
+    Wp = bf(torch.randn(D, Kp, generator=g) * 0.05)
+    buf = torch.zeros(Bimg * tok, D, dtype=torch.float16, device=DEV)
+    for variant in (0, 2):
+        ops.gemm_bf16(N.EPI_PATCH_TOKENS_H16, Ap.to(DEV), Wp.to(DEV), buf, Bimg * npatch, D, Kp, bias=torch.zeros(D, device=DEV),
+                      pos=torch.zeros(tok, D, device=DEV), tok=tok, variant=variant)
+        assert _resid16_counter() > 0, variant
+
+
 def test_fp16_library_refuses_the_bf16_only_entry_points():
     from ucod_dpl_amd import native
     lib = native.load("f16")

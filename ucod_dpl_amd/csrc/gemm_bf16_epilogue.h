@@ -458,8 +458,8 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
           const f32x4 v1 = (*reinterpret_cast<const f32x4*>(src + 16) + cbias[H16 ? 1 : 0]) + __builtin_bit_cast(f32x4, pv[it][1]);
 #pragma unroll
           for (int e = 0; e < 4; e += 2) {
-            amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v0[e]), __builtin_fabsf(v0[e + 1])));
-            amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v1[e]), __builtin_fabsf(v1[e + 1])));
+            amax = __builtin_elementwise_maximum(amax, __builtin_elementwise_maximum(__builtin_fabsf(v0[e]), __builtin_fabsf(v0[e + 1])));      // IEEE maximum: a NaN stays a NaN
+            amax = __builtin_elementwise_maximum(amax, __builtin_elementwise_maximum(__builtin_fabsf(v1[e]), __builtin_fabsf(v1[e + 1])));
           }
           u32x4 w;
           w[0] = pack_f16x2(clamp_f16(v0[0]), clamp_f16(v0[1]));
@@ -474,7 +474,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if constexpr (H16) {
-      if (amax > F16_MAX) atomicAdd(a.ovf, 1u);
+      if (!(amax <= F16_MAX)) atomicAdd(a.ovf, 1u);          // true for NaN too (beyond_f16's convention, common.h)
     }
   } else if constexpr (!kColFused<EPI>) {
 #pragma unroll
@@ -665,7 +665,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
 #pragma unroll
             for (int e = 0; e < 4; ++e) { x[e] = v0[e] + r[e]; x[4 + e] = v1[e] + r[4 + e]; }
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x[e]), __builtin_fabsf(x[e + 1])));   // (v_max3 with |.| modifiers)
+            for (int e = 0; e < 8; e += 2) amax = __builtin_elementwise_maximum(amax, __builtin_elementwise_maximum(__builtin_fabsf(x[e]), __builtin_fabsf(x[e + 1])));   // (v_maximum3 with |.| modifiers; NaN-propagating)
 #pragma unroll
             for (int e = 0; e < 4; ++e) w[e] = pack_f16x2(clamp_f16(x[2 * e]), clamp_f16(x[2 * e + 1]));
           } else {
@@ -680,7 +680,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       if constexpr (RH16) {                                         // after the last store: nothing waits on this
-        if (amax > F16_MAX) atomicAdd(a.ovf, 1u);
+        if (!(amax <= F16_MAX)) atomicAdd(a.ovf, 1u);          // true for NaN too (beyond_f16's convention, common.h)
       }
     }
   }

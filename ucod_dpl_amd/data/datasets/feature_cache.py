@@ -217,6 +217,9 @@ def build_feature_cache(images, feature_extractor, features_cache, batch_size=32
             return
         _, key = feature_extractor(torch.stack(pending).to(device))
         key = key.to("cpu")                                       # base_dataset.py:138: features.squeeze(0).to('cpu')
+        eng = getattr(feature_extractor, "engine", None)
+        if eng is not None and hasattr(eng, "check_overflow"):
+            eng.check_overflow(wait=True)                         # these key maps go to disk: a saturated fp16 residual stream must fail HERE
         for row in key:
             fname = store.reserve(written)
             if pool is None:

@@ -144,7 +144,7 @@ class LocalRefineValidationLoop(BaseLoop):
         self.runner.refiner.eval()
         for batch in parallel.shard(self.runner.val_dataloader):
             self._process_validation_batch(batch, stats)
-        stats.gather_records(device=self.device)
+        stats.gather_records(device=self.device, dataset_len=parallel.padded_sampler_len(self.runner.val_dataloader))
         result = stats.get_result()
         self.runner.logger.log_table({k: [round(v, 4)] for k, v in result.items()})
         return result

@@ -265,6 +265,7 @@ class TrainLoop(BaseLoop):
             self.global_step += 1                             # run_epoch's increment (loop_UCOD_DPL.py:143)
             yield loss
             cur = nxt
+        engine.check_overflow(wait=True)                      # the LAST passes' saturation report (the polls inside forward() see finished passes only)
 
     # ------------------------------------------------------------------ backbone-backward mode
     def attach_lora_backbone(self, engine, lr=None):
@@ -458,6 +459,9 @@ class TrainLoop(BaseLoop):
             if self.log_scalars and self._cur_epoch % self.log_interval == 0:
                 self.runner.logger.log(f"iter{self.global_step}:loss:{loss.item():.4f}")
             self.global_step += 1                             # second increment per batch (:143)
+        for eng in (getattr(self, "lora_engine_ema", None), getattr(self, "lora_engine", None)):
+            if eng is not None:                               # backbone-backward mode: the teacher's fp16-stream passes report at the epoch boundary
+                eng.check_overflow(wait=True)
 
     def run(self):
         self.runner.logger.log(self.cfg)

@@ -272,7 +272,7 @@ class ValLoop_Look_Twice(BaseLoop):
                 preds_up = self.look_twice(img_path[0], bboxes, preds_up).to(self.device)
             out = ops.bilinear_resize(preds_up.reshape(1, 1, *preds_up.shape[-2:]).to(self.device), label_tensor.shape[-2], label_tensor.shape[-1])
             stats.step(label_tensor.to(self.device), (out.reshape(1, *out.shape[-2:]) > 0.5))
-        stats.gather_records(device=self.device)
+        stats.gather_records(device=self.device, dataset_len=parallel.padded_sampler_len(self.runner.val_dataloader))
         result = stats.get_result()
         self.runner.logger.log_table({k: [round(v, 4)] for k, v in result.items()})
         return result

@@ -46,13 +46,15 @@ class statistics:
         """f64 [images, 1032] on the device (layout: include/ucod_dpl.h)."""
         return torch.cat(self._records, dim=0)
 
-    def gather_records(self, device=None):
+    def gather_records(self, device=None, dataset_len=None):
         """Multi-rank validation (what ``accelerator.gather_for_metrics`` is for in the reference, loop_UCOD_DPL.py:310): every rank
         has stepped over ITS shard of the validation set; collect all ranks' per-image records so that ``get_result`` is the
         measure over the whole set and identical on every rank.  Two collectives per validation run (counts, then the records
         padded to the longest shard), none per image; ranks may hold different numbers of images, including none.  ``device``: where a
         rank WITHOUT records builds its empty contribution (default: the current GPU under nccl, the CPU under gloo) -- it must be the
-        device the other ranks' records live on."""
+        device the other ranks' records live on.  ``dataset_len``: for shards cut by an interleaving DistributedSampler WITHOUT drop_last
+        (rank r holds images r, r + world, ...; the sampler pads the tail with repeats of the first images): the i-th record of rank r is
+        image i * world + r, and records at or past ``dataset_len`` are those repeats -- they are dropped, as gather_for_metrics drops them."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
@@ -72,6 +74,10 @@ class statistics:
         padded[:mine.shape[0]] = mine
         parts = [torch.empty_like(padded) for _ in range(world)]
         dist.all_gather(parts, padded)
+        if dataset_len is not None:
+            parts = [p[:max(0, min(n, -(-(int(dataset_len) - r) // world)))] for r, (p, n) in enumerate(zip(parts, counts))]
+            self._records = [torch.cat(parts, dim=0)]
+            return
         self._records = [torch.cat([p[:n] for p, n in zip(parts, counts)], dim=0)]      # rank order: deterministic on every rank
 
     def get_result(self):

@@ -12,6 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_native", "libucod_dpl.so")
 # Experiment builds (`make -C ucod_dpl_amd/csrc variant ...`) are selected by tools/ with UCOD_DPL_EXPERIMENT_LIB; the variable is honoured
 # only together with UCOD_DPL_ALLOW_EXPERIMENT=1, so that a stray environment variable cannot swap the product library.
+if os.environ.get("UCOD_DPL_LIB"):
+    raise RuntimeError("UCOD_DPL_LIB is no longer read (a stray variable must not swap the product library): use "
+                       "UCOD_DPL_ALLOW_EXPERIMENT=1 UCOD_DPL_EXPERIMENT_LIB=<path> for an experiment build")
 if os.environ.get("UCOD_DPL_EXPERIMENT_LIB") and os.environ.get("UCOD_DPL_ALLOW_EXPERIMENT") == "1":
     LIB_PATH = os.environ["UCOD_DPL_EXPERIMENT_LIB"]
 ABI_VERSION = 2                                            # include/ucod_dpl.h: UCOD_ABI_VERSION

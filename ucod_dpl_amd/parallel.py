@@ -118,15 +118,39 @@ def barrier():
         dist.barrier()
 
 
+def padded_sampler_len(loader):
+    """len(dataset) when ``loader`` walks a DistributedSampler that pads its tail with repeats (no drop_last), else None: what
+    ``statistics.gather_records`` needs to drop those repeats (the reference's gather_for_metrics does)"""
+    sampler = getattr(loader, "sampler", None)
+    if getattr(sampler, "num_replicas", None) is None or getattr(sampler, "drop_last", False) or getattr(sampler, "shuffle", False):
+        return None
+    try:
+        return len(loader.dataset)
+    except TypeError:
+        return None
+
+
 def shard(loader):
-    """This rank's share of a validation loader: batches rank, rank + world, rank + 2 world, ... -- unless the loader is already sharded
-    (its sampler carries ``num_replicas``, i.e. a DistributedSampler: what accelerator.prepare makes of it in the reference,
-    engine/runner/runner.py:372), in which case it is walked as it is.  With world_size 1 the loader itself.  Interleaved shards hold no
-    duplicates, so the gathered records are exactly one per image (a pre-sharded DistributedSampler pads its last batches with repeats
-    unless built with drop_last; the reference's gather_for_metrics drops those -- build such a sampler with drop_last or let this shard)."""
+    """This rank's share of a validation loader.  A plain ``DataLoader`` over a map-style dataset with a sequential sampler is REBUILT over
+    ``Subset(dataset, range(rank, N, world))`` (same batch size, collate function and workers): a rank then loads and decodes only its own
+    images (an ``islice`` over the original loader materialises every batch on every rank and throws (world - 1) / world of them away).
+    A loader that is already sharded (its sampler carries ``num_replicas``: a DistributedSampler, what accelerator.prepare makes of it in
+    the reference, engine/runner/runner.py:372) is walked as it is -- such a sampler pads its last batches with repeats unless built with
+    drop_last, and the reference's gather_for_metrics drops them: ``statistics.gather_records`` truncates to the dataset length
+    for the same reason.  Anything else (an iterable, a custom sampler) falls back to batches rank, rank + world, ...  World size 1: the
+    loader itself."""
     import itertools
     world = world_size()
     if world == 1 or getattr(getattr(loader, "sampler", None), "num_replicas", None) is not None:
         return loader
     rank = dist.get_rank()
+    try:
+        from torch.utils.data import DataLoader, SequentialSampler, Subset
+        if isinstance(loader, DataLoader) and isinstance(loader.sampler, SequentialSampler) and loader.batch_sampler is not None \
+                and hasattr(loader.dataset, "__getitem__") and hasattr(loader.dataset, "__len__"):
+            sub = Subset(loader.dataset, range(rank, len(loader.dataset), world))
+            return DataLoader(sub, batch_size=loader.batch_size, shuffle=False, num_workers=loader.num_workers, collate_fn=loader.collate_fn,
+                              pin_memory=loader.pin_memory, drop_last=False)
+    except ImportError:
+        pass
     return itertools.islice(loader, rank, None, world)

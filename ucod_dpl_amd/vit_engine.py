@@ -186,9 +186,10 @@ class ViTEngine:
         return d
 
     # ---- fp16 residual stream: saturation guard --------------------------------------------------------------------------------
-    def _arm_overflow_check(self, stream):
-        """Enqueue an asynchronous copy of the device's saturation counter behind the pass just launched on ``stream``."""
-        if not self.resid16:
+    def _arm_overflow_check(self, stream, used_resid16=None):
+        """Enqueue an asynchronous copy of the device's saturation counter behind the pass just launched on ``stream``.  ``used_resid16``:
+        whether THAT pass ran the fp16 stream (default: the engine's setting; the LoRA engine's no-grad teacher pass says so itself)."""
+        if not (self.resid16 if used_resid16 is None else used_resid16):
             return
         if self._ovf_host is None:
             self._ovf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
@@ -201,7 +202,7 @@ class ViTEngine:
     def check_overflow(self, wait=False):
         """Raise FloatingPointError if any finished pass saturated the fp16 residual stream.  ``wait``: block until every pass enqueued so far
         has finished (otherwise only passes that already have)."""
-        if not self.resid16 or self._ovf_host is None:
+        if self._ovf_host is None:                              # no pass of this engine has used the fp16 stream
             return
         if wait:
             for ev in self._ovf_events:
@@ -211,10 +212,18 @@ class ViTEngine:
             return
         n = int(self._ovf_host[0])
         if n > 0:
+            # before the reset: every fetch still queued on a side stream must have landed, or its (stale, non-zero) count would arrive
+            # AFTER the host word is cleared and raise a second time for the same saturation
+            for ev in self._ovf_events:
+                ev.synchronize()
+            self._ovf_events = []
             N.check(self.lib.ucod_resid16_overflow_reset(N.stream()), "ucod_resid16_overflow_reset")
+            torch.cuda.current_stream(self.device).synchronize()
             self._ovf_host.zero_()
-            raise FloatingPointError(f"the fp16 residual stream saturated at +-65504 in {n} wave-lane(s): this checkpoint's activations do not fit "
-                                     f"fp16; build the engine with resid='f32'")
+            how = "build the engine with resid='f32'" if self.resid16 else "call forward_nograd(..., resid16=False)"
+            raise FloatingPointError(f"the fp16 residual stream saturated at +-65504 (or met a NaN) in {n} wave-lane(s) on this device: the "
+                                     f"activations do not fit fp16; {how}.  (The counter is per device: another engine of this process that "
+                                     f"runs the fp16 stream on the same GPU shares it.)")
 
     _allow_resid16 = True                                      # the backbone-backward engine keeps the f32 stream (its kernels read it)
     _sync_check = os.environ.get("UCOD_CHECK_RESID") == "1"    # debug: check the saturation counter synchronously after every pass
@@ -519,6 +528,8 @@ class ViTLoRAEngine(ViTEngine):
         if getattr(self, "_iside_ws", None) is None or len(self._iside_ws) != len(self._tside):
             self._iside_ws = [None] * len(self._tside)
 
+        self.check_overflow()                                      # (non-blocking) teacher passes that have finished since the last call
+
         def run(i, b0, b1):
             t = self._train_desc(b1 - b0, H, W)
             t.vit.resid16 = int(bool(resid16))
@@ -531,6 +542,9 @@ class ViTLoRAEngine(ViTEngine):
             T, TT, keep = self._tables(gh, gw, self._tside_grad[i])
             N.check(lib.ucod_vit_forward_lora_infer(C.byref(t), T, TT, N.ptr(img[b0:b1]), N.ptr(key[b0:b1]), N.ptr(self._iside_ws[i]),
                                                     self._iside_ws[i].numel(), N.stream()), "ucod_vit_forward_lora_infer")
+            # this engine's own stream type is f32 (its backward reads it), but THIS pass may run the fp16 one: its saturation counter is
+            # fetched behind every chunk and polled by the next call / check_overflow(wait=True) at the loop's boundaries
+            self._arm_overflow_check(torch.cuda.current_stream(self.device), used_resid16=bool(resid16))
 
         self._fan_out(run, (img, key))
         return key
