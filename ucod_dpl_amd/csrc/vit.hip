@@ -37,8 +37,9 @@ Plan make_plan(const ucod_vit_desc* d) {
 // attn_variant of the pass: 0 (auto) and 2 = the pre-scaled-Q product kernel, 1 = the generic-scale kernel (Q as the reference holds it,
 // the scale applied inside the softmax), 8 = the fp8 path of BASELINE configs[4].  Laboratory variants (variants/attention_lab.hip) are
 // not reachable from the ViT driver: bench / tools that want to time one call ucod_attention_fwd_lab directly.
-inline bool attn_variant_known(int av) { return av == 0 || av == 1 || av == 2 || av == 8; }
-inline bool attn_variant_takes_prescaled_q(int av) { return av == 0 || av == 2 || av == 8; }
+// 5 / 64 / 32: attn_fwd_v5_kernel / the two assembly kernels by name (ucod_attention_fwd's variant), whatever UCOD_ATTN_ASM selects for 0 / 2
+inline bool attn_variant_known(int av) { return av == 0 || av == 1 || av == 2 || av == 8 || av == 5 || av == 64 || av == 32; }
+inline bool attn_variant_takes_prescaled_q(int av) { return av != 1; }
 
 bool valid(const ucod_vit_desc* d) {
   return d && d->B > 0 && d->C > 0 && d->P > 0 && d->H > 0 && d->W > 0 && d->H % d->P == 0 && d->W % d->P == 0 && d->D > 0 &&
@@ -113,7 +114,7 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
       RUN(ucod_attention_fwd_fp8_fused(ws + p.off_f8, a, d->B, tok, d->heads, QE, KE, VE, stream));
     } else {
       RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_BF16, h, W[2], qkv, M, 3 * D, D, (const float*)W[3], prescale ? qscale : nullptr, nullptr, nullptr, tok, gv, stream));
-      RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, prescale ? 0.f : scale, 0, stream));
+      RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, prescale ? 0.f : scale, (av == 5 || av == 64 || av == 32) ? av : 0, stream));
     }
     RUN(ucod_gemm_bf16(epi_resid, a, W[4], x, M, D, D, (const float*)W[5], (const float*)W[6], x, nullptr, tok, gv, stream));
     RUN(layernorm((const float*)W[7], (const float*)W[8]));

@@ -58,6 +58,34 @@ def random_state_dict(arch, seed=0, image_size=None):
     return sd
 
 
+def trained_like_state_dict(arch, seed=0, image_size=None, qk_gain=4.0, layer_scale=(0.1, 1.0), massive=200.0):
+    """``random_state_dict`` reshaped towards the statistics a TRAINED DINOv2 checkpoint shows (no checkpoint travels with this repository
+    and there is no network): (1) query / key projections scaled by ``qk_gain`` each, which moves the pre-softmax scores from a standard
+    deviation of ~0.3 (trunc-normal init: nearly uniform attention rows) to ~4, i.e. peaked rows whose entropy is far below ln(tokens);
+    (2) LayerScale drawn from ``layer_scale`` instead of 1; (3) two "massive activation" channels: the position embedding puts
+    +-``massive`` into them at the CLS token and a few patch tokens, so the residual stream carries values of that size through every
+    layer.  Used by the parity tests and by bench.py's ``parity_full_size`` leg ("peaked" rows) next to the flat init."""
+    D, heads, L, P, img, ls = ARCHS[arch]
+    sd = random_state_dict(arch, seed, image_size)
+    g = torch.Generator().manual_seed(seed + 7919)
+    for i in range(L):
+        p = f"encoder.layer.{i}."
+        for nm in ("query", "key"):
+            sd[p + f"attention.attention.{nm}.weight"] *= qk_gain
+            sd[p + f"attention.attention.{nm}.bias"] *= qk_gain
+        if ls:
+            lo, hi = layer_scale
+            sd[p + "layer_scale1.lambda1"] = lo + (hi - lo) * torch.rand(D, generator=g)
+            sd[p + "layer_scale2.lambda1"] = lo + (hi - lo) * torch.rand(D, generator=g)
+    if massive:
+        pos = sd["embeddings.position_embeddings"]
+        n = pos.shape[1]
+        for t in (0, 17 % n, 100 % n, n - 1):
+            pos[0, t, 5 % D] = massive
+            pos[0, t, (D * 3) // 4] = -0.75 * massive
+    return sd
+
+
 def _read_checkpoint(folder):
     folder = Path(folder).expanduser()
     cfg = {}
