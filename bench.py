@@ -385,6 +385,7 @@ def main():
     par = (cpu or {}).get("parity_full_size") or {}
     own = par if a.half == "bf16" else par.get("f16_operands") or {}
     logit_max_abs = own.get("logit_max_abs")
+    own_tl = (par.get("trained_like_weights") or {}).get("bf16" if a.half == "bf16" else "f16_operands") or {}
     bar_meeting, f16_vs_bf16 = None, None
     if par.get("f16_operands") and f16_children:
         cands = []
@@ -392,9 +393,13 @@ def main():
             pf = par["f16_operands"] if ch["residual_stream"] == "f32" else par.get("f16_operands_f16_stream") or {}
             if not pf:
                 continue
+            tlw = (par.get("trained_like_weights") or {}).get("f16_operands" if ch["residual_stream"] == "f32" else "f16_operands_f16_stream") or {}
             cands.append({"dtype": "f16", "residual_stream": ch["residual_stream"], "value": ch["value"], "unit": "images/s", "ms_per_step": ch["ms_per_step"],
                           "logit_max_abs": pf["logit_max_abs"], "key_rel_l2": pf["key_rel_l2"], "mask_flipped_fraction": pf["mask_flipped_fraction"],
                           "bar": BAR, "bar_met": bool(pf["logit_max_abs"] <= BAR), "margin": round(BAR / max(pf["logit_max_abs"], 1e-12), 2),
+                          # the same engine on trained-like synthetic weights (peaked attention, massive channels): the honest figure for a real checkpoint
+                          "trained_like_weights": {k: tlw.get(k) for k in ("logit_max_abs", "logit_rel_l2", "key_rel_l2", "mask_flipped_fraction")},
+                          "bar_met_on_trained_like_weights": (None if not tlw else bool(tlw["logit_max_abs"] <= BAR)),
                           "engine": f"ViTEngine(half='f16', resid='{ch['resid']}')"})
         met = [c_ for c_ in cands if c_["bar_met"]]
         if met:
@@ -417,6 +422,8 @@ def main():
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.half, "data": "synthetic",
         "logit_max_abs": logit_max_abs, "bar": BAR, "bar_met": (None if logit_max_abs is None else bool(logit_max_abs <= BAR)),
+        "logit_max_abs_trained_like_weights": own_tl.get("logit_max_abs"),
+        "bar_met_trained_like_weights": (None if not own_tl else bool(own_tl["logit_max_abs"] <= BAR)),
         "bar_meeting_config": bar_meeting, "f16_vs_bf16_per_kernel": f16_vs_bf16,
         "host_enqueue_ms_per_step": round(host_enqueue / a.steps * 1e3, 3), "host_threads": host_threads,
         "config": {"workload": f"{which_config(a.arch, a.image, B, a.attn_variant)}: {a.arch} @{a.image}x{a.image}, batch {B}/GPU, full APM+DBA+discriminator step, "
@@ -472,27 +479,42 @@ def cpu_baseline(a, D, heads, L, P):
         d = ops.bilinear_resize(ops.dba_project(key_dev, dec["decoupling.weight"].reshape(128, D).to(dev), dec["decoupling.bias"].to(dev)).view(n, 128, *key_dev.shape[-2:]), 68, 68).view(n, 128, 68 * 68)
         return ops.dba_heads(d, 0, emb, ops.dba_colnorm(d, 0, emb), hw, hb, want_bg=False)[0].view(n, 1, 68, 68).cpu()
 
-    def parity(half, resid="auto"):
+    def parity(half, resid="auto", sd=sd, img=img, key=key, fg_ref=fg_ref, layer_ref=layer_ref):
         eng = ViTEngine(sd, heads=heads, eps=1e-6, device=dev, attn_variant=a.attn_variant, half=half, resid=resid)
         key_dev = eng(img.to(dev))
         kd, fd = key_dev.cpu(), device_logits(key_dev)
         per_layer = []
-        for li in range(1, L + 1):                              # error budget: key map after li layers vs the oracle's
+        for li in range(1, L + 1) if layer_ref is not None else ():       # error budget: key map after li layers vs the oracle's
             kl = eng.forward(img.to(dev), n_layers=li).cpu()
             per_layer.append(round(float((kl - layer_ref[li - 1]).norm() / layer_ref[li - 1].norm()), 6))
         eng.check_overflow(wait=True)
-        return {"residual_stream": "fp16" if eng.resid16 else "f32",
-                "key_rel_l2": round(float((kd - key).norm() / key.norm()), 6), "key_max_abs": round(float((kd - key).abs().max()), 5),
-                "logit_max_abs": round(float((fd - fg_ref).abs().max()), 6), "logit_rel_l2": round(float((fd - fg_ref).norm() / fg_ref.norm()), 6),
-                "mask_flipped_fraction": round(float(((fd > 0) != (fg_ref > 0)).float().mean()), 6),
-                "key_rel_l2_after_layer": per_layer}
+        res = {"residual_stream": "fp16" if eng.resid16 else "f32",
+               "key_rel_l2": round(float((kd - key).norm() / key.norm()), 6), "key_max_abs": round(float((kd - key).abs().max()), 5),
+               "logit_max_abs": round(float((fd - fg_ref).abs().max()), 6), "logit_rel_l2": round(float((fd - fg_ref).norm() / fg_ref.norm()), 6),
+               "mask_flipped_fraction": round(float(((fd > 0) != (fg_ref > 0)).float().mean()), 6)}
+        if per_layer:
+            res["key_rel_l2_after_layer"] = per_layer
+        return res
+
+    # The same comparison on TRAINED-LIKE synthetic weights (peaked attention rows, LayerScale 0.1 .. 1, two massive residual channels:
+    # feature_extractor.trained_like_state_dict) -- the regime a real checkpoint puts the kernels in; the random init above is the flattest.
+    from ucod_dpl_amd.data.utils.feature_extractor import trained_like_state_dict
+    sd_p = trained_like_state_dict(a.arch, 0, a.image)
+    with torch.no_grad():
+        _, key_p = OV.dinov2_forward(img, sd_p, heads=heads, patch=P, eps=1e-6, full_last_layer=False)
+        fg_p, _, _ = OD.rev_decoder_forward(torch_bilinear(key_p, 68, 68), dec, orth="gram")
+    peaked = dict(sd=sd_p, key=key_p, fg_ref=fg_p, layer_ref=None)
 
     out["parity_full_size"] = {
         "what": f"{n} images at {a.image}x{a.image}, {a.arch}: device backbone + f32 device decoder vs the f32 oracle (same random-init weights); "
                 f"north-star bar: logit max-abs <= 1e-3",
         **parity("bf16"),
         "f16_operands": parity("f16"),                            # engine default for fp16 operands: f32 residual stream
-        "f16_operands_f16_stream": parity("f16", "f16")}
+        "f16_operands_f16_stream": parity("f16", "f16"),
+        "trained_like_weights": {
+            "what": "same images, trained_like_state_dict (pre-softmax score std ~4, row entropy ~3.7 of ln 1370 = 7.2, LayerScale 0.1 .. 1, "
+                    "massive channels +-200); reference logits reach |%.2f| (flat init: |%.2f|)" % (float(fg_p.abs().max()), float(fg_ref.abs().max())),
+            "bf16": parity("bf16", **peaked), "f16_operands": parity("f16", **peaked), "f16_operands_f16_stream": parity("f16", "f16", **peaked)}}
     return out
 
 
