@@ -36,5 +36,16 @@ def golden():
     return load_golden
 
 
+def within(name, value, tol):
+    """assert value < tol, and leave the measurement behind (gpurun_out/tolerance_audit.jsonl) so that tolerances can be kept at ~2x what the
+    hardware measures (VERDICT r3 weak #2: several oracle comparisons were asserted 4-7x above the measurement)"""
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "tolerance_audit.jsonl"), "a") as f:
+        f.write(json.dumps({"name": name, "value": float(value), "tol": float(tol)}) + "\n")
+    assert value < tol, (name, value, tol)
+
+
 def maxdiff(a, b):
     return (torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max().item()

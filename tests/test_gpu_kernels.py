@@ -9,7 +9,7 @@ import math
 import pytest
 import torch
 
-from conftest import load_golden, sub, maxdiff
+from conftest import load_golden, sub, maxdiff, within
 
 pytestmark = pytest.mark.gpu
 
@@ -434,7 +434,7 @@ def test_vit_key_against_reference_golden(name, heads, fn, full, av):
     key = eng(gd["x"].to(DEV)).cpu()
     ref = gd["key"]
     # bf16 operands through 3 layers: report-level tolerance (f32 reference); structure errors are O(1)
-    assert rel_l2(key, ref) < 2e-2, rel_l2(key, ref)
+    within(f"g8:{name}:full={full}:av={av}", rel_l2(key, ref), 6e-3)          # measured 2.9-3.0e-3 (bf16 operands through 3 layers)
     assert maxdiff(key, ref) < 0.1 * ref.abs().max().item()
 
 
@@ -466,7 +466,7 @@ def test_config_c1_dinov1_vits8_224_batch2():
     eng = ViTEngine(sd, heads=6, eps=1e-6, device=DEV, attn_variant=2)
     key = eng(x.to(DEV))
     assert key.shape == (2, 384, 28, 28)
-    assert rel_l2(key.cpu(), ref) < 2e-2, rel_l2(key.cpu(), ref)
+    within("c1:key_rel_l2", rel_l2(key.cpu(), ref), 1.1e-2)          # measured 5.4e-3
     gen = torch.Generator().manual_seed(7)
     p = OD.init_params(384, gen)
     fg_ref, bg_ref, _ = OD.rev_decoder_forward(ref, p, orth="gram")
@@ -477,7 +477,7 @@ def test_config_c1_dinov1_vits8_224_batch2():
     norm = ops.dba_colnorm(d, 0, emb)
     fg, bg, _ = ops.dba_heads(d, 0, emb, norm, hw, hb, want_bg=True)
     # logits inherit the bf16 backbone's error (key rel-L2 ~4e-3): compare at that level, and exactly-f32 on the oracle's own key
-    assert rel_l2(fg.cpu().reshape(-1), fg_ref.reshape(-1)) < 3e-2
+    within("c1:logit_rel_l2", rel_l2(fg.cpu().reshape(-1), fg_ref.reshape(-1)), 5e-3)          # measured 2.5e-3
     d2 = ops.dba_project(ref.contiguous().to(DEV), p["decoupling.weight"].reshape(128, 384).to(DEV), p["decoupling.bias"].to(DEV))
     n2 = ops.dba_colnorm(d2, 0, emb)
     fg2, bg2, _ = ops.dba_heads(d2, 0, emb, n2, hw, hb, want_bg=True)
@@ -496,7 +496,7 @@ def test_config_c4_dinov2_vitl14_518():
     eng = ViTEngine(sd, heads=16, eps=1e-6, device=DEV, attn_variant=2)
     key = eng(x.to(DEV))
     assert key.shape == (1, 1024, 37, 37)
-    assert rel_l2(key.cpu(), ref) < 3e-2, rel_l2(key.cpu(), ref)
+    within("c4:key_rel_l2", rel_l2(key.cpu(), ref), 1.3e-2)          # measured 6.4e-3 (24 layers)
 
 
 def test_config_c4_vitl14_batch16_properties():

@@ -6,7 +6,7 @@ import sys
 import pytest
 import torch
 
-from conftest import load_golden, maxdiff
+from conftest import load_golden, maxdiff, within
 
 pytestmark = pytest.mark.gpu
 if not torch.cuda.is_available():
@@ -59,10 +59,10 @@ def test_sparse_refiner_matches_reference(tag):
     wp, wref = opt["window_preds"].cpu(), g[tag + ".window_preds"]
     assert wp.shape == wref.shape
     # bf16 projections + bf16 attention probabilities vs the f32 reference
-    assert rel_l2(wp, wref) < 2e-2, rel_l2(wp, wref)
+    within("refiner:window_preds", rel_l2(wp, wref), 3.5e-3)          # measured 1.5-1.6e-3 (bf16 projections)
     assert maxdiff(opt["h_preds"].cpu(), g[tag + ".h_preds"]) < 0.05 * wref.abs().max().item()
     assert maxdiff(opt["GE_w"].cpu(), g[tag + ".GE_w"]) < 1e-4
-    assert rel_l2(out, g[tag + ".outputs"]) < 2e-2
+    within("refiner:outputs:" + tag, rel_l2(out, g[tag + ".outputs"]), 5e-4)          # measured 2.6e-5 / 2.0e-4
 
 
 def test_refiner_small_kernels_exact_f32():
@@ -152,7 +152,7 @@ def test_coral_validation_loop_matches_reference(req_m):
     assert int(loop._should_crop_center(fd["preds"])) == int(g[t + "crop"])
     with torch.no_grad():
         out, _, _ = runner.refiner(fd["l_features"], fd["h_features"], fd["preds"])
-    assert rel_l2(out, g[t + "outputs"]) < 2e-2                                    # bf16 projections inside the refiner
+    within("refiner:e2e_outputs", rel_l2(out, g[t + "outputs"]), 6e-4)                        # bf16 projections inside the refiner
     assert torch.equal(loop._center_pad(g[t + "outputs"].cuda()).cpu(), g[t + "padded"])
     for src, ref in ((t + "outputs", t + "up"), (t + "padded", t + "up_pad")):
         up = loop.process_preds(g[src].cuda(), (50, 70)).cpu()
@@ -250,8 +250,9 @@ def test_sparse_refiner_training_mode_matches_reference(tag, kind):
         out, ex, opt = m(l.cuda(), h.cuda(), preds.cuda(), ht.cuda())
     ref = float(g[k + "ex_loss"])
     assert torch.equal(opt["window_targets"].cpu(), g[k + "window_targets"])
-    assert abs(float(ex) - ref) < 2e-2 * ref, (float(ex), ref)
-    assert rel_l2(out, g[k + "outputs"]) < 2e-2 and rel_l2(out, g9[tag + ".outputs"]) < 2e-2
+    within("refiner:train_ex_loss_rel", abs(float(ex) - ref) / ref, 5e-4)          # measured 1.2e-5 .. 1.4e-4
+    within("refiner:train_outputs", rel_l2(out, g[k + "outputs"]), 5e-4)
+    within("refiner:train_outputs_vs_eval", rel_l2(out, g9[tag + ".outputs"]), 5e-4)
     # the loss kernel on the reference's own window logits
     mask = g9[tag + ".mask"].bool()
     win_flat = torch.nonzero(mask.flatten()).flatten().to(torch.int32).cuda()
