@@ -391,6 +391,27 @@ size_t ucod_bn_lrelu_workspace_bytes(int C);
 int ucod_bn_lrelu_train(float* y, const float* gamma, const float* beta, float* running_mean, float* running_var, int B, int C, int HW, float eps,
                         float momentum, float slope, int update_running, void* workspace, size_t workspace_bytes, void* stream);
 int ucod_linear_sigmoid(const float* x, const float* w, const float* bias, float* out, int B, int K, void* stream);
+/* Training that discriminator (the discriminator phase, engine/runner/loop_UCOD_DPL.py:230-255, with dis_use_features=True): the backward of the
+ * same pieces.  A ConvBlock's backward is  ucod_bn_lrelu_bwd -> ucod_conv_wgrad_f32 (weight gradient from the saved unfold) -> [input gradient:
+ * ucod_dba_project with W^T on the gradient, then ucod_fold3x3].
+ * ucod_bn_lrelu_train_save: as ucod_bn_lrelu_train, out of place (y_pre is kept for the backward) and with the batch statistics left in `stats`
+ *   (ucod_bn_lrelu_workspace_bytes(C) bytes, owned by the caller until the backward has run).
+ * ucod_bn_lrelu_bwd: gout = dL/d(block output) -> gy_pre = dL/d(conv output); dgamma / dbeta written, or added to when accumulate != 0 (the phase
+ *   calls the discriminator twice per step).  f64 sums in a fixed order.
+ * ucod_fold3x3: the adjoint of ucod_unfold3x3 (col2im): gcols [B,Kpad,Ho*Wo] -> gx [B,C,H,W].
+ * ucod_conv_wgrad_f32: gW [Nout,C] (+)= sum_{b,p} gd[b][n][p] * cols[b][c][p]  (exact-f32 MFMA, split over pixel chunks, f32 atomics).
+ * ucod_linear_sigmoid_bwd: gprob = dL/dprob -> gx [B,K], gw [K], gb [1] (written or accumulated).
+ * ucod_disc_bce: nn.BCELoss(cat(probs_student, probs_pseudo), [0..0, 1..1]) (mean over 2B, logs clamped at -100 like torch) -> loss[0], and its
+ *   gradient times `inv` / (the mean's 1 / 2B is part of inv = 1 / (2 B world)) with torch's max(p (1 - p), 1e-12) denominator. */
+int ucod_bn_lrelu_train_save(const float* y_pre, float* y_out, const float* gamma, const float* beta, float* running_mean, float* running_var, int B, int C,
+                             int HW, float eps, float momentum, float slope, int update_running, void* stats, size_t stats_bytes, void* stream);
+int ucod_bn_lrelu_bwd(const float* y_pre, const float* gout, float* gy_pre, const void* stats, const float* gamma, const float* beta, float* dgamma,
+                      float* dbeta, int B, int C, int HW, float eps, float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+int ucod_fold3x3(const float* gcols, float* gx, int B, int C, int H, int W, int stride, int Kpad, void* stream);
+int ucod_conv_wgrad_f32(const float* gd, const float* cols, float* gW, int B, int C, int HW, int Nout, int accumulate, void* stream);
+int ucod_linear_sigmoid_bwd(const float* x, const float* w, const float* prob, const float* gprob, float* gx, float* gw, float* gb, int B, int K,
+                            int accumulate, void* stream);
+int ucod_disc_bce(const float* probs_student, const float* probs_pseudo, float* g_student, float* g_pseudo, float* loss, int B, float inv, void* stream);
 
 /* ------------------------------------------------------------------ Look-Twice (rows L1-L3) */
 

@@ -228,10 +228,10 @@ class NullLogger:
     info = error = log_table = log
 
 
-def make_loop(C, fs, seed, lr0=6e-4, dis_lr0=1e-3):
+def make_loop(C, fs, seed, lr0=6e-4, dis_lr0=1e-3, dis_use_features=False):
     torch.manual_seed(seed)
     cfg = CfgNode(dict(
-        model_cfg=dict(dim=C, feature_size=fs, ema_weight=0.99, dis_use_features=False),
+        model_cfg=dict(dim=C, feature_size=fs, ema_weight=0.99, dis_use_features=dis_use_features),
         train_cfg=dict(max_epoch=25, start_finetune=-5, lr0=lr0, dis_lr0=dis_lr0, step_lr_size=2, dis_step_lr_size=2,
                        step_lr_gamma=0.95, dis_step_lr_gamma=0.95, merge_alpha=0.5, dist_train=False, dis_epoch=1),
     ))
@@ -332,6 +332,45 @@ def g6():
     out["loss_str"] = np.array(losses)
     out.update(sd_flat("disc1.", d))
     save("g6_discriminator_step", **out)
+
+
+def g6b():
+    """G6b: the feature-branch discriminator (dis_use_features=True, models/discriminator.py:77-90) through the REAL loop: one
+    Discriminator_epoch step (loop_UCOD_DPL.py:230-255: features resized 14 -> 12, both discriminator calls on them, BCE, backward, AdamW,
+    StepLR) and, on the stepped module, one merge_pseudo_label (:257-272).  dim 16, feature_size 12 -> 48 / 24 / 12 channels, Linear 12 * 3 * 3."""
+    loop = make_loop(16, 12, seed=66, dis_use_features=True)
+    d = loop.runner.discriminator
+    with torch.no_grad():                                   # non-trivial BatchNorm affine terms
+        for n, p in d.named_parameters():
+            if ".layers.1." in n:
+                p.add_(0.2 * torch.randn_like(p))
+    out = {}
+    out.update(sd_flat("model0.", loop.runner.model))
+    out.update(sd_flat("disc0.", d))
+    b = batch(4, 16, 660)
+    out["features"] = b["features"]
+    out["pl"] = b["pseudo_label"]
+    loop.runner.train_dataloader = [b]
+    losses = []
+    loop.runner.logger = SimpleNamespace(log=lambda s, *a, **k: losses.append(s), info=lambda *a: None)
+    for p in d.parameters():
+        p.requires_grad = True
+    loop.Discriminator_epoch()
+    for n, p in d.named_parameters():
+        out["grad." + n] = p.grad.clone()
+    out["loss_str"] = np.array(losses)
+    out.update(sd_flat("disc1.", d))
+    # APM merge with the feature branch (what _process_batch calls): 12 x 12 logits and features
+    g = torch.Generator().manual_seed(661)
+    pl = torch.rand(4, 1, 12, 12, generator=g)
+    teacher, student = torch.randn(4, 1, 12, 12, generator=g) * 2, torch.randn(4, 1, 12, 12, generator=g) * 2
+    feats = torch.randn(4, 16, 12, 12, generator=g)
+    loop._cur_epoch = 10
+    with torch.no_grad():
+        merged, dl = loop.merge_pseudo_label(pl, teacher, student, feats)
+    out.update(dict(apm_pl=pl, apm_teacher=teacher, apm_student=student, apm_features=feats, apm_merged=merged, apm_dis_loss=dl))
+    out.update(sd_flat("disc2.", d))
+    save("g6b_discriminator_features_step", **out)
 
 
 # ----------------------------------------------------------------------------- G7: Look-Twice integer table
@@ -895,6 +934,6 @@ def g17():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g3b", "g4", "g5", "g6", "g7", "g8", "g9", "g9b", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3b", "g4", "g5", "g6", "g6b", "g7", "g8", "g9", "g9b", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     for w in which:
         globals()[w]()

@@ -153,14 +153,16 @@ __global__ __launch_bounds__(256, 2) void dba_project_kernel(const float* __rest
 // block: 128 (n) x 128 (c) output tile, reduction over one pixel chunk of one image; waves 2x2, 64x64 each
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void dba_wgrad_kernel(const float* __restrict__ gd, const float* __restrict__ x,
-                                                        float* __restrict__ gW, int C, int HW, int WG_CHUNK) {
+                                                        float* __restrict__ gW, int C, int HW, int WG_CHUNK, int Nout) {
+  // Nout rows of gd per image (128 for the decoupling conv; any count for ucod_conv_wgrad_f32: blockIdx.x also walks 128-row blocks of gd)
   __shared__ float As[2][FK * LDP];
   __shared__ float Bs[2][FK * LDP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-  const int c0 = blockIdx.x * 128, b = blockIdx.z;
+  const int cblocks = (C + 127) / 128;
+  const int c0 = (blockIdx.x % cblocks) * 128, n0 = (blockIdx.x / cblocks) * 128, b = blockIdx.z;
   const int ps = blockIdx.y * WG_CHUNK;
   const int pe = min(ps + WG_CHUNK, HW);
-  const float* gdb = gd + (long)b * 128 * HW;
+  const float* gdb = gd + (long)b * Nout * HW;
   const float* xb = x + (long)b * C * HW;
 
   f32x16 acc[2][2];
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void dba_wgrad_kernel(const float* __restri
 
   float4 ra[2], rb[2];
   const int nt = (pe - ps + FK - 1) / FK;
-  load_kcontig<VEC>(gdb, HW, 0, 128, ps, pe, tid, ra);
+  load_kcontig<VEC>(gdb, HW, n0, Nout, ps, pe, tid, ra);
   load_kcontig<VEC>(xb, HW, c0, C, ps, pe, tid, rb);
   store_kcontig<LDP>(As[0], tid, ra);
   store_kcontig<LDP>(Bs[0], tid, rb);
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void dba_wgrad_kernel(const float* __restri
     __syncthreads();
     const bool more = t + 1 < nt;
     if (more) {
-      load_kcontig<VEC>(gdb, HW, 0, 128, ps + (t + 1) * FK, pe, tid, ra);
+      load_kcontig<VEC>(gdb, HW, n0, Nout, ps + (t + 1) * FK, pe, tid, ra);
       load_kcontig<VEC>(xb, HW, c0, C, ps + (t + 1) * FK, pe, tid, rb);
     }
     const float* as = As[t & 1];
@@ -207,8 +209,8 @@ __global__ __launch_bounds__(256, 2) void dba_wgrad_kernel(const float* __restri
       if (c >= C) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        atomicAdd(&gW[(long)n * C + c], acc[i][j][r]);
+        const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n < Nout) atomicAdd(&gW[(long)n * C + c], acc[i][j][r]);
       }
     }
 }
@@ -240,9 +242,31 @@ extern "C" int ucod_dba_wgrad(const float* gd, const float* x, float* gW, int B,
   hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * 128 * (size_t)C, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   if ((HW % 4) == 0 && (((uintptr_t)x) % 16) == 0 && (((uintptr_t)gd) % 16) == 0)
-    hipLaunchKernelGGL((dba_wgrad_kernel<true>), grid, block, 0, (hipStream_t)stream, gd, x, gW, C, HW, WG_CHUNK);
+    hipLaunchKernelGGL((dba_wgrad_kernel<true>), grid, block, 0, (hipStream_t)stream, gd, x, gW, C, HW, WG_CHUNK, 128);
   else
-    hipLaunchKernelGGL((dba_wgrad_kernel<false>), grid, block, 0, (hipStream_t)stream, gd, x, gW, C, HW, WG_CHUNK);
+    hipLaunchKernelGGL((dba_wgrad_kernel<false>), grid, block, 0, (hipStream_t)stream, gd, x, gW, C, HW, WG_CHUNK, 128);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+// weight gradient of a convolution given as unfold + GEMM (disc_features.hip): gW[n][c] (+)= sum_{b,p} gd[b][n][p] * cols[b][c][p] with any
+// number of output channels Nout (the decoupling conv's kernel, walked over 128-row blocks of gd); f32 atomics, gW zeroed first unless accumulate.
+extern "C" int ucod_conv_wgrad_f32(const float* gd, const float* cols, float* gW, int B, int C, int HW, int Nout, int accumulate, void* stream) {
+  using namespace ucod;
+  if (!gd || !cols || !gW || B <= 0 || C <= 0 || HW <= 0 || Nout <= 0) return UCOD_EINVAL;
+  int WG_CHUNK = 1024;
+  const long tiles = (long)cdiv(C, 128) * cdiv(Nout, 128);
+  while (WG_CHUNK > 128 && tiles * cdiv(HW, WG_CHUNK) * B < 1024) WG_CHUNK >>= 1;
+  if (tiles > 65535) return UCOD_EINVAL;
+  dim3 grid((unsigned)tiles, cdiv(HW, WG_CHUNK), B), block(256);
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * (size_t)Nout * C, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  if ((HW % 4) == 0 && (((uintptr_t)cols) % 16) == 0 && (((uintptr_t)gd) % 16) == 0)
+    hipLaunchKernelGGL((dba_wgrad_kernel<true>), grid, block, 0, (hipStream_t)stream, gd, cols, gW, C, HW, WG_CHUNK, Nout);
+  else
+    hipLaunchKernelGGL((dba_wgrad_kernel<false>), grid, block, 0, (hipStream_t)stream, gd, cols, gW, C, HW, WG_CHUNK, Nout);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }

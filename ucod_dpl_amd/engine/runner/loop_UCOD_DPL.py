@@ -77,7 +77,7 @@ class DecoderArena:
 
 
 class DiscArena:
-    """Flat storage for the 11 discriminator parameters, their grads and Adam moments (reference order)."""
+    """Flat storage for the discriminator's parameters (11; 14 with the feature branch), their grads and Adam moments (reference order)."""
 
     def __init__(self, disc, device):
         self.disc = disc
@@ -96,7 +96,7 @@ class DiscArena:
             off += n
         # buffers to the device too; the three num_batches_tracked counters become views of ONE tensor, so that a forward call bumps them
         # with one launch (discriminator._bump_num_batches) instead of three
-        blocks = (disc.maskConv, disc.convs[0], disc.convs[1])
+        blocks = disc._blocks()
         disc._nbt = torch.stack([b.layers[1].num_batches_tracked.data.to(device) for b in blocks])
         for i, b in enumerate(blocks):
             bn = b.layers[1]
@@ -206,11 +206,7 @@ class TrainLoop(BaseLoop):
         extra, gram = ops.orth_gram(d, 0, emb_s, norm_s, sdiag)
 
         # APM (:257-272) + both BCE losses and their gradients (:161-173)
-        disc_t = r.discriminator.tensor_table()
-        p_s, _ = ops.disc_fwd(ops.binarize(fg, logits=True).view(B, 1, fs, fs), disc_t, update_running=True, saved=r.disc_saved(B, fs))
-        r.discriminator._bump_num_batches()
-        p_p, _ = ops.disc_fwd(ops.binarize(pl, logits=False), disc_t, update_running=True, saved=r.disc_saved(B, fs))
-        r.discriminator._bump_num_batches()
+        p_s, p_p = self._disc_probs(ops.binarize(fg, logits=True).view(B, 1, fs, fs), ops.binarize(pl, logits=False), features, fs)
         epoch_frac = self._cur_epoch / (self._max_epoch + self._start_finetune)
         w, merged, gfg, gbg, losses = ops.apm_bce(pl.view(B, -1), teacher, fg, bg, p_s, p_p, epoch_frac, gscale=1.0 / world)
 
@@ -335,11 +331,7 @@ class TrainLoop(BaseLoop):
         fg, bg, sdiag = ops.dba_heads(d_s, 0, emb_s, norm_s, hw_s, hb_s, want_bg=True, want_sdiag=True)
         teacher, _, _ = ops.dba_heads(d_t, 0, emb_t, norm_t, hw_t, hb_t, want_bg=False)
         extra, gram = ops.orth_gram(d_s, 0, emb_s, norm_s, sdiag)
-        disc_t = r.discriminator.tensor_table()
-        p_s, _ = ops.disc_fwd(ops.binarize(fg, logits=True).view(B, 1, fs, fs), disc_t, update_running=True, saved=r.disc_saved(B, fs))
-        r.discriminator._bump_num_batches()
-        p_p, _ = ops.disc_fwd(ops.binarize(pl, logits=False), disc_t, update_running=True, saved=r.disc_saved(B, fs))
-        r.discriminator._bump_num_batches()
+        p_s, p_p = self._disc_probs(ops.binarize(fg, logits=True).view(B, 1, fs, fs), ops.binarize(pl, logits=False), feat_s.detach(), fs)
         epoch_frac = self._cur_epoch / (self._max_epoch + self._start_finetune)
         w, merged, gfg, gbg, losses = ops.apm_bce(pl.view(B, -1), teacher, fg, bg, p_s, p_p, epoch_frac, gscale=1.0 / world)
         g_emb, g_W, g_b, g_hw, g_hb = A.slices(A.g)
@@ -372,15 +364,33 @@ class TrainLoop(BaseLoop):
         self.last = dict(loss=loss, dis_loss=losses[2], extra=extra[0], w=w, merged=merged, fg=fg, bg=bg, teacher=teacher, p_s=p_s, p_p=p_p)
         return loss
 
+    def _disc_probs(self, student_mask, pseudo_mask, features, fs):
+        """the two discriminator calls of the APM merge (:259-262): the student's binarised prediction first, then the pseudo label (the order
+        fixes the BatchNorm running statistics).  dis_use_features: both see the features at fs x fs (the reference resizes them first, :153)."""
+        r = self.runner
+        disc = r.discriminator
+        B = student_mask.shape[0]
+        if disc.use_features:
+            if features is None:
+                raise ValueError("dis_use_features=True: the APM merge needs the feature map")
+            feats = features.to(student_mask.device, torch.float32).contiguous()
+            if tuple(feats.shape[-2:]) != (fs, fs):
+                feats = ops.bilinear_resize(feats, fs, fs)
+            p_s, _ = disc.forward_features(student_mask, feats)
+            p_p, _ = disc.forward_features(pseudo_mask, feats)
+            return p_s, p_p
+        disc_t = disc.tensor_table()
+        p_s, _ = ops.disc_fwd(student_mask, disc_t, update_running=True, saved=r.disc_saved(B, fs))
+        disc._bump_num_batches()
+        p_p, _ = ops.disc_fwd(pseudo_mask, disc_t, update_running=True, saved=r.disc_saved(B, fs))
+        disc._bump_num_batches()
+        return p_s, p_p
+
     def merge_pseudo_label(self, pseudo_labels, p_teachers, p_students, features=None):
         """Stand-alone APM fusion with the reference's signature (:257-272) -> (merged [B,1,H,W], dis_loss)."""
         r = self.runner
         B, _, H, W = pseudo_labels.shape
-        t = r.discriminator.tensor_table()
-        p_s, _ = ops.disc_fwd(ops.binarize(p_students.contiguous(), logits=True), t, update_running=True)
-        r.discriminator._bump_num_batches()
-        p_p, _ = ops.disc_fwd(ops.binarize(pseudo_labels.contiguous(), logits=False), t, update_running=True)
-        r.discriminator._bump_num_batches()
+        p_s, p_p = self._disc_probs(ops.binarize(p_students.contiguous(), logits=True), ops.binarize(pseudo_labels.contiguous(), logits=False), features, H)
         frac = self._cur_epoch / (self._max_epoch + self._start_finetune)
         zeros = torch.zeros(B, H * W, device=pseudo_labels.device)
         _, merged, _, _, losses = ops.apm_bce(pseudo_labels.reshape(B, -1).contiguous(), p_teachers.reshape(B, -1).contiguous(), zeros, zeros, p_s, p_p, frac)
@@ -429,20 +439,27 @@ class TrainLoop(BaseLoop):
         fg, _, _ = ops.dba_heads(d, 0, emb_s, norm, hw_s, hb_s, want_bg=False)
         preds = ops.binarize(fg, logits=True).view(B, 1, fs, fs)
         pl = ops.binarize(ops.bilinear_resize(pseudo_labels.to(dev, torch.float32), fs, fs), logits=False)           # :241
-        t = r.discriminator.tensor_table()
+        disc = r.discriminator
         world = r.world_size
-        probs_pseudo, saved_p = ops.disc_fwd(pl, t, update_running=True)                                              # :244
-        r.discriminator._bump_num_batches()
-        probs_student, saved_s = ops.disc_fwd(preds, t, update_running=True)                                          # :245
-        r.discriminator._bump_num_batches()
-        # BCELoss(cat(student, pseudo), [0..0, 1..1]) mean over 2B (:246-247); torch clamps log at -100 and its backward is
-        # (p - t) / max(p (1 - p), 1e-12): finite (about 1e12) when the sigmoid saturates to exactly 0 or 1 in f32
-        inv = 1.0 / (2 * B * world)
-        g_student = probs_student / (probs_student * (1.0 - probs_student)).clamp_min(1e-12) * inv
-        g_pseudo = (probs_pseudo - 1.0) / (probs_pseudo * (1.0 - probs_pseudo)).clamp_min(1e-12) * inv
-        loss = (-(torch.log(1 - probs_student).clamp_min(-100.0).sum() + torch.log(probs_pseudo).clamp_min(-100.0).sum())) / (2 * B)
-        ops.disc_bwd(pl, t, saved_p, g_pseudo, grads=DA.grad_views, accumulate=False)
-        ops.disc_bwd(preds, t, saved_s, g_student, grads=DA.grad_views, accumulate=True)
+        if disc.use_features:
+            feats = features if tuple(features.shape[-2:]) == (fs, fs) else ops.bilinear_resize(features, fs, fs)           # :236
+            probs_pseudo, saved_p = disc.forward_features(pl, feats, save=True)                                       # :244
+            probs_student, saved_s = disc.forward_features(preds, feats, save=True)                                   # :245
+        else:
+            t = disc.tensor_table()
+            probs_pseudo, saved_p = ops.disc_fwd(pl, t, update_running=True)                                          # :244
+            disc._bump_num_batches()
+            probs_student, saved_s = ops.disc_fwd(preds, t, update_running=True)                                      # :245
+            disc._bump_num_batches()
+        # BCELoss(cat(student, pseudo), [0..0, 1..1]) mean over 2B (:246-247) and its gradient, one launch (ucod_disc_bce: torch's clamp of the
+        # logarithms at -100 and its max(p (1 - p), 1e-12) denominator); the gradient carries 1 / (2 B world) for the pre-scaled all-reduce
+        g_student, g_pseudo, loss = ops.disc_bce(probs_student, probs_pseudo, 1.0 / (2 * B * world))
+        if disc.use_features:
+            disc.backward_features(saved_p, g_pseudo, DA.grad_views, accumulate=False)
+            disc.backward_features(saved_s, g_student, DA.grad_views, accumulate=True)
+        else:
+            ops.disc_bwd(pl, t, saved_p, g_pseudo, grads=DA.grad_views, accumulate=False)
+            ops.disc_bwd(preds, t, saved_s, g_student, grads=DA.grad_views, accumulate=True)
         parallel.allreduce_prescaled_(DA.g)
         r.dis_optimizer.step()
         r.dis_lr_scheduler.step()

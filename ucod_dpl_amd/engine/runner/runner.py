@@ -60,16 +60,15 @@ class StandardRunner:
     # ------------------------------------------------------------------ builders (runner.py:266-308)
     def _build_model(self):
         self.model = baseline(self.config.model_cfg)
-        if self.config.model_cfg.get("dis_use_features", False):
-            raise NotImplementedError("the fused first-stage step is built for dis_use_features=False (every shipped config, configs/uscod/*.py); "
-                                      "the feature-branch discriminator exists as a module (ucod_dpl_amd.models.discriminator, forward only)")
+        # dis_use_features=True (no shipped config): the same step with the discriminator's feature branch (models/discriminator.py:77-90) on the
+        # generic convolution kernels of csrc/disc_features.hip instead of the fused small-channel ones
         self.discriminator = Discriminator(self.config.model_cfg)
         ckpt = self.config.train_cfg.get("checkpoint", None)
         if ckpt:
             self.load_checkpoint(ckpt)
         self.arena = DecoderArena(self.model, self.device)
         self.disc_arena = DiscArena(self.discriminator, self.device)
-        bn = [b.layers[1] for b in (self.discriminator.maskConv, self.discriminator.convs[0], self.discriminator.convs[1])]
+        bn = [b.layers[1] for b in self.discriminator._blocks()]
         parallel.broadcast_state([self.arena.p, self.arena.ema, self.disc_arena.p] + [m.running_mean for m in bn] + [m.running_var for m in bn])
 
     def _build_optimizer(self):

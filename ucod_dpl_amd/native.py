@@ -117,6 +117,12 @@ SIGNATURES = {
     "ucod_bn_lrelu_workspace_bytes": (sz, [ci]),
     "ucod_bn_lrelu_train": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cf, cf, ci, vp, sz, vp]),
     "ucod_linear_sigmoid": (ci, [vp, vp, vp, vp, ci, ci, vp]),
+    "ucod_bn_lrelu_train_save": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cf, cf, ci, vp, sz, vp]),
+    "ucod_bn_lrelu_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cf, ci, vp, sz, vp]),
+    "ucod_fold3x3": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "ucod_conv_wgrad_f32": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ucod_linear_sigmoid_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
+    "ucod_disc_bce": (ci, [vp, vp, vp, vp, vp, ci, cf, vp]),
     "ucod_apm_bce": (ci, [vp, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, ci, ci, vp]),
     "ucod_binarize": (ci, [vp, vp, sz, ci, vp]),
     "ucod_ccl8_host": (ci, [vp, ci, ci, vp]),

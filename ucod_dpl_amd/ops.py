@@ -253,6 +253,15 @@ def disc_fwd(mask, tensors, update_running=True, saved=None):
     return prob, saved
 
 
+def disc_bce(probs_student, probs_pseudo, inv):
+    """nn.BCELoss(cat(student, pseudo), [0..0, 1..1]) (mean over 2B) and inv * d(sum)/dprob, one launch -> (g_student, g_pseudo, loss 0-d)"""
+    B = probs_student.numel()
+    gs, gp = torch.empty_like(probs_student), torch.empty_like(probs_pseudo)
+    loss = torch.empty(1, dtype=torch.float32, device=probs_student.device)
+    check(N.load().ucod_disc_bce(ptr(_f32(probs_student)), ptr(_f32(probs_pseudo)), ptr(gs), ptr(gp), ptr(loss), B, float(inv), stream()), "ucod_disc_bce")
+    return gs, gp, loss[0]
+
+
 def binarize(x, logits):
     x = _f32(x).contiguous()
     out = torch.empty_like(x)
