@@ -271,25 +271,12 @@ def test_discriminator_with_the_feature_branch_matches_reference():
 
 # ----------------------------------------------------------------------------------------- the feature-branch discriminator (dis_use_features=True)
 def _build_feature_branch(g):
-    from ucod_dpl_amd.engine.runner import StandardRunner
-    from ucod_dpl_amd.engine.runner.loop_UCOD_DPL import TrainLoop
-    cfg = CfgNode(dict(
-        model_cfg=dict(dim=16, feature_size=12, ema_weight=0.99, dis_use_features=True),
-        train_cfg=dict(max_epoch=25, start_finetune=-5, lr0=6e-4, dis_lr0=1e-3, step_lr_size=2, dis_step_lr_size=2, step_lr_gamma=0.95,
-                       dis_step_lr_gamma=0.95, merge_alpha=0.5, dist_train=False, dis_epoch=1, merge_method="dis", dis_intertrain=2,
-                       save_cfg=dict(save_start=100, save_interval=100)),
-        val_cfg=dict(enable_val=False, val_interval=1, start_val=100, look_twice=False),
-        log_cfg=dict(log_interval=100, log_path="/tmp/ucod_g6b", name="g6b", multi_rank=[0]),
-    ))
+    cfg = make_cfg()
+    cfg.model_cfg["dim"], cfg.model_cfg["feature_size"], cfg.model_cfg["dis_use_features"] = 16, 12, True
     runner = StandardRunner(cfg)
-    runner.model.load_state_dict({k: v for k, v in sub(g, "model0.").items()}, strict=True)
-    runner.discriminator.load_state_dict({k: v for k, v in sub(g, "disc0.").items()}, strict=True)
-    from ucod_dpl_amd.engine.runner.loop_UCOD_DPL import DecoderArena, DiscArena
-    runner.arena = DecoderArena(runner.model, runner.device)
-    runner.disc_arena = DiscArena(runner.discriminator, runner.device)
-    runner._build_optimizer()
-    loop = TrainLoop(cfg, runner)
-    return runner, loop
+    runner.model.load_state_dict({k: v.to(runner.device) for k, v in sub(g, "model0.").items()}, strict=True)
+    runner.discriminator.load_state_dict({k: v.to(runner.device) for k, v in sub(g, "disc0.").items()}, strict=True)
+    return runner, TrainLoop(runner.config, runner)
 
 
 def test_feature_branch_discriminator_step_matches_reference():
