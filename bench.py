@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=4)
     ap.add_argument("--gemm-variant", type=int, default=0)
-    ap.add_argument("--attn-variant", type=int, default=2, choices=[0, 1, 2, 8], help="0 / 2 product kernel, 1 generic-scale kernel, 8 fp8 path (BASELINE configs[4])")
+    ap.add_argument("--attn-variant", type=int, default=2, choices=[0, 1, 2, 5, 8, 32, 64], help="0 / 2 product kernel, 1 generic-scale kernel, 8 fp8 path (BASELINE configs[4]), 5 / 64 / 32 attn_fwd_v5_kernel / the assembly kernels by name")
     ap.add_argument("--resid", default=os.environ.get("UCOD_RESID", "auto"), choices=["auto", "f32", "f16"],
                     help="residual-stream type of the backbone (auto: fp16 for bf16 operands, f32 for fp16 operands)")
     ap.add_argument("--streams", type=int, default=2, help="image-parallel sub-batches of the backbone pass on independent HIP streams")
@@ -118,6 +118,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {a.gpus}: launch with --nproc-per-node equal to --gpus")
+    from ucod_dpl_amd import parallel as _par
+    pinned_cores = _par.pin_rank_cores(local_rank, world)     # before the first GPU call: each rank on its own slice of the host's cores
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path is HIP-only)")
     from ucod_dpl_amd import parallel
@@ -136,6 +138,9 @@ def main():
     D, heads, L, P, _, _ = ARCHS[a.arch]
     cfg = make_cfg(68, D)
     runner = StandardRunner(cfg)                              # initialises the RCCL process group when WORLD_SIZE > 1
+    ranks_seen = parallel.ranks_seen(dev)                     # (a collective: every rank calls it) who took part, on which device
+    if world > 1 and len({(r[2], r[3]) for r in ranks_seen}) != world and os.environ.get("UCOD_SINGLE_DEVICE") != "1":
+        raise SystemExit(f"bench.py: {world} ranks but the devices seen are {ranks_seen}: ranks share a GPU")
     loop = TrainLoop(cfg, runner)
     bb = backbone.random_init(a.arch, seed=0, image_size=a.image, device=dev, full_last_layer=a.full_last_layer,
                               gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half=a.half, resid=a.resid)
@@ -425,7 +430,8 @@ def main():
         "logit_max_abs_trained_like_weights": own_tl.get("logit_max_abs"),
         "bar_met_trained_like_weights": (None if not own_tl else bool(own_tl["logit_max_abs"] <= BAR)),
         "bar_meeting_config": bar_meeting, "f16_vs_bf16_per_kernel": f16_vs_bf16,
-        "host_enqueue_ms_per_step": round(host_enqueue / a.steps * 1e3, 3), "host_threads": host_threads,
+        "host_enqueue_ms_per_step": round(host_enqueue / a.steps * 1e3, 3), "host_threads": host_threads, "host_cores_pinned": pinned_cores,
+        "ranks_seen": ranks_seen,
         "config": {"workload": f"{which_config(a.arch, a.image, B, a.attn_variant)}: {a.arch} @{a.image}x{a.image}, batch {B}/GPU, full APM+DBA+discriminator step, "
                                f"decoder path f32 (1x1 conv as a three-way bf16 split on the matrix pipe: f32-equivalent), backbone {a.half} MFMA", "global_batch": B * world, "parallelism": f"dp{world}",
                    "backbone_last_layer": "full (as reference)" if a.full_last_layer else "key-minimal (identical key output; 279.6 of 303.1 GFLOP/img)",

@@ -35,7 +35,9 @@ extern "C" {
 
 /* 2 (round 3): ucod_vit_desc gained resid16 (shifts ucod_vit_train_desc), epilogues 9 / 10, ucod_resid16_overflow_*, ucod_gemm_reload_tuning;
  * the experiment variants of ucod_gemm_bf16 / ucod_attention_fwd left the product library.  native.load() refuses any other version. */
-#define UCOD_ABI_VERSION 2
+/* 3 (round 4): ucod_disc_params gained `nbt`; ucod_step_loss, ucod_disc_bce, the feature-branch discriminator's backward entry points and
+ * the assembly attention variants (ucod_attention_fwd variant 64 / 32 / 5) were added. */
+#define UCOD_ABI_VERSION 3
 int ucod_abi_version(void);
 /* 1 when a gfx950 device is visible to this process (hipGetDeviceProperties().gcnArchName) */
 int ucod_device_is_gfx950(void);
@@ -349,6 +351,7 @@ int ucod_dba_wgrad_split(const float* gd, const float* x, float* gW, int B, int 
 typedef struct {
   const float *w1, *g1, *b1, *w2, *g2, *b2, *w3, *g3, *b3, *lin_w, *lin_b;
   float *rm1, *rv1, *rm2, *rv2, *rm3, *rv3;
+  long long* nbt; /* ABI 3: the three num_batches_tracked counters as ONE int64[3] (or NULL): += 1 per call with update_running */
 } ucod_disc_params;
 size_t ucod_disc_saved_bytes(int B, int fs);
 int ucod_disc_fwd(const float* mask, const ucod_disc_params* p_host, float* prob, void* saved, int B, int fs,
@@ -375,6 +378,9 @@ int ucod_binarize(const float* x, float* out, size_t n, int logits, void* stream
 
 /* torch.optim.AdamW step + EMA teacher update over a flat f32 arena
  * (engine/runner/runner.py:282-298; loop_UCOD_DPL.py:178,186-191).  ema may be NULL. */
+/* loss of TrainLoop._process_batch (loop_UCOD_DPL.py:161-169): out[0] = losses[0] + losses[1] + extra[0] (- losses[2] unless finetune), from
+ * the four scalars ucod_apm_bce left in `losses` and the orthogonality loss -- one launch instead of three elementwise adds (ABI 3). */
+int ucod_step_loss(const float* losses, const float* extra, int finetune, float* out, void* stream);
 int ucod_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float ema_alpha, void* stream);
 

@@ -169,3 +169,33 @@ def test_validation_records_are_gathered_across_ragged_ranks(tmp_path):
         res, per_image, small = torch.load(out + str(r))
         assert res == ref
         assert torch.equal(per_image, rec) and torch.equal(small, rec[:3])
+
+
+def _pin_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, ROOT)
+    from ucod_dpl_amd import parallel
+    before = sorted(os.sched_getaffinity(0))
+    n = parallel.pin_rank_cores()
+    mine = sorted(os.sched_getaffinity(0))
+    threads = parallel.cap_host_threads(world)
+    parallel.init_from_env("gloo")
+    seen = parallel.ranks_seen(torch.device("cpu"))
+    torch.save((before, mine, n, threads, seen), out + str(rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_eight_ranks_pin_disjoint_core_slices_and_see_each_other(tmp_path):
+    """parallel.pin_rank_cores / cap_host_threads / ranks_seen with world 8 over gloo: disjoint, covering slices of the cores this process
+    may use (when there are at least eight), one intra-op thread count per rank that fits its slice, and every rank reports all eight."""
+    out = str(tmp_path / "pin")
+    mp.start_processes(_pin_worker, args=(8, _free_port(), out), nprocs=8, join=True, start_method="spawn")
+    res = [torch.load(out + str(r)) for r in range(8)]
+    cores = res[0][0]
+    if len(cores) >= 8:
+        per = len(cores) // 8
+        for r, (before, mine, n, threads, seen) in enumerate(res):
+            assert mine == cores[r * per:(r + 1) * per] and n == per and 1 <= threads <= per
+    for before, mine, n, threads, seen in res:
+        assert sorted(s[0] for s in seen) == list(range(8))

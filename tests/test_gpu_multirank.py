@@ -200,3 +200,27 @@ def test_bench_launches_two_ranks_itself(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
     assert d["backbone_backward_mode"]["value"] > 0 and d["discriminator_phase"]["value"] > 0
+    assert sorted(r[0] for r in d["ranks_seen"]) == [0, 1] and d["host_cores_pinned"] >= 1
+
+
+def test_eight_ranks_on_one_gpu_first_contact(tmp_path):
+    """First-contact insurance for the 8-GPU node: `python bench.py --gpus 8` -- eight processes, each pinned to its slice of
+    the host's cores before it touches the GPU, rendezvous on 127.0.0.1, broadcast, the asynchronous all-reduces of all three modes, max-over-
+    ranks timing, ONE JSON line with eight entries in ranks_seen -- on a tiny geometry, all ranks sharing this box's one GPU over gloo
+    (UCOD_SINGLE_DEVICE=1).  What it cannot show is RCCL / xGMI itself."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, UCOD_SINGLE_DEVICE="1", UCOD_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "2", "--lora-steps", "1",
+                        "--no-cpu-baseline", "--image", "224", "--arch", "dino_vits8"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp8" and d["value"] > 0
+    assert sorted(r_[0] for r_ in d["ranks_seen"]) == list(range(8)) and sorted(r_[1] for r_ in d["ranks_seen"]) == list(range(8))
+    assert d["host_cores_pinned"] == max(1, len(os.sched_getaffinity(0)) // 8)
+    assert d["backbone_backward_mode"]["value"] > 0 and d["discriminator_phase"]["value"] > 0

@@ -386,9 +386,14 @@ extern "C" int ucod_dba_bwd(const float* d, int ld_c, int c0, const float* emb, 
   hipStream_t s = (hipStream_t)stream;
   float* gfeat = (float*)ws;
   UCOD_PROF(PROF_DBA_BWD, s);
-  hipError_t e = hipMemsetAsync(g_head_w, 0, sizeof(float) * 128, s);
-  if (e == hipSuccess) e = hipMemsetAsync(g_head_b, 0, sizeof(float) * 2, s);
-  if (e == hipSuccess) e = hipMemsetAsync(g_dec_bias, 0, sizeof(float) * 128, s);
+  hipError_t e;
+  if (g_head_w == g_dec_bias + 128 && g_head_b == g_head_w + 128) {      // the flat gradient arena (bias | head_w | head_b): one fill
+    e = hipMemsetAsync(g_dec_bias, 0, sizeof(float) * 258, s);
+  } else {
+    e = hipMemsetAsync(g_head_w, 0, sizeof(float) * 128, s);
+    if (e == hipSuccess) e = hipMemsetAsync(g_head_b, 0, sizeof(float) * 2, s);
+    if (e == hipSuccess) e = hipMemsetAsync(g_dec_bias, 0, sizeof(float) * 128, s);
+  }
   if (e != hipSuccess) return (int)e;
   const float coef = (float)(2.0 * (double)gextra / ((double)B * (double)HW * (double)HW));
   hipLaunchKernelGGL(dba_bwd_a_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, s, d, ld_c, c0, emb, norm, head_w, gram, gfg, gbg, coef, gfeat, HW);

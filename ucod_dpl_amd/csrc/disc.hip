@@ -175,7 +175,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ gacc, int C, doubl
 __global__ __launch_bounds__(256) void disc_head_kernel(const float* __restrict__ y3, const float* __restrict__ stats,
                                                         const float* __restrict__ g, const float* __restrict__ bta,
                                                         const float* __restrict__ lw, const float* __restrict__ lb,
-                                                        float* __restrict__ prob, int HW3) {
+                                                        float* __restrict__ prob, int HW3, long long* __restrict__ nbt) {
   __shared__ float red[16];
   const int b = blockIdx.x, tid = threadIdx.x, n = 8 * HW3;
   float acc = 0.f;
@@ -185,6 +185,9 @@ __global__ __launch_bounds__(256) void disc_head_kernel(const float* __restrict_
   }
   acc = block_sum(acc, red);
   if (tid == 0) prob[b] = sigmoid_acc(acc + lb[0]);
+  // nn.BatchNorm2d.num_batches_tracked of the three blocks (one training-mode call = +1 each): done here, in the pass's last launch, so
+  // that the host issues no elementwise kernel for it
+  if (nbt && b == 0 && tid < 3) nbt[tid] += 1;
 }
 
 }  // namespace ucod
@@ -219,7 +222,7 @@ extern "C" int ucod_disc_fwd(const float* mask, const ucod_disc_params* p, float
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, ac2, 16, (double)B * d.s2 * d.s2, st2, p->rm2, p->rv2, update_running);
   hipLaunchKernelGGL((conv3x3_kernel<16, 8, 2, true, 2>), dim3(cdiv((long)B * d.s3 * d.s3, 256), 4), dim3(256), 0, s, y2, p->w3, st2, p->g2, p->b2, y3, ac3, B, d.s2, d.s3);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, ac3, 8, (double)B * d.s3 * d.s3, st3, p->rm3, p->rv3, update_running);
-  hipLaunchKernelGGL(disc_head_kernel, dim3(B), dim3(256), 0, s, y3, st3, p->g3, p->b3, p->lin_w, p->lin_b, prob, d.s3 * d.s3);
+  hipLaunchKernelGGL(disc_head_kernel, dim3(B), dim3(256), 0, s, y3, st3, p->g3, p->b3, p->lin_w, p->lin_b, prob, d.s3 * d.s3, update_running ? p->nbt : nullptr);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }

@@ -297,6 +297,12 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, c
   }
 }
 
+__global__ void step_loss_kernel(const float* __restrict__ losses, const float* __restrict__ extra, int finetune, float* __restrict__ out) {
+  float l = losses[0] + losses[1] + extra[0];
+  if (!finetune) l -= losses[2];
+  out[0] = l;
+}
+
 static inline int nblocks(size_t n, int cap) { return (int)((n + 255) / 256 < (size_t)cap ? (n + 255) / 256 : (size_t)cap); }
 
 }  // namespace ucod
@@ -358,6 +364,13 @@ extern "C" int ucod_apm_bce(const float* pl, const float* teacher, const float* 
   hipError_t e = hipMemsetAsync(losses, 0, 4 * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(apm_bce_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, s, pl, teacher, fg, bg, p_s, p_p, epoch_frac, gscale, w, merged, gfg, gbg, losses, B, HW);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_step_loss(const float* losses, const float* extra, int finetune, float* out, void* stream) {
+  if (!losses || !extra || !out) return UCOD_EINVAL;
+  hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, losses, extra, finetune, out);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }

@@ -219,9 +219,7 @@ class TrainLoop(BaseLoop):
         # RCCL: one flat 128C+386-float buffer, pre-scaled by 1/world, issued asynchronously on the process group's stream; the
         # loss scalars below are assembled meanwhile and the optimiser launch is the first consumer.
         reduced = parallel.allreduce_prescaled_async(A.g)
-        loss = losses[0] + losses[1] + extra[0]
-        if not self.finetune:
-            loss = loss - losses[2]
+        loss = ops.step_loss(losses, extra, self.finetune)     # losses[0] + losses[1] + extra (- dis loss unless finetune), one launch
 
         # AdamW + StepLR + EMA (:178-181,186-191)
         alpha = min(1 - 1 / (self.global_step + 1), self.ema_alpha)
@@ -358,9 +356,7 @@ class TrainLoop(BaseLoop):
         eng.repack()
         eng_t.repack()
         self.global_step += 1
-        loss = losses[0] + losses[1] + extra[0]
-        if not self.finetune:
-            loss = loss - losses[2]
+        loss = ops.step_loss(losses, extra, self.finetune)     # losses[0] + losses[1] + extra (- dis loss unless finetune), one launch
         self.last = dict(loss=loss, dis_loss=losses[2], extra=extra[0], w=w, merged=merged, fg=fg, bg=bg, teacher=teacher, p_s=p_s, p_p=p_p)
         return loss
 
@@ -381,9 +377,9 @@ class TrainLoop(BaseLoop):
             return p_s, p_p
         disc_t = disc.tensor_table()
         p_s, _ = ops.disc_fwd(student_mask, disc_t, update_running=True, saved=r.disc_saved(B, fs))
-        disc._bump_num_batches()
+        disc._bump_num_batches(disc_t)                        # (a no-op: the kernel call bumps the counters the table carries)
         p_p, _ = ops.disc_fwd(pseudo_mask, disc_t, update_running=True, saved=r.disc_saved(B, fs))
-        disc._bump_num_batches()
+        disc._bump_num_batches(disc_t)
         return p_s, p_p
 
     def merge_pseudo_label(self, pseudo_labels, p_teachers, p_students, features=None):
@@ -448,9 +444,9 @@ class TrainLoop(BaseLoop):
         else:
             t = disc.tensor_table()
             probs_pseudo, saved_p = ops.disc_fwd(pl, t, update_running=True)                                          # :244
-            disc._bump_num_batches()
+            disc._bump_num_batches(t)
             probs_student, saved_s = ops.disc_fwd(preds, t, update_running=True)                                      # :245
-            disc._bump_num_batches()
+            disc._bump_num_batches(t)
         # BCELoss(cat(student, pseudo), [0..0, 1..1]) mean over 2B (:246-247) and its gradient, one launch (ucod_disc_bce: torch's clamp of the
         # logarithms at -100 and its max(p (1 - p), 1e-12) denominator); the gradient carries 1 / (2 B world) for the pre-scaled all-reduce
         g_student, g_pseudo, loss = ops.disc_bce(probs_student, probs_pseudo, 1.0 / (2 * B * world))

@@ -37,7 +37,7 @@ class _DiscFunction(torch.autograd.Function):
         mask = mask.float().contiguous()
         t = module.tensor_table()
         prob, saved = ops.disc_fwd(mask, t, update_running=True)
-        module._bump_num_batches()
+        module._bump_num_batches(t)
         ctx.module, ctx.saved, ctx.mask = module, saved, mask
         return prob.view(-1, 1)
 
@@ -95,9 +95,16 @@ class Discriminator(nn.Module):
         t = dict(zip(self.FIELDS, (p.detach() for p in self._param_list())))
         for i, b in enumerate(blocks, 1):
             t[f"rm{i}"], t[f"rv{i}"] = b.layers[1].running_mean, b.layers[1].running_var
+        # the three counters as one int64[3] (DiscArena makes them views of one tensor): ucod_disc_fwd bumps them in its last launch
+        nbt = getattr(self, "_nbt", None)
+        if nbt is not None and nbt.is_cuda and all(b.layers[1].num_batches_tracked.data_ptr() == nbt[i].data_ptr() for i, b in enumerate(blocks)):
+            t["nbt"] = nbt
         return t
 
-    def _bump_num_batches(self):
+    def _bump_num_batches(self, table=None):
+        """+1 on every block's num_batches_tracked -- unless the kernel call already did it (``table`` carries the counters: tensor_table())"""
+        if table is not None and table.get("nbt") is not None:
+            return
         nbt = getattr(self, "_nbt", None)           # set by DiscArena: the counters as views of one tensor
         if nbt is not None and all(b.layers[1].num_batches_tracked.data_ptr() == nbt[i].data_ptr() for i, b in enumerate(self._blocks())):
             nbt += 1

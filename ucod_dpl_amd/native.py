@@ -17,7 +17,7 @@ if os.environ.get("UCOD_DPL_LIB"):
                        "UCOD_DPL_ALLOW_EXPERIMENT=1 UCOD_DPL_EXPERIMENT_LIB=<path> for an experiment build")
 if os.environ.get("UCOD_DPL_EXPERIMENT_LIB") and os.environ.get("UCOD_DPL_ALLOW_EXPERIMENT") == "1":
     LIB_PATH = os.environ["UCOD_DPL_EXPERIMENT_LIB"]
-ABI_VERSION = 2                                            # include/ucod_dpl.h: UCOD_ABI_VERSION
+ABI_VERSION = 3                                            # include/ucod_dpl.h: UCOD_ABI_VERSION
 
 EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_SCALE_RESID_F32, EPI_PATCH_TOKENS_F32, EPI_KEY_NCHW_F32, EPI_BIAS_F32 = range(6)
 EPI_GELU_BWD_BF16, EPI_BIAS_GELU_SAVE_BF16 = 6, 7          # ucod_gemm_bf16_train only (backbone-backward mode)
@@ -45,7 +45,7 @@ class LoraDropout(C.Structure):
 
 class DiscParams(C.Structure):
     _fields_ = [(n, vp) for n in ("w1", "g1", "b1", "w2", "g2", "b2", "w3", "g3", "b3", "lin_w", "lin_b",
-                                  "rm1", "rv1", "rm2", "rv2", "rm3", "rv3")]
+                                  "rm1", "rv1", "rm2", "rv2", "rm3", "rv3", "nbt")]
 
 
 class DiscGrads(C.Structure):
@@ -145,6 +145,7 @@ SIGNATURES = {
     "ucod_window_loss": (ci, [vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ucod_gated_ensemble_workspace_bytes": (sz, [ci, ci, ci]),
     "ucod_gated_ensemble": (ci, [vp, vp, vp, vp, vp, cf, vp, vp, vp, ci, ci, ci, vp]),
+    "ucod_step_loss": (ci, [vp, vp, ci, vp, vp]),
     "ucod_adamw_ema": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, ci, cf, vp]),
     "ucod_cod_metrics_workspace_bytes": (sz, [ci, ci, ci]),
     "ucod_cod_metrics": (ci, [vp, vp, ci, ci, ci, vp, vp, sz, vp]),

@@ -238,8 +238,18 @@ def disc_params_struct(tensors):
     """tensors: dict with the 17 DiscParams field names -> CUDA f32 tensors."""
     s = N.DiscParams()
     for name, _ in N.DiscParams._fields_:
+        if name == "nbt":                                   # int64[3] view of the three num_batches_tracked counters, or absent
+            t = tensors.get("nbt")
+            s.nbt = None if t is None else t.data_ptr()
+            continue
         setattr(s, name, ptr(_f32(tensors[name])))
     return s
+
+
+def step_loss(losses, extra, finetune):
+    out = torch.empty(1, dtype=torch.float32, device=losses.device)
+    check(N.load().ucod_step_loss(ptr(losses), ptr(extra), int(bool(finetune)), ptr(out), stream()), "ucod_step_loss")
+    return out[0]
 
 
 def disc_fwd(mask, tensors, update_running=True, saved=None):

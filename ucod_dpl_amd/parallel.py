@@ -37,9 +37,53 @@ def cap_host_threads(world=None):
     one); UCOD_RANK_THREADS overrides.  Returns the count in force."""
     world = world if world is not None else env_world()[2]
     if world > 1 or os.environ.get("UCOD_RANK_THREADS"):
-        n = int(os.environ.get("UCOD_RANK_THREADS") or max(1, (os.cpu_count() or 1) // world))
+        try:
+            avail = len(os.sched_getaffinity(0))                # after pin_rank_cores: this rank's own share
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        share = avail if avail < (os.cpu_count() or 1) else max(1, (os.cpu_count() or 1) // world)
+        n = int(os.environ.get("UCOD_RANK_THREADS") or max(1, share))
         torch.set_num_threads(n)
     return torch.get_num_threads()
+
+
+def pin_rank_cores(local_rank=None, world=None):
+    """Give this rank its own share of the host's cores (``os.sched_setaffinity``), BEFORE anything initialises the GPU runtime: eight ranks
+    on one host otherwise float over all cores -- each rank's single launch thread, its HIP runtime threads and the other ranks' pools
+    migrate over each other (scripts/launch_train_first_stage.sh:20-40 leaves this to accelerate / the OS).  Rank r of ``world`` takes the
+    r-th contiguous slice of the cores this process may run on; UCOD_NO_PIN=1 disables.  Returns the number of cores in force."""
+    rank, lr, w = env_world()
+    local_rank = lr if local_rank is None else local_rank
+    world = w if world is None else world
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:                                      # not Linux
+        return os.cpu_count() or 1
+    if world <= 1 or os.environ.get("UCOD_NO_PIN") == "1" or len(cores) < world:
+        return len(cores)
+    per = len(cores) // world
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    return len(mine)
+
+
+def ranks_seen(device):
+    """[(rank, local_rank, device index, PCI bus id or device name)] of every rank, identical on all of them: what bench.py's ``--gpus N`` line
+    carries so that a reader can verify N distinct devices took part (and RCCL membership: the gather itself is a collective)."""
+    rank, local_rank, world = env_world()
+    idx = device.index if getattr(device, "index", None) is not None else device_index()
+    try:
+        props = torch.cuda.get_device_properties(idx)
+        where = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1) & 0xFF, getattr(props, "pci_device_id", 0) & 0xFF) \
+            if hasattr(props, "pci_bus_id") else str(getattr(props, "uuid", props.name))
+    except Exception as e:                                       # noqa: BLE001
+        where = f"unknown ({type(e).__name__})"
+    mine = [rank, local_rank, int(idx), where]
+    if world_size() == 1:
+        return [mine]
+    out = [None] * world_size()
+    dist.all_gather_object(out, mine)
+    return out
 
 
 def init_from_env(backend="nccl", timeout_s=None):
