@@ -118,76 +118,80 @@ __global__ __launch_bounds__(256) void layernorm4_kernel(const float* __restrict
 template <int NC>                                          // NC = D / 256 chunks per lane
 __global__ __launch_bounds__(256) void layernorm_h16_strip_kernel(const u32x4* __restrict__ x, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, u32x4* __restrict__ y, int rows, int D, float eps) {
+  // A wave walks the strips  w, w + (waves of the grid), ...  with gamma / beta held in registers: per strip they are TWICE the bytes of the
+  // strip's own fp16 rows (2 x D x 4 B of f32 against 2 x D x 2 B), all of it L2 -> CU traffic when every strip re-reads them (round 4: the
+  // launcher sizes the grid so that a wave takes 2 - 4 strips; measured in profiles/r04_layernorm_strips.txt).
   const int lane = threadIdx.x & 63;
-  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
-  if (row0 >= rows) return;
-  const bool two = row0 + 1 < rows;
   const int cpr = D >> 3;                                  // chunks per row
-  const u32x4* xs = x + (size_t)row0 * cpr;
-  float v[NC][8];
   bool second[NC];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int c = lane + 64 * i;
-    second[i] = c >= cpr;
-    const u32x4 w = xs[(second[i] && !two) ? c - cpr : c];  // an odd last row: re-read row 0 (never used)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) unpack_f16x2(w[e], v[i][2 * e], v[i][2 * e + 1]);
-  }
-  // gamma / beta of the lane's chunks, requested behind the row loads and before the reductions: loaded inside the output loop they sat
-  // between two stores, and the wait for them also waited for the store in front (vmcnt counts stores): one store round trip per chunk
   const float4* g4 = reinterpret_cast<const float4*>(gamma);
   const float4* b4 = reinterpret_cast<const float4*>(beta);
   float4 ga[NC], gb[NC], ba[NC], bb[NC];
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
-    const int c = lane + 64 * i, col = second[i] ? c - cpr : c;
+    const int c = lane + 64 * i;
+    second[i] = c >= cpr;
+    const int col = second[i] ? c - cpr : c;
     ga[i] = g4[2 * col];
     gb[i] = g4[2 * col + 1];
     ba[i] = b4[2 * col];
     bb[i] = b4[2 * col + 1];
   }
-  // (LLVM sinks loads into the conditional block that uses them -- the odd-last-row skip below -- unless the values are opaque here)
+  const int nstrips = (rows + 1) >> 1, stride = gridDim.x * 4;
+  for (int strip = blockIdx.x * 4 + (threadIdx.x >> 6); strip < nstrips; strip += stride) {
+    const int row0 = strip * 2;
+    const bool two = row0 + 1 < rows;
+    const u32x4* xs = x + (size_t)row0 * cpr;
+    float v[NC][8];
 #pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    asm volatile("" : "+v"(ga[i].x), "+v"(ga[i].y), "+v"(ga[i].z), "+v"(ga[i].w), "+v"(gb[i].x), "+v"(gb[i].y), "+v"(gb[i].z), "+v"(gb[i].w));
-    asm volatile("" : "+v"(ba[i].x), "+v"(ba[i].y), "+v"(ba[i].z), "+v"(ba[i].w), "+v"(bb[i].x), "+v"(bb[i].y), "+v"(bb[i].z), "+v"(bb[i].w));
-  }
-  float s0 = 0.f, s1 = 0.f;
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      const u32x4 w = xs[(second[i] && !two) ? c - cpr : c];  // an odd last row: re-read row 0 (never used)
 #pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const float t = ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
-    s0 += second[i] ? 0.f : t;
-    s1 += second[i] ? t : 0.f;
-  }
-  const float inv_d = 1.0f / (float)D;
-  const float mean0 = wave_sum(s0) * inv_d, mean1 = wave_sum(s1) * inv_d;
-  float q0 = 0.f, q1 = 0.f;
-#pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const float m = second[i] ? mean1 : mean0;
-    float t = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      v[i][e] -= m;
-      t += v[i][e] * v[i][e];
+      for (int e = 0; e < 4; ++e) unpack_f16x2(w[e], v[i][2 * e], v[i][2 * e + 1]);
     }
-    q0 += second[i] ? 0.f : t;
-    q1 += second[i] ? t : 0.f;
-  }
-  const float rstd0 = rsqrtf(wave_sum(q0) * inv_d + eps), rstd1 = rsqrtf(wave_sum(q1) * inv_d + eps);
-  u32x4* ys = y + (size_t)row0 * cpr;
+    // (LLVM sinks loads into the conditional block that uses them -- the odd-last-row skip below -- unless the values are opaque here)
 #pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int c = lane + 64 * i;
-    if (second[i] && !two) continue;
-    const float rstd = second[i] ? rstd1 : rstd0;
-    u32x4 w;
-    w[0] = pack_h2(v[i][0] * rstd * ga[i].x + ba[i].x, v[i][1] * rstd * ga[i].y + ba[i].y);
-    w[1] = pack_h2(v[i][2] * rstd * ga[i].z + ba[i].z, v[i][3] * rstd * ga[i].w + ba[i].w);
-    w[2] = pack_h2(v[i][4] * rstd * gb[i].x + bb[i].x, v[i][5] * rstd * gb[i].y + bb[i].y);
-    w[3] = pack_h2(v[i][6] * rstd * gb[i].z + bb[i].z, v[i][7] * rstd * gb[i].w + bb[i].w);
-    ys[c] = w;
+    for (int i = 0; i < NC; ++i) {
+      asm volatile("" : "+v"(ga[i].x), "+v"(ga[i].y), "+v"(ga[i].z), "+v"(ga[i].w), "+v"(gb[i].x), "+v"(gb[i].y), "+v"(gb[i].z), "+v"(gb[i].w));
+      asm volatile("" : "+v"(ba[i].x), "+v"(ba[i].y), "+v"(ba[i].z), "+v"(ba[i].w), "+v"(bb[i].x), "+v"(bb[i].y), "+v"(bb[i].z), "+v"(bb[i].w));
+    }
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const float t = ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+      s0 += second[i] ? 0.f : t;
+      s1 += second[i] ? t : 0.f;
+    }
+    const float inv_d = 1.0f / (float)D;
+    const float mean0 = wave_sum(s0) * inv_d, mean1 = wave_sum(s1) * inv_d;
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const float m = second[i] ? mean1 : mean0;
+      float t = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] -= m;
+        t += v[i][e] * v[i][e];
+      }
+      q0 += second[i] ? 0.f : t;
+      q1 += second[i] ? t : 0.f;
+    }
+    const float rstd0 = rsqrtf(wave_sum(q0) * inv_d + eps), rstd1 = rsqrtf(wave_sum(q1) * inv_d + eps);
+    u32x4* ys = y + (size_t)row0 * cpr;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (second[i] && !two) continue;
+      const float rstd = second[i] ? rstd1 : rstd0;
+      u32x4 w;
+      w[0] = pack_h2(v[i][0] * rstd * ga[i].x + ba[i].x, v[i][1] * rstd * ga[i].y + ba[i].y);
+      w[1] = pack_h2(v[i][2] * rstd * ga[i].z + ba[i].z, v[i][3] * rstd * ga[i].w + ba[i].w);
+      w[2] = pack_h2(v[i][4] * rstd * gb[i].x + bb[i].x, v[i][5] * rstd * gb[i].y + bb[i].y);
+      w[3] = pack_h2(v[i][6] * rstd * gb[i].z + bb[i].z, v[i][7] * rstd * gb[i].w + bb[i].w);
+      ys[c] = w;
+    }
   }
 }
 
@@ -412,10 +416,17 @@ extern "C" int ucod_layernorm_h16(const void* x, const float* gamma, const float
   const unsigned* xp = (const unsigned*)x;
   bf16_raw* yp = (bf16_raw*)y;
   static const bool no_strip = getenv("UCOD_LN_NO_STRIP") != nullptr;     // measurement knob: the 8-byte form
+  // strips (row pairs) per wave of the 16-byte form: gamma / beta stay in registers over them.  UCOD_LN_STRIPS (read once): 0 = one strip per
+  // wave (the round-3 launch); default 2 below D = 1024, 4 from there (profiles/r04_layernorm_strips.txt: 24.3 -> 23.1 us at 43840 x 768,
+  // 18.6 -> 17.9 us = 0.63 of the HBM peak at 21920 x 1024, BASELINE configs[3]; 8 and more lose to the shorter tail)
+  static const int strips_env = [] { const char* e = getenv("UCOD_LN_STRIPS"); return e ? atoi(e) : -1; }();
+  const int strips_per_wave = strips_env >= 0 ? strips_env : (D >= 1024 ? 4 : 2);
   if ((D % 256) == 0 && !no_strip) {
+    const int nstrips = (rows + 1) / 2;
+    const dim3 sgrid(strips_per_wave > 1 ? (unsigned)(cdiv(cdiv(nstrips, strips_per_wave), 4) > 256 ? cdiv(cdiv(nstrips, strips_per_wave), 4) : 256) : (unsigned)cdiv(nstrips, 4));
     switch (D / 256) {
 #define LNS_CASE(n) \
-  case n: hipLaunchKernelGGL(layernorm_h16_strip_kernel<n>, grid, block, 0, s, (const u32x4*)x, gamma, beta, (u32x4*)y, rows, D, eps); break;
+  case n: hipLaunchKernelGGL(layernorm_h16_strip_kernel<n>, sgrid, block, 0, s, (const u32x4*)x, gamma, beta, (u32x4*)y, rows, D, eps); break;
       LNS_CASE(1) LNS_CASE(2) LNS_CASE(3) LNS_CASE(4) LNS_CASE(5) LNS_CASE(6)
 #undef LNS_CASE
       default: return UCOD_EINVAL;
