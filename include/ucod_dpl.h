@@ -166,10 +166,12 @@ int ucod_gemm_bf16_train(int epilogue, const void* A, const void* B, void* out, 
                          const void* aux_bf16, void* out2_bf16, int variant, void* stream);
 
 /* LoRA dropout (LoraConfig.lora_dropout, full_model.py:50: nn.Dropout on the input of every lora_A, an independent mask per target
- * module).  Counter-based: element (row, col) of projection p (0 q, 1 k, 2 v) in `layer` is dropped iff
- *   h = seed_lo ^ (idx * 0x9E3779B1);  h ^= seed_hi + (3*layer + p) * 0x85EBCA77;  h ^= h >> 16;  h *= 0x7FEB352D;  h ^= h >> 15;
+ * module).  Counter-based (ABI 3: one mix per element for the three projections): with
+ *   h = seed_lo ^ (idx * 0x9E3779B1);  h ^= seed_hi + layer * 0x85EBCA77;  h ^= h >> 16;  h *= 0x7FEB352D;  h ^= h >> 15;
  *   h *= 0x846CA68B;  h ^= h >> 16;      (32-bit wrap-around arithmetic, idx = row * D + col)
- * is below p * 2^32; kept elements are scaled by 1 / (1 - p).  Forward and backward regenerate the mask; nothing is stored.
+ * element (row, col) of projection p (0 q, 1 k, 2 v) in `layer` is dropped iff  (h >> (10 * p)) & 1023  <  T,  T = floor(p_drop * 1024);
+ * kept elements are scaled by 1 / (1 - T / 1024) (the effective drop probability is T / 1024).  Forward and backward regenerate the
+ * mask; nothing is stored.
  * Pass NULL (or p == 0) for no dropout. */
 typedef struct {
   float p;

@@ -64,15 +64,15 @@ def lora_dropout_mask(seed, layer, proj, rows, D, p):
     with np.errstate(over="ignore"):
         idx = np.arange(rows * D, dtype=np.uint64).astype(np.uint32)
         h = np.uint32(seed & 0xFFFFFFFF) ^ (idx * np.uint32(0x9E3779B1))
-        h = h ^ (np.uint32((seed >> 32) & 0xFFFFFFFF) + np.uint32(3 * layer + proj) * np.uint32(0x85EBCA77))
+        h = h ^ (np.uint32((seed >> 32) & 0xFFFFFFFF) + np.uint32(layer) * np.uint32(0x85EBCA77))
         h = h ^ (h >> np.uint32(16))
         h = h * np.uint32(0x7FEB352D)
         h = h ^ (h >> np.uint32(15))
         h = h * np.uint32(0x846CA68B)
         h = h ^ (h >> np.uint32(16))
-    thresh = min(int(np.float32(p).astype(np.float64) * 4294967296.0), 0xFFFFFFFF)
-    keep = h >= np.uint32(thresh)
-    inv = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    thresh = min(int(np.float32(p).astype(np.float64) * 1024.0), 1023)          # ABI 3: one mix per element, a 10-bit field per projection
+    keep = ((h >> np.uint32(10 * proj)) & np.uint32(1023)) >= np.uint32(thresh)
+    inv = np.float32(1.0) / (np.float32(1.0) - np.float32(thresh) / np.float32(1024.0))
     return torch.from_numpy(np.where(keep, inv, np.float32(0.0)).astype(np.float32).reshape(rows, D))
 
 
