@@ -344,6 +344,7 @@ def test_weight_gradient_run_to_run_spread_is_at_rounding_level():
     dba_wgrad_kernel): the order of the partial sums is not fixed, so two runs differ in the last bits.  This documents HOW MUCH (VERDICT r3
     weak #10): relative to the largest entry the spread over five launches stays below 2e-6 -- the level `test_process_batch_three_steps`
     has to allow for, and what "N ranks == one rank with the global batch" can be asserted to."""
+    from ucod_dpl_amd import ops
     g = torch.Generator().manual_seed(5)
     B, C, HW = 8, 768, 37 * 37
     gd = torch.randn(B, 128, HW, generator=g).cuda()
