@@ -11,7 +11,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 streams = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 lib = N.load()
-eng = ViTLoRAEngine(random_state_dict("dinov2_vitb14", seed=0), heads=12, device="cuda")
+drop = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0   # the reference trains with lora_dropout 0.05 (configs/model/UCOD_DPL.py)
+eng = ViTLoRAEngine(random_state_dict("dinov2_vitb14", seed=0), heads=12, device="cuda", lora_dropout=drop)
 eng.train_streams = streams
 x = torch.randn(B, 3, 518, 518, device="cuda")
 dkey = torch.randn(B, 768, 37, 37, device="cuda")

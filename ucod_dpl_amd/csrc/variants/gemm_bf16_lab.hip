@@ -434,9 +434,247 @@ __global__ __launch_bounds__(512) void gemm_bf16_park_kernel(const GemmArgs a) {
   for (int q = 0; q < 12; ++q) park_store(q);
 }
 
+// =====================================================================================================
+// Variant 21 (round 4, experiment): variant 20 with the conversion IN REGISTERS.  The MFMA operands are swapped (weight fragment as A,
+// activation fragment as B), so the accumulator tile is the TRANSPOSED 16 x 16 block: lane (g = lane >> 4, c = lane & 15) holds row c,
+// columns 4g..4g+3 -- four consecutive output columns, 8 bytes of bf16.  Two tiles (T0, T1) make 16-byte row chunks with two
+// v_permlane16_swap (odd 16-lane rows of T0's words <-> even rows of T1's): afterwards an even-g lane holds columns 4g..4g+7 of T0's row c and
+// an odd-g lane columns 4(g-1)..4(g-1)+7 of T1's row c.  Per wave tile (24 tiles): 48 v_cvt_pk + 24 swaps = 72 vector instructions instead of
+// 96 ds_write + 24 ds_read_b128 + waits; no staging area.  tools/probes/acc_transpose_probe.hip prices the alternative (8 x 8 transposes
+// inside the untransposed tile with DPP) at 2-4 k cycles per wave tile.
+// =====================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_park2_kernel(const GemmArgs a) {
+  constexpr int NT = 3, IT = 4, NPH = 2, SLOT = 128 * 128, NB = 3, BN_ = 192, WCOLS = 48;
+  constexpr int BUF = 2 * SLOT + BN_ * 128;                      // 57 344 bytes: A0 | A1 | B of one K-tile
+  constexpr unsigned DROP = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int K = a.K, nt = K / BK;                                // (launch: nt even, >= 2)
+  const int ntiles = a.tiles_m * a.tiles_n, G = gridDim.x;
+
+  const unsigned long bytesA = (unsigned long)a.M * K * 2ul, bytesB = (unsigned long)a.N * K * 2ul;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(a.A), 0, bytesA > 0xFFFFFFFFul ? 0xFFFFFFFFu : (unsigned)bytesA, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(a.B), 0, bytesB > 0xFFFFFFFFul ? 0xFFFFFFFFu : (unsigned)bytesB, 0x00020000);
+  const auto rsO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out), 0, (unsigned)((unsigned long)a.M * a.N * 2ul), 0x00020000);
+
+  auto tile_xy = [&](int orig, int& m0, int& n0) {
+    const int q = ntiles >> 3, r8 = ntiles & 7, xcd = orig & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    int tm, tn;
+    tile_of(a, wg, tm, tn);
+    m0 = tm * 256;
+    n0 = tn * BN_;
+  };
+  unsigned offA[2][2], offB[NB];
+  auto set_offsets = [&](int m0, int n0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = (i * 8 + wave) * 8 + (lane >> 3);
+        offA[h][i] = ((unsigned)(m0 + h * 128 + r) * (unsigned)K + (unsigned)swz(r, lane & 7) * 8u) * 2u;
+      }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int r = (i * 8 + wave) * 8 + (lane >> 3);
+      offB[i] = ((unsigned)(n0 + r) * (unsigned)K + (unsigned)swz(r, lane & 7) * 8u) * 2u;
+    }
+  };
+  auto stageA = [&](int t, int h) {
+    char* slot = smem + (t & 1) * BUF + h * SLOT;
+    const unsigned kt = (unsigned)t * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(slot + (i * 8 + wave) * 1024), 16, offA[h][i], kt, 0, UCOD_LD_AUX_A);
+  };
+  auto stageB = [&](int t) {
+    char* slot = smem + (t & 1) * BUF + 2 * SLOT;
+    const unsigned kt = (unsigned)t * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(slot + (i * 8 + wave) * 1024), 16, offB[i], kt, 0, UCOD_LD_AUX_B);
+  };
+
+  int orig = blockIdx.x;
+  int m0, n0;
+  tile_xy(orig, m0, n0);
+  set_offsets(m0, n0);
+  // column constants of the lane's four columns per column tile (the transposed tile: columns 4g..4g+3)
+  const float* biasp = a.bias;
+  const float* scalep = (EPI == UCOD_EPI_BIAS_BF16 && a.scale) ? a.scale : nullptr;
+  auto load_cc = [&](int ncol0, f32x4 (&b4)[NT], f32x4 (&s4)[NT]) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      int n = ncol0 + j * 16;
+      n = n + 4 <= a.N ? n : a.N - 4;
+      b4[j] = *reinterpret_cast<const f32x4*>(biasp + n);
+      if constexpr (EPI == UCOD_EPI_BIAS_BF16) s4[j] = scalep ? *reinterpret_cast<const f32x4*>(scalep + n) : (f32x4){1.f, 1.f, 1.f, 1.f};
+      else s4[j] = (f32x4){1.f, 1.f, 1.f, 1.f};
+    }
+  };
+  // (bias and scale are applied at the conversion, from loads issued there: 24 registers the main loop does not have)
+  stageA(0, 0);
+  stageA(0, 1);
+  stageB(0);
+  stageB(1);
+  wait_vmcnt<NB>();                                              // K-tile 0 landed, B(1) in flight
+  f32x4 acc[8][NT];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();                     // staggered wave groups
+
+  // pair q of the wave tile's 24 transposed 16 x 16 tiles: q < 8: (row tile q, column tiles 0 | 1); q >= 8: (row tiles 2(q-8) | 2(q-8)+1, column tile 2)
+  u32x4 park[12];                                                // the previous tile, packed bf16, one 16-byte row chunk per pair
+  bool have_parked = false;
+  int pm = 0, pn = 0;                                            // first row / column of the parked wave tile
+  const unsigned row_bytes = (unsigned)a.N * 2u;
+  const int godd = (lane >> 4) & 1, gcol = ((lane >> 4) & 2) * 4;   // odd-g lanes store T1's chunk; chunk column 0 or 8 inside the tile
+  auto park_store = [&](int q) {
+    const int i = q < 8 ? q : 2 * (q - 8) + godd, j = q < 8 ? godd : 2;
+    const int m = pm + i * 16 + (lane & 15), n = pn + j * 16 + gcol;
+    const unsigned off = (m < a.M && n < a.N) ? (unsigned)m * row_bytes + (unsigned)n * 2u : DROP;
+    __builtin_amdgcn_raw_buffer_store_b128(park[q], rsO, off, 0, UCOD_ST_AUX);
+  };
+  const int spk = (12 + nt - 1) / nt;                            // parked stores per K-tile
+
+  for (;;) {
+    const bool has_next = orig + G < ntiles;
+    int m0n = 0, n0n = 0;
+    for (int t = 0; t < nt; ++t) {
+      const char* bufA = smem + (t & 1) * BUF + wm * SLOT;
+      const char* bufB = smem + (t & 1) * BUF + 2 * SLOT;
+      const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+      hx8 fb[NT][2];
+#pragma unroll
+      for (int ph = 0; ph < NPH; ++ph) {
+        bool stored = false;
+        if (ph == 0) {
+          if (more1) { stageA(t + 1, 0); stageA(t + 1, 1); }
+          else if (has_next) { stageA(0, 0); stageA(0, 1); }     // (offsets already those of the next tile: switched at K-tile nt-2)
+          if (t == nt - 2 && has_next) {                         // no DMA of this tile is left to issue: switch to the next tile's sources
+            tile_xy(orig + G, m0n, n0n);
+            set_offsets(m0n, n0n);
+          }
+        }
+        if (ph == 1) {
+          if (more2) stageB(t + 2);
+          else if (has_next) stageB(t + 2 - nt);
+          // the parked store goes out BEHIND this K-tile's DMAs and is left outstanding by the counted wait below (vmcnt NB + 1): it has a
+          // whole K-tile to be acknowledged (variant 20 issues it ahead of the DMAs, so the wait half a K-tile later includes it)
+          if (have_parked && spk == 1 && t < 12) {
+            switch (t) {                                         // (register array: compile-time indices)
+#define PK(Q) case Q: park_store(Q); break;
+              PK(0) PK(1) PK(2) PK(3) PK(4) PK(5) PK(6) PK(7) PK(8) PK(9) PK(10) PK(11)
+#undef PK
+            }
+            stored = true;
+          } else if (have_parked) {
+            for (int q = t * spk; q < (t + 1) * spk && q < 12; ++q) {
+              switch (q) {
+#define PK(Q) case Q: park_store(Q); break;
+                PK(0) PK(1) PK(2) PK(3) PK(4) PK(5) PK(6) PK(7) PK(8) PK(9) PK(10) PK(11)
+#undef PK
+              }
+            }
+          }
+        }
+        if (ph == 0) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const int r = wn * WCOLS + j * 16 + (lane & 15);
+              fb[j][ks] = *reinterpret_cast<const hx8*>(bufB + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+            }
+        }
+        hx8 fa[IT][2];
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int r = ph * (IT * 16) + i * 16 + (lane & 15);
+            fa[i][ks] = *reinterpret_cast<const hx8*>(bufA + r * 128 + swz(r, ks * 4 + (lane >> 4)) * 16);
+          }
+        if (ph == NPH - 1) {
+          if (!(more2 || has_next)) wait_vmcnt<0>();
+          else if (stored) wait_vmcnt<NB + 1>();
+          else wait_vmcnt<NB>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < IT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[ph * IT + i][j] = UCOD_MFMA16(fb[j][ks], fa[i][ks], acc[ph * IT + i][j]);   // transposed tile: lane = row, registers = 4 columns
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- conversion: accumulators -> (scale, GELU) -> packed bf16 row chunks, in registers
+    if (have_parked) {                                           // (only when nt * spk < 12: never for nt >= 12)
+      for (int q = nt * spk; q < 12; ++q) {
+        switch (q) {
+#define PK(Q) case Q: park_store(Q); break;
+          PK(0) PK(1) PK(2) PK(3) PK(4) PK(5) PK(6) PK(7) PK(8) PK(9) PK(10) PK(11)
+#undef PK
+        }
+      }
+    }
+    f32x4 cb[NT], cs[NT];
+    load_cc(n0 + wn * WCOLS + (lane >> 4) * 4, cb, cs);
+    auto cvt = [&](int i, int j, unsigned& w0, unsigned& w1) {
+      f32x4 v = acc[i][j] + cb[j];
+      if constexpr (EPI == UCOD_EPI_BIAS_BF16) v = v * cs[j];
+      if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) {
+        const f32x2 g0 = gelu_erf2((f32x2){v[0], v[1]}), g1 = gelu_erf2((f32x2){v[2], v[3]});
+        v = (f32x4){g0[0], g0[1], g1[0], g1[1]};
+      }
+      w0 = pack_h2(v[0], v[1]);
+      w1 = pack_h2(v[2], v[3]);
+    };
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      const int i0 = q < 8 ? q : 2 * (q - 8), i1 = q < 8 ? q : 2 * (q - 8) + 1, j0 = q < 8 ? 0 : 2, j1 = q < 8 ? 1 : 2;
+      unsigned a0, a1, b0, b1;
+      cvt(i0, j0, a0, a1);
+      cvt(i1, j1, b0, b1);
+      const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);   // [0]: a0 with its odd rows <- b0's even rows; [1]: b0 with its even rows <- a0's odd rows
+      const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+      park[q] = (u32x4){r0[0], r1[0], r0[1], r1[1]};
+    }
+    pm = m0 + wm * 128;
+    pn = n0 + wn * WCOLS;
+    have_parked = true;
+    if (!has_next) break;
+    orig += G;
+    m0 = m0n;
+    n0 = n0n;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int q = 0; q < 12; ++q) park_store(q);
+}
+
 template <int EPI>
 static int launch_lab(GemmArgs a, int variant, hipStream_t s) {
-  if (variant == 20) {                                           // persistent 192-wide kernel with the parked tile (bf16 epilogues only)
+  if (variant == 20 || variant == 21) {                          // persistent 192-wide kernels with the parked tile (bf16 epilogues only)
     if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) {
       const int nt = a.K / BK;
       if ((a.N & 7) != 0 || nt < 2 || (nt & 1) || !a.bias || (long)a.M * a.N * 2 >= (1L << 31) || (long)a.M * a.K * 2 >= (1L << 32) || (long)a.N * a.K * 2 >= (1L << 32))
@@ -445,7 +683,8 @@ static int launch_lab(GemmArgs a, int variant, hipStream_t s) {
       a.tiles_n = cdiv(a.N, 192);
       a.col_fast = a.tiles_n <= 4;
       const int n_cu = device_cus(), ntiles = a.tiles_m * a.tiles_n;
-      hipLaunchKernelGGL((gemm_bf16_park_kernel<EPI>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), 0, s, a);
+      if (variant == 21) hipLaunchKernelGGL((gemm_bf16_park2_kernel<EPI>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((gemm_bf16_park_kernel<EPI>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), 0, s, a);
       UCOD_CHECK_LAUNCH();
       return UCOD_OK;
     } else {
