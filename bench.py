@@ -342,7 +342,7 @@ def main():
     dom = max((n for n in kernels if "tflops" in kernels[n] and n.startswith(("gemm_bf16", "attention"))),
               key=lambda n: kernels[n]["ms_per_step"])
     traffic = None                                            # HBM-side bytes per launch from committed PMC passes (see the file's "source")
-    tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    tpath = next((t for t in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (4, 3)) if os.path.exists(t)), "")
     if os.path.exists(tpath) and a.arch == "dinov2_vitb14" and B == 32 and a.image == 518:
         traffic = json.load(open(tpath)).get("kernels", {}).get(dom, {}).get("traffic_bytes")
     roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
