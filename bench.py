@@ -468,9 +468,16 @@ def cpu_baseline(a, D, heads, L, P):
     dec, ema, disc = OD.init_params(D, gen), OD.init_params(D, gen), ODISC.init_state(68, gen)
     st = OT.TrainState(dec, ema, disc, dict(feature_size=68, ema_weight=0.99, lr0=2e-4, dis_lr0=1e-3, step_lr_size=25, step_lr_gamma=0.95,
                                             dis_step_lr_size=25, dis_step_lr_gamma=0.95, max_epoch=25, start_finetune=-5))
+    v1 = any(k.startswith("blocks.") for k in sd)               # DINO (v1) state dict: timm key names, no LayerScale (BASELINE configs[0])
+    oracle_fwd = OV.dinov1_forward if v1 else OV.dinov2_forward
+    if not v1 and "encoder.layer.0.layer_scale1.lambda1" not in sd:  # HF-format DINO (v1) weights carry no LayerScale: the engine multiplies by nothing,
+        sd = dict(sd)                                                # the oracle by ones
+        for i in range(L):
+            sd[f"encoder.layer.{i}.layer_scale1.lambda1"] = sd[f"encoder.layer.{i}.layer_scale2.lambda1"] = torch.ones(D)
+        v1 = True                                                    # (and the trained-like recipe below does not apply)
     t0 = time.perf_counter()
     with torch.no_grad():
-        _, key = OV.dinov2_forward(img, sd, heads=heads, patch=P, eps=1e-6, full_last_layer=True)
+        _, key = oracle_fwd(img, sd, heads=heads, patch=P, eps=1e-6, full_last_layer=True)
     t1 = time.perf_counter()
     with torch.no_grad():
         fg_ref, _, _ = OD.rev_decoder_forward(torch_bilinear(key, 68, 68), dec, orth="gram")
@@ -485,7 +492,7 @@ def cpu_baseline(a, D, heads, L, P):
     from ucod_dpl_amd.vit_engine import ViTEngine
     from ucod_dpl_amd import parallel
     dev = torch.device("cuda", parallel.device_index())
-    layer_ref = list(OV.dinov2_forward.layer_keys)             # the key hook's map after every layer, f32 oracle
+    layer_ref = list(OV.dinov2_forward.layer_keys) if oracle_fwd is OV.dinov2_forward else None   # the key hook's map after every layer, f32 oracle
     emb = dec["learnable_embedding"].reshape(128).to(dev)
     hw = torch.cat((dec["conv_out_fg.weight"].reshape(64), dec["conv_out_bg.weight"].reshape(64))).to(dev)
     hb = torch.cat((dec["conv_out_fg.bias"], dec["conv_out_bg.bias"])).to(dev)
@@ -514,6 +521,10 @@ def cpu_baseline(a, D, heads, L, P):
     # The same comparison on TRAINED-LIKE synthetic weights (peaked attention rows, LayerScale 0.1 .. 1, two massive residual channels:
     # feature_extractor.trained_like_state_dict) -- the regime a real checkpoint puts the kernels in; the random init above is the flattest.
     from ucod_dpl_amd.data.utils.feature_extractor import trained_like_state_dict
+    if v1:                                                      # (the trained-like recipe scales LayerScale and the HF key names: DINOv2 only)
+        out["parity_full_size"] = {"what": f"{n} images at {a.image}x{a.image}, {a.arch}: device backbone + f32 device decoder vs the f32 oracle "
+                                           f"(same random-init weights); north-star bar: logit max-abs <= 1e-3", **parity("bf16"), "f16_operands": parity("f16")}
+        return out
     sd_p = trained_like_state_dict(a.arch, 0, a.image)
     with torch.no_grad():
         _, key_p = OV.dinov2_forward(img, sd_p, heads=heads, patch=P, eps=1e-6, full_last_layer=False)

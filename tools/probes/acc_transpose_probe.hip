@@ -156,6 +156,36 @@ RATE_KERNEL(rate_cnd_e64, "v_cndmask_b32_e64 %0, %1, %2, %3")
 RATE_KERNEL(rate_bfi, "v_bfi_b32 %0, %1, %2, %1")
 RATE_KERNEL(rate_perm, "v_perm_b32 %0, %1, %2, %1")
 
+// the same without the s_nop the compiler puts between single-instruction asm statements: 30 blocks of 8 independent instructions per pass
+#define RATE8_KERNEL(NAME, I0, I1, I2, I3, I4, I5, I6, I7)                                                  \
+  __global__ void __launch_bounds__(512) NAME(float* __restrict__ sink, int reps, float seed) {            \
+    const int lane = threadIdx.x & 63;                                                                      \
+    float acc[96];                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 96; ++i) acc[i] = seed * (float)(i + 1) + (float)lane;          \
+    for (int it = 0; it < reps; ++it) {                                                                     \
+      _Pragma("unroll") for (int i = 0; i < 96; ++i) asm volatile("" : "+v"(acc[i]));                     \
+      _Pragma("unroll") for (int k = 0; k < 30; ++k) {                                                     \
+        float d0, d1, d2, d3, d4, d5, d6, d7;                                                               \
+        u64 m;                                                                                              \
+        asm volatile(I0 "\n" I1 "\n" I2 "\n" I3 "\n" I4 "\n" I5 "\n" I6 "\n" I7                       \
+                     : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7), "=&s"(m) \
+                     : "v"(acc[(3 * k) % 96]), "v"(acc[(3 * k + 7) % 96]), "s"(0xF0F0F0F0F0F0F0F0ull) : "vcc");        \
+        asm volatile("" :: "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(d4), "v"(d5), "v"(d6), "v"(d7), "s"(m)); \
+      }                                                                                                     \
+    }                                                                                                       \
+    if (seed == 0.12345f) sink[threadIdx.x] = acc[0];                                                       \
+  }
+RATE8_KERNEL(rate8_add, "v_add_f32 %0, %9, %10", "v_add_f32 %1, %9, %10", "v_add_f32 %2, %9, %10", "v_add_f32 %3, %9, %10", "v_add_f32 %4, %9, %10", "v_add_f32 %5, %9, %10",
+             "v_add_f32 %6, %9, %10", "v_add_f32 %7, %9, %10\n s_mov_b64 %8, 0")
+RATE8_KERNEL(rate8_cnd_vcc, "s_mov_b64 vcc, %11\n v_cndmask_b32 %0, %9, %10, vcc", "v_cndmask_b32 %1, %9, %10, vcc", "v_cndmask_b32 %2, %9, %10, vcc", "v_cndmask_b32 %3, %9, %10, vcc",
+             "v_cndmask_b32 %4, %9, %10, vcc", "v_cndmask_b32 %5, %9, %10, vcc", "v_cndmask_b32 %6, %9, %10, vcc", "v_cndmask_b32 %7, %9, %10, vcc\n s_mov_b64 %8, 0")
+RATE8_KERNEL(rate8_cnd_e64, "v_cndmask_b32_e64 %0, %9, %10, %11", "v_cndmask_b32_e64 %1, %9, %10, %11", "v_cndmask_b32_e64 %2, %9, %10, %11", "v_cndmask_b32_e64 %3, %9, %10, %11",
+             "v_cndmask_b32_e64 %4, %9, %10, %11", "v_cndmask_b32_e64 %5, %9, %10, %11", "v_cndmask_b32_e64 %6, %9, %10, %11", "v_cndmask_b32_e64 %7, %9, %10, %11\n s_mov_b64 %8, 0")
+RATE8_KERNEL(rate8_cmp_cnd_vcc, "v_cmp_gt_f32 vcc, %9, %10", "s_nop 1\n v_cndmask_b32 %0, %9, %10, vcc", "v_cmp_lt_f32 vcc, %9, %10", "s_nop 1\n v_cndmask_b32 %1, %9, %10, vcc",
+             "v_cmp_gt_f32 vcc, %10, %9", "s_nop 1\n v_cndmask_b32 %2, %9, %10, vcc", "v_cmp_lt_f32 vcc, %10, %9", "s_nop 1\n v_cndmask_b32 %3, %9, %10, vcc\n v_mov_b32 %4, 0\n v_mov_b32 %5, 0\n v_mov_b32 %6, 0\n v_mov_b32 %7, 0\n s_mov_b64 %8, 0")
+RATE8_KERNEL(rate8_cmp_cnd_e64, "v_cmp_gt_f32 %8, %9, %10", "s_nop 1\n v_cndmask_b32_e64 %0, %9, %10, %8", "v_cmp_lt_f32 %8, %9, %10", "s_nop 1\n v_cndmask_b32_e64 %1, %9, %10, %8",
+             "v_cmp_gt_f32 %8, %10, %9", "s_nop 1\n v_cndmask_b32_e64 %2, %9, %10, %8", "v_cmp_lt_f32 %8, %10, %9", "s_nop 1\n v_cndmask_b32_e64 %3, %9, %10, %8\n v_mov_b32 %4, 0\n v_mov_b32 %5, 0\n v_mov_b32 %6, 0\n v_mov_b32 %7, 0")
+
 static float bf16_to_f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
 static unsigned short f_to_bf16_rne(float f) {
   unsigned u; memcpy(&u, &f, 4);
@@ -214,6 +244,21 @@ int main() {
         CHECK(hipEventElapsedTime(&ms[wps], e0, e1));
       }
     printf("  %-40s 1 wave %7.1f ns   2 waves %7.1f ns\n", e.name, ms[1] * 1e6 / reps, ms[2] * 1e6 / reps);
+  }
+  struct { const char* name; kern_t k; } table8[] = {
+      {"8 x v_add_f32 per block", rate8_add}, {"8 x v_cndmask_b32 (VOP2, vcc) per block", rate8_cnd_vcc}, {"8 x v_cndmask_b32_e64 (sgpr pair) per block", rate8_cnd_e64},
+      {"4 x (v_cmp -> vcc, s_nop 1, v_cndmask VOP2) + 4 v_mov", rate8_cmp_cnd_vcc}, {"4 x (v_cmp -> sgpr pair, s_nop 1, v_cndmask_e64) + 4 v_mov", rate8_cmp_cnd_e64}};
+  printf("blocks of 8 (no compiler s_nop inside a block): ns per pass of 30 blocks\n");
+  for (auto& e : table8) {
+    float ms[3] = {0, 0, 0};
+    for (int wps = 1; wps <= 2; ++wps)
+      for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(e.k, dim3(256), dim3(256 * wps), 0, 0, d_sink, reps, 1.0f);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms[wps], e0, e1));
+      }
+    printf("  %-62s 1 wave %7.1f ns   2 waves %7.1f ns\n", e.name, ms[1] * 1e6 / reps, ms[2] * 1e6 / reps);
   }
   return bad != 0;
 }
