@@ -438,6 +438,9 @@ def main():
         "logit_max_abs": logit_max_abs, "bar": BAR, "bar_met": (None if logit_max_abs is None else bool(logit_max_abs <= BAR)),
         "logit_max_abs_trained_like_weights": own_tl.get("logit_max_abs"),
         "bar_met_trained_like_weights": (None if not own_tl else bool(own_tl["logit_max_abs"] <= BAR)),
+        # the reference's OWN fp16-autocast forward against its f32 forward (emulated on the CPU oracle): [random-init weights, trained-like weights]
+        "logit_max_abs_of_reference_fp16_autocast": [((par or {}).get("reference_fp16_autocast_emulation") or {}).get("logit_max_abs"),
+                                                     (((par or {}).get("trained_like_weights") or {}).get("reference_fp16_autocast_emulation") or {}).get("logit_max_abs")],
         "bar_meeting_config": bar_meeting, "f16_vs_bf16_per_kernel": f16_vs_bf16,
         "host_enqueue_ms_per_step": round(host_enqueue / a.steps * 1e3, 3), "host_threads": host_threads, "host_cores_pinned": pinned_cores,
         "ranks_seen": ranks_seen,
@@ -531,16 +534,29 @@ def cpu_baseline(a, D, heads, L, P):
         fg_p, _, _ = OD.rev_decoder_forward(torch_bilinear(key_p, 68, 68), dec, orth="gram")
     peaked = dict(sd=sd_p, key=key_p, fg_ref=fg_p, layer_ref=None)
 
+    # Second data point: the REFERENCE's own launcher numerics.  `accelerate launch --mixed_precision fp16`
+    # (scripts/launch_train_first_stage.sh:20) autocasts the model forward; oracle/vit.py emulates those roundings (checked against torch's
+    # autocast on the real HF module in tests/test_oracle_autocast.py).  How far that forward sits from ITS f32 self, same images and weights:
+    def autocast_deviation(sd_x, key_x, fg_x):
+        with torch.no_grad():
+            _, key_ac = OV.dinov2_forward(img, sd_x, heads=heads, patch=P, eps=1e-6, full_last_layer=False, autocast=torch.float16)
+            fg_ac, _, _ = OD.rev_decoder_forward(torch_bilinear(key_ac, 68, 68), dec, orth="gram")
+        return {"what": "f32 oracle with torch-autocast(fp16) roundings (linear / matmul operands and results in fp16, LayerNorm / softmax f32) vs the plain f32 oracle; f32 decoder",
+                "key_rel_l2": round(float((key_ac - key_x).norm() / key_x.norm()), 6), "logit_max_abs": round(float((fg_ac - fg_x).abs().max()), 6),
+                "logit_rel_l2": round(float((fg_ac - fg_x).norm() / fg_x.norm()), 6), "mask_flipped_fraction": round(float(((fg_ac > 0) != (fg_x > 0)).float().mean()), 6)}
+
     out["parity_full_size"] = {
         "what": f"{n} images at {a.image}x{a.image}, {a.arch}: device backbone + f32 device decoder vs the f32 oracle (same random-init weights); "
                 f"north-star bar: logit max-abs <= 1e-3",
         **parity("bf16"),
+        "reference_fp16_autocast_emulation": autocast_deviation(sd, key, fg_ref),
         "f16_operands": parity("f16"),                            # engine default for fp16 operands: f32 residual stream
         "f16_operands_f16_stream": parity("f16", "f16"),
         "trained_like_weights": {
             "what": "same images, trained_like_state_dict (pre-softmax score std ~4, row entropy ~3.7 of ln 1370 = 7.2, LayerScale 0.1 .. 1, "
                     "massive channels +-200); reference logits reach |%.2f| (flat init: |%.2f|)" % (float(fg_p.abs().max()), float(fg_ref.abs().max())),
-            "bf16": parity("bf16", **peaked), "f16_operands": parity("f16", **peaked), "f16_operands_f16_stream": parity("f16", "f16", **peaked)}}
+            "bf16": parity("bf16", **peaked), "f16_operands": parity("f16", **peaked), "f16_operands_f16_stream": parity("f16", "f16", **peaked),
+            "reference_fp16_autocast_emulation": autocast_deviation(sd_p, key_p, fg_p)}}
     return out
 
 

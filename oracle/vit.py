@@ -29,16 +29,28 @@ def gelu_erf(x):
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
-def attention(q, k, v, heads):
-    """eager_attention_forward (modeling_dinov2.py:153-179): softmax(QK^T * hd^-0.5) V."""
+def _identity(t):
+    return t
+
+
+def autocast_rounding(dtype):
+    """Rounding of a tensor to the autocast type and back (the f32 container keeps the arithmetic of this file unchanged).  Used to EMULATE what
+    `accelerate launch --mixed_precision fp16` (scripts/launch_train_first_stage.sh:20) does to the reference's forward: torch's CUDA autocast runs
+    linear / matmul / conv in the 16-bit type (operands rounded, f32 accumulation, result rounded) and layer_norm / softmax in f32; mixed adds
+    promote to f32.  None = plain f32 (the cached-feature pass of the reference, base_dataset.py:135-138)."""
+    return _identity if dtype is None else (lambda t: t.to(dtype).float())
+
+
+def attention(q, k, v, heads, r=_identity):
+    """eager_attention_forward (modeling_dinov2.py:153-179): softmax(QK^T * hd^-0.5) V.  ``r``: autocast rounding (see autocast_rounding)."""
     B, N, D = q.shape
     hd = D // heads
     q = q.view(B, N, heads, hd).transpose(1, 2)
     k = k.view(B, N, heads, hd).transpose(1, 2)
     v = v.view(B, N, heads, hd).transpose(1, 2)
-    s = torch.matmul(q, k.transpose(2, 3)) * (hd ** -0.5)
+    s = r(r(torch.matmul(r(q), r(k).transpose(2, 3))) * (hd ** -0.5))
     p = torch.softmax(s, dim=-1)
-    return torch.matmul(p, v).transpose(1, 2).reshape(B, N, D)
+    return r(torch.matmul(r(p), r(v))).transpose(1, 2).reshape(B, N, D)
 
 
 def patch_embed(img, w, b, patch):
@@ -76,23 +88,25 @@ def lora_dropout_mask(seed, layer, proj, rows, D, p):
     return torch.from_numpy(np.where(keep, inv, np.float32(0.0)).astype(np.float32).reshape(rows, D))
 
 
-def _lora_linear(h, sd, name, lora_scale, mask=None):
+def _lora_linear(h, sd, name, lora_scale, mask=None, r=_identity):
     """nn.Linear, plus -- when the state dict carries ``<name>.lora_A.weight`` [r,D] / ``<name>.lora_B.weight`` [D,r] -- the
     peft LoRA branch the reference wraps query/key/value in (models/modules/full_model.py:47-72: r=2, lora_alpha=4,
     bias='none'; peft is not installed here, its published forward is ``base(x) + lora_B(lora_A(dropout(x))) * alpha/r``;
     dropout is the identity in this restatement -- SURVEY.md 8a row B9)."""
-    y = h @ sd[name + ".weight"].t() + sd[name + ".bias"]
+    y = r(r(h) @ r(sd[name + ".weight"]).t() + r(sd[name + ".bias"]))
     if name + ".lora_A.weight" in sd:
         hd = h if mask is None else h * mask.reshape(h.shape)       # nn.Dropout on lora_A's input (train mode)
-        y = y + (hd @ sd[name + ".lora_A.weight"].t()) @ sd[name + ".lora_B.weight"].t() * lora_scale
+        y = r(y + r(r(r(hd) @ r(sd[name + ".lora_A.weight"]).t()) @ r(sd[name + ".lora_B.weight"]).t()) * lora_scale)
     return y
 
 
-def dinov2_forward(img, sd, heads, patch=14, eps=1e-6, n_layers=None, full_last_layer=True, lora_scale=2.0, lora_masks=None):
-    """Returns (last_hidden_state [B,N,D] after the final LayerNorm, key [B,D,h,w])."""
+def dinov2_forward(img, sd, heads, patch=14, eps=1e-6, n_layers=None, full_last_layer=True, lora_scale=2.0, lora_masks=None, autocast=None):
+    """Returns (last_hidden_state [B,N,D] after the final LayerNorm, key [B,D,h,w]).  ``autocast`` = torch.float16 / torch.bfloat16: the same forward
+    with the roundings torch's CUDA autocast would apply (autocast_rounding) -- the reference's launcher numerics as a second data point beside f32."""
     B, _, H, W = img.shape
     pre = "embeddings."
-    x = patch_embed(img, sd[pre + "patch_embeddings.projection.weight"], sd[pre + "patch_embeddings.projection.bias"], patch)
+    r = autocast_rounding(autocast)
+    x = r(patch_embed(r(img), r(sd[pre + "patch_embeddings.projection.weight"]), r(sd[pre + "patch_embeddings.projection.bias"]), patch))
     x = torch.cat((sd[pre + "cls_token"].expand(B, -1, -1), x), 1)
     x = x + dinov2_pos_embed(sd[pre + "position_embeddings"], H // patch, W // patch)
     L = n_layers if n_layers is not None else 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.layer."))
@@ -104,21 +118,21 @@ def dinov2_forward(img, sd, heads, patch=14, eps=1e-6, n_layers=None, full_last_
         h = layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
         a = p + "attention.attention."
         lm = (lambda nm: None) if lora_masks is None else (lambda nm: lora_masks.get((i, nm)))
-        k = _lora_linear(h, sd, a + "key", lora_scale, lm("key"))
+        k = _lora_linear(h, sd, a + "key", lora_scale, lm("key"), r)
         dinov2_forward.layer_keys.append(k[:, 1:, :].reshape(B, gh, gw, -1).permute(0, 3, 1, 2))
         if i == L - 1:
             key = k
             dinov2_forward.last_ln1 = h                 # LN1 output of the last layer (CLS-attention row of the pseudo-label generator)
             if not full_last_layer:
                 break
-        q = _lora_linear(h, sd, a + "query", lora_scale, lm("query"))
-        v = _lora_linear(h, sd, a + "value", lora_scale, lm("value"))
-        o = attention(q, k, v, heads)
-        o = o @ sd[p + "attention.output.dense.weight"].t() + sd[p + "attention.output.dense.bias"]
+        q = _lora_linear(h, sd, a + "query", lora_scale, lm("query"), r)
+        v = _lora_linear(h, sd, a + "value", lora_scale, lm("value"), r)
+        o = attention(q, k, v, heads, r)
+        o = r(r(o) @ r(sd[p + "attention.output.dense.weight"]).t() + r(sd[p + "attention.output.dense.bias"]))
         x = o * sd[p + "layer_scale1.lambda1"] + x
         h = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
-        h = gelu_erf(h @ sd[p + "mlp.fc1.weight"].t() + sd[p + "mlp.fc1.bias"])
-        h = h @ sd[p + "mlp.fc2.weight"].t() + sd[p + "mlp.fc2.bias"]
+        h = r(gelu_erf(r(r(h) @ r(sd[p + "mlp.fc1.weight"]).t() + r(sd[p + "mlp.fc1.bias"]))))
+        h = r(h @ r(sd[p + "mlp.fc2.weight"]).t() + r(sd[p + "mlp.fc2.bias"]))
         x = h * sd[p + "layer_scale2.lambda1"] + x
     last = layer_norm(x, sd["layernorm.weight"], sd["layernorm.bias"], eps) if full_last_layer else None
     key_map = key[:, 1:, :].reshape(B, gh, gw, -1).permute(0, 3, 1, 2)   # feature_extractor.py:55-58

@@ -86,6 +86,24 @@ def test_layernorm_bwd(M, D, with_res):
     assert maxdiff(s.float().cpu(), ref * sc.double()) < 1e-2 * max(1.0, (ref * sc.double()).abs().max().item())
 
 
+@pytest.mark.parametrize("M,D", [(37, 128), (300, 768), (20, 1024)])
+def test_layernorm_bwd_with_bf16_upstream_gradient_equals_the_f32_form_on_rounded_input(M, D):
+    """ucod_layernorm_bwd_b16dy (what ucod_vit_backward feeds from its bf16 dgrad outputs) == ucod_layernorm_bwd on the same values."""
+    g = torch.Generator().manual_seed(M * 5 + D)
+    x = (torch.randn(M, D, generator=g) * 2 + 0.3).to(DEV)
+    gam, sc = torch.randn(D, generator=g).to(DEV), (torch.rand(D, generator=g) + 0.5).to(DEV)
+    dy16 = torch.randn(M, D, generator=g).to(torch.bfloat16).to(DEV)
+    dy32 = dy16.float()
+    dres = torch.randn(M, D, generator=g).to(DEV)
+    out = {}
+    for name, fn, dy in (("f32", N.load().ucod_layernorm_bwd, dy32), ("b16", N.load().ucod_layernorm_bwd_b16dy, dy16)):
+        dx = torch.empty(M, D, device=DEV)
+        s = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+        N.check(fn(N.ptr(dy), N.ptr(x), N.ptr(gam), N.ptr(dres), N.ptr(sc), N.ptr(dx), N.ptr(s), M, D, 1e-6, N.stream()), name)
+        out[name] = (dx.cpu(), s.float().cpu())
+    assert torch.equal(out["f32"][0], out["b16"][0]) and torch.equal(out["f32"][1], out["b16"][1])
+
+
 def test_key_grad_tokens_and_lora_pack():
     B, tok, D, r = 2, 26, 128, 2
     g = torch.Generator().manual_seed(5)

@@ -159,8 +159,9 @@ __global__ __launch_bounds__(256) void ln_lora_kernel(const void* __restrict__ x
 // One wave per row; a lane owns NCH chunks of VW consecutive floats (VW = 4: 16-byte accesses, rows of a multiple of 256 floats; VW = 2 for
 // the other widths).  Everything the row needs from memory -- x, dy, the residual cotangent -- is requested before the first reduction, so
 // that one latency covers all three streams (round 3: 103 -> see profiles/r03_ln_bwd.txt).
-template <int NCH, int VW, bool LORA>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// DYB: dy arrives as bf16 (the dgrad GEMMs of the backward driver write their output in the 16-bit type: half the bytes on both sides).
+template <int NCH, int VW, bool LORA, bool DYB>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      const float* __restrict__ scale, float* __restrict__ dx,
                                                      bf16_raw* __restrict__ sout, int rows, int D, float eps,
@@ -170,14 +171,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const vecf* xr = reinterpret_cast<const vecf*>(x + (size_t)row * D);
-  const vecf* dyr = reinterpret_cast<const vecf*>(dy + (size_t)row * D);
+  typedef unsigned short vech __attribute__((ext_vector_type(VW)));
+  const vecf* dyr = reinterpret_cast<const vecf*>(reinterpret_cast<const float*>(dy_) + (size_t)row * D);
+  const vech* dyh = reinterpret_cast<const vech*>(reinterpret_cast<const bf16_raw*>(dy_) + (size_t)row * D);
   const vecf* rr = dres ? reinterpret_cast<const vecf*>(dres + (size_t)row * D) : nullptr;
   const vecf* g2 = reinterpret_cast<const vecf*>(gamma);
   vecf v[NCH], g[NCH], res[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) v[i] = xr[lane + 64 * i];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) g[i] = dyr[lane + 64 * i];
+  for (int i = 0; i < NCH; ++i) {
+    if constexpr (DYB) {
+      const vech h = dyh[lane + 64 * i];
+#pragma unroll
+      for (int e = 0; e < VW; ++e) g[i][e] = bf16_to_f32(h[e]);
+    } else {
+      g[i] = dyr[lane + 64 * i];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) res[i] = rr ? rr[lane + 64 * i] : (vecf)(0.f);
   float s = 0.f;
@@ -532,14 +543,17 @@ extern "C" int ucod_layernorm_lora_h16(const void* x_f16, const float* gamma, co
   return launch_ln_lora(x_f16, true, gamma, beta, lora, r, y_aug, rows, D, eps, dropout, stream);
 }
 
-static int launch_ln_bwd(const float* dy, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx, void* s_bf16,
+static int launch_ln_bwd(const void* dy, bool dy_bf16, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx, void* s_bf16,
                          int rows, int D, float eps, const bf16_raw* tq, int ldt, const float* lora, int r, const Drop& drop, hipStream_t s) {
   dim3 grid(cdiv(rows, 4)), block(256);
   const bool lo = tq != nullptr;
+#define L(n, vw, lora_, dyb_) hipLaunchKernelGGL((ln_bwd_kernel<n, vw, lora_, dyb_>), grid, block, 0, s, dy, x, gamma, dres, next_scale, dx, (bf16_raw*)s_bf16, rows, D, eps, tq, ldt, lora, r, drop)
 #define C(n, vw)                                                                                                                               \
   case n:                                                                                                                                      \
-    if (lo) hipLaunchKernelGGL((ln_bwd_kernel<n, vw, true>), grid, block, 0, s, dy, x, gamma, dres, next_scale, dx, (bf16_raw*)s_bf16, rows, D, eps, tq, ldt, lora, r, drop); \
-    else hipLaunchKernelGGL((ln_bwd_kernel<n, vw, false>), grid, block, 0, s, dy, x, gamma, dres, next_scale, dx, (bf16_raw*)s_bf16, rows, D, eps, tq, ldt, lora, r, drop); \
+    if (lo && dy_bf16) L(n, vw, true, true);                                                                                                   \
+    else if (lo) L(n, vw, true, false);                                                                                                        \
+    else if (dy_bf16) L(n, vw, false, true);                                                                                                   \
+    else L(n, vw, false, false);                                                                                                               \
     break;
   if (D % 256 == 0) {                                      // 16-byte accesses
     switch (D / 256) {
@@ -553,6 +567,7 @@ static int launch_ln_bwd(const float* dy, const float* x, const float* gamma, co
     }
   }
 #undef C
+#undef L
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }
@@ -562,7 +577,15 @@ extern "C" int ucod_layernorm_bwd(const float* dy, const float* x, const float* 
   UCOD_BF16_ONLY();
   if (!dy || !x || !gamma || (!dx && !s_bf16) || rows <= 0 || D <= 0 || (D % 128) != 0) return UCOD_EINVAL;
   UCOD_PROF(PROF_LN_BWD, stream);
-  return launch_ln_bwd(dy, x, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, nullptr, 0, nullptr, 0, make_drop(nullptr), (hipStream_t)stream);
+  return launch_ln_bwd(dy, false, x, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, nullptr, 0, nullptr, 0, make_drop(nullptr), (hipStream_t)stream);
+}
+
+extern "C" int ucod_layernorm_bwd_b16dy(const void* dy_bf16, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
+                                        void* s_bf16, int rows, int D, float eps, void* stream) {
+  UCOD_BF16_ONLY();
+  if (!dy_bf16 || !x || !gamma || (!dx && !s_bf16) || rows <= 0 || D <= 0 || (D % 128) != 0) return UCOD_EINVAL;
+  UCOD_PROF(PROF_LN_BWD, stream);
+  return launch_ln_bwd(dy_bf16, true, x, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, nullptr, 0, nullptr, 0, make_drop(nullptr), (hipStream_t)stream);
 }
 
 extern "C" int ucod_layernorm_bwd_lora(const float* dy, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
@@ -573,7 +596,19 @@ extern "C" int ucod_layernorm_bwd_lora(const float* dy, const float* x, const fl
       !dropout || dropout->p < 0.f || dropout->p >= 1.f)
     return UCOD_EINVAL;
   UCOD_PROF(PROF_LN_BWD, stream);
-  return launch_ln_bwd(dy, x, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, (const bf16_raw*)dqkv_aug + 3 * D, 3 * D + AUG, lora_layer, r,
+  return launch_ln_bwd(dy, false, x, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, (const bf16_raw*)dqkv_aug + 3 * D, 3 * D + AUG, lora_layer, r,
+                       make_drop(dropout), (hipStream_t)stream);
+}
+
+extern "C" int ucod_layernorm_bwd_lora_b16dy(const void* dy_bf16, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
+                                             void* s_bf16, int rows, int D, float eps, const void* dqkv_aug, const float* lora_layer, int r,
+                                             const ucod_lora_dropout* dropout, void* stream) {
+  UCOD_BF16_ONLY();
+  if (!dy_bf16 || !x || !gamma || (!dx && !s_bf16) || rows <= 0 || D <= 0 || (D % 128) != 0 || !dqkv_aug || !lora_layer || r < 1 || 3 * r > AUG ||
+      !dropout || dropout->p < 0.f || dropout->p >= 1.f)
+    return UCOD_EINVAL;
+  UCOD_PROF(PROF_LN_BWD, stream);
+  return launch_ln_bwd(dy_bf16, true, x, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, (const bf16_raw*)dqkv_aug + 3 * D, 3 * D + AUG, lora_layer, r,
                        make_drop(dropout), (hipStream_t)stream);
 }
 

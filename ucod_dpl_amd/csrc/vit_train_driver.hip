@@ -237,13 +237,21 @@ extern "C" int ucod_vit_backward(const ucod_vit_train_desc* t, const void* const
   void* lgw = ws + p.lgw;
   const size_t lgw_bytes = ucod_lora_grad_workspace_bytes(D);
 
+  // dgrad outputs that feed a LayerNorm backward (dh) are written as bf16 (UCOD_DGRAD_F32=1: f32, the round-3 path): the GEMM's drain and the
+  // LayerNorm backward's read side move half the bytes; the residual cotangent stream (dx) stays f32
+  static const bool dgrad16 = !(getenv("UCOD_DGRAD_F32") && getenv("UCOD_DGRAD_F32")[0] == '1');
+  const int epi_dh = dgrad16 ? UCOD_EPI_BIAS_BF16 : UCOD_EPI_BIAS_F32;
+  auto ln_bwd_plain = [&](const void* dy, const float* x, const float* gam, const float* dres, const float* next_scale) -> int {
+    return dgrad16 ? ucod_layernorm_bwd_b16dy(dy, x, gam, dres, next_scale, dx, s, M, D, d->eps, stream)
+                   : ucod_layernorm_bwd((const float*)dy, x, gam, dres, next_scale, dx, s, M, D, d->eps, stream);
+  };
   auto qkv_side = [&](int l) -> int {   // dqkv_aug (k/q/v thirds filled) -> LoRA grads of layer l, dh = d LN1 output
     const void* const* X = TT + UCOD_VIT_TRAIN_STRIDE * l;
     const void* h_aug = ws + p.h_aug + p.s_h * l;
     const ucod_lora_dropout drop{t->lora_dropout, t->seed, l};
     RUN(ucod_lora_grad(dqkv, h_aug, (const float*)X[5], r, t->lora_scaling, (float*)X[6], 0, lgw, lgw_bytes, M, D,
                        t->lora_dropout > 0.f ? &drop : nullptr, stream));
-    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_F32, dqkv, X[1], dh, M, D, KQ, nullptr, nullptr, nullptr, nullptr, tok, gv, stream));
+    RUN(ucod_gemm_bf16(epi_dh, dqkv, X[1], dh, M, D, KQ, nullptr, nullptr, nullptr, nullptr, tok, gv, stream));
     return UCOD_OK;
   };
 
@@ -251,10 +259,11 @@ extern "C" int ucod_vit_backward(const ucod_vit_train_desc* t, const void* const
   auto ln1_bwd = [&](int l, const float* dy, const float* x, const float* gam, const float* dres, const float* next_scale) -> int {
     if (t->lora_dropout > 0.f) {
       const ucod_lora_dropout drop{t->lora_dropout, t->seed, l};
-      return ucod_layernorm_bwd_lora(dy, x, gam, dres, next_scale, dx, s, M, D, d->eps, dqkv, (const float*)(TT + UCOD_VIT_TRAIN_STRIDE * l)[5], r, &drop,
-                                     stream);
+      const float* lora_l = (const float*)(TT + UCOD_VIT_TRAIN_STRIDE * l)[5];
+      return dgrad16 ? ucod_layernorm_bwd_lora_b16dy(dy, x, gam, dres, next_scale, dx, s, M, D, d->eps, dqkv, lora_l, r, &drop, stream)
+                     : ucod_layernorm_bwd_lora(dy, x, gam, dres, next_scale, dx, s, M, D, d->eps, dqkv, lora_l, r, &drop, stream);
     }
-    return ucod_layernorm_bwd(dy, x, gam, dres, next_scale, dx, s, M, D, d->eps, stream);
+    return ln_bwd_plain(dy, x, gam, dres, next_scale);
   };
 
   // last layer: only the key projection reaches the loss
@@ -278,8 +287,8 @@ extern "C" int ucod_vit_backward(const ucod_vit_train_desc* t, const void* const
     const void* pre = ws + p.pre + p.s_pre * l;
     // MLP branch: s = ls2 * dx  ->  fc2 dgrad (x gelu')  ->  fc1 dgrad  ->  LN2 backward + residual
     RUN(ucod_gemm_bf16_train(UCOD_EPI_GELU_BWD_BF16, s, X[4], dpre, M, F, D, nullptr, pre, nullptr, gv, stream));
-    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_F32, dpre, X[3], dh, M, D, F, nullptr, nullptr, nullptr, nullptr, tok, gv, stream));
-    RUN(ucod_layernorm_bwd(dh, x_mid, (const float*)W[7], dx, (const float*)W[6], dx, s, M, D, d->eps, stream));
+    RUN(ucod_gemm_bf16(epi_dh, dpre, X[3], dh, M, D, F, nullptr, nullptr, nullptr, nullptr, tok, gv, stream));
+    RUN(ln_bwd_plain(dh, x_mid, (const float*)W[7], dx, (const float*)W[6]));
     // attention branch: s = ls1 * dx  ->  out-proj dgrad  ->  attention backward  ->  LoRA grads + qkv dgrad  ->  LN1 backward
     RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_BF16, s, X[2], da, M, D, D, nullptr, nullptr, nullptr, nullptr, tok, gv, stream));
     RUN(ucod_attention_bwd(qkv, att, da, lse, delta, dqkv, KQ, d->B, tok, d->heads, stream));
