@@ -98,10 +98,11 @@ v_dma_v = V(18, 2)
 v_qoff = V(20, 2)
 v_ooff = V(22, 2)
 v_lseoff = V(24)
-v_l = V(25, 2)
-v_m = V(27, 2)
-v_tt = V(29)              # DETECT's copy of T[0]
-v_tmp = V(30, 2)
+v_lp = [V(30, 2), V(26, 2)]   # per q-block: the two partial row sums as one 64-bit aligned pair (v_pk_add_f32)
+v_l = [v_lp[0][0], v_lp[1][0]]
+v_tmp = [v_lp[0][1], v_lp[1][1]]
+v_m = V(28, 2)
+v_tt = V(25)              # DETECT's copy of T[0]
 v_E = V(32, 8)
 v_P = [V(40, 8), V(48, 8)]
 v_negm = [V(56, 16), V(72, 16)]
@@ -520,12 +521,21 @@ class Gen:
             def ad(k):
                 return (lambda: p.v_add_f32(acc[k & 1], acc[k & 1], v_E[k % 8]), 1, "add")
 
+            def pad(w):      # both partial sums at once: (l, tmp) += (E[2w], E[2w+1]) -- the same additions as ad(2w), ad(2w+1)
+                return (lambda: p.v_pk_add_f32(v_lp[qb], v_lp[qb], v_E[(2 * w) % 8:(2 * w) % 8 + 2]), 1, "add")
+
             def cv(w):
                 return (lambda: self.cvt_pk(Px[w], v_E[(2 * w) % 8], v_E[(2 * w + 1) % 8]), 1, "cvt")
-            order += [ex(0), ex(1), ex(2), ad(0), ex(3), ad(1), cv(0)]
+            if "pksum" not in self.abl:      # default: plain adds.  v_pk_add_f32 does not overlap with an MFMA in flight (~10 matrix-pipe cycles each): pw64 190 -> 230 us with it
+                order += [ex(0), ex(1), ex(2), ad(0), ex(3), ad(1), cv(0)]
+                for w in range(1, 7):
+                    order += [ex(2 * w + 2), ad(2 * w), ex(2 * w + 3), ad(2 * w + 1), cv(w)]
+                order += [ad(14), ad(15), cv(7)]
+                return order
+            order += [ex(0), ex(1), ex(2), ex(3), pad(0), cv(0)]
             for w in range(1, 7):
-                order += [ex(2 * w + 2), ad(2 * w), ex(2 * w + 3), ad(2 * w + 1), cv(w)]
-            order += [ad(14), ad(15), cv(7)]
+                order += [ex(2 * w + 2), ex(2 * w + 3), pad(w), cv(w)]
+            order += [pad(7), cv(7)]
             return order
 
         def ex(k):

@@ -60,7 +60,7 @@ v_tid, v_lane, v_l31, v_h5 = V(0), V(1), V(2), V(3)
 v_koffb, v_ka = V(4, 4), V(8, 4)
 v_voffb, v_va = V(12, 2), V(14, 2)
 v_dma_k, v_dma_v, v_qoff, v_ooff, v_lseoff = V(16), V(17), V(18), V(19), V(20)
-v_l = V(21, 2)
+v_l = V(26, 2)          # the two partial row sums: a 64-bit aligned pair (v_pk_add_f32)
 v_m = V(23)
 v_qdma = V(24)
 v_qrd = V(25)            # LDS address of this lane's Q fragment (sd = 0)
@@ -430,10 +430,18 @@ class Gen32:
 
         def cv(w):
             return (lambda: self.cvt_pk(Px[w], v_E[(2 * w) % 8], v_E[(2 * w + 1) % 8]), 1, "cvt")
-        order = [ex(0), ex(1), ex(2), ad(0), ex(3), ad(1), cv(0)]
+        def pad(w):          # (l0, l1) += (E[2w], E[2w+1]): the additions of ad(2w), ad(2w+1) in one packed instruction
+            return (lambda: p.v_pk_add_f32(v_l, v_l, v_E[(2 * w) % 8:(2 * w) % 8 + 2]), 1, "add")
+        if "pksum" not in self.abl:      # default: plain adds.  v_pk_add_f32 does not overlap with an MFMA in flight (~10 matrix-pipe cycles each): pw64 190 -> 230 us with it
+            order = [ex(0), ex(1), ex(2), ad(0), ex(3), ad(1), cv(0)]
+            for w in range(1, 7):
+                order += [ex(2 * w + 2), ad(2 * w), ex(2 * w + 3), ad(2 * w + 1), cv(w)]
+            order += [ad(14), ad(15), cv(7)]
+            return order
+        order = [ex(0), ex(1), ex(2), ex(3), pad(0), cv(0)]
         for w in range(1, 7):
-            order += [ex(2 * w + 2), ad(2 * w), ex(2 * w + 3), ad(2 * w + 1), cv(w)]
-        order += [ad(14), ad(15), cv(7)]
+            order += [ex(2 * w + 2), ex(2 * w + 3), pad(w), cv(w)]
+        order += [pad(7), cv(7)]
         return order
 
     def item_start(self, Sx, Px):

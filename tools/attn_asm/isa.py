@@ -175,6 +175,12 @@ class Prog:
 
     def v_mov_b32(self, d, a): return self._valu("v_mov_b32", d, a)
     def v_add_f32(self, d, a, b): return self._valu("v_add_f32", d, a, b)
+    def v_pk_add_f32(self, d, a, b):
+        """packed f32 add: d[0:1] = a[0:1] + b[0:1] (64-bit aligned register pairs; full rate: two adds per lane and instruction)"""
+        for r in (d, a, b):
+            assert r.n == 2 and r.idx % 2 == 0, r
+        return self._valu("v_pk_add_f32", d, a, b)
+
     def v_sub_f32(self, d, a, b): return self._valu("v_sub_f32", d, a, b)
     def v_mul_f32(self, d, a, b): return self._valu("v_mul_f32", d, a, b)
     def v_max_f32(self, d, a, b): return self._valu("v_max_f32", d, a, b)

@@ -243,6 +243,9 @@ class Machine:
             self.wv(w, d, rd(w, s[0]))
         elif n == "v_add_f32":
             self.wf(w, d, rf(w, s[0]) + rf(w, s[1]))
+        elif n == "v_pk_add_f32":
+            for k in range(2):
+                self.wf(w, d[k], rf(w, s[0][k]) + rf(w, s[1][k]))
         elif n == "v_sub_f32":
             self.wf(w, d, rf(w, s[0]) - rf(w, s[1]))
         elif n == "v_mul_f32":

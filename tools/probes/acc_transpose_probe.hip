@@ -177,6 +177,12 @@ RATE_KERNEL(rate_perm, "v_perm_b32 %0, %1, %2, %1")
   }
 RATE8_KERNEL(rate8_add, "v_add_f32 %0, %9, %10", "v_add_f32 %1, %9, %10", "v_add_f32 %2, %9, %10", "v_add_f32 %3, %9, %10", "v_add_f32 %4, %9, %10", "v_add_f32 %5, %9, %10",
              "v_add_f32 %6, %9, %10", "v_add_f32 %7, %9, %10\n s_mov_b64 %8, 0")
+RATE8_KERNEL(rate8_add_chain, "v_add_f32 %0, %9, %10", "v_add_f32 %0, %0, %10", "v_add_f32 %0, %0, %10", "v_add_f32 %0, %0, %10", "v_add_f32 %0, %0, %10", "v_add_f32 %0, %0, %10",
+             "v_add_f32 %0, %0, %10", "v_add_f32 %0, %0, %10\n v_mov_b32 %1, %0\n v_mov_b32 %2, %0\n v_mov_b32 %3, %0\n v_mov_b32 %4, %0\n v_mov_b32 %5, %0\n v_mov_b32 %6, %0\n v_mov_b32 %7, %0\n s_mov_b64 %8, 0")
+RATE8_KERNEL(rate8_exp_chain, "v_exp_f32 %0, %9", "v_exp_f32 %0, %0", "v_exp_f32 %0, %0", "v_exp_f32 %0, %0", "v_exp_f32 %0, %0", "v_exp_f32 %0, %0",
+             "v_exp_f32 %0, %0", "v_exp_f32 %0, %0\n v_mov_b32 %1, %0\n v_mov_b32 %2, %0\n v_mov_b32 %3, %0\n v_mov_b32 %4, %0\n v_mov_b32 %5, %0\n v_mov_b32 %6, %0\n v_mov_b32 %7, %0\n s_mov_b64 %8, 0")
+RATE8_KERNEL(rate8_exp, "v_exp_f32 %0, %9", "v_exp_f32 %1, %9", "v_exp_f32 %2, %9", "v_exp_f32 %3, %9", "v_exp_f32 %4, %10", "v_exp_f32 %5, %10",
+             "v_exp_f32 %6, %10", "v_exp_f32 %7, %10\n s_mov_b64 %8, 0")
 RATE8_KERNEL(rate8_cnd_vcc, "s_mov_b64 vcc, %11\n v_cndmask_b32 %0, %9, %10, vcc", "v_cndmask_b32 %1, %9, %10, vcc", "v_cndmask_b32 %2, %9, %10, vcc", "v_cndmask_b32 %3, %9, %10, vcc",
              "v_cndmask_b32 %4, %9, %10, vcc", "v_cndmask_b32 %5, %9, %10, vcc", "v_cndmask_b32 %6, %9, %10, vcc", "v_cndmask_b32 %7, %9, %10, vcc\n s_mov_b64 %8, 0")
 RATE8_KERNEL(rate8_cnd_e64, "v_cndmask_b32_e64 %0, %9, %10, %11", "v_cndmask_b32_e64 %1, %9, %10, %11", "v_cndmask_b32_e64 %2, %9, %10, %11", "v_cndmask_b32_e64 %3, %9, %10, %11",
@@ -185,6 +191,64 @@ RATE8_KERNEL(rate8_cmp_cnd_vcc, "v_cmp_gt_f32 vcc, %9, %10", "s_nop 1\n v_cndmas
              "v_cmp_gt_f32 vcc, %10, %9", "s_nop 1\n v_cndmask_b32 %2, %9, %10, vcc", "v_cmp_lt_f32 vcc, %10, %9", "s_nop 1\n v_cndmask_b32 %3, %9, %10, vcc\n v_mov_b32 %4, 0\n v_mov_b32 %5, 0\n v_mov_b32 %6, 0\n v_mov_b32 %7, 0\n s_mov_b64 %8, 0")
 RATE8_KERNEL(rate8_cmp_cnd_e64, "v_cmp_gt_f32 %8, %9, %10", "s_nop 1\n v_cndmask_b32_e64 %0, %9, %10, %8", "v_cmp_lt_f32 %8, %9, %10", "s_nop 1\n v_cndmask_b32_e64 %1, %9, %10, %8",
              "v_cmp_gt_f32 %8, %10, %9", "s_nop 1\n v_cndmask_b32_e64 %2, %9, %10, %8", "v_cmp_lt_f32 %8, %10, %9", "s_nop 1\n v_cndmask_b32_e64 %3, %9, %10, %8\n v_mov_b32 %4, 0\n v_mov_b32 %5, 0\n v_mov_b32 %6, 0\n v_mov_b32 %7, 0")
+
+// packed f32: 240 instructions per pass on 64-bit aligned register pairs (independent destinations)
+#define RATEPK_KERNEL(NAME, TEXT)                                                                          \
+  __global__ void __launch_bounds__(512) NAME(float* __restrict__ sink, int reps, float seed) {            \
+    const int lane = threadIdx.x & 63;                                                                      \
+    double acc[48];                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 48; ++i) acc[i] = (double)(seed * (float)(i + 1) + (float)lane); \
+    for (int it = 0; it < reps; ++it) {                                                                     \
+      _Pragma("unroll") for (int i = 0; i < 48; ++i) asm volatile("" : "+v"(acc[i]));                     \
+      _Pragma("unroll") for (int k = 0; k < 30; ++k) {                                                     \
+        double d0, d1, d2, d3, d4, d5, d6, d7;                                                              \
+        asm volatile(TEXT : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7) \
+                     : "v"(acc[(3 * k) % 48]), "v"(acc[(3 * k + 7) % 48]));                                 \
+        asm volatile("" :: "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(d4), "v"(d5), "v"(d6), "v"(d7));        \
+      }                                                                                                     \
+    }                                                                                                       \
+    if (seed == 0.12345f) sink[threadIdx.x] = (float)acc[0];                                                \
+  }
+#define PK8(OP) OP " %0, %8, %9\n" OP " %1, %8, %9\n" OP " %2, %8, %9\n" OP " %3, %8, %9\n" OP " %4, %8, %9\n" OP " %5, %8, %9\n" OP " %6, %8, %9\n" OP " %7, %8, %9"
+RATEPK_KERNEL(ratepk_add, PK8("v_pk_add_f32"))
+RATEPK_KERNEL(ratepk_mul, PK8("v_pk_mul_f32"))
+RATEPK_KERNEL(ratepk_fma, "v_pk_fma_f32 %0, %8, %9, %8\n v_pk_fma_f32 %1, %8, %9, %8\n v_pk_fma_f32 %2, %8, %9, %8\n v_pk_fma_f32 %3, %8, %9, %8\n v_pk_fma_f32 %4, %8, %9, %8\n v_pk_fma_f32 %5, %8, %9, %8\n v_pk_fma_f32 %6, %8, %9, %8\n v_pk_fma_f32 %7, %8, %9, %8")
+RATEPK_KERNEL(ratepk_addf64, PK8("v_add_f64"))
+// dependent chains: every instruction reads the previous one's result
+RATEPK_KERNEL(ratepk_add_chain, "v_pk_add_f32 %0, %8, %9\n v_pk_add_f32 %0, %0, %9\n v_pk_add_f32 %0, %0, %9\n v_pk_add_f32 %0, %0, %9\n v_pk_add_f32 %0, %0, %9\n v_pk_add_f32 %0, %0, %9\n v_pk_add_f32 %0, %0, %9\n v_pk_add_f32 %0, %0, %9\n v_pk_mov_b32 %1, %0, %0\n v_pk_mov_b32 %2, %0, %0\n v_pk_mov_b32 %3, %0, %0\n v_pk_mov_b32 %4, %0, %0\n v_pk_mov_b32 %5, %0, %0\n v_pk_mov_b32 %6, %0, %0\n v_pk_mov_b32 %7, %0, %0")
+RATEPK_KERNEL(ratepk_addf64_chain, "v_add_f64 %0, %8, %9\n v_add_f64 %0, %0, %9\n v_add_f64 %0, %0, %9\n v_add_f64 %0, %0, %9\n v_add_f64 %0, %0, %9\n v_add_f64 %0, %0, %9\n v_add_f64 %0, %0, %9\n v_add_f64 %0, %0, %9\n v_pk_mov_b32 %1, %0, %0\n v_pk_mov_b32 %2, %0, %0\n v_pk_mov_b32 %3, %0, %0\n v_pk_mov_b32 %4, %0, %0\n v_pk_mov_b32 %5, %0, %0\n v_pk_mov_b32 %6, %0, %0\n v_pk_mov_b32 %7, %0, %0")
+
+// does a vector instruction overlap with an MFMA in flight on the same SIMD?  One wave per SIMD, per pass 32 x { one 32x32x16 MFMA (8 passes = 32
+// cycles, four independent accumulators in rotation), FILL }.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+#define MFMA_MIX_KERNEL(NAME, FILL)                                                                        \
+  __global__ void __launch_bounds__(256) NAME(float* __restrict__ sink, int reps, float seed) {            \
+    const int lane = threadIdx.x & 63;                                                                      \
+    f32x16_t c0, c1, c2, c3;                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) { c0[i] = seed; c1[i] = seed; c2[i] = seed; c3[i] = seed; } \
+    f32x4_t a = {seed, seed, seed, seed}, b = {seed + (float)lane, seed, seed, seed};                       \
+    double x = (double)seed, y = (double)lane;                                                              \
+    float xf = seed, yf = (float)lane;                                                                      \
+    for (int it = 0; it < reps; ++it) {                                                                     \
+      _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                      \
+        double d0, d1, d2, d3;                                                                              \
+        float f0, f1, f2, f3;                                                                               \
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %12, %13, %0\n" FILL "v_mfma_f32_32x32x16_bf16 %1, %12, %13, %1\n" FILL   \
+                     "v_mfma_f32_32x32x16_bf16 %2, %12, %13, %2\n" FILL "v_mfma_f32_32x32x16_bf16 %3, %12, %13, %3\n" FILL   \
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3) \
+                     : "v"(a), "v"(b), "v"(x), "v"(y), "v"(xf), "v"(yf));                                   \
+        asm volatile("" :: "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(f0), "v"(f1), "v"(f2), "v"(f3));        \
+      }                                                                                                     \
+    }                                                                                                       \
+    if (seed == 0.12345f) sink[threadIdx.x] = c0[0] + c1[0] + c2[0] + c3[0];                               \
+  }
+MFMA_MIX_KERNEL(mix_none, "")
+MFMA_MIX_KERNEL(mix_add4, "v_add_f32 %8, %16, %17\n v_add_f32 %9, %16, %17\n v_add_f32 %10, %16, %17\n v_add_f32 %11, %16, %17\n")
+MFMA_MIX_KERNEL(mix_pk2, "v_pk_add_f32 %4, %14, %15\n v_pk_add_f32 %5, %14, %15\n")
+MFMA_MIX_KERNEL(mix_pk1_add2, "v_pk_add_f32 %4, %14, %15\n v_add_f32 %8, %16, %17\n v_add_f32 %9, %16, %17\n")
+MFMA_MIX_KERNEL(mix_exp2, "v_exp_f32 %8, %16\n v_exp_f32 %9, %17\n")
+MFMA_MIX_KERNEL(mix_f64, "v_add_f64 %4, %14, %15\n")
 
 static float bf16_to_f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
 static unsigned short f_to_bf16_rne(float f) {
@@ -246,7 +310,8 @@ int main() {
     printf("  %-40s 1 wave %7.1f ns   2 waves %7.1f ns\n", e.name, ms[1] * 1e6 / reps, ms[2] * 1e6 / reps);
   }
   struct { const char* name; kern_t k; } table8[] = {
-      {"8 x v_add_f32 per block", rate8_add}, {"8 x v_cndmask_b32 (VOP2, vcc) per block", rate8_cnd_vcc}, {"8 x v_cndmask_b32_e64 (sgpr pair) per block", rate8_cnd_e64},
+      {"8 x v_add_f32 per block", rate8_add}, {"8 x v_add_f32, each reading the previous result (+ 7 v_mov)", rate8_add_chain}, {"8 x v_exp_f32 independent", rate8_exp}, {"8 x v_exp_f32, each reading the previous result (+ 7 v_mov)", rate8_exp_chain},
+      {"8 x v_cndmask_b32 (VOP2, vcc) per block", rate8_cnd_vcc}, {"8 x v_cndmask_b32_e64 (sgpr pair) per block", rate8_cnd_e64},
       {"4 x (v_cmp -> vcc, s_nop 1, v_cndmask VOP2) + 4 v_mov", rate8_cmp_cnd_vcc}, {"4 x (v_cmp -> sgpr pair, s_nop 1, v_cndmask_e64) + 4 v_mov", rate8_cmp_cnd_e64}};
   printf("blocks of 8 (no compiler s_nop inside a block): ns per pass of 30 blocks\n");
   for (auto& e : table8) {
@@ -259,6 +324,36 @@ int main() {
         CHECK(hipEventElapsedTime(&ms[wps], e0, e1));
       }
     printf("  %-62s 1 wave %7.1f ns   2 waves %7.1f ns\n", e.name, ms[1] * 1e6 / reps, ms[2] * 1e6 / reps);
+  }
+  struct { const char* name; kern_t k; } tablepk[] = {
+      {"8 x v_pk_add_f32 per block", ratepk_add}, {"8 x v_pk_mul_f32 per block", ratepk_mul}, {"8 x v_pk_fma_f32 per block", ratepk_fma},
+      {"8 x v_add_f64 per block", ratepk_addf64},
+      {"8 x v_pk_add_f32, each reading the previous result (+ 7 v_pk_mov)", ratepk_add_chain}, {"8 x v_add_f64, each reading the previous result (+ 7 v_pk_mov)", ratepk_addf64_chain}};
+  printf("packed f32 (64-bit register pairs): ns per pass of 30 blocks of 8\n");
+  for (auto& e : tablepk) {
+    float ms[3] = {0, 0, 0};
+    for (int wps = 1; wps <= 2; ++wps)
+      for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(e.k, dim3(256), dim3(256 * wps), 0, 0, d_sink, reps, 1.0f);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms[wps], e0, e1));
+      }
+    printf("  %-62s 1 wave %7.1f ns   2 waves %7.1f ns\n", e.name, ms[1] * 1e6 / reps, ms[2] * 1e6 / reps);
+  }
+  struct { const char* name; kern_t k; } tablemix[] = {
+      {"MFMA alone", mix_none}, {"MFMA + 4 v_add_f32", mix_add4}, {"MFMA + 2 v_pk_add_f32", mix_pk2}, {"MFMA + 1 v_pk_add_f32 + 2 v_add_f32", mix_pk1_add2},
+      {"MFMA + 2 v_exp_f32", mix_exp2}, {"MFMA + 1 v_add_f64", mix_f64}};
+  printf("32x32x16 bf16 MFMA (32 cycles) with vector fillers behind each, one wave per SIMD: ns per 32 MFMAs (zero data: the clock is not power-limited)\n");
+  for (auto& e : tablemix) {
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+      CHECK(hipEventRecord(e0));
+      hipLaunchKernelGGL(e.k, dim3(256), dim3(256), 0, 0, d_sink, reps, 0.0f);
+      CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    printf("  %-50s %7.1f ns\n", e.name, ms * 1e6 / reps);
   }
   return bad != 0;
 }

@@ -204,12 +204,19 @@ constexpr float DEFER_THR = 8.0f;
 #ifndef UCOD_ATTN_SCALAR_SUM
 #define UCOD_ATTN_SCALAR_SUM 1
 #endif
-__device__ __forceinline__ void sum_pair(f32x2_t& acc, const f32x2_t& e) {
+// Round 4: the accumulators are two SCALARS -- with a two-element vector accumulator the DAG combiner still re-forms a v_pk_add_f32 for the
+// pairs whose registers happen to be adjacent (2 per 32-key block), and a v_pk_*_f32 does not overlap with an MFMA in flight: it costs ~10
+// cycles of matrix-pipe time (tools/probes/acc_transpose_probe.hip, "MFMA + 2 v_pk_add_f32": 438.7 -> 721.7 ns per 32 MFMAs; four plain
+// v_add_f32 overlap completely).
+__device__ __forceinline__ void sum_pair(float& acc0, float& acc1, const f32x2_t& e) {
 #if UCOD_ATTN_SCALAR_SUM
-  acc[0] += e[0];
-  acc[1] += e[1];
+  acc0 += e[0];
+  acc1 += e[1];
 #else
-  acc += e;
+  f32x2_t a = {acc0, acc1};
+  a += e;
+  acc0 = a[0];
+  acc1 = a[1];
 #endif
 }
 
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
   float m_run = 0.f;
-  f32x2_t lsum = {0.f, 0.f};
+  float lsum0 = 0.f, lsum1 = 0.f;
   const int nt = (N + KT - 1) / KT, nfull = nt - 1;
   const bool half_dead = nfull * KT + 32 >= N;           // (uniform) the keys of the last tile's second 32-key block all lie past the last token
 
@@ -359,7 +366,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
           o[0][i] *= alpha;
           o[1][i] *= alpha;
         }
-        lsum *= alpha;
+        lsum0 *= alpha;
+        lsum1 *= alpha;
       }
       hx8 pb[2];
 #pragma unroll
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const f32x2_t e = {__builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(s[kt][8 * ks + 2 * jj + 1])};
-          sum_pair(lsum, e);
+          sum_pair(lsum0, lsum1, e);
           w[jj] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_t));
         }
         pb[ks] = __builtin_bit_cast(hx8, w);
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
   }
   if (!live) return;
 
-  const float lane_sum = lsum[0] + lsum[1];
+  const float lane_sum = lsum0 + lsum1;
   const float denom = lane_sum + __shfl_xor(lane_sum, 32, 64);
   const float inv = 1.0f / denom;
   const int q = q0 + l31;
