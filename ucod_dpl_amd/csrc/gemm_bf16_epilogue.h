@@ -340,27 +340,18 @@ constexpr bool kRowMapped = (EPI == UCOD_EPI_KEY_NCHW_F32 || EPI == UCOD_EPI_PAT
 template <int EPI, int NT>
 constexpr bool kFastRowMapped = kRowMapped<EPI> && NT == 4;
 
-template <int EPI, int NT, int NI = 8, int AUX = UCOD_ST_AUX, bool FASTRM = false>
-__device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI][NT], const float (&cs)[NT], char* wbase,
-                                             int m_first, int n_first, int lane) {
+// The drain proper takes a STAGER: stage(pass) writes the wave's 32 x WCOLS f32 values of pass `pass` (column scale applied) into the wave-private
+// staging area, row-major.  big_epilogue() below supplies the one for 16 x 16 accumulator tiles; a kernel on 32 x 32 MFMA tiles supplies its own.
+template <int EPI>
+constexpr bool kStageScaled = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_QKV_FP8 ||
+                               EPI == UCOD_EPI_BIAS_SCALE_RESID_H16);
+
+template <int EPI, int NT, int NI, int AUX, bool FASTRM, class Stage>
+__device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Stage& stage, char* wbase, int m_first, int n_first, int lane) {
   constexpr int WCOLS = 16 * NT, PR = 32;
   constexpr int NP = (NI + 1) / 2;                    // passes of 32 rows; with NI odd the last pass holds 16 rows (rows 16..31 masked off)
   static_assert(NI == 8 || kColFused<EPI>, "odd row-tile counts only in the column-fused epilogues");
   auto rows_in = [&](int pass) { return (NI - 2 * pass) >= 2 ? 32 : 16; };
-  auto stage = [&](int pass) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        if (pass * 2 + i >= NI) continue;
-        f32x4 v = acc[pass * 2 + i < NI ? pass * 2 + i : 0][j];
-        if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_QKV_FP8 ||
-                      EPI == UCOD_EPI_BIAS_SCALE_RESID_H16) v = v * cs[j];
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * (WCOLS * 4) + (j * 16 + (lane & 15)) * 4) = v[rg];
-      }
-  };
   if constexpr (FASTRM && EPI == UCOD_EPI_KEY_NCHW_F32) {
     // out f32 [B, C = M, tok-1]; the lane's four tokens (columns) are the same for every row, so its byte offset is one register plus a
     // wave-uniform row term.  Four consecutive tokens of one image, none of them CLS: one 16-byte store (rows start 4-byte aligned only:
@@ -686,5 +677,26 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
   }
 }
 
+
+// 16 x 16 accumulator tiles (C layout: col = lane & 15, row = 4 * (lane >> 4) + reg), bias already inside, cs = per-column scale
+template <int EPI, int NT, int NI = 8, int AUX = UCOD_ST_AUX, bool FASTRM = false>
+__device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI][NT], const float (&cs)[NT], char* wbase,
+                                             int m_first, int n_first, int lane) {
+  constexpr int WCOLS = 16 * NT;
+  auto stage = [&](int pass) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (pass * 2 + i >= NI) continue;
+        f32x4 v = acc[pass * 2 + i < NI ? pass * 2 + i : 0][j];
+        if constexpr (kStageScaled<EPI>) v = v * cs[j];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * (WCOLS * 4) + (j * 16 + (lane & 15)) * 4) = v[rg];
+      }
+  };
+  big_epilogue_staged<EPI, NT, NI, AUX, FASTRM>(a, stage, wbase, m_first, n_first, lane);
+}
 
 }  // namespace ucod

@@ -672,6 +672,151 @@ __global__ __launch_bounds__(512) void gemm_bf16_park2_kernel(const GemmArgs a) 
   for (int q = 0; q < 12; ++q) park_store(q);
 }
 
+// =====================================================================================================
+// Variant 22 (round 4, experiment): the product's large-tile kernel (256 x 256 x 64, 8 waves, two barrier intervals per K-tile, staggered wave
+// groups) on v_mfma_f32_32x32x16 instead of v_mfma_f32_16x16x32.  Why: an MFMA holds its SIMD's vector issue for 8 cycles whatever its shape
+// (MI355X_MICROARCH.md, per-instruction constants) -- 8 of 16 for the 16 x 16 x 32 form, 8 of 32 for the 32 x 32 x 16 form -- and the wave
+// that shares the SIMD issues its fragment reads and LDS-DMAs (~60 cycles of issue each) exactly while its partner is in its MFMA interval:
+// with 16 x 16 tiles that interval leaves half the issue cycles, with 32 x 32 tiles three quarters.  Same LDS images, same DMA schedule, same
+// number of fragment reads; accumulators 4 x 2 tiles of 16 registers; drain through big_epilogue_staged with a stager for the 32 x 32 C layout
+// (col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).
+// =====================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_big32_kernel(const GemmArgs a) {
+  constexpr int NT = 4, NPH = 2, IT = 2, JT = 2;                  // per phase: 2 row tiles of 32; 2 column tiles of 32 per wave
+  using Cfg = BigCfg<NT>;
+  __shared__ __attribute__((aligned(16))) char smem[2 * Cfg::BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+  int tm, tn;
+  tile_of(a, wg, tm, tn);
+  const int m0 = tm * 256, n0 = tn * Cfg::BN_;
+  const int K = a.K, nt = K / BK;
+  const bf16_raw* srcA[2][2];
+  const bf16_raw* srcB[Cfg::NB];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (i * 8 + wave) * 8 + (lane >> 3);
+      int gr = m0 + h * 128 + r;
+      gr = gr < a.M ? gr : a.M - 1;
+      srcA[h][i] = a.A + (size_t)gr * K + swz(r, lane & 7) * 8;
+    }
+#pragma unroll
+  for (int i = 0; i < Cfg::NB; ++i) {
+    const int r = (i * 8 + wave) * 8 + (lane >> 3);
+    int gr = n0 + r;
+    gr = gr < a.N ? gr : a.N - 1;
+    srcB[i] = a.B + (size_t)gr * K + swz(r, lane & 7) * 8;
+  }
+  auto dmaA = [&](const bf16_raw* src, char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, UCOD_LD_AUX_A);
+  };
+  auto dmaB = [&](const bf16_raw* src, char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, UCOD_LD_AUX_B);
+  };
+  auto stageA = [&](int t, int h) {
+    char* slot = smem + (t & 1) * Cfg::BUF + h * SLOT_A;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dmaA(srcA[h][i] + t * BK, slot + (i * 8 + wave) * 1024);
+  };
+  auto stageB = [&](int t) {
+    char* slot = smem + (t & 1) * Cfg::BUF + 2 * SLOT_A;
+#pragma unroll
+    for (int i = 0; i < Cfg::NB; ++i) dmaB(srcB[i] + t * BK, slot + (i * 8 + wave) * 1024);
+  };
+  // per-column constants of the lane's two columns (32-wide tiles: col = lane & 31)
+  float cb[JT], cs[JT];
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+    int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    n = n < a.N ? n : a.N - 1;
+    cb[j] = a.bias ? a.bias[n] : 0.f;
+    cs[j] = (EPI == UCOD_EPI_BIAS_BF16 && a.scale) ? a.scale[n] : 1.f;
+  }
+  stageA(0, 0);
+  stageA(0, 1);
+  stageB(0);
+  if (nt > 1) stageB(1);
+  if (nt > 1) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
+  f32x16 acc[4][JT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = cb[j];
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+  const int chunk_hi = lane >> 5;                                  // which 8 of a k-step's 16 k values this lane supplies
+  for (int t = 0; t < nt; ++t) {
+    const char* bufA = smem + (t & 1) * Cfg::BUF + wm * SLOT_A;
+    const char* bufB = smem + (t & 1) * Cfg::BUF + 2 * SLOT_A;
+    const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+    hx8 fb[JT][4];
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+      if (ph == 0 && more1) { stageA(t + 1, 0); stageA(t + 1, 1); }
+      if (ph == 1 && more2) stageB(t + 2);
+      if (ph == 0) {
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const int r = wn * 64 + j * 32 + (lane & 31);
+            fb[j][ks] = *reinterpret_cast<const hx8*>(bufB + r * 128 + swz(r, ks * 2 + chunk_hi) * 16);
+          }
+      }
+      hx8 fa[IT][4];
+#pragma unroll
+      for (int i = 0; i < IT; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int r = ph * 64 + i * 32 + (lane & 31);
+          fa[i][ks] = *reinterpret_cast<const hx8*>(bufA + r * 128 + swz(r, ks * 2 + chunk_hi) * 16);
+        }
+      if (ph == NPH - 1) {
+        if (more2) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+#pragma unroll
+          for (int j = 0; j < JT; ++j)
+            acc[ph * IT + i][j] = UCOD_MFMA32(fa[i][ks], fb[j][ks], acc[ph * IT + i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+  char* wbase = smem + wave * (32 * 16 * NT * 4);
+  auto stage = [&](int pass) {                                     // pass = the wave's row tile of 32
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      f32x16 v = acc[pass][j];
+      if constexpr (kStageScaled<EPI>) v = v * cs[j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        *reinterpret_cast<float*>(wbase + ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * (16 * NT * 4) + (j * 32 + (lane & 31)) * 4) = v[r];
+    }
+  };
+  big_epilogue_staged<EPI, NT, 8, UCOD_ST_AUX, false>(a, stage, wbase, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
+
 template <int EPI>
 static int launch_lab(GemmArgs a, int variant, hipStream_t s) {
   if (variant == 20 || variant == 21) {                          // persistent 192-wide kernels with the parked tile (bf16 epilogues only)
@@ -685,6 +830,19 @@ static int launch_lab(GemmArgs a, int variant, hipStream_t s) {
       const int n_cu = device_cus(), ntiles = a.tiles_m * a.tiles_n;
       if (variant == 21) hipLaunchKernelGGL((gemm_bf16_park2_kernel<EPI>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), 0, s, a);
       else hipLaunchKernelGGL((gemm_bf16_park_kernel<EPI>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), 0, s, a);
+      UCOD_CHECK_LAUNCH();
+      return UCOD_OK;
+    } else {
+      return UCOD_EINVAL;
+    }
+  }
+  if (variant == 22) {                                           // the plain large-tile kernel on 32 x 32 x 16 MFMAs (no patches: whole grid)
+    if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_BIAS_F32) {
+      if ((a.N & 7) != 0) return UCOD_EINVAL;
+      a.tiles_m = cdiv(a.M, 256);
+      a.tiles_n = cdiv(a.N, 256);
+      a.col_fast = a.tiles_n <= 4;
+      hipLaunchKernelGGL((gemm_bf16_big32_kernel<EPI>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
       UCOD_CHECK_LAUNCH();
       return UCOD_OK;
     } else {
