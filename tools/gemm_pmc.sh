@@ -11,8 +11,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/gemm_pmc/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "gemm_bf16_big_kernel" in k:
-            key = k.split("gemm_bf16_big_kernel")[1][:14] + " grid" + r.get("Grid_Size", "?")
+        if "gemm_bf16_big_kernel" in k or "gemm_bf16_mixed_kernel" in k:
+            key = k.split("gemm_bf16_")[1][:28] + " grid" + r.get("Grid_Size", "?")
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for key in sorted(agg):
     c = {n: sum(v) / len(v) for n, v in agg[key].items()}
