@@ -98,6 +98,10 @@ void ucod_gemm_reload_tuning(void);
  * stream sync).  A non-zero count means the f16 stream cannot hold this checkpoint's activations: use resid16 = 0 (ViTEngine(resid="f32")). */
 int ucod_resid16_overflow_fetch(unsigned* host_dst, void* stream);
 int ucod_resid16_overflow_reset(void* stream);
+/* A counter of the caller's own (round 4): the launches issued NEXT FROM THIS HOST THREAD count into `device_counter` (one zero-initialised
+ * device word, e.g. one per engine) instead of the per-device word, and fetch / reset act on it; NULL restores the per-device word.  The
+ * binding is host-side state read at launch time: bind, issue the pass, unbind. */
+int ucod_resid16_overflow_bind(unsigned* device_counter);
 
 /* nn.LayerNorm over the last dim (modeling_dinov2.py:348,353,365,373,441; dino.py:127,131,184):
  * x f32 [rows,D] -> y bf16 [rows,D] (or f32 when out_f32 != 0).  D % 128 == 0. */

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 if not torch.cuda.is_available():
     pytest.skip("needs a GPU", allow_module_level=True)
 
-from ucod_dpl_amd import ops  # noqa: E402
+from ucod_dpl_amd import ops, native as N  # noqa: E402
 from ucod_dpl_amd.vit_engine import ViTEngine  # noqa: E402
 from ucod_dpl_amd.data.utils.feature_extractor import random_state_dict, trained_like_state_dict, ARCHS  # noqa: E402
 from oracle import decoder as OD, vit as OV  # noqa: E402
@@ -249,6 +249,26 @@ def test_fp16_stream_saturates_and_reports(half):
     # the f32 stream holds the same model without complaint
     e32 = ViTEngine(sd, heads=4, eps=1e-6, device=DEV, half=half, resid="f32")
     assert bool(torch.isfinite(e32(img.to(DEV))).all())
+
+
+def test_saturation_is_reported_by_the_engine_that_caused_it():
+    """Two engines with the fp16 stream on one GPU: each counts into its own device word (ucod_resid16_overflow_bind), so the healthy one never raises
+    for the other's saturation, in either order of polling (the counter used to be one word per device)."""
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(11))
+    bad = ViTEngine(_massive_state_dict(1.0e5), heads=4, eps=1e-6, device=DEV, half="bf16", resid="f16")
+    good = ViTEngine(_massive_state_dict(1.0e3), heads=4, eps=1e-6, device=DEV, half="bf16", resid="f16")
+    for order in ((bad, good), (good, bad)):
+        for e in order:
+            e(img.to(DEV))
+        good.check_overflow(wait=True)                          # no FloatingPointError
+        good(img.to(DEV))                                       # (the non-blocking poll inside forward) neither
+        with pytest.raises(FloatingPointError):
+            bad.check_overflow(wait=True)
+    # the per-device word is untouched by bound passes
+    host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    N.check(N.load().ucod_resid16_overflow_fetch(host.data_ptr(), N.stream()), "fetch")
+    torch.cuda.synchronize()
+    assert int(host[0]) == 0
 
 
 def test_backward_engine_refuses_the_fp16_stream():

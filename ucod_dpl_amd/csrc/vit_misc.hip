@@ -372,7 +372,12 @@ __global__ void cast_kernel(const float* __restrict__ s, bf16_raw* __restrict__ 
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = f32_to_h(s[i]);
 }
 
+// A caller that wants its OWN counter (one per engine instead of one per device) binds a device word for the launches it issues next on
+// this host thread (ucod_resid16_overflow_bind); NULL restores the per-device word.
+static thread_local unsigned* t_bound_counter = nullptr;
+
 unsigned* resid16_overflow_counter() {
+  if (t_bound_counter) return t_bound_counter;
   static unsigned* table[64] = {};                                   // one address per device of this process
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -386,6 +391,11 @@ unsigned* resid16_overflow_counter() {
 }
 
 }  // namespace ucod
+
+extern "C" int ucod_resid16_overflow_bind(unsigned* device_counter) {
+  ucod::t_bound_counter = device_counter;
+  return UCOD_OK;
+}
 
 extern "C" int ucod_resid16_overflow_fetch(unsigned* host_dst, void* stream) {
   unsigned* c = ucod::resid16_overflow_counter();

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ucod_gemm_reload_tuning": (None, []),
     "ucod_resid16_overflow_fetch": (ci, [vp, vp]),
     "ucod_resid16_overflow_reset": (ci, [vp]),
+    "ucod_resid16_overflow_bind": (ci, [vp]),
     "ucod_layernorm": (ci, [vp, vp, vp, vp, ci, ci, cf, ci, vp]),
     "ucod_layernorm_h16": (ci, [vp, vp, vp, vp, ci, ci, cf, vp]),
     "ucod_attention_fwd": (ci, [vp, vp, ci, ci, ci, cf, ci, vp]),

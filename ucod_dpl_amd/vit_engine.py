@@ -125,7 +125,7 @@ class ViTEngine:
             raise ValueError("the backbone-backward engine keeps the f32 residual stream (its backward kernels read it): resid='f16' is not available")
         self.resid = resid
         self.resid16 = bool(resid == "f16" or (resid == "auto" and half == "bf16" and self._allow_resid16))
-        self._ovf_host, self._ovf_events = None, []
+        self._ovf_host, self._ovf_events, self._ovf_dev = None, [], None
         if attn_variant not in (0, 1, 2, 8, 5, 64, 32):
             raise ValueError(f"attn_variant must be 0, 1, 2, 5, 8, 32 or 64 (laboratory kernels are reached through ops.attention(variant=...)), got {attn_variant}")
         c = normalize_state_dict(state_dict)
@@ -187,6 +187,22 @@ class ViTEngine:
         return d
 
     # ---- fp16 residual stream: saturation guard --------------------------------------------------------------------------------
+    def _own_counter(self):
+        """Context: the library's fp16-stream kernels launched from this thread count into THIS engine's device word (ucod_resid16_overflow_bind),
+        so that one engine's saturation is never reported by another engine that shares the GPU."""
+        eng = self
+
+        class _Bound:
+            def __enter__(self_):
+                if eng._ovf_dev is None:
+                    eng._ovf_dev = torch.zeros(1, dtype=torch.int32, device=eng.device)
+                N.check(eng.lib.ucod_resid16_overflow_bind(eng._ovf_dev.data_ptr()), "ucod_resid16_overflow_bind")
+
+            def __exit__(self_, *exc):
+                eng.lib.ucod_resid16_overflow_bind(None)
+                return False
+        return _Bound()
+
     def _arm_overflow_check(self, stream, used_resid16=None):
         """Enqueue an asynchronous copy of the device's saturation counter behind the pass just launched on ``stream``.  ``used_resid16``:
         whether THAT pass ran the fp16 stream (default: the engine's setting; the LoRA engine's no-grad teacher pass says so itself)."""
@@ -194,7 +210,8 @@ class ViTEngine:
             return
         if self._ovf_host is None:
             self._ovf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        N.check(self.lib.ucod_resid16_overflow_fetch(self._ovf_host.data_ptr(), stream.cuda_stream), "ucod_resid16_overflow_fetch")
+        with self._own_counter():
+            N.check(self.lib.ucod_resid16_overflow_fetch(self._ovf_host.data_ptr(), stream.cuda_stream), "ucod_resid16_overflow_fetch")
         ev = torch.cuda.Event()
         ev.record(stream)
         self._ovf_events.append(ev)
@@ -218,13 +235,13 @@ class ViTEngine:
             for ev in self._ovf_events:
                 ev.synchronize()
             self._ovf_events = []
-            N.check(self.lib.ucod_resid16_overflow_reset(N.stream()), "ucod_resid16_overflow_reset")
+            with self._own_counter():
+                N.check(self.lib.ucod_resid16_overflow_reset(N.stream()), "ucod_resid16_overflow_reset")
             torch.cuda.current_stream(self.device).synchronize()
             self._ovf_host.zero_()
             how = "build the engine with resid='f32'" if self.resid16 else "call forward_nograd(..., resid16=False)"
-            raise FloatingPointError(f"the fp16 residual stream saturated at +-65504 (or met a NaN) in {n} wave-lane(s) on this device: the "
-                                     f"activations do not fit fp16; {how}.  (The counter is per device: another engine of this process that "
-                                     f"runs the fp16 stream on the same GPU shares it.)")
+            raise FloatingPointError(f"the fp16 residual stream of this engine saturated at +-65504 (or met a NaN) in {n} wave-lane(s): the "
+                                     f"activations do not fit fp16; {how}.")
 
     _allow_resid16 = True                                      # the backbone-backward engine keeps the f32 stream (its kernels read it)
     _sync_check = os.environ.get("UCOD_CHECK_RESID") == "1"    # debug: check the saturation counter synchronously after every pass
@@ -255,8 +272,9 @@ class ViTEngine:
                 raise ValueError("unsupported ViT geometry")
             if self._ws is None or self._ws.numel() < need:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-            N.check(lib.ucod_vit_forward(C.byref(d), table, N.ptr(img), N.ptr(key), N.ptr(self._ws), self._ws.numel(), N.stream()),
-                    "ucod_vit_forward")
+            with self._own_counter():
+                N.check(lib.ucod_vit_forward(C.byref(d), table, N.ptr(img), N.ptr(key), N.ptr(self._ws), self._ws.numel(), N.stream()),
+                        "ucod_vit_forward")
             self._arm_overflow_check(torch.cuda.current_stream(self.device))
             if self._sync_check:
                 self.check_overflow(wait=True)
@@ -289,8 +307,9 @@ class ViTEngine:
             img.record_stream(st)                                  # allocated on the caller's stream, consumed on this one: keep the
             key.record_stream(st)                                  # caching allocator from recycling them before this stream is done
             with torch.cuda.stream(st):
-                N.check(lib.ucod_vit_forward(C.byref(d), table, N.ptr(img[b0:b1]), N.ptr(key[b0:b1]), N.ptr(self._side_ws[i]),
-                                             self._side_ws[i].numel(), N.stream()), "ucod_vit_forward")
+                with self._own_counter():
+                    N.check(lib.ucod_vit_forward(C.byref(d), table, N.ptr(img[b0:b1]), N.ptr(key[b0:b1]), N.ptr(self._side_ws[i]),
+                                                 self._side_ws[i].numel(), N.stream()), "ucod_vit_forward")
                 self._arm_overflow_check(st)
                 done = torch.cuda.Event()
                 done.record(st)
@@ -541,8 +560,9 @@ class ViTLoRAEngine(ViTEngine):
             if self._iside_ws[i] is None or self._iside_ws[i].numel() < need:
                 self._iside_ws[i] = torch.empty(need, dtype=torch.uint8, device=self.device)
             T, TT, keep = self._tables(gh, gw, self._tside_grad[i])
-            N.check(lib.ucod_vit_forward_lora_infer(C.byref(t), T, TT, N.ptr(img[b0:b1]), N.ptr(key[b0:b1]), N.ptr(self._iside_ws[i]),
-                                                    self._iside_ws[i].numel(), N.stream()), "ucod_vit_forward_lora_infer")
+            with self._own_counter():
+                N.check(lib.ucod_vit_forward_lora_infer(C.byref(t), T, TT, N.ptr(img[b0:b1]), N.ptr(key[b0:b1]), N.ptr(self._iside_ws[i]),
+                                                        self._iside_ws[i].numel(), N.stream()), "ucod_vit_forward_lora_infer")
             # this engine's own stream type is f32 (its backward reads it), but THIS pass may run the fp16 one: its saturation counter is
             # fetched behind every chunk and polled by the next call / check_overflow(wait=True) at the loop's boundaries
             self._arm_overflow_check(torch.cuda.current_stream(self.device), used_resid16=bool(resid16))
