@@ -200,13 +200,17 @@ int ucod_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
 int ucod_layernorm_bwd_lora(const float* dy, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
                             void* s_bf16, int rows, int D, float eps, const void* dqkv_aug_bf16, const float* lora_layer, int r,
                             const ucod_lora_dropout* dropout, void* stream);
-/* Both with dy as bf16 [rows,D] (what ucod_vit_backward's dgrad GEMMs write since round 4: half the bytes on the GEMM's store-bound drain and on
- * this kernel's read side; the upstream gradient is rounded to 8 mantissa bits once, the residual cotangent stream dx stays f32). */
-int ucod_layernorm_bwd_b16dy(const void* dy_bf16, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
-                             void* s_bf16, int rows, int D, float eps, void* stream);
-int ucod_layernorm_bwd_lora_b16dy(const void* dy_bf16, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
-                                  void* s_bf16, int rows, int D, float eps, const void* dqkv_aug_bf16, const float* lora_layer, int r,
-                                  const ucod_lora_dropout* dropout, void* stream);
+/* Both with 16-bit inputs (round 4): flags & UCOD_LNB_DY_BF16: dy is bf16 [rows,D] (what ucod_vit_backward's dgrad GEMMs write: half the bytes on the
+ * GEMM's store-bound drain and on this kernel's read side; the upstream gradient is rounded to 8 mantissa bits once, the residual cotangent
+ * stream dx stays f32); flags & UCOD_LNB_X_F16 (only together with DY_BF16): x is IEEE fp16 (the saved residual stream of a training pass
+ * with vit.resid16).  flags = 0: the two functions above. */
+#define UCOD_LNB_DY_BF16 1
+#define UCOD_LNB_X_F16 2
+int ucod_layernorm_bwd_ex(const void* dy, const void* x, int flags, const float* gamma, const float* dres, const float* next_scale, float* dx,
+                          void* s_bf16, int rows, int D, float eps, void* stream);
+int ucod_layernorm_bwd_lora_ex(const void* dy, const void* x, int flags, const float* gamma, const float* dres, const float* next_scale, float* dx,
+                               void* s_bf16, int rows, int D, float eps, const void* dqkv_aug_bf16, const float* lora_layer, int r,
+                               const ucod_lora_dropout* dropout, void* stream);
 
 /* Attention forward that also returns the base-2 log-sum-exp of the scaled scores, lse f32 [B, heads, tok]
  * (Q must carry head_dim^-0.5 * log2(e), as for ucod_attention_fwd with scale == 0). */

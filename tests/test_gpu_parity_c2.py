@@ -271,10 +271,27 @@ def test_saturation_is_reported_by_the_engine_that_caused_it():
     assert int(host[0]) == 0
 
 
-def test_backward_engine_refuses_the_fp16_stream():
+def test_backward_engine_on_both_residual_streams():
+    """Round 4: the backbone-backward engine saves the fp16 residual stream by default (bf16 operands), like the frozen engine; LayerNorm backward reads
+    it (ucod_layernorm_bwd_ex).  Key map and LoRA gradients of the two streams agree at the level of the operands' own rounding."""
     from ucod_dpl_amd.vit_engine import ViTLoRAEngine
-    ARCHS["tiny_vit"] = (128, 2, 2, 14, 70, True)
-    eng = ViTLoRAEngine(random_state_dict("tiny_vit", seed=1), heads=2, device=DEV)
-    assert eng.resid16 is False and eng._desc(64, 70, 70).resid16 == 0
-    with pytest.raises(ValueError):
-        ViTEngine.__init__(ViTLoRAEngine.__new__(ViTLoRAEngine), random_state_dict("tiny_vit", seed=1), heads=2, device=DEV, resid="f16")
+    ARCHS["tiny_vit"] = (128, 2, 3, 14, 70, True)
+    sd = random_state_dict("tiny_vit", seed=1)
+    out = {}
+    for resid in ("auto", "f32"):
+        eng = ViTLoRAEngine(sd, heads=2, device=DEV, resid=resid, generator=torch.Generator().manual_seed(3))
+        lsd = eng.lora_state_dict()
+        g = torch.Generator().manual_seed(5)
+        for k in lsd:
+            if "lora_B" in k:
+                lsd[k] = 0.05 * torch.randn(lsd[k].shape, generator=g)
+        eng.load_lora_state_dict(lsd)
+        assert eng.resid16 is (resid == "auto") and eng._desc(64, 70, 70).resid16 == int(resid == "auto")
+        x = torch.randn(4, 3, 70, 70, generator=torch.Generator().manual_seed(6))
+        key = eng.forward_train(x.to(DEV))
+        eng.backward(torch.randn(key.shape, generator=torch.Generator().manual_seed(7)).to(DEV))
+        eng.check_overflow(wait=True)
+        out[resid] = (key.cpu(), eng.lora_grad.cpu().clone())
+    assert rel_l2(out["auto"][0], out["f32"][0]) < 5e-3
+    assert rel_l2(out["auto"][1], out["f32"][1]) < 2e-2
+    record("lora_engine_streams", dict(key_rel_l2=rel_l2(out["auto"][0], out["f32"][0]), grad_rel_l2=rel_l2(out["auto"][1], out["f32"][1])))

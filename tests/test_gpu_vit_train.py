@@ -87,21 +87,28 @@ def test_layernorm_bwd(M, D, with_res):
 
 
 @pytest.mark.parametrize("M,D", [(37, 128), (300, 768), (20, 1024)])
-def test_layernorm_bwd_with_bf16_upstream_gradient_equals_the_f32_form_on_rounded_input(M, D):
-    """ucod_layernorm_bwd_b16dy (what ucod_vit_backward feeds from its bf16 dgrad outputs) == ucod_layernorm_bwd on the same values."""
+def test_layernorm_bwd_with_16_bit_inputs_equals_the_f32_form_on_rounded_input(M, D):
+    """ucod_layernorm_bwd_ex: dy as bf16 (what ucod_vit_backward feeds from its dgrad GEMMs) and x as fp16 (the saved residual stream of a training pass with
+    vit.resid16) == ucod_layernorm_bwd on the same values held in f32."""
     g = torch.Generator().manual_seed(M * 5 + D)
-    x = (torch.randn(M, D, generator=g) * 2 + 0.3).to(DEV)
+    x16 = (torch.randn(M, D, generator=g) * 2 + 0.3).to(torch.float16).to(DEV)
+    x32 = x16.float()
     gam, sc = torch.randn(D, generator=g).to(DEV), (torch.rand(D, generator=g) + 0.5).to(DEV)
     dy16 = torch.randn(M, D, generator=g).to(torch.bfloat16).to(DEV)
     dy32 = dy16.float()
     dres = torch.randn(M, D, generator=g).to(DEV)
-    out = {}
-    for name, fn, dy in (("f32", N.load().ucod_layernorm_bwd, dy32), ("b16", N.load().ucod_layernorm_bwd_b16dy, dy16)):
+    lib, out = N.load(), {}
+    for name, dy, x, flags in (("f32", dy32, x32, None), ("dy16", dy16, x32, 1), ("both16", dy16, x16, 3)):
         dx = torch.empty(M, D, device=DEV)
         s = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
-        N.check(fn(N.ptr(dy), N.ptr(x), N.ptr(gam), N.ptr(dres), N.ptr(sc), N.ptr(dx), N.ptr(s), M, D, 1e-6, N.stream()), name)
+        if flags is None:
+            N.check(lib.ucod_layernorm_bwd(N.ptr(dy), N.ptr(x), N.ptr(gam), N.ptr(dres), N.ptr(sc), N.ptr(dx), N.ptr(s), M, D, 1e-6, N.stream()), name)
+        else:
+            N.check(lib.ucod_layernorm_bwd_ex(N.ptr(dy), N.ptr(x), flags, N.ptr(gam), N.ptr(dres), N.ptr(sc), N.ptr(dx), N.ptr(s), M, D, 1e-6, N.stream()), name)
         out[name] = (dx.cpu(), s.float().cpu())
-    assert torch.equal(out["f32"][0], out["b16"][0]) and torch.equal(out["f32"][1], out["b16"][1])
+    for name in ("dy16", "both16"):
+        assert torch.equal(out["f32"][0], out[name][0]) and torch.equal(out["f32"][1], out[name][1]), name
+    assert lib.ucod_layernorm_bwd_ex(N.ptr(dy32), N.ptr(x16), 2, N.ptr(gam), N.ptr(dres), N.ptr(sc), N.ptr(dx), N.ptr(s), M, D, 1e-6, N.stream()) != 0   # fp16 x only with bf16 dy
 
 
 def test_key_grad_tokens_and_lora_pack():

@@ -12,7 +12,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 streams = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 lib = N.load()
 drop = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0   # the reference trains with lora_dropout 0.05 (configs/model/UCOD_DPL.py)
-eng = ViTLoRAEngine(random_state_dict("dinov2_vitb14", seed=0), heads=12, device="cuda", lora_dropout=drop)
+resid = sys.argv[5] if len(sys.argv) > 5 else "auto"      # residual stream of the training pass: auto (fp16 with bf16 operands) / f32
+eng = ViTLoRAEngine(random_state_dict("dinov2_vitb14", seed=0), heads=12, device="cuda", lora_dropout=drop, resid=resid)
 eng.train_streams = streams
 x = torch.randn(B, 3, 518, 518, device="cuda")
 dkey = torch.randn(B, 768, 37, 37, device="cuda")

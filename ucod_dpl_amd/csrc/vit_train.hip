@@ -149,6 +149,107 @@ __global__ __launch_bounds__(256) void ln_lora_kernel(const void* __restrict__ x
   }
 }
 
+// The same for D % 256 == 0 (ViT-B 768, ViT-L 1024) with a lane owning FOUR consecutive columns per chunk (round 4): 16-byte (f32) / 8-byte (fp16)
+// loads, 8-byte stores instead of 4-byte ones, and the dropout mix of an element computed ONCE for its three masks (in the form above the compiler
+// shared it between only some of the projections: 177 v_mul_lo_u32 per two rows instead of 72).
+template <int NV, bool XH16>
+__global__ __launch_bounds__(256) void ln_lora4_kernel(const void* __restrict__ x_, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ lora,
+                                                       int r, bf16_raw* __restrict__ y, int rows, int D, float eps, Drop drop) {
+  extern __shared__ float a_lds[];                               // [3r][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 3 * r * D; i += 256) {
+    const int p = i / (r * D), rem = i - p * r * D;
+    a_lds[i] = lora[(size_t)p * 2 * r * D + rem];
+  }
+  __syncthreads();
+  constexpr int R = 2;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4* g4 = reinterpret_cast<const f4*>(gamma);
+  const f4* b4 = reinterpret_cast<const f4*>(beta);
+  f4 gm[NV], bt[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { gm[i] = g4[lane + 64 * i]; bt[i] = b4[lane + 64 * i]; }
+  for (int row0 = (blockIdx.x * 4 + wave) * R; row0 < rows; row0 += gridDim.x * 4 * R) {
+    f4 v[R][NV];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int row = (row0 + q) < rows ? (row0 + q) : rows - 1;
+      if constexpr (XH16) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4* xr = reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(x_) + (size_t)row * D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const h4 h = xr[lane + 64 * i];
+          v[q][i] = (f4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        }
+      } else {
+        const f4* xr = reinterpret_cast<const f4*>(reinterpret_cast<const float*>(x_) + (size_t)row * D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[q][i] = xr[lane + 64 * i];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int row = row0 + q;
+      if (row >= rows) break;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) s += (v[q][i][0] + v[q][i][1]) + (v[q][i][2] + v[q][i][3]);
+      const float mean = wave_sum(s) / (float)D;
+      float qq = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = v[q][i][e] - mean;
+          qq += a * a;
+        }
+      const float rstd = rsqrtf(wave_sum(qq) / (float)D + eps);
+      bf16_raw* yr = y + (size_t)row * (D + AUG);
+      unsigned hsh[NV][4];                                        // the element's one mix: bits 0-9 query, 10-19 key, 20-29 value
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[q][i][e] = (v[q][i][e] - mean) * rstd * gm[i][e] + bt[i][e];
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        reinterpret_cast<u2*>(yr)[lane + 64 * i] = (u2){pack_bf16x2(v[q][i][0], v[q][i][1]), pack_bf16x2(v[q][i][2], v[q][i][3])};
+        if (drop.thresh) {
+          const unsigned idx = (unsigned)row * (unsigned)D + 4u * (unsigned)(lane + 64 * i);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hsh[i][e] = drop_hash(drop.seed_lo, drop.seed_hi, (unsigned)drop.key0, idx + (unsigned)e);
+        }
+      }
+      float mine = 0.f;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        f4 vm[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          vm[i] = v[q][i];
+          if (drop.thresh) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vm[i][e] *= ((hsh[i][e] >> (10 * p)) & 1023u) < drop.thresh ? 0.f : drop.inv_keep;
+          }
+        }
+        for (int jr = 0; jr < r; ++jr) {
+          const int j = p * r + jr;
+          const f4* a4 = reinterpret_cast<const f4*>(a_lds + (size_t)j * D);
+          float d = 0.f;
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            const f4 a = a4[lane + 64 * i];
+            d += (vm[i][0] * a[0] + vm[i][1] * a[1]) + (vm[i][2] * a[2] + vm[i][3] * a[3]);
+          }
+          d = wave_sum(d);
+          if (lane == j) mine = d;
+        }
+      }
+      yr[D + lane] = f32_to_bf16(lane < 3 * r ? mine : 0.f);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // LayerNorm backward w.r.t. its input (gamma / beta are frozen), fused with the residual add and with the column scale +
 // bf16 cast the NEXT dgrad GEMM wants as its A operand:
@@ -160,8 +261,9 @@ __global__ __launch_bounds__(256) void ln_lora_kernel(const void* __restrict__ x
 // the other widths).  Everything the row needs from memory -- x, dy, the residual cotangent -- is requested before the first reduction, so
 // that one latency covers all three streams (round 3: 103 -> see profiles/r03_ln_bwd.txt).
 // DYB: dy arrives as bf16 (the dgrad GEMMs of the backward driver write their output in the 16-bit type: half the bytes on both sides).
-template <int NCH, int VW, bool LORA, bool DYB>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
+// XH: x (the saved LayerNorm input = the residual stream) is IEEE fp16 (training pass with vit.resid16).
+template <int NCH, int VW, bool LORA, bool DYB, bool XH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const void* __restrict__ x_,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      const float* __restrict__ scale, float* __restrict__ dx,
                                                      bf16_raw* __restrict__ sout, int rows, int D, float eps,
@@ -170,15 +272,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const vecf* xr = reinterpret_cast<const vecf*>(x + (size_t)row * D);
+  const vecf* xr = reinterpret_cast<const vecf*>(reinterpret_cast<const float*>(x_) + (size_t)row * D);
   typedef unsigned short vech __attribute__((ext_vector_type(VW)));
   const vecf* dyr = reinterpret_cast<const vecf*>(reinterpret_cast<const float*>(dy_) + (size_t)row * D);
   const vech* dyh = reinterpret_cast<const vech*>(reinterpret_cast<const bf16_raw*>(dy_) + (size_t)row * D);
   const vecf* rr = dres ? reinterpret_cast<const vecf*>(dres + (size_t)row * D) : nullptr;
   const vecf* g2 = reinterpret_cast<const vecf*>(gamma);
   vecf v[NCH], g[NCH], res[NCH];
+  if constexpr (XH) {
+    typedef _Float16 vecx __attribute__((ext_vector_type(VW)));
+    const vecx* xh = reinterpret_cast<const vecx*>(reinterpret_cast<const _Float16*>(x_) + (size_t)row * D);
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) v[i] = xr[lane + 64 * i];
+    for (int i = 0; i < NCH; ++i) {
+      const vecx h = xh[lane + 64 * i];
+#pragma unroll
+      for (int e = 0; e < VW; ++e) v[i][e] = (float)h[e];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) v[i] = xr[lane + 64 * i];
+  }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     if constexpr (DYB) {
@@ -351,7 +464,8 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict_
 // The next row's loads are issued before the current row's arithmetic.  Lane owns columns {2*lane, 2*lane+1} + 128*i of
 // its D-wide slice.  Per-block partials, summed in a fixed order by lora_grad_reduce_kernel (deterministic).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NCH, int RW>
+// VW = columns per lane and chunk: 2 (4-byte loads) or, for D % 256 == 0, 4 (8-byte loads: half the load instructions per row -- round 4)
+template <int NCH, int RW, int VW>
 __global__ __launch_bounds__(384) void lora_grad_kernel(bf16_raw* __restrict__ dqkv, const bf16_raw* __restrict__ h,
                                                         const float* __restrict__ lora, int r, int j0, float scaling,
                                                         float* __restrict__ partial, int rows, int D, Drop drop) {
@@ -360,78 +474,90 @@ __global__ __launch_bounds__(384) void lora_grad_kernel(bf16_raw* __restrict__ d
   const int p = wave % 3, strm = wave / 3;
   const int ldq = 3 * D + AUG, ldh = D + AUG;
   // this lane's B_p[n][j0 + j] (n = its 2*NCH columns)
-  float bw[NCH][2][RW];
+  float bw[NCH][VW][RW];
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < VW; ++e)
 #pragma unroll
       for (int j = 0; j < RW; ++j) {
-        const int n = 2 * (lane + 64 * i) + e;
+        const int n = VW * (lane + 64 * i) + e;
         bw[i][e][j] = (j0 + j < r) ? lora[(size_t)p * 2 * r * D + (size_t)r * D + (size_t)n * r + j0 + j] : 0.f;
       }
-  float accA[RW][NCH][2], accB[NCH][2][RW];
+  float accA[RW][NCH][VW], accB[NCH][VW][RW];
 #pragma unroll
   for (int j = 0; j < RW; ++j)
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      accA[j][i][0] = accA[j][i][1] = 0.f;
-      accB[i][0][j] = accB[i][1][j] = 0.f;
-    }
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int e = 0; e < VW; ++e) accA[j][i][e] = accB[i][e][j] = 0.f;
   const int step = gridDim.x * 2;
   int row = blockIdx.x * 2 + strm;
-  unsigned dw[NCH], hw_[NCH], uw = 0;
-  auto issue = [&](int rw) {
-    const unsigned* dq = reinterpret_cast<const unsigned*>(dqkv + (size_t)rw * ldq) + p * (D / 2);
-    const unsigned* hr = reinterpret_cast<const unsigned*>(h + (size_t)rw * ldh);
+  typedef unsigned uvw __attribute__((ext_vector_type(VW / 2)));
+  // PF rows of this wave in flight beside the one being reduced.  Measured (round 4, ViT-B, 32 images): PF = 1 -> 153-158 us per launch, PF = 4 -> 161-169
+  // (185 VGPRs: two waves per SIMD), 4-byte or 8-byte loads alike: the kernel is bound neither by load latency nor by load width.
+  constexpr int PF = 1;
+  uvw dw[PF][NCH], hw_[PF][NCH];
+  unsigned uw[PF];
+  auto issue = [&](int k, int rw) {
+    const uvw* dq = reinterpret_cast<const uvw*>(dqkv + (size_t)rw * ldq + (size_t)p * D);
+    const uvw* hr = reinterpret_cast<const uvw*>(h + (size_t)rw * ldh);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      dw[i] = dq[lane + 64 * i];
-      hw_[i] = hr[lane + 64 * i];
+      dw[k][i] = dq[lane + 64 * i];
+      hw_[k][i] = hr[lane + 64 * i];
     }
     // u[p][j0 .. j0+RW): bf16 pair read as one dword when aligned, else two halves (wave-uniform address: broadcast)
     const bf16_raw* up = h + (size_t)rw * ldh + D + p * r + j0;
     const unsigned lo = up[0], hi = (RW > 1 && j0 + 1 < r) ? up[1] : 0u;
-    uw = lo | (hi << 16);
+    uw[k] = lo | (hi << 16);
   };
-  if (row < rows) issue(row);
+#pragma unroll
+  for (int k = 0; k < PF; ++k)
+    if (row + k * step < rows) issue(k, row + k * step);
   while (row < rows) {
-    float dv[NCH][2], hv[NCH][2], u[RW], t[RW];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      dv[i][0] = __uint_as_float(dw[i] << 16);
-      dv[i][1] = __uint_as_float(dw[i] & 0xFFFF0000u);
-      hv[i][0] = __uint_as_float(hw_[i] << 16);
-      hv[i][1] = __uint_as_float(hw_[i] & 0xFFFF0000u);
-    }
-    u[0] = __uint_as_float(uw << 16);
-    if (RW > 1) u[1] = __uint_as_float(uw & 0xFFFF0000u);
-    const int cur = row;
-    if (drop.thresh) {                                               // dA sees the SAME dropped input the forward's lora_A saw
+    for (int k = 0; k < PF; ++k) {
+      if (row >= rows) break;
+      float dv[NCH][VW], hv[NCH][VW], u[RW], t[RW];
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        const unsigned idx = (unsigned)cur * (unsigned)D + 2u * (unsigned)(lane + 64 * i);
-        hv[i][0] *= drop_scale(drop, p, idx);
-        hv[i][1] *= drop_scale(drop, p, idx + 1u);
+      for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int w = 0; w < VW / 2; ++w) {
+          dv[i][2 * w] = __uint_as_float(dw[k][i][w] << 16);
+          dv[i][2 * w + 1] = __uint_as_float(dw[k][i][w] & 0xFFFF0000u);
+          hv[i][2 * w] = __uint_as_float(hw_[k][i][w] << 16);
+          hv[i][2 * w + 1] = __uint_as_float(hw_[k][i][w] & 0xFFFF0000u);
+        }
+      u[0] = __uint_as_float(uw[k] << 16);
+      if (RW > 1) u[1] = __uint_as_float(uw[k] & 0xFFFF0000u);
+      const int cur = row;
+      if (drop.thresh) {                                             // dA sees the SAME dropped input the forward's lora_A saw
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const unsigned idx = (unsigned)cur * (unsigned)D + (unsigned)VW * (unsigned)(lane + 64 * i);
+#pragma unroll
+          for (int e = 0; e < VW; ++e) hv[i][e] *= drop_scale(drop, p, idx + (unsigned)e);
+        }
       }
-    }
-    row += step;
-    if (row < rows) issue(row);                                    // next row in flight under this row's arithmetic
+      if (row + PF * step < rows) issue(k, row + PF * step);         // this slot's next row, PF rows ahead
+      row += step;
 #pragma unroll
-    for (int j = 0; j < RW; ++j) {
-      float s = 0.f;
+      for (int j = 0; j < RW; ++j) {
+        float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        s += dv[i][0] * bw[i][0][j] + dv[i][1] * bw[i][1][j];
-        accB[i][0][j] += dv[i][0] * u[j];
-        accB[i][1][j] += dv[i][1] * u[j];
-      }
-      t[j] = bf16_to_f32(f32_to_bf16(scaling * wave_sum(s)));      // the dgrad GEMM sees the bf16 value: use it for dA too
-      if (lane == 0 && j0 + j < r) dqkv[(size_t)cur * ldq + 3 * D + p * r + j0 + j] = f32_to_bf16(t[j]);
+        for (int i = 0; i < NCH; ++i)
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        accA[j][i][0] += t[j] * hv[i][0];
-        accA[j][i][1] += t[j] * hv[i][1];
+          for (int e = 0; e < VW; ++e) {
+            s += dv[i][e] * bw[i][e][j];
+            accB[i][e][j] += dv[i][e] * u[j];
+          }
+        t[j] = bf16_to_f32(f32_to_bf16(scaling * wave_sum(s)));      // the dgrad GEMM sees the bf16 value: use it for dA too
+        if (lane == 0 && j0 + j < r) dqkv[(size_t)cur * ldq + 3 * D + p * r + j0 + j] = f32_to_bf16(t[j]);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+          for (int e = 0; e < VW; ++e) accA[j][i][e] += t[j] * hv[i][e];
       }
     }
   }
@@ -445,8 +571,8 @@ __global__ __launch_bounds__(384) void lora_grad_kernel(bf16_raw* __restrict__ d
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int d = 2 * (lane + 64 * i) + e;
+          for (int e = 0; e < VW; ++e) {
+            const int d = VW * (lane + 64 * i) + e;
             const int ia = (p * RW + j) * D + d, ib = nA + (p * D + d) * RW + j;
             if (s2 == 0) {
               lds[ia] = accA[j][i][e];
@@ -517,6 +643,20 @@ static int launch_ln_lora(const void* x, bool x_h16, const float* gamma, const f
   dim3 grid(nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)3 * r * D * sizeof(float);
+  static const bool narrow = getenv("UCOD_LN_LORA_NARROW") != nullptr;     // measurement knob: the 8-byte / 4-byte form
+  if ((D % 256) == 0 && D <= 1536 && !narrow) {
+    switch (D / 256) {
+#define C4(n)                                                                                                                                        \
+  case n:                                                                                                                                            \
+    if (x_h16) hipLaunchKernelGGL((ln_lora4_kernel<n, true>), grid, block, lds, s, x, gamma, beta, lora, r, (bf16_raw*)y_aug, rows, D, eps, drop);     \
+    else hipLaunchKernelGGL((ln_lora4_kernel<n, false>), grid, block, lds, s, x, gamma, beta, lora, r, (bf16_raw*)y_aug, rows, D, eps, drop);          \
+    break;
+      C4(1) C4(2) C4(3) C4(4) C4(5) C4(6)
+#undef C4
+    }
+    UCOD_CHECK_LAUNCH();
+    return UCOD_OK;
+  }
   switch (D / 128) {
 #define C(n)                                                                                                                                         \
   case n:                                                                                                                                            \
@@ -543,17 +683,20 @@ extern "C" int ucod_layernorm_lora_h16(const void* x_f16, const float* gamma, co
   return launch_ln_lora(x_f16, true, gamma, beta, lora, r, y_aug, rows, D, eps, dropout, stream);
 }
 
-static int launch_ln_bwd(const void* dy, bool dy_bf16, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx, void* s_bf16,
+static int launch_ln_bwd(const void* dy, bool dy_bf16, const void* x, bool x_f16, const float* gamma, const float* dres, const float* next_scale, float* dx, void* s_bf16,
                          int rows, int D, float eps, const bf16_raw* tq, int ldt, const float* lora, int r, const Drop& drop, hipStream_t s) {
   dim3 grid(cdiv(rows, 4)), block(256);
   const bool lo = tq != nullptr;
-#define L(n, vw, lora_, dyb_) hipLaunchKernelGGL((ln_bwd_kernel<n, vw, lora_, dyb_>), grid, block, 0, s, dy, x, gamma, dres, next_scale, dx, (bf16_raw*)s_bf16, rows, D, eps, tq, ldt, lora, r, drop)
+  if (x_f16 && !dy_bf16) return UCOD_EINVAL;                // (the fp16 stream comes with bf16 dgrad outputs: the driver's only use)
+#define L(n, vw, lora_, dyb_, xh_) hipLaunchKernelGGL((ln_bwd_kernel<n, vw, lora_, dyb_, xh_>), grid, block, 0, s, dy, x, gamma, dres, next_scale, dx, (bf16_raw*)s_bf16, rows, D, eps, tq, ldt, lora, r, drop)
 #define C(n, vw)                                                                                                                               \
   case n:                                                                                                                                      \
-    if (lo && dy_bf16) L(n, vw, true, true);                                                                                                   \
-    else if (lo) L(n, vw, true, false);                                                                                                        \
-    else if (dy_bf16) L(n, vw, false, true);                                                                                                   \
-    else L(n, vw, false, false);                                                                                                               \
+    if (lo && x_f16) L(n, vw, true, true, true);                                                                                               \
+    else if (lo && dy_bf16) L(n, vw, true, true, false);                                                                                       \
+    else if (lo) L(n, vw, true, false, false);                                                                                                 \
+    else if (x_f16) L(n, vw, false, true, true);                                                                                               \
+    else if (dy_bf16) L(n, vw, false, true, false);                                                                                            \
+    else L(n, vw, false, false, false);                                                                                                        \
     break;
   if (D % 256 == 0) {                                      // 16-byte accesses
     switch (D / 256) {
@@ -577,15 +720,16 @@ extern "C" int ucod_layernorm_bwd(const float* dy, const float* x, const float* 
   UCOD_BF16_ONLY();
   if (!dy || !x || !gamma || (!dx && !s_bf16) || rows <= 0 || D <= 0 || (D % 128) != 0) return UCOD_EINVAL;
   UCOD_PROF(PROF_LN_BWD, stream);
-  return launch_ln_bwd(dy, false, x, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, nullptr, 0, nullptr, 0, make_drop(nullptr), (hipStream_t)stream);
+  return launch_ln_bwd(dy, false, x, false, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, nullptr, 0, nullptr, 0, make_drop(nullptr), (hipStream_t)stream);
 }
 
-extern "C" int ucod_layernorm_bwd_b16dy(const void* dy_bf16, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
-                                        void* s_bf16, int rows, int D, float eps, void* stream) {
+extern "C" int ucod_layernorm_bwd_ex(const void* dy, const void* x, int flags, const float* gamma, const float* dres, const float* next_scale, float* dx,
+                                     void* s_bf16, int rows, int D, float eps, void* stream) {
   UCOD_BF16_ONLY();
-  if (!dy_bf16 || !x || !gamma || (!dx && !s_bf16) || rows <= 0 || D <= 0 || (D % 128) != 0) return UCOD_EINVAL;
+  if (!dy || !x || !gamma || (!dx && !s_bf16) || rows <= 0 || D <= 0 || (D % 128) != 0 || (flags & ~3)) return UCOD_EINVAL;
   UCOD_PROF(PROF_LN_BWD, stream);
-  return launch_ln_bwd(dy_bf16, true, x, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, nullptr, 0, nullptr, 0, make_drop(nullptr), (hipStream_t)stream);
+  return launch_ln_bwd(dy, (flags & UCOD_LNB_DY_BF16) != 0, x, (flags & UCOD_LNB_X_F16) != 0, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, nullptr, 0, nullptr, 0,
+                       make_drop(nullptr), (hipStream_t)stream);
 }
 
 extern "C" int ucod_layernorm_bwd_lora(const float* dy, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
@@ -596,20 +740,20 @@ extern "C" int ucod_layernorm_bwd_lora(const float* dy, const float* x, const fl
       !dropout || dropout->p < 0.f || dropout->p >= 1.f)
     return UCOD_EINVAL;
   UCOD_PROF(PROF_LN_BWD, stream);
-  return launch_ln_bwd(dy, false, x, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, (const bf16_raw*)dqkv_aug + 3 * D, 3 * D + AUG, lora_layer, r,
+  return launch_ln_bwd(dy, false, x, false, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, (const bf16_raw*)dqkv_aug + 3 * D, 3 * D + AUG, lora_layer, r,
                        make_drop(dropout), (hipStream_t)stream);
 }
 
-extern "C" int ucod_layernorm_bwd_lora_b16dy(const void* dy_bf16, const float* x, const float* gamma, const float* dres, const float* next_scale, float* dx,
-                                             void* s_bf16, int rows, int D, float eps, const void* dqkv_aug, const float* lora_layer, int r,
-                                             const ucod_lora_dropout* dropout, void* stream) {
+extern "C" int ucod_layernorm_bwd_lora_ex(const void* dy, const void* x, int flags, const float* gamma, const float* dres, const float* next_scale, float* dx,
+                                          void* s_bf16, int rows, int D, float eps, const void* dqkv_aug, const float* lora_layer, int r,
+                                          const ucod_lora_dropout* dropout, void* stream) {
   UCOD_BF16_ONLY();
-  if (!dy_bf16 || !x || !gamma || (!dx && !s_bf16) || rows <= 0 || D <= 0 || (D % 128) != 0 || !dqkv_aug || !lora_layer || r < 1 || 3 * r > AUG ||
-      !dropout || dropout->p < 0.f || dropout->p >= 1.f)
+  if (!dy || !x || !gamma || (!dx && !s_bf16) || rows <= 0 || D <= 0 || (D % 128) != 0 || !dqkv_aug || !lora_layer || r < 1 || 3 * r > AUG ||
+      !dropout || dropout->p < 0.f || dropout->p >= 1.f || (flags & ~3))
     return UCOD_EINVAL;
   UCOD_PROF(PROF_LN_BWD, stream);
-  return launch_ln_bwd(dy_bf16, true, x, gamma, dres, next_scale, dx, s_bf16, rows, D, eps, (const bf16_raw*)dqkv_aug + 3 * D, 3 * D + AUG, lora_layer, r,
-                       make_drop(dropout), (hipStream_t)stream);
+  return launch_ln_bwd(dy, (flags & UCOD_LNB_DY_BF16) != 0, x, (flags & UCOD_LNB_X_F16) != 0, gamma, dres, next_scale, dx, s_bf16, rows, D, eps,
+                       (const bf16_raw*)dqkv_aug + 3 * D, 3 * D + AUG, lora_layer, r, make_drop(dropout), (hipStream_t)stream);
 }
 
 extern "C" int ucod_key_grad_tokens(const float* dkey, void* dqkv_aug, int B, int tok, int D, void* stream) {
@@ -649,12 +793,24 @@ extern "C" int ucod_lora_grad(void* dqkv_aug, const void* h_aug, const float* lo
   const int nblk = rows < LORA_GRAD_BLOCKS * 2 ? cdiv(rows, 2) : LORA_GRAD_BLOCKS;
   const size_t lds_bytes = (size_t)6 * D * RW * sizeof(float);      // B window (3*D*RW) <= block reduction buffer (6*D*RW)
   for (int j0 = 0; j0 < r; j0 += RW) {
-    switch (D / 128) {
-#define C(n) case n: hipLaunchKernelGGL((lora_grad_kernel<n, RW>), dim3(nblk), dim3(384), lds_bytes, s, (bf16_raw*)dqkv_aug, (const bf16_raw*)h_aug, lora_layer, r, j0, scaling, (float*)workspace, rows, D, drop); break;
-      C(1) C(2) C(3) C(4) C(5) C(6) C(8)
+    static const bool narrow = getenv("UCOD_LORA_GRAD_NARROW") != nullptr;    // measurement knob: the 4-byte-load form
+#define LG(n, vw) hipLaunchKernelGGL((lora_grad_kernel<n, RW, vw>), dim3(nblk), dim3(384), lds_bytes, s, (bf16_raw*)dqkv_aug, (const bf16_raw*)h_aug, lora_layer, r, j0, scaling, (float*)workspace, rows, D, drop)
+    if ((D % 256) == 0 && D <= 1024 && !narrow) {
+      switch (D / 256) {
+        case 1: LG(1, 4); break;
+        case 2: LG(2, 4); break;
+        case 3: LG(3, 4); break;
+        case 4: LG(4, 4); break;
+      }
+    } else {
+      switch (D / 128) {
+#define C(n) case n: LG(n, 2); break;
+        C(1) C(2) C(3) C(4) C(5) C(6) C(8)
 #undef C
-      default: return UCOD_EINVAL;
+        default: return UCOD_EINVAL;
+      }
     }
+#undef LG
     UCOD_CHECK_LAUNCH();
     hipLaunchKernelGGL((lora_grad_reduce_kernel<RW>), dim3(cdiv(6 * RW * D, 32)), dim3(256), 0, s, (const float*)workspace, nblk, r, j0,
                        grad_layer, D, accumulate);

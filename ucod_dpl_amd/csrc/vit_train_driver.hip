@@ -27,7 +27,7 @@ bool valid(const ucod_vit_train_desc* t) {
   return d->B > 0 && d->C > 0 && d->P > 0 && d->H > 0 && d->W > 0 && d->H % d->P == 0 && d->W % d->P == 0 && d->D > 0 && d->heads > 0 &&
          d->D == d->heads * 64 && d->D % 128 == 0 && d->F % 128 == 0 && d->L >= 1 && d->Kpad % 64 == 0 && d->Kpad >= d->C * d->P * d->P &&
          t->lora_r >= 1 && 3 * t->lora_r <= UCOD_LORA_AUG && t->lora_dropout >= 0.f && t->lora_dropout < 1.f &&
-         d->resid16 == 0;                                        // the backward kernels read the f32 residual stream
+         (d->resid16 == 0 || d->resid16 == 1);                   // resid16: the saved residual stream is IEEE fp16 (round 4: LayerNorm backward reads it)
 }
 
 TPlan make_plan(const ucod_vit_train_desc* t) {
@@ -40,7 +40,7 @@ TPlan make_plan(const ucod_vit_train_desc* t) {
   const size_t M = p.M, D = d->D, F = d->F, L = d->L;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += up(bytes); return r; };
-  p.s_x = up(M * D * 4);
+  p.s_x = up(M * D * (d->resid16 ? 2 : 4));
   p.s_h = up(M * (D + UCOD_LORA_AUG) * 2);
   p.s_qkv = up(M * 3 * D * 2);
   p.s_att = up(M * D * 2);
@@ -93,11 +93,15 @@ extern "C" int ucod_vit_forward_train(const ucod_vit_train_desc* t, const void* 
   void* patches = ws + p.patch;
   RUN(ucod_fill_qscale(qscale, D, 0.125f * 1.4426950408889634f, stream));
 
+  const bool r16 = d->resid16 != 0;                               // fp16 residual stream (saved as such: half the bytes forward and backward)
+  const int epi_patch = r16 ? UCOD_EPI_PATCH_TOKENS_H16 : UCOD_EPI_PATCH_TOKENS_F32;
+  const int epi_resid = r16 ? UCOD_EPI_BIAS_SCALE_RESID_H16 : UCOD_EPI_BIAS_SCALE_RESID_F32;
   float* x0 = (float*)(ws + p.x_in);
   RUN(ucod_patch_im2col(img, patches, d->B, d->C, d->H, d->W, d->P, d->Kpad, stream));
-  RUN(ucod_gemm_bf16(UCOD_EPI_PATCH_TOKENS_F32, patches, T[0], x0, d->B * (tok - 1), D, d->Kpad, (const float*)T[1], nullptr, nullptr,
+  RUN(ucod_gemm_bf16(epi_patch, patches, T[0], x0, d->B * (tok - 1), D, d->Kpad, (const float*)T[1], nullptr, nullptr,
                      (const float*)T[3], tok, gv, stream));
-  RUN(ucod_cls_rows(x0, (const float*)T[2], (const float*)T[3], d->B, tok, D, stream));
+  if (r16) RUN(ucod_cls_rows_h16(x0, (const float*)T[2], (const float*)T[3], d->B, tok, D, stream));
+  else RUN(ucod_cls_rows(x0, (const float*)T[2], (const float*)T[3], d->B, tok, D, stream));
 
   for (int l = 0; l < d->L; ++l) {
     const void* const* W = T + 4 + UCOD_VIT_LAYER_STRIDE * l;
@@ -106,8 +110,10 @@ extern "C" int ucod_vit_forward_train(const ucod_vit_train_desc* t, const void* 
     float* x_in = (float*)(ws + p.x_in + p.s_x * l);
     void* h_aug = ws + p.h_aug + p.s_h * l;
     const ucod_lora_dropout drop{t->lora_dropout, t->seed, l};
-    RUN(ucod_layernorm_lora(x_in, (const float*)W[0], (const float*)W[1], (const float*)X[5], t->lora_r, h_aug, M, D, d->eps,
-                            t->lora_dropout > 0.f ? &drop : nullptr, stream));
+    if (r16) RUN(ucod_layernorm_lora_h16(x_in, (const float*)W[0], (const float*)W[1], (const float*)X[5], t->lora_r, h_aug, M, D, d->eps,
+                                         t->lora_dropout > 0.f ? &drop : nullptr, stream));
+    else RUN(ucod_layernorm_lora(x_in, (const float*)W[0], (const float*)W[1], (const float*)X[5], t->lora_r, h_aug, M, D, d->eps,
+                                 t->lora_dropout > 0.f ? &drop : nullptr, stream));
     if (last) {   // key hook: K rows of the augmented qkv weight; [B,D,h,w] out
       const char* wk = (const char*)X[0] + (size_t)D * KA * 2;
       RUN(ucod_gemm_bf16(UCOD_EPI_KEY_NCHW_F32, wk, h_aug, key_out, D, M, KA, (const float*)W[3] + D, nullptr, nullptr, nullptr, tok, gv, stream));
@@ -121,10 +127,11 @@ extern "C" int ucod_vit_forward_train(const ucod_vit_train_desc* t, const void* 
     void* pre = ws + p.pre + p.s_pre * l;
     RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_BF16, h_aug, X[0], qkv, M, 3 * D, KA, (const float*)W[3], qscale, nullptr, nullptr, tok, gv, stream));
     RUN(ucod_attention_fwd_lse(qkv, att, lse, d->B, tok, d->heads, stream));
-    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_SCALE_RESID_F32, att, W[4], x_mid, M, D, D, (const float*)W[5], (const float*)W[6], x_in, nullptr, tok, gv, stream));
-    RUN(ucod_layernorm(x_mid, (const float*)W[7], (const float*)W[8], h2, M, D, d->eps, 0, stream));
+    RUN(ucod_gemm_bf16(epi_resid, att, W[4], x_mid, M, D, D, (const float*)W[5], (const float*)W[6], x_in, nullptr, tok, gv, stream));
+    if (r16) RUN(ucod_layernorm_h16(x_mid, (const float*)W[7], (const float*)W[8], h2, M, D, d->eps, stream));
+    else RUN(ucod_layernorm(x_mid, (const float*)W[7], (const float*)W[8], h2, M, D, d->eps, 0, stream));
     RUN(ucod_gemm_bf16_train(UCOD_EPI_BIAS_GELU_SAVE_BF16, h2, W[9], g, M, F, D, (const float*)W[10], nullptr, pre, gv, stream));
-    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_SCALE_RESID_F32, g, W[11], x_next, M, D, F, (const float*)W[12], (const float*)W[13], x_mid, nullptr, tok, gv, stream));
+    RUN(ucod_gemm_bf16(epi_resid, g, W[11], x_next, M, D, F, (const float*)W[12], (const float*)W[13], x_mid, nullptr, tok, gv, stream));
   }
   return UCOD_OK;
 }
@@ -239,11 +246,13 @@ extern "C" int ucod_vit_backward(const ucod_vit_train_desc* t, const void* const
 
   // dgrad outputs that feed a LayerNorm backward (dh) are written as bf16 (UCOD_DGRAD_F32=1: f32, the round-3 path): the GEMM's drain and the
   // LayerNorm backward's read side move half the bytes; the residual cotangent stream (dx) stays f32
-  static const bool dgrad16 = !(getenv("UCOD_DGRAD_F32") && getenv("UCOD_DGRAD_F32")[0] == '1');
+  static const bool dgrad16_env = !(getenv("UCOD_DGRAD_F32") && getenv("UCOD_DGRAD_F32")[0] == '1');
+  const bool r16 = d->resid16 != 0;                               // the saved residual stream is fp16 (then the dgrad outputs are bf16 whatever the variable says)
+  const bool dgrad16 = dgrad16_env || r16;
   const int epi_dh = dgrad16 ? UCOD_EPI_BIAS_BF16 : UCOD_EPI_BIAS_F32;
-  auto ln_bwd_plain = [&](const void* dy, const float* x, const float* gam, const float* dres, const float* next_scale) -> int {
-    return dgrad16 ? ucod_layernorm_bwd_b16dy(dy, x, gam, dres, next_scale, dx, s, M, D, d->eps, stream)
-                   : ucod_layernorm_bwd((const float*)dy, x, gam, dres, next_scale, dx, s, M, D, d->eps, stream);
+  const int lnb_flags = (dgrad16 ? UCOD_LNB_DY_BF16 : 0) | (r16 ? UCOD_LNB_X_F16 : 0);
+  auto ln_bwd_plain = [&](const void* dy, const void* x, const float* gam, const float* dres, const float* next_scale) -> int {
+    return ucod_layernorm_bwd_ex(dy, x, lnb_flags, gam, dres, next_scale, dx, s, M, D, d->eps, stream);
   };
   auto qkv_side = [&](int l) -> int {   // dqkv_aug (k/q/v thirds filled) -> LoRA grads of layer l, dh = d LN1 output
     const void* const* X = TT + UCOD_VIT_TRAIN_STRIDE * l;
@@ -256,12 +265,11 @@ extern "C" int ucod_vit_backward(const ucod_vit_train_desc* t, const void* const
   };
 
   // LayerNorm-1 backward of layer l: with dropout on, the masked LoRA branch t A is added here (it cannot ride on the dgrad GEMM)
-  auto ln1_bwd = [&](int l, const float* dy, const float* x, const float* gam, const float* dres, const float* next_scale) -> int {
+  auto ln1_bwd = [&](int l, const void* dy, const void* x, const float* gam, const float* dres, const float* next_scale) -> int {
     if (t->lora_dropout > 0.f) {
       const ucod_lora_dropout drop{t->lora_dropout, t->seed, l};
       const float* lora_l = (const float*)(TT + UCOD_VIT_TRAIN_STRIDE * l)[5];
-      return dgrad16 ? ucod_layernorm_bwd_lora_b16dy(dy, x, gam, dres, next_scale, dx, s, M, D, d->eps, dqkv, lora_l, r, &drop, stream)
-                     : ucod_layernorm_bwd_lora(dy, x, gam, dres, next_scale, dx, s, M, D, d->eps, dqkv, lora_l, r, &drop, stream);
+      return ucod_layernorm_bwd_lora_ex(dy, x, lnb_flags, gam, dres, next_scale, dx, s, M, D, d->eps, dqkv, lora_l, r, &drop, stream);
     }
     return ln_bwd_plain(dy, x, gam, dres, next_scale);
   };

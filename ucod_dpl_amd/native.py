@@ -91,8 +91,8 @@ SIGNATURES = {
     "ucod_layernorm_lora_h16": (ci, [vp, vp, vp, vp, ci, vp, ci, ci, cf, C.POINTER(LoraDropout), vp]),
     "ucod_layernorm_bwd_lora": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp, vp, ci, C.POINTER(LoraDropout), vp]),
     "ucod_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp]),
-    "ucod_layernorm_bwd_b16dy": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp]),
-    "ucod_layernorm_bwd_lora_b16dy": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp, vp, ci, C.POINTER(LoraDropout), vp]),
+    "ucod_layernorm_bwd_ex": (ci, [vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, cf, vp]),
+    "ucod_layernorm_bwd_lora_ex": (ci, [vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, cf, vp, vp, ci, C.POINTER(LoraDropout), vp]),
     "ucod_attention_fwd_lse": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "ucod_attention_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "ucod_key_grad_tokens": (ci, [vp, vp, ci, ci, ci, vp]),

@@ -121,10 +121,8 @@ class ViTEngine:
         self.lib = N.load(half)
         if resid not in ("auto", "f32", "f16"):
             raise ValueError(f"resid must be 'auto', 'f32' or 'f16', got {resid!r}")
-        if resid == "f16" and not self._allow_resid16:
-            raise ValueError("the backbone-backward engine keeps the f32 residual stream (its backward kernels read it): resid='f16' is not available")
         self.resid = resid
-        self.resid16 = bool(resid == "f16" or (resid == "auto" and half == "bf16" and self._allow_resid16))
+        self.resid16 = bool(resid == "f16" or (resid == "auto" and half == "bf16"))
         self._ovf_host, self._ovf_events, self._ovf_dev = None, [], None
         if attn_variant not in (0, 1, 2, 8, 5, 64, 32):
             raise ValueError(f"attn_variant must be 0, 1, 2, 5, 8, 32 or 64 (laboratory kernels are reached through ops.attention(variant=...)), got {attn_variant}")
@@ -243,7 +241,6 @@ class ViTEngine:
             raise FloatingPointError(f"the fp16 residual stream of this engine saturated at +-65504 (or met a NaN) in {n} wave-lane(s): the "
                                      f"activations do not fit fp16; {how}.")
 
-    _allow_resid16 = True                                      # the backbone-backward engine keeps the f32 stream (its kernels read it)
     _sync_check = os.environ.get("UCOD_CHECK_RESID") == "1"    # debug: check the saturation counter synchronously after every pass
 
     def forward(self, img, out=None, _async=False, n_layers=None):
@@ -360,7 +357,6 @@ _QKV = ("query", "key", "value")
 
 
 class ViTLoRAEngine(ViTEngine):
-    _allow_resid16 = False
 
     """Backbone-backward mode (SURVEY.md 8a row B9): the frozen ViT with peft-style LoRA on query / key / value of every
     encoder layer, as models/modules/full_model.py:47-72 configures it (r=2, lora_alpha=4, bias='none', target
@@ -373,8 +369,10 @@ class ViTLoRAEngine(ViTEngine):
     in ``self.lora_grad`` with the same layout -- ready for a single flat all-reduce and the fused AdamW kernel."""
 
     def __init__(self, state_dict, heads, r=2, lora_alpha=4, eps=1e-6, device="cuda", gemm_variant=0, generator=None, lora_dropout=0.0,
-                 seed=0):
-        super().__init__(state_dict, heads, eps=eps, device=device, full_last_layer=False, gemm_variant=gemm_variant, attn_variant=2)
+                 seed=0, resid="auto"):
+        # resid: as ViTEngine ("auto" = the fp16 residual stream with bf16 operands).  Round 4: the training pass SAVES the stream in that
+        # type and LayerNorm backward reads it (ucod_layernorm_bwd_ex); resid="f32" keeps the round-3 path.
+        super().__init__(state_dict, heads, eps=eps, device=device, full_last_layer=False, gemm_variant=gemm_variant, attn_variant=2, resid=resid)
         if not 0.0 <= lora_dropout < 1.0:
             raise ValueError("lora_dropout must be in [0, 1)")
         # LoRA dropout (LoraConfig.lora_dropout, full_model.py:50): active while `self.training` is True; the mask of a step is a pure
@@ -521,8 +519,10 @@ class ViTLoRAEngine(ViTEngine):
             if self._tside_ws[i] is None or self._tside_ws[i].numel() < need:
                 self._tside_ws[i] = torch.empty(need, dtype=torch.uint8, device=self.device)
             T, TT, keep = self._tables(gh, gw, self._tside_grad[i])
-            N.check(lib.ucod_vit_forward_train(C.byref(t), T, TT, N.ptr(img[b0:b1]), N.ptr(key[b0:b1]), N.ptr(self._tside_ws[i]),
-                                               self._tside_ws[i].numel(), N.stream()), "ucod_vit_forward_train")
+            with self._own_counter():
+                N.check(lib.ucod_vit_forward_train(C.byref(t), T, TT, N.ptr(img[b0:b1]), N.ptr(key[b0:b1]), N.ptr(self._tside_ws[i]),
+                                                   self._tside_ws[i].numel(), N.stream()), "ucod_vit_forward_train")
+            self._arm_overflow_check(torch.cuda.current_stream(self.device))     # (no-op with the f32 stream)
 
         self._fan_out(run, (img, key))
         self._saved_for = (B, H, W)
