@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, help="image-parallel sub-batches of the backbone pass on independent HIP streams")
     ap.add_argument("--no-pipeline", action="store_true", help="serial order: backbone pass, then decoder step, on one stream")
     ap.add_argument("--half", default="bf16", choices=["bf16", "f16"], help="16-bit operand type of the backbone (bf16 = BASELINE configs[1])")
+    ap.add_argument("--lora-resid", default="auto", choices=["auto", "f32", "f16"], help="residual stream of the backbone-backward engine (auto: fp16 with bf16 operands)")
     ap.add_argument("--lora-steps", type=int, default=4, help="steps of the separate backbone-backward (LoRA) measurement; 0 = skip")
     return ap.parse_args()
 
@@ -265,7 +266,7 @@ def main():
         from ucod_dpl_amd.vit_engine import ViTLoRAEngine
         from ucod_dpl_amd.data.utils.feature_extractor import random_state_dict
         eng = ViTLoRAEngine(random_state_dict(a.arch, 0, a.image), heads, r=2, lora_alpha=4, device=dev, gemm_variant=a.gemm_variant,
-                            generator=torch.Generator().manual_seed(7), lora_dropout=0.05, seed=1234 + rank)
+                            generator=torch.Generator().manual_seed(7), lora_dropout=0.05, seed=1234 + rank, resid=a.lora_resid)
         loop.attach_lora_backbone(eng)
         for _ in range(2):
             loop._process_batch_full(images, pl)
