@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __re
   grad[dst] = accumulate ? grad[dst] + s : s;
 }
 
-constexpr int LORA_GRAD_BLOCKS = 512;
+constexpr int LORA_GRAD_BLOCKS = 512;                            // (1024 measured: 153 -> 183 us per launch: more partials to combine, no more rows in flight per SIMD)
 
 }  // namespace ucod
 
