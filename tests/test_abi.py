@@ -64,3 +64,9 @@ def test_product_path_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
+
+
+def test_graft_entry_build_assertions_hold():
+    """__graft_entry__.build() = make + these assertions; the driver runs it every round (a stale ABI number there fails the round's build check)."""
+    import __graft_entry__ as G
+    G.check_build()
