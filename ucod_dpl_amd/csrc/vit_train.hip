@@ -465,8 +465,9 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict_
 // its D-wide slice.  Per-block partials, summed in a fixed order by lora_grad_reduce_kernel (deterministic).
 // ---------------------------------------------------------------------------------------------------------------------
 // VW = columns per lane and chunk: 2 (4-byte loads) or, for D % 256 == 0, 4 (8-byte loads: half the load instructions per row -- round 4)
-template <int NCH, int RW, int VW>
-__global__ __launch_bounds__(384) void lora_grad_kernel(bf16_raw* __restrict__ dqkv, const bf16_raw* __restrict__ h,
+// NS = row streams per block (block = 3 NS waves): the per-block combine and the partials the reduce kernel walks are paid once per NS streams
+template <int NCH, int RW, int VW, int NS>
+__global__ __launch_bounds__(192 * NS) void lora_grad_kernel(bf16_raw* __restrict__ dqkv, const bf16_raw* __restrict__ h,
                                                         const float* __restrict__ lora, int r, int j0, float scaling,
                                                         float* __restrict__ partial, int rows, int D, Drop drop) {
   extern __shared__ float lds[];                                  // block reduction buffer [3][RW][D] | [3][D][RW]
@@ -491,8 +492,8 @@ __global__ __launch_bounds__(384) void lora_grad_kernel(bf16_raw* __restrict__ d
     for (int i = 0; i < NCH; ++i)
 #pragma unroll
       for (int e = 0; e < VW; ++e) accA[j][i][e] = accB[i][e][j] = 0.f;
-  const int step = gridDim.x * 2;
-  int row = blockIdx.x * 2 + strm;
+  const int step = gridDim.x * NS;
+  int row = blockIdx.x * NS + strm;
   typedef unsigned uvw __attribute__((ext_vector_type(VW / 2)));
   // PF rows of this wave in flight beside the one being reduced.  Measured (round 4, ViT-B, 32 images): PF = 1 -> 153-158 us per launch, PF = 4 -> 161-169
   // (185 VGPRs: two waves per SIMD), 4-byte or 8-byte loads alike: the kernel is bound neither by load latency nor by load width.
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(384) void lora_grad_kernel(bf16_raw* __restrict__ d
   // block combine: [3][RW][D] (dA window) then [3][D][RW] (dB window); stream 0 writes, stream 1 adds
   const int nA = 3 * RW * D, nB = 3 * D * RW;
   float* out = partial + (size_t)blockIdx.x * (nA + nB);
-  for (int s2 = 0; s2 < 2; ++s2) {
+  for (int s2 = 0; s2 < NS; ++s2) {
     if (strm == s2) {
 #pragma unroll
       for (int j = 0; j < RW; ++j)
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(384) void lora_grad_kernel(bf16_raw* __restrict__ d
     }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < nA + nB; i += 384) out[i] = lds[i];
+  for (int i = threadIdx.x; i < nA + nB; i += 192 * NS) out[i] = lds[i];
 }
 
 // grad layout = parameter layout of the layer: [A_q | B_q | A_k | B_k | A_v | B_v]; accumulate = add to existing content
@@ -790,11 +791,23 @@ extern "C" int ucod_lora_grad(void* dqkv_aug, const void* h_aug, const float* lo
   const Drop drop = make_drop(dropout);
   hipStream_t s = (hipStream_t)stream;
   constexpr int RW = 2;                                           // ranks per pass (the reference's r = 2 is one pass)
-  const int nblk = rows < LORA_GRAD_BLOCKS * 2 ? cdiv(rows, 2) : LORA_GRAD_BLOCKS;
+  static const int ns_env = [] { const char* e = getenv("UCOD_LORA_GRAD_STREAMS"); return e ? atoi(e) : 0; }();   // measurement knob: 2 or 4 row streams per block
+  const int NSr = ns_env == 2 ? 2 : ns_env == 5 ? 5 : 4;
+  static const int nb_env = [] { const char* e = getenv("UCOD_LORA_GRAD_NBLK"); return e ? atoi(e) : 0; }();       // measurement knob (<= LORA_GRAD_BLOCKS)
+  // default: one block per CU (12 waves of 4 row streams x 3 projections), a whole round -- round 4: 512 blocks of 6 waves 158 us -> 109 us per launch at
+  // ViT-B / 32 images (fewer partials to combine and to reduce; 384 blocks = 1.5 rounds: 140 us)
+  static const int n_cu = [] { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); return hipGetDeviceProperties(&pr, dv) == hipSuccess ? pr.multiProcessorCount : 256; }();
+  const int nb_max = nb_env > 0 && nb_env <= LORA_GRAD_BLOCKS ? nb_env : (n_cu < LORA_GRAD_BLOCKS ? n_cu : LORA_GRAD_BLOCKS);
+  const int nblk = rows < nb_max * NSr ? cdiv(rows, NSr) : nb_max;
   const size_t lds_bytes = (size_t)6 * D * RW * sizeof(float);      // B window (3*D*RW) <= block reduction buffer (6*D*RW)
   for (int j0 = 0; j0 < r; j0 += RW) {
-    static const bool narrow = getenv("UCOD_LORA_GRAD_NARROW") != nullptr;    // measurement knob: the 4-byte-load form
-#define LG(n, vw) hipLaunchKernelGGL((lora_grad_kernel<n, RW, vw>), dim3(nblk), dim3(384), lds_bytes, s, (bf16_raw*)dqkv_aug, (const bf16_raw*)h_aug, lora_layer, r, j0, scaling, (float*)workspace, rows, D, drop)
+    static const bool narrow = getenv("UCOD_LORA_GRAD_WIDE") == nullptr;      // default: the 4-byte-load form (88 VGPRs; the 8-byte one: 148, 4 % slower)
+#define LG(n, vw)                                                                                                                                   \
+  do {                                                                                                                                              \
+    if (NSr == 2) hipLaunchKernelGGL((lora_grad_kernel<n, RW, vw, 2>), dim3(nblk), dim3(384), lds_bytes, s, (bf16_raw*)dqkv_aug, (const bf16_raw*)h_aug, lora_layer, r, j0, scaling, (float*)workspace, rows, D, drop); \
+    else if (NSr == 5) hipLaunchKernelGGL((lora_grad_kernel<n, RW, vw, 5>), dim3(nblk), dim3(960), lds_bytes, s, (bf16_raw*)dqkv_aug, (const bf16_raw*)h_aug, lora_layer, r, j0, scaling, (float*)workspace, rows, D, drop); \
+    else hipLaunchKernelGGL((lora_grad_kernel<n, RW, vw, 4>), dim3(nblk), dim3(768), lds_bytes, s, (bf16_raw*)dqkv_aug, (const bf16_raw*)h_aug, lora_layer, r, j0, scaling, (float*)workspace, rows, D, drop);     \
+  } while (0)
     if ((D % 256) == 0 && D <= 1024 && !narrow) {
       switch (D / 256) {
         case 1: LG(1, 4); break;
