@@ -234,7 +234,7 @@ def test_attention(variant, B, tok, heads):
     assert rel_l2(out, ref) < 1e-2
 
 
-@pytest.mark.parametrize("variant", [64, 32])
+@pytest.mark.parametrize("variant", [64, 32, 66])
 @pytest.mark.parametrize("B,tok,heads", [(1, 200, 3), (2, 1370, 2), (3, 129, 2), (2, 300, 12), (1, 785, 6), (9, 257, 1)])
 def test_attention_assembly_kernels(B, tok, heads, variant):
     """The hand-placed assembly kernels (variant 64: 4 waves x 64 rows, one wave per SIMD; 32: 8 waves x 32 rows, two per SIMD; generated by

@@ -428,6 +428,201 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v5_kernel(const bf16_raw* __r
 }
 
 // =====================================================================================================
+// v6 (round 4, late): the v5 kernel with 64 query rows per wave (two 32-row blocks) and 256 rows per workgroup, two workgroups per CU =
+// two waves per SIMD.  Why: with 32 rows per wave and four waves per SIMD every wave re-reads the whole K / V tile from LDS -- 256 KB per
+// 64 keys and CU = the matrix time of those keys at 128 B/clk -- so v5 is bound by LDS as much as by its vector work; here a K or V
+// fragment read serves two MFMAs (128 KB per 64 keys and CU) and the two resident workgroups run unsynchronised, so one wave's
+// exponentials sit beside the other's MFMAs.  Same arithmetic per element as v5 (deferred max per 32-row block, scalar row sums).
+// =====================================================================================================
+__global__ __launch_bounds__(256, 2) void attn_fwd_v6_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, int N, int heads,
+                                                              int npairs, float* __restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * KV_BYTES];       // [buffer][K | V]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h5 = lane >> 5, l31 = lane & 31;
+  constexpr int QT6 = 256, RB = 2;                       // 4 waves x 64 query rows = two 32-row blocks per wave
+  const int nq = (N + QT6 - 1) / QT6;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pair = (slot / nq) * 8 + xcd, qt = slot - (slot / nq) * nq;
+  if (pair >= npairs) return;
+  const int head = pair % heads, b = pair / heads;
+  const int D = heads * HD, ld = 3 * D;
+  const int q0 = qt * QT6 + wave * 64;
+  const bool live = q0 < N;                              // wave-uniform: this wave owns at least one real query row
+  const bool live1 = q0 + 32 < N;                        // ... and its second 32-row block too
+  const bf16_raw* base = qkv + (size_t)b * N * ld + head * HD;
+
+  hx8 qf[RB][4];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    int qr = q0 + rb * 32 + l31;
+    qr = qr < N ? qr : N - 1;
+    const bf16_raw* qp = base + (size_t)qr * ld + 8 * h5;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[rb][s] = *reinterpret_cast<const hx8*>(qp + 16 * s);
+  }
+
+  // this image's qkv rows as one buffer: byte offsets fit 32 bits, a key row >= N is out of range and reads as zero
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(qkv + (size_t)b * N * ld), 0, (unsigned)N * (unsigned)ld * 2u, 0x00020000);
+  unsigned sk[2], sv[2];                                 // loop-carried source offsets of this lane's four DMA chunks
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = i * 32 + wave * 8 + (lane >> 3), ch = lane & 7;
+    sk[i] = (unsigned)(row * ld + D + head * HD + swz_k(row, ch) * 8) * 2u;
+    sv[i] = (unsigned)(row * ld + 2 * D + head * HD + swz_v(row, ch) * 8) * 2u;
+  }
+  const unsigned tile_step = (unsigned)(KT * ld) * 2u;
+  auto stage = [&](auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      char* dst = smem + BUF * (2 * KV_BYTES) + (i * 32 + wave * 8) * 128;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, sk[i], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + KV_BYTES), 16, sv[i], 0, 0, 0);
+      sk[i] += tile_step;
+      sv[i] += tile_step;
+    }
+  };
+
+  // loop-invariant LDS byte offsets: K fragment chunk per 16-wide d step, V fragment per 32-wide d half
+  int koff[4], voff[2];
+#pragma unroll
+  for (int sd = 0; sd < 4; ++sd) koff[sd] = l31 * 128 + swz_k(l31, 2 * sd + h5) * 16;      // +4096 per 32 keys keeps the swizzle
+  {
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    const int key = 4 * h5 + (i16 >> 2);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int dst = dt * 32 + g1 * 16 + 4 * (i16 & 3);
+      voff[dt] = KV_BYTES + key * 128 + swz_v(key, dst >> 3) * 16 + (dst & 7) * 2;          // +8/16/32 keys keep the swizzle
+    }
+  }
+
+  f32x16 o[RB][2];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[rb][0][i] = 0.f; o[rb][1][i] = 0.f; }
+  float m_run[RB] = {0.f, 0.f};
+  float lsum0[RB] = {0.f, 0.f}, lsum1[RB] = {0.f, 0.f};
+  const int nt = (N + KT - 1) / KT, nfull = nt - 1;
+  const bool half_dead = nfull * KT + 32 >= N;           // (uniform) the keys of the last tile's second 32-key block all lie past the last token
+
+  auto tile = [&](int t, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    dma_landed_barrier();                                // this wave's DMAs of tile t have landed; everyone is done reading tile t-1
+    if (t + 1 < nt) stage(IntC<BUF ^ 1>{});
+    if (!live) return;                                   // (wave-uniform) nothing to compute for rows past the last token
+    const char* kb = smem + BUF * (2 * KV_BYTES);
+
+    // one 32-key block at a time: its K fragments serve both row blocks, its V fragments too (half the LDS reads per MFMA of the 32-row kernel)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      if (t == nfull && kt == 1 && half_dead) break;     // (wave-uniform; last tile only) no real key in the second 32-key block
+      f32x16 s[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[rb][i] = -m_run[rb];
+#pragma unroll
+      for (int sd = 0; sd < 4; ++sd) {
+        const hx8 kf = *reinterpret_cast<const hx8*>(kb + kt * 4096 + koff[sd]);
+        s[0] = UCOD_MFMA32(kf, qf[0][sd], s[0]);
+        if (live1) s[1] = UCOD_MFMA32(kf, qf[1][sd], s[1]);
+      }
+      if (t == nfull && (N & (KT - 1)) != 0) {
+        const int kbase = t * KT + kt * 32 + 4 * h5;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kbase + (r & 3) + 8 * (r >> 2);
+            if (key >= N) s[rb][r] = -1e30f;
+          }
+      }
+      hx8 pb[RB][2];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        if (rb == 1 && !live1) break;
+        float mloc = __builtin_elementwise_maximum(s[rb][0], s[rb][1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) mloc = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mloc, s[rb][r]), s[rb][r + 1]);
+        const bool first = (t == 0 && kt == 0);
+        if (first || __any(mloc > DEFER_THR)) {
+          mloc = xhalf_max(mloc);
+          const float delta = first ? mloc : fmaxf(mloc, 0.f);
+          const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+          m_run[rb] += delta;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            s[rb][i] -= delta;
+            o[rb][0][i] *= alpha;
+            o[rb][1][i] *= alpha;
+          }
+          lsum0[rb] *= alpha;
+          lsum1[rb] *= alpha;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          u32x4 w;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const f32x2_t e = {__builtin_amdgcn_exp2f(s[rb][8 * ks + 2 * jj]), __builtin_amdgcn_exp2f(s[rb][8 * ks + 2 * jj + 1])};
+            sum_pair(lsum0[rb], lsum1[rb], e);
+            w[jj] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_t));
+          }
+          pb[rb][ks] = __builtin_bit_cast(hx8, w);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const char* p0 = kb + (kt * 32 + ks * 16) * 128 + voff[dt];
+          const hx4 lo = UCOD_TR16(p0);
+          const hx4 hi = UCOD_TR16(p0 + 8 * 128);
+          const hx8 vf = (hx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[0][dt] = UCOD_MFMA32(vf, pb[0][ks], o[0][dt]);
+          if (live1) o[1][dt] = UCOD_MFMA32(vf, pb[1][ks], o[1][dt]);
+        }
+    }
+  };
+
+  // two tiles per iteration: the LDS buffer index is a compile-time constant
+  stage(IntC<0>{});
+  for (int t = 0; t < nt; t += 2) {
+    tile(t, IntC<0>{});
+    if (t + 1 < nt) tile(t + 1, IntC<1>{});
+  }
+  if (!live) return;
+
+  const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(out + ((size_t)b * N) * D, 0, (unsigned)N * (unsigned)D * 2u, 0x00020000);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    if (rb == 1 && !live1) break;
+    const float lane_sum = lsum0[rb] + lsum1[rb];
+    const float denom = lane_sum + __shfl_xor(lane_sum, 32, 64);
+    const float inv = 1.0f / denom;
+    const int q = q0 + rb * 32 + l31;
+    if (lse && h5 == 0 && q < N) lse[((size_t)b * heads + head) * N + q] = m_run[rb] + __builtin_amdgcn_logf(denom);
+    const unsigned row_off = q < N ? ((unsigned)q * (unsigned)D + (unsigned)(head * HD + 8 * h5)) * 2u : 0x80000000u;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        const int g = 2 * gp;
+        const f32x16& oo = o[rb][dt];
+        unsigned a0 = cvt_pk_bf16(oo[4 * g + 0] * inv, oo[4 * g + 1] * inv), a1 = cvt_pk_bf16(oo[4 * g + 2] * inv, oo[4 * g + 3] * inv);
+        unsigned b0 = cvt_pk_bf16(oo[4 * g + 4] * inv, oo[4 * g + 5] * inv), b1 = cvt_pk_bf16(oo[4 * g + 6] * inv, oo[4 * g + 7] * inv);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        const u32x4 w = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, row_off + (unsigned)(dt * 32 + 16 * gp) * 2u, 0, 0);
+      }
+  }
+}
+
+// =====================================================================================================
 // Cross-attention, head_dim 96 (CORAL refiner: nn.MultiheadAttention with 8 heads on C=768, models/modules/mlp.py:122,143).
 // Same arithmetic as the pre-scaled-Q kernel above (pre-scaled Q, accumulator initialised with -m, per-half deferred max, denominator on
 // the matrix pipe, V through ds_read_b64_tr_b16) with separate query / key-value sources and lengths.  LDS rows are padded
@@ -622,7 +817,7 @@ static int attn_asm_default() {
 extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, int heads, float scale, int variant, void* stream) {
   using namespace ucod;
   if (!qkv || !out || B <= 0 || tok <= 0 || heads <= 0) return UCOD_EINVAL;
-  if (variant != 0 && variant != 2 && variant != 64 && variant != 32 && variant != 5) return UCOD_EINVAL;
+  if (variant != 0 && variant != 2 && variant != 64 && variant != 32 && variant != 5 && variant != 66) return UCOD_EINVAL;
   if ((size_t)tok * heads * HD * 3 * 2 >= (1ull << 32)) return UCOD_EINVAL;       // per-image qkv rows are addressed with 32-bit byte offsets
   // variant 64 / 32 = the assembly kernels (4 waves x 64 rows, one wave per SIMD / 8 waves x 32 rows, two per SIMD; refused where they do
   // not apply), 5 = attn_fwd_v5_kernel whatever the default, 0 / 2 = the default
@@ -632,12 +827,17 @@ extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, in
 #endif
   UCOD_PROF(PROF_ATTN, stream);
   int form = variant == 64 ? 0 : variant == 32 ? 1 : -1;
-  if (form < 0 && variant != 5 && scale == 0.f && attn_asm_default() > 0 && attn_asm_eligible(B, tok, heads)) form = attn_asm_default() == 2 ? 1 : 0;
+  if (variant == 66 && scale != 0.f) return UCOD_EINVAL;         // 66 = attn_fwd_v6_kernel by name (64 query rows per wave)
+  if (form < 0 && variant != 5 && variant != 66 && scale == 0.f && attn_asm_default() > 0 && attn_asm_eligible(B, tok, heads)) form = attn_asm_default() == 2 ? 1 : 0;
 #ifdef UCOD_HALF_F16
   if (form == 1) form = 0;
 #endif
   if (form >= 0) return attn_asm_launch(qkv, out, nullptr, B, tok, heads, form, (hipStream_t)stream);
-  if (scale == 0.f) {   // Q pre-scaled by head_dim^-0.5 * log2(e)
+  if (scale == 0.f && variant == 66) {
+    const int npairs = B * heads, nq6 = cdiv(tok, 256);
+    hipLaunchKernelGGL(attn_fwd_v6_kernel, dim3(cdiv(npairs, 8) * 8 * nq6), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads,
+                       npairs, (float*)nullptr);
+  } else if (scale == 0.f) {   // Q pre-scaled by head_dim^-0.5 * log2(e)
     const int npairs = B * heads, nq = cdiv(tok, QT);
     hipLaunchKernelGGL(attn_fwd_v5_kernel, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads,
                        npairs, (float*)nullptr);

@@ -640,7 +640,9 @@ static int launch_ln_lora(const void* x, bool x_h16, const float* gamma, const f
   if (dropout && (dropout->p < 0.f || dropout->p >= 1.f)) return UCOD_EINVAL;
   UCOD_PROF(PROF_LN, stream);
   const Drop drop = make_drop(dropout);
-  const int nblk = cdiv(rows, 8) < 2048 ? cdiv(rows, 8) : 2048;   // block-stride over rows: the A rows are staged once per block
+  static const int lnl_env = [] { const char* e = getenv("UCOD_LN_LORA_NBLK"); return e ? atoi(e) : 0; }();          // measurement knob
+  const int lnl_max = lnl_env > 0 ? lnl_env : 2048;
+  const int nblk = cdiv(rows, 8) < lnl_max ? cdiv(rows, 8) : lnl_max;   // block-stride over rows: the A rows are staged once per block
   dim3 grid(nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)3 * r * D * sizeof(float);

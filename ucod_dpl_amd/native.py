@@ -189,7 +189,7 @@ LAB_SIGNATURES = {
     "ucod_attention_fwd_lab": (ci, [vp, vp, ci, ci, ci, cf, ci, vp]),
     "ucod_gemm_bf16_lab": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
 }
-ATTN_PRODUCT_VARIANTS = (0, 2, 5, 32, 64)   # 64 / 32 = the hand-placed assembly kernels (4 waves x 64 rows / 8 waves x 32 rows), 5 = attn_fwd_v5_kernel whatever UCOD_ATTN_ASM says
+ATTN_PRODUCT_VARIANTS = (0, 2, 5, 32, 64, 66)   # 64 / 32 = the hand-placed assembly kernels (4 waves x 64 rows / 8 waves x 32 rows), 5 = attn_fwd_v5_kernel whatever UCOD_ATTN_ASM says
 GEMM_PRODUCT_VARIANTS = (0, 1, 2, 9, 10, 12, 13, 14)
 
 
