@@ -301,7 +301,7 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
     }
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();
-  big_epilogue<EPI, NT, NI, AUX>(a, acc, cs, smem + wave * (32 * 16 * NT * 4), m0 + wm * Cfg::RG, n0 + wn * 16 * NT, lane);
+  big_epilogue<EPI, NT, NI, AUX>(a, acc, cs, smem + wave * (32 * EPI_PITCH(16 * NT)), m0 + wm * Cfg::RG, n0 + wn * 16 * NT, lane);
 }
 
 // first row of row-tile tm when every `stride`-th row-tile (n_tall of them in all) is 32 rows taller

@@ -9,6 +9,13 @@
 #include "common.h"
 #include "../../include/ucod_dpl.h"
 
+// Row pitch of the wave-private staging area.  UCOD_EPI_PAD (bytes, default 0) pads it: with 0 the four 16-lane groups of a ds_write_b32 of the stager land on
+// the same 16 banks (rows 4 apart = 4 * 256 B); 16 shifts them by 16 banks each.  Measured (round 4, tools/gemm_ab.py): see DESIGN section 0.
+#ifndef UCOD_EPI_PAD
+#define UCOD_EPI_PAD 0
+#endif
+#define EPI_PITCH(wcols) ((wcols) * 4 + UCOD_EPI_PAD)
+
 namespace ucod {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -259,8 +266,8 @@ __device__ __forceinline__ void drain_rows(const GemmArgs& a, const char* wbase,
 #pragma unroll
       for (int it = 0; it < ROWS * CH / 64; ++it) {
         const int idx = it * 64 + lane, r = idx / CH, c = idx - r * CH;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(wbase + r * (WCOLS * 4) + c * 32);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(wbase + r * (WCOLS * 4) + c * 32 + 16);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(wbase + r * EPI_PITCH(WCOLS) + c * 32);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(wbase + r * EPI_PITCH(WCOLS) + c * 32 + 16);
         epilogue_store8_bf16<EPI>(a, m_first + r, n_first + c * 8, v0, v1);
       }
       return;
@@ -271,7 +278,7 @@ __device__ __forceinline__ void drain_rows(const GemmArgs& a, const char* wbase,
 #pragma unroll
   for (int it = 0; it < ROWS * CH / 64; ++it) {
     const int idx = it * 64 + lane, r = idx / CH, c = idx - r * CH;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + r * (WCOLS * 4) + c * 16);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + r * EPI_PITCH(WCOLS) + c * 16);
     epilogue_store4<EPI>(a, m_first + r, n_first + c * 4, v);
   }
 }
@@ -387,7 +394,7 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + (it * 4 + (lane >> 4)) * (WCOLS * 4) + (lane & 15) * 16) + (f32x4){bm[it], bm[it], bm[it], bm[it]};
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + (it * 4 + (lane >> 4)) * EPI_PITCH(WCOLS) + (lane & 15) * 16) + (f32x4){bm[it], bm[it], bm[it], bm[it]};
         const unsigned rowterm = (unsigned)(pass * PR + it * 4) * row_bytes;
         const bool row_ok = lrow + pass * PR + it * 4 < a.M;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, row_ok ? off_w + rowterm : DROP, 0, 0);
@@ -443,7 +450,7 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int it = 0; it < ITS; ++it) {
-        const char* src = wbase + (it * RPI + lane / CH) * (WCOLS * 4) + (lane % CH) * (EW * 4);
+        const char* src = wbase + (it * RPI + lane / CH) * EPI_PITCH(WCOLS) + (lane % CH) * (EW * 4);
         f32x4 v0 = (*reinterpret_cast<const f32x4*>(src) + cbias[0]) + __builtin_bit_cast(f32x4, pv[it][0]);
         if constexpr (H16) {
           const f32x4 v1 = (*reinterpret_cast<const f32x4*>(src + 16) + cbias[H16 ? 1 : 0]) + __builtin_bit_cast(f32x4, pv[it][1]);
@@ -507,7 +514,7 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
           u32x4 w;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + r * (WCOLS * 4) + c * 64 + e * 16);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + r * EPI_PITCH(WCOLS) + c * 64 + e * 16);
             int p = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[0], -448.f), 448.f), fminf(fmaxf(v[1], -448.f), 448.f), 0, false);
             p = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[2], -448.f), 448.f), fminf(fmaxf(v[3], -448.f), 448.f), p, true);
             w[e] = (unsigned)p;
@@ -555,7 +562,7 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
-          f32x4 o = *reinterpret_cast<const f32x4*>(wbase + lrow[it] * (WCOLS * 4) + lchk[it] * 16);
+          f32x4 o = *reinterpret_cast<const f32x4*>(wbase + lrow[it] * EPI_PITCH(WCOLS) + lchk[it] * 16);
           if constexpr (RESID) o = o + __builtin_bit_cast(f32x4, rb[pass & 1][it]);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, at(it, pass), 0, AUX);
         }
@@ -582,7 +589,7 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
       auto lrow = [&](int it) { return (it * 64 + lane) / CH; };
       auto lchk = [&](int it) { return (it * 64 + lane) - lrow(it) * CH; };
       const unsigned off0 = (n_first + (lane & 7) * 8 < a.N) ? (unsigned)(lane >> 3) * row_bytes + (unsigned)(n_first + (lane & 7) * 8) * 2u : DROP;
-      const char* lds0 = wbase + (lane >> 3) * (WCOLS * 4) + (lane & 7) * 32;
+      const char* lds0 = wbase + (lane >> 3) * EPI_PITCH(WCOLS) + (lane & 7) * 32;
       auto live = [&](int it, int pass) { return !FAST || it * 8 < rows_in(pass); };   // (compile-time after unrolling) rows 16..31 of a 16-row last pass
       auto at = [&](int it, int pass) -> unsigned {
         if constexpr (FAST) return off0 + (unsigned)(pass * PR + it * 8) * row_bytes;
@@ -590,8 +597,8 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
         return (n < a.N && lrow(it) < rows_in(pass)) ? (unsigned)(pass * PR + lrow(it)) * row_bytes + (unsigned)n * 2u : OOB;
       };
       auto lds_at = [&](int it) -> const char* {
-        if constexpr (FAST) return lds0 + it * 8 * (WCOLS * 4);
-        return wbase + lrow(it) * (WCOLS * 4) + lchk(it) * 32;
+        if constexpr (FAST) return lds0 + it * 8 * EPI_PITCH(WCOLS);
+        return wbase + lrow(it) * EPI_PITCH(WCOLS) + lchk(it) * 32;
       };
       float amax = 0.f;                                             // RH16: largest |x_new| this lane produced (saturation test after the stores)
       u32x4 pre[2][ITS];
@@ -693,7 +700,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
         if constexpr (kStageScaled<EPI>) v = v * cs[j];
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
-          *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * (WCOLS * 4) + (j * 16 + (lane & 15)) * 4) = v[rg];
+          *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * EPI_PITCH(WCOLS) + (j * 16 + (lane & 15)) * 4) = v[rg];
       }
   };
   big_epilogue_staged<EPI, NT, NI, AUX, FASTRM>(a, stage, wbase, m_first, n_first, lane);

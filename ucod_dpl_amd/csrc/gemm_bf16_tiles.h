@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();
 
   // epilogue through a wave-private LDS region (operand tiles are dead: last barrier passed)
-  big_epilogue<EPI, NT, 8, UCOD_ST_AUX, FASTRM>(a, acc, cs, smem + wave * (32 * 16 * NT * 4), m0 + wm * 128, n0 + wn * 16 * NT, lane);
+  big_epilogue<EPI, NT, 8, UCOD_ST_AUX, FASTRM>(a, acc, cs, smem + wave * (32 * EPI_PITCH(16 * NT)), m0 + wm * 128, n0 + wn * 16 * NT, lane);
 }
 
 }  // namespace ucod

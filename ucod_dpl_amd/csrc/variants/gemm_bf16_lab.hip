@@ -802,7 +802,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big32_kernel(const GemmArgs a) 
     }
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();
-  char* wbase = smem + wave * (32 * 16 * NT * 4);
+  char* wbase = smem + wave * (32 * EPI_PITCH(16 * NT));
   auto stage = [&](int pass) {                                     // pass = the wave's row tile of 32
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big32_kernel(const GemmArgs a) 
       if constexpr (kStageScaled<EPI>) v = v * cs[j];
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        *reinterpret_cast<float*>(wbase + ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * (16 * NT * 4) + (j * 32 + (lane & 31)) * 4) = v[r];
+        *reinterpret_cast<float*>(wbase + ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_PITCH(16 * NT) + (j * 32 + (lane & 31)) * 4) = v[r];
     }
   };
   big_epilogue_staged<EPI, NT, 8, UCOD_ST_AUX, false>(a, stage, wbase, m0 + wm * 128, n0 + wn * 64, lane);
