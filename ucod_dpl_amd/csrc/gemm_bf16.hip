@@ -172,6 +172,12 @@ struct MixCfg {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// (ablation build only: -DUCOD_GEMM_NOBAR removes the K loop's barriers of the mixed-height kernel -- wrong results, timing only)
+#ifdef UCOD_GEMM_NOBAR
+#define UCOD_MIXED_BARRIER() do {} while (0)
+#else
+#define UCOD_MIXED_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 template <int EPI, int NT, int XT, int AUX>
 __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0, int n0, int wave, int lane) {
   using Cfg = MixCfg<NT, XT>;
@@ -244,8 +250,8 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){cb[j], cb[j], cb[j], cb[j]};
-  __builtin_amdgcn_s_barrier();
-  if (wm == 1) __builtin_amdgcn_s_barrier();            // staggered wave groups (see gemm_bf16_big_kernel)
+  UCOD_MIXED_BARRIER();
+  if (wm == 1) UCOD_MIXED_BARRIER();            // staggered wave groups (see gemm_bf16_big_kernel)
 
   for (int t = 0; t < nt; ++t) {
     const char* bufA = smem + (t & 1) * Cfg::BUF + wm * Cfg::SLOT;
@@ -284,7 +290,7 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
         if (more2) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
       }
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      UCOD_MIXED_BARRIER();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -296,11 +302,11 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
             acc[ph * IT + i][j] = UCOD_MFMA16(fa[i][ks], fb[j][ks], acc[ph * IT + i][j]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      UCOD_MIXED_BARRIER();
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if (wm == 0) __builtin_amdgcn_s_barrier();
+  if (wm == 0) UCOD_MIXED_BARRIER();
   big_epilogue<EPI, NT, NI, AUX>(a, acc, cs, smem + wave * (32 * EPI_PITCH(16 * NT)), m0 + wm * Cfg::RG, n0 + wn * 16 * NT, lane);
 }
 
