@@ -503,6 +503,7 @@ class ViTLoRAEngine(ViTEngine):
         gh, gw = H // self.P, W // self.P
         lib = N.load()
         key = out if out is not None else torch.empty(B, self.D, gh, gw, dtype=torch.float32, device=self.device)
+        self.check_overflow()                                      # (non-blocking) training passes on the fp16 stream that have finished since the last call
         self._bounds = self._chunks(B)
         self._step += 1
         self._step_seed = (self._seed * 0x9E3779B97F4A7C15 + self._step) & 0xFFFFFFFFFFFFFFFF     # fresh masks every step
