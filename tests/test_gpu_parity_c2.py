@@ -295,3 +295,22 @@ def test_backward_engine_on_both_residual_streams():
     assert rel_l2(out["auto"][0], out["f32"][0]) < 5e-3
     assert rel_l2(out["auto"][1], out["f32"][1]) < 2e-2
     record("lora_engine_streams", dict(key_rel_l2=rel_l2(out["auto"][0], out["f32"][0]), grad_rel_l2=rel_l2(out["auto"][1], out["f32"][1])))
+
+
+def test_backward_engine_reports_saturation_of_its_fp16_stream():
+    """The training pass on the fp16 residual stream saturates and counts like the frozen pass: forward_train + check_overflow raises for a model whose
+    residual stream reaches 1e5, not for one at 1e3; resid="f32" holds the former without complaint."""
+    from ucod_dpl_amd.vit_engine import ViTLoRAEngine
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(12)).to(DEV)
+    ok = ViTLoRAEngine(_massive_state_dict(1.0e3), heads=4, device=DEV)
+    ok.forward_train(img)
+    ok.check_overflow(wait=True)
+    bad = ViTLoRAEngine(_massive_state_dict(1.0e5), heads=4, device=DEV)
+    key = bad.forward_train(img)
+    assert bool(torch.isfinite(key).all())
+    with pytest.raises(FloatingPointError):
+        bad.check_overflow(wait=True)
+    f32 = ViTLoRAEngine(_massive_state_dict(1.0e5), heads=4, device=DEV, resid="f32")
+    assert bool(torch.isfinite(f32.forward_train(img)).all())
+    f32.check_overflow(wait=True)
+
