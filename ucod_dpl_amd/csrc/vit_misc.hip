@@ -430,7 +430,10 @@ extern "C" int ucod_layernorm_h16(const void* x, const float* gamma, const float
   // wave (the round-3 launch); default 2 below D = 1024, 4 from there (profiles/r04_layernorm_strips.txt: 24.3 -> 23.1 us at 43840 x 768,
   // 18.6 -> 17.9 us = 0.63 of the HBM peak at 21920 x 1024, BASELINE configs[3]; 8 and more lose to the shorter tail)
   static const int strips_env = [] { const char* e = getenv("UCOD_LN_STRIPS"); return e ? atoi(e) : -1; }();
-  const int strips_per_wave = strips_env >= 0 ? strips_env : (D >= 1024 ? 4 : 2);
+  // (round 4, late) below D = 1024: 3, not the isolated launch's optimum of 2 -- in the pipelined step, where this kernel runs beside the other stream's
+  // large-tile GEMM, 3 and 4 strips give 3 381-3 398 images/s against 3 356-3 374 with 2 (three alternating runs each, one box); 3 keeps the launch at
+  // 26.0 us (0.65 of the HBM peak; 2: 25.3 us, 4: 27.0 us)
+  const int strips_per_wave = strips_env >= 0 ? strips_env : (D >= 1024 ? 4 : 3);
   if ((D % 256) == 0 && !no_strip) {
     const int nstrips = (rows + 1) / 2;
     const dim3 sgrid(strips_per_wave > 1 ? (unsigned)(cdiv(cdiv(nstrips, strips_per_wave), 4) > 256 ? cdiv(cdiv(nstrips, strips_per_wave), 4) : 256) : (unsigned)cdiv(nstrips, 4));
