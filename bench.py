@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=4)
     ap.add_argument("--gemm-variant", type=int, default=0)
-    ap.add_argument("--attn-variant", type=int, default=2, choices=[0, 1, 2, 5, 8, 32, 64], help="0 / 2 product kernel, 1 generic-scale kernel, 8 fp8 path (BASELINE configs[4]), 5 / 64 / 32 attn_fwd_v5_kernel / the assembly kernels by name")
+    ap.add_argument("--attn-variant", type=int, default=2, choices=[0, 1, 2, 5, 8, 32, 64, 66], help="0 / 2 product kernel, 1 generic-scale kernel, 8 fp8 path (BASELINE configs[4]), 5 / 64 / 32 attn_fwd_v5_kernel / the assembly kernels by name")
     ap.add_argument("--resid", default=os.environ.get("UCOD_RESID", "auto"), choices=["auto", "f32", "f16"],
                     help="residual-stream type of the backbone (auto: fp16 for bf16 operands, f32 for fp16 operands)")
     ap.add_argument("--streams", type=int, default=2, help="image-parallel sub-batches of the backbone pass on independent HIP streams")

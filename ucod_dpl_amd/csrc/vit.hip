@@ -38,7 +38,7 @@ Plan make_plan(const ucod_vit_desc* d) {
 // the scale applied inside the softmax), 8 = the fp8 path of BASELINE configs[4].  Laboratory variants (variants/attention_lab.hip) are
 // not reachable from the ViT driver: bench / tools that want to time one call ucod_attention_fwd_lab directly.
 // 5 / 64 / 32: attn_fwd_v5_kernel / the two assembly kernels by name (ucod_attention_fwd's variant), whatever UCOD_ATTN_ASM selects for 0 / 2
-inline bool attn_variant_known(int av) { return av == 0 || av == 1 || av == 2 || av == 8 || av == 5 || av == 64 || av == 32; }
+inline bool attn_variant_known(int av) { return av == 0 || av == 1 || av == 2 || av == 8 || av == 5 || av == 64 || av == 32 || av == 66; }
 inline bool attn_variant_takes_prescaled_q(int av) { return av != 1; }
 
 bool valid(const ucod_vit_desc* d) {

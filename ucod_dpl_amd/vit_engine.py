@@ -124,7 +124,7 @@ class ViTEngine:
         self.resid = resid
         self.resid16 = bool(resid == "f16" or (resid == "auto" and half == "bf16"))
         self._ovf_host, self._ovf_events, self._ovf_dev = None, [], None
-        if attn_variant not in (0, 1, 2, 8, 5, 64, 32):
+        if attn_variant not in (0, 1, 2, 8, 5, 64, 32, 66):
             raise ValueError(f"attn_variant must be 0, 1, 2, 5, 8, 32 or 64 (laboratory kernels are reached through ops.attention(variant=...)), got {attn_variant}")
         c = normalize_state_dict(state_dict)
         self.kind = c["kind"]
