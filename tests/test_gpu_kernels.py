@@ -258,6 +258,27 @@ def test_attention_assembly_kernels(B, tok, heads, variant):
     assert maxdiff(out, prod) < 4e-2          # two bf16 roundings of the same value: up to 2 ulp at |out| ~ 4
 
 
+@pytest.mark.parametrize("B,tok,heads", [(1, 50, 2), (2, 64, 1), (1, 65, 3), (2, 255, 2), (1, 256, 1), (1, 257, 2), (1, 513, 1)])
+def test_attention_v6_small_and_boundary_token_counts(B, tok, heads):
+    """attn_fwd_v6_kernel (variant 66: 64 query rows per wave, 256 per workgroup) at token counts below one tile, at and around its work-item size:
+    the second row block of a wave, whole waves and the second 32-key block of the last tile are dead in some of them."""
+    g = torch.Generator().manual_seed(tok * 7 + heads)
+    D = heads * 64
+    qkv = torch.randn(B * tok, 3 * D, generator=g) * 1.5
+    qkv[:, :D] *= 0.125 * math.log2(math.e)
+    qkv = bf(qkv)
+    q, k, v = (qkv.double()[:, i * D:(i + 1) * D].reshape(B, tok, heads, 64).transpose(1, 2) for i in range(3))
+    p = torch.softmax(torch.matmul(q, k.transpose(2, 3)) * math.log(2.0), dim=-1)
+    ref = torch.matmul(p, v).transpose(1, 2).reshape(B * tok, D).float()
+    qd = qkv.to(DEV)
+    out = ops.attention(qd, B, tok, heads, scale=0.0, variant=66).float().cpu()
+    assert maxdiff(out, ref) < 2.5e-2, maxdiff(out, ref)
+    assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
+    # v5 subtracts a rescale's delta from the second key block's finished scores, v6 starts that block's accumulator at the new -m: the same value up to
+    # one f32 rounding of the score, i.e. at most a bf16 ulp or two of the output
+    assert maxdiff(out, ops.attention(qd, B, tok, heads, scale=0.0, variant=5).float().cpu()) < 4e-2
+
+
 def test_attention_assembly_kernels_refuse_what_they_cannot_do():
     qkv = torch.zeros(64, 192, dtype=torch.bfloat16, device=DEV)
     out = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)
