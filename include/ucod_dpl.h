@@ -398,6 +398,9 @@ int ucod_binarize(const float* x, float* out, size_t n, int logits, void* stream
 /* loss of TrainLoop._process_batch (loop_UCOD_DPL.py:161-169): out[0] = losses[0] + losses[1] + extra[0] (- losses[2] unless finetune), from
  * the four scalars ucod_apm_bce left in `losses` and the orthogonality loss -- one launch instead of three elementwise adds (ABI 3). */
 int ucod_step_loss(const float* losses, const float* extra, int finetune, float* out, void* stream);
+/* dst[q][0..n[q]) = src[q][0..n[q]) for q < count <= 4, one launch (host arrays of device pointers / element counts; f32).  What
+ * loop_UCOD_DPL.py's refresh of the shared student | teacher projection needs per step instead of four device-to-device copies. */
+int ucod_copy_segments(float* const* dst, const float* const* src, const size_t* n, int count, void* stream);
 int ucod_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float ema_alpha, void* stream);
 

@@ -375,6 +375,37 @@ extern "C" int ucod_step_loss(const float* losses, const float* extra, int finet
   return UCOD_OK;
 }
 
+// Up to four f32 segment copies in ONE launch (loop_UCOD_DPL.py's shared student | teacher projection: two weight blocks, two bias blocks per step;
+// four hipMemcpyAsync = four rocclr copy kernels before round 4).  Segments with n == 0 are skipped.
+namespace ucod {
+struct CopySegs { float* dst[4]; const float* src[4]; size_t n[4]; };
+__global__ __launch_bounds__(256) void copy_segments_kernel(const CopySegs s, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    size_t k = i;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (k < s.n[q]) { s.dst[q][k] = s.src[q][k]; break; }
+      k -= s.n[q];
+    }
+  }
+}
+}  // namespace ucod
+
+extern "C" int ucod_copy_segments(float* const* dst, const float* const* src, const size_t* n, int count, void* stream) {
+  if (!dst || !src || !n || count < 1 || count > 4) return UCOD_EINVAL;
+  ucod::CopySegs s{};
+  size_t total = 0;
+  for (int q = 0; q < count; ++q) {
+    if (n[q] && (!dst[q] || !src[q])) return UCOD_EINVAL;
+    s.dst[q] = dst[q]; s.src[q] = src[q]; s.n[q] = n[q];
+    total += n[q];
+  }
+  if (total == 0) return UCOD_OK;
+  hipLaunchKernelGGL(ucod::copy_segments_kernel, dim3(ucod::nblocks(total, 1024)), dim3(256), 0, (hipStream_t)stream, s, total);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
 extern "C" int ucod_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float beta1,
                               float beta2, float eps, float weight_decay, int step, float ema_alpha, void* stream) {
   if (!p || !g || !m || !v || step <= 0) return UCOD_EINVAL;

@@ -70,10 +70,7 @@ class DecoderArena:
         """student rows 0..127 | teacher rows 128..255 of ONE projection (the 147 968 x 768 feature read is shared)."""
         _, Ws, bs, _, _ = self.slices(self.p)
         _, Wt, bt, _, _ = self.slices(self.ema)
-        self.Wcat[:128].copy_(Ws)
-        self.Wcat[128:].copy_(Wt)
-        self.bcat[:128].copy_(bs)
-        self.bcat[128:].copy_(bt)
+        ops.copy_segments([(self.Wcat[:128], Ws), (self.Wcat[128:], Wt), (self.bcat[:128], bs), (self.bcat[128:], bt)])
 
 
 class DiscArena:

@@ -149,6 +149,7 @@ SIGNATURES = {
     "ucod_gated_ensemble_workspace_bytes": (sz, [ci, ci, ci]),
     "ucod_gated_ensemble": (ci, [vp, vp, vp, vp, vp, cf, vp, vp, vp, ci, ci, ci, vp]),
     "ucod_step_loss": (ci, [vp, vp, ci, vp, vp]),
+    "ucod_copy_segments": (ci, [vp, vp, vp, ci, vp]),
     "ucod_adamw_ema": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, ci, cf, vp]),
     "ucod_cod_metrics_workspace_bytes": (sz, [ci, ci, ci]),
     "ucod_cod_metrics": (ci, [vp, vp, ci, ci, ci, vp, vp, sz, vp]),

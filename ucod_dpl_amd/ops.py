@@ -272,6 +272,18 @@ def disc_bce(probs_student, probs_pseudo, inv):
     return gs, gp, loss[0]
 
 
+def copy_segments(pairs):
+    """[(dst, src), ...] (at most four contiguous f32 tensors each way, same numel pairwise): one launch instead of one copy kernel per pair"""
+    k = len(pairs)
+    for d, s_ in pairs:
+        if d.dtype != torch.float32 or s_.dtype != torch.float32 or not d.is_contiguous() or not s_.is_contiguous() or d.numel() != s_.numel():
+            raise ValueError("copy_segments: contiguous f32 tensors of equal size")
+    dst = (C.c_void_p * k)(*[d.data_ptr() for d, _ in pairs])
+    src = (C.c_void_p * k)(*[s_.data_ptr() for _, s_ in pairs])
+    n = (C.c_size_t * k)(*[d.numel() for d, _ in pairs])
+    check(N.load().ucod_copy_segments(dst, src, n, k, stream()), "ucod_copy_segments")
+
+
 def binarize(x, logits):
     x = _f32(x).contiguous()
     out = torch.empty_like(x)
