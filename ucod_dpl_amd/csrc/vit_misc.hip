@@ -198,7 +198,17 @@ __global__ __launch_bounds__(256) void layernorm_h16_strip_kernel(const u32x4* _
 // LayerNorm of an IEEE-fp16 residual stream (ucod_vit_desc.resid16): the row arrives as 8-byte (4 x f16, D % 256 == 0) or 4-byte
 // (2 x f16) chunks per lane, is widened to f32 in registers, and the same two-pass f32 statistics follow; output = operand type.
 template <int NV, int W, int R = 2>                       // NV chunks of W f16 per lane: D = 64 * NV * W; R rows per wave
+__device__ __forceinline__ void layernorm_h16_body(const unsigned* __restrict__ x, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, bf16_raw* __restrict__ y, int rows, int D, float eps);
+
+template <int NV, int W, int R = 2>
 __global__ __launch_bounds__(256) void layernorm_h16_kernel(const unsigned* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_raw* __restrict__ y, int rows, int D, float eps) {
+  layernorm_h16_body<NV, W, R>(x, gamma, beta, y, rows, D, eps);
+}
+
+template <int NV, int W, int R>
+__device__ __forceinline__ void layernorm_h16_body(const unsigned* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_raw* __restrict__ y, int rows, int D, float eps) {
   constexpr int PW = W / 2;                                // packed dwords per chunk
   const int lane = threadIdx.x & 63;
