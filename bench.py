@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, help="image-parallel sub-batches of the backbone pass on independent HIP streams")
     ap.add_argument("--no-pipeline", action="store_true", help="serial order: backbone pass, then decoder step, on one stream")
     ap.add_argument("--half", default="bf16", choices=["bf16", "f16"], help="16-bit operand type of the backbone (bf16 = BASELINE configs[1])")
+    ap.add_argument("--ln-fold", default="auto", choices=["auto", "on", "off"], help="LayerNorm folded into the QKV / fc1 GEMMs (auto: on with fp16 operands on the fp16 stream)")
     ap.add_argument("--lora-resid", default="auto", choices=["auto", "f32", "f16"], help="residual stream of the backbone-backward engine (auto: fp16 with bf16 operands)")
     ap.add_argument("--lora-steps", type=int, default=4, help="steps of the separate backbone-backward (LoRA) measurement; 0 = skip")
     return ap.parse_args()
@@ -144,7 +145,9 @@ def main():
         raise SystemExit(f"bench.py: {world} ranks but the devices seen are {ranks_seen}: ranks share a GPU")
     loop = TrainLoop(cfg, runner)
     bb = backbone.random_init(a.arch, seed=0, image_size=a.image, device=dev, full_last_layer=a.full_last_layer,
-                              gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half=a.half, resid=a.resid)
+                              gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half=a.half, resid=a.resid,
+                              ln_fold={"auto": "auto", "on": True, "off": False}[a.ln_fold])
+    ln_fold = bool(bb.engine.ln_fold)
     bb.engine.streams = a.streams
     B = a.batch
     resid16 = bool(bb.engine.resid16)                         # fp16 residual stream (ViTEngine resid="auto": a property of the engine)
@@ -382,14 +385,14 @@ def main():
         for resid in ("auto", "f16"):
             cmd = [sys.executable, os.path.abspath(__file__), "--half", "f16", "--resid", resid, "--steps", str(a.steps), "--warmup", str(a.warmup),
                    "--batch", str(B), "--arch", a.arch, "--image", str(a.image), "--streams", str(a.streams), "--attn-variant", str(a.attn_variant),
-                   "--lora-steps", "-1", "--no-cpu-baseline"] + (["--no-pipeline"] if a.no_pipeline else []) + (["--full-last-layer"] if a.full_last_layer else [])
+                   "--lora-steps", "-1", "--no-cpu-baseline", "--ln-fold", a.ln_fold] + (["--no-pipeline"] if a.no_pipeline else []) + (["--full-last-layer"] if a.full_last_layer else [])
             r = subprocess.run(cmd, env=dict(os.environ, UCOD_BENCH_CHILD="1"), capture_output=True, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
                 raise SystemExit("bench.py: the fp16-operand child run failed:\n" + r.stderr[-2000:])
             c = json.loads(line[-1])
             f16_children.append({"resid": resid, "value": c["value"], "unit": "images/s", "ms_per_step": c["ms_per_step"],
-                                 "residual_stream": c["config"]["residual_stream"], "serial_ms_per_step": c["roofline"]["serial_ms_per_step_without_events"],
+                                 "residual_stream": c["config"]["residual_stream"], "ln_fold": c["config"].get("ln_fold"), "serial_ms_per_step": c["roofline"]["serial_ms_per_step_without_events"],
                                  "kernels_avg_us": {k: v["avg_us"] for k, v in c["kernels"].items()}})
         f16_option = {k: v for k, v in f16_children[0].items() if k != "kernels_avg_us"}
         f16_option["what"] = "the timed step with fp16 backbone operands (libucod_dpl_f16.so), same schedule, own process (python bench.py --half f16)"
@@ -415,7 +418,8 @@ def main():
                           # the same engine on trained-like synthetic weights (peaked attention, massive channels): the honest figure for a real checkpoint
                           "trained_like_weights": {k: tlw.get(k) for k in ("logit_max_abs", "logit_rel_l2", "key_rel_l2", "mask_flipped_fraction")},
                           "bar_met_on_trained_like_weights": (None if not tlw else bool(tlw["logit_max_abs"] <= BAR)),
-                          "engine": f"ViTEngine(half='f16', resid='{ch['resid']}')"})
+                          "ln_fold": ch.get("ln_fold"),
+                          "engine": f"ViTEngine(half='f16', resid='{ch['resid']}')" + (" with LayerNorm folded into the QKV / fc1 GEMMs" if ch.get("ln_fold") else "")})
         met = [c_ for c_ in cands if c_["bar_met"]]
         if met:
             bar_meeting = dict(max(met, key=lambda c_: c_["value"]))       # the fastest configuration under the bar
@@ -448,7 +452,7 @@ def main():
         "config": {"workload": f"{which_config(a.arch, a.image, B, a.attn_variant)}: {a.arch} @{a.image}x{a.image}, batch {B}/GPU, full APM+DBA+discriminator step, "
                                f"decoder path f32 (1x1 conv as a three-way bf16 split on the matrix pipe: f32-equivalent), backbone {a.half} MFMA", "global_batch": B * world, "parallelism": f"dp{world}",
                    "backbone_last_layer": "full (as reference)" if a.full_last_layer else "key-minimal (identical key output; 279.6 of 303.1 GFLOP/img)",
-                   "random_init_weights": True, "residual_stream": "fp16" if resid16 else "f32",
+                   "random_init_weights": True, "residual_stream": "fp16" if resid16 else "f32", "ln_fold": ln_fold,
                    "schedule": "serial, one stream" if a.no_pipeline else
                                f"backbone pass of step k+1 on {a.streams} side stream(s) overlapped with the decoder step of step k"},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "final_loss": round(final_loss, 6),
@@ -505,8 +509,8 @@ def cpu_baseline(a, D, heads, L, P):
         d = ops.bilinear_resize(ops.dba_project(key_dev, dec["decoupling.weight"].reshape(128, D).to(dev), dec["decoupling.bias"].to(dev)).view(n, 128, *key_dev.shape[-2:]), 68, 68).view(n, 128, 68 * 68)
         return ops.dba_heads(d, 0, emb, ops.dba_colnorm(d, 0, emb), hw, hb, want_bg=False)[0].view(n, 1, 68, 68).cpu()
 
-    def parity(half, resid="auto", sd=sd, img=img, key=key, fg_ref=fg_ref, layer_ref=layer_ref):
-        eng = ViTEngine(sd, heads=heads, eps=1e-6, device=dev, attn_variant=a.attn_variant, half=half, resid=resid)
+    def parity(half, resid="auto", sd=sd, img=img, key=key, fg_ref=fg_ref, layer_ref=layer_ref, ln_fold="auto"):
+        eng = ViTEngine(sd, heads=heads, eps=1e-6, device=dev, attn_variant=a.attn_variant, half=half, resid=resid, ln_fold=ln_fold)
         key_dev = eng(img.to(dev))
         kd, fd = key_dev.cpu(), device_logits(key_dev)
         per_layer = []
@@ -514,7 +518,7 @@ def cpu_baseline(a, D, heads, L, P):
             kl = eng.forward(img.to(dev), n_layers=li).cpu()
             per_layer.append(round(float((kl - layer_ref[li - 1]).norm() / layer_ref[li - 1].norm()), 6))
         eng.check_overflow(wait=True)
-        res = {"residual_stream": "fp16" if eng.resid16 else "f32",
+        res = {"residual_stream": "fp16" if eng.resid16 else "f32", "ln_fold": bool(eng.ln_fold),
                "key_rel_l2": round(float((kd - key).norm() / key.norm()), 6), "key_max_abs": round(float((kd - key).abs().max()), 5),
                "logit_max_abs": round(float((fd - fg_ref).abs().max()), 6), "logit_rel_l2": round(float((fd - fg_ref).norm() / fg_ref.norm()), 6),
                "mask_flipped_fraction": round(float(((fd > 0) != (fg_ref > 0)).float().mean()), 6)}
@@ -552,11 +556,13 @@ def cpu_baseline(a, D, heads, L, P):
         **parity("bf16"),
         "reference_fp16_autocast_emulation": autocast_deviation(sd, key, fg_ref),
         "f16_operands": parity("f16"),                            # engine default for fp16 operands: f32 residual stream
-        "f16_operands_f16_stream": parity("f16", "f16"),
+        "f16_operands_f16_stream": parity("f16", "f16"),            # (LayerNorm folded into QKV / fc1: the engine's default for this pair)
+        "f16_operands_f16_stream_unfolded": parity("f16", "f16", ln_fold=False),
         "trained_like_weights": {
             "what": "same images, trained_like_state_dict (pre-softmax score std ~4, row entropy ~3.7 of ln 1370 = 7.2, LayerScale 0.1 .. 1, "
                     "massive channels +-200); reference logits reach |%.2f| (flat init: |%.2f|)" % (float(fg_p.abs().max()), float(fg_ref.abs().max())),
             "bf16": parity("bf16", **peaked), "f16_operands": parity("f16", **peaked), "f16_operands_f16_stream": parity("f16", "f16", **peaked),
+            "f16_operands_f16_stream_unfolded": parity("f16", "f16", ln_fold=False, **peaked),
             "reference_fp16_autocast_emulation": autocast_deviation(sd_p, key_p, fg_p)}}
     return out
 

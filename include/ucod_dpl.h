@@ -37,7 +37,9 @@ extern "C" {
  * the experiment variants of ucod_gemm_bf16 / ucod_attention_fwd left the product library.  native.load() refuses any other version. */
 /* 3 (round 4): ucod_disc_params gained `nbt`; ucod_step_loss, ucod_disc_bce, the feature-branch discriminator's backward entry points and
  * the assembly attention variants (ucod_attention_fwd variant 64 / 32 / 5) were added. */
-#define UCOD_ABI_VERSION 3
+/* 4 (round 5): LayerNorm folded into its consumer GEMMs -- epilogues 11 / 12, ucod_gemm_lnfold, ucod_row_stats_h16, ucod_vit_desc.ln_fold,
+ * UCOD_VIT_LAYER_STRIDE 14 -> 16 (two column-sum slots per layer). */
+#define UCOD_ABI_VERSION 4
 int ucod_abi_version(void);
 /* 1 when a gfx950 device is visible to this process (hipGetDeviceProperties().gcnArchName) */
 int ucod_device_is_gfx950(void);
@@ -76,6 +78,11 @@ enum {
                                         scale[n]*(C+bias[n])) (ucod_vit_desc.resid16; `resid` / `out` point at f16 rows).  sat = clamp to
                                         +-65504 (never inf); every clamp is counted: ucod_resid16_overflow_fetch.  Any shape. */
   UCOD_EPI_PATCH_TOKENS_H16 = 10,    /* as UCOD_EPI_PATCH_TOKENS_F32 with f16 token rows (same saturation) */
+  UCOD_EPI_LNFOLD_BIAS_BF16 = 11,    /* ucod_gemm_lnfold only.  LayerNorm folded into the QKV projection (modeling_dinov2.py:348-353,199-212: norm1 -> query / key /
+                                        value): A = the fp16 residual stream x itself, B = fp16(gamma (.) W), colsum[n] = sum_k B[n][k], bias = W beta + b,
+                                        stats[m] = (rstd, -mean * rstd) of row m:  out 16-bit [M,N] = (stats[m][0] * C + stats[m][1] * colsum[n] + bias[n]) * scale[n] */
+  UCOD_EPI_LNFOLD_GELU_BF16 = 12,    /* ucod_gemm_lnfold only.  The same fold for norm2 -> fc1 -> GELU (modeling_dinov2.py:365-373,281-297):
+                                        out = gelu_erf(stats[m][0] * C + stats[m][1] * colsum[n] + bias[n]) */
   UCOD_EPI_QKV_FP8 = 8               /* QKV projection of the fp8 attention path (BASELINE configs[4]): out = e4m3 bytes
                                         [3 (q|k|v)][Bimg*heads][Npad][64], Npad = tokens rounded up to 64, value = clamp((C + bias[n]) *
                                         scale[n], +-448); N = 3*heads*64, M = Bimg*tokens_per_image; large-tile kernel only */
@@ -90,6 +97,19 @@ enum {
 int ucod_gemm_bf16(int epilogue, const void* A_bf16, const void* B_bf16, void* out, int M, int N, int K,
                    const float* bias, const float* scale, const float* resid, const float* pos,
                    int tokens_per_image, int variant, void* stream);
+/* LayerNorm folded into its consumer GEMM (epilogues UCOD_EPI_LNFOLD_*; libucod_dpl_f16.so only -- an MFMA takes both operands in one type and
+ * the A operand here is the IEEE fp16 residual stream itself; the bf16 build returns UCOD_EINVAL).  Replaces nn.LayerNorm + nn.Linear of
+ * modeling_dinov2.py:348-381 (norm1 -> attention, norm2 -> mlp) and dino.py:127-131:
+ *   LN(x) W^T + b = rstd[m] * (x W'^T - mean[m] * colsum[n]) + bias'[n],   W' = fp16(gamma (.) W),  colsum[n] = sum_k W'[n][k] (of the ROUNDED
+ *   W', so that the subtraction cancels what the MFMA summed),  bias' = W beta + b.
+ * x_f16 [M,K] fp16, w_folded [N,K] fp16, colsum / bias_folded f32 [N], stats f32 [M][2] = (rstd, -mean * rstd) per row (ucod_row_stats_h16),
+ * scale: optional column scale (UCOD_EPI_LNFOLD_BIAS_BF16 only), out fp16 [M,N].  N % 8 == 0, K % 64 == 0.  variant as ucod_gemm_bf16
+ * (the 192-wide forms 10 / 14 are taken as 9 / 13). */
+int ucod_gemm_lnfold(int epilogue, const void* x_f16, const void* w_folded, void* out, int M, int N, int K, const float* bias_folded,
+                     const float* colsum, const float* stats, const float* scale, int variant, void* stream);
+/* Row statistics of the fp16 residual stream for the folded epilogues: stats[m] = (rstd, -mean * rstd), two-pass in f32 over the row held in
+ * registers, biased variance + eps like nn.LayerNorm.  x f16 [rows,D], D % 256 == 0, D <= 1536. */
+int ucod_row_stats_h16(const void* x_f16, float* stats, int rows, int D, float eps, void* stream);
 /* The UCOD_GEMM_* tuning variables (csrc/gemm_bf16_plan.h) are read once per process; this re-reads them (tests, sweep tools). */
 void ucod_gemm_reload_tuning(void);
 
@@ -245,11 +265,14 @@ int ucod_lora_grad(void* dqkv_aug_bf16, const void* h_aug_bf16, const float* lor
  *     +0 ln1_g  +1 ln1_b  +2 qkv_w bf16 [3D,D] (rows q|k|v)  +3 qkv_b [3D]  +4 proj_w bf16 [D,D]  +5 proj_b
  *     +6 ls1 [D] (LayerScale lambda1; ones for DINOv1)  +7 ln2_g  +8 ln2_b  +9 fc1_w bf16 [F,D]  +10 fc1_b [F]
  *     +11 fc2_w bf16 [D,F]  +12 fc2_b [D]  +13 ls2 [D]
+ *     +14 qkv_colsum [3D]  +15 fc1_colsum [F]   (ln_fold only, else unused: with ln_fold the entries +2 / +3 / +9 / +10 of every layer BUT THE LAST
+ *     of the pass hold the folded forms fp16(gamma (.) W) and W beta + b, and +14 / +15 the column sums of the folded weights; the last
+ *     layer keeps plain weights -- its LayerNorm 1 runs as a kernel and feeds the key hook)
  * The last layer uses only ln1 and the K slice (rows D..2D-1) of qkv_w / qkv_b: that projection, bias included and
  * before the head split, is what the reference's forward hook captures (feature_extractor.py:42,46-47).
  * key_out f32 [B, D, H/P, W/P].  full_last_layer != 0 additionally runs the rest of the last layer exactly as the
  * reference does (its output is discarded there too); key_out is identical either way. */
-#define UCOD_VIT_LAYER_STRIDE 14
+#define UCOD_VIT_LAYER_STRIDE 16
 typedef struct {
   int B, C, H, W, P;      /* images */
   int D, heads, F, L;     /* width, heads (head_dim = D/heads = 64), MLP width, layers */
@@ -267,6 +290,9 @@ typedef struct {
                              Logit max-abs vs the f32 reference at full size, random-init weights: bf16 operands 3.2e-3 either way; fp16
                              operands 3.8e-4 (f32 stream) / 6.4e-4 (fp16 stream).  Works for any batch size (small passes take the
                              128 x 128 / 64 x 64 kernels with the same epilogue). */
+  int ln_fold;            /* 1 (libucod_dpl_f16.so with resid16 = 1 only): LayerNorm 1 / 2 of every layer but the last are folded into the QKV / fc1
+                             GEMMs (ucod_gemm_lnfold): the fp16 stream is the A operand, no LayerNorm output is written or rounded.  The table then
+                             carries folded weights (see the table layout).  0: LayerNorm kernels. */
 } ucod_vit_desc;
 size_t ucod_vit_workspace_bytes(const ucod_vit_desc* d);
 int ucod_vit_forward(const ucod_vit_desc* d, const void* const* table_host, const float* img, float* key_out,

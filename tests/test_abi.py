@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_argument_validation(lib):
-    assert lib.ucod_abi_version() == 3
+    assert lib.ucod_abi_version() == 4
     # rejected before any device work: null pointers / bad sizes return UCOD_EINVAL (-1)
     assert lib.ucod_gemm_bf16(0, None, None, None, 1, 1, 64, None, None, None, None, 0, 0, None) == -1
     assert lib.ucod_layernorm(None, None, None, None, 1, 100, 1e-6, 0, None) == -1

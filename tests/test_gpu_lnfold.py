@@ -1,0 +1,179 @@
+"""GPU: LayerNorm folded into its consumer GEMMs (round 5; include/ucod_dpl.h: ucod_gemm_lnfold, ucod_row_stats_h16, ucod_vit_desc.ln_fold).
+
+The reference computes nn.LayerNorm -> nn.Linear (transformers modeling_dinov2.py:348-381: norm1 -> query / key / value, norm2 -> fc1 -> GELU).
+The folded form multiplies the UN-normalised fp16 rows by fp16(gamma (.) W) and applies the row's (rstd, -mean * rstd) in the epilogue:
+   LN(x) W^T + b = rstd * (x W'^T - mean * colsum(W')) + (W beta + b).
+Checked here: the row statistics; the epilogues on every tile path (64 x 64, 128 x 128, large-tile one-shot with patches, mixed-height) against
+(a) an f64 evaluation of the SAME rounded operands (bound: f32 accumulation + one fp16 output rounding) and (b) LayerNorm -> Linear in f64 on the
+unrounded weights (bound: the fp16 rounding of the weights on top); the cancellation x W'^T - mean * colsum with massive channels; the engine with
+the fold against the f32 oracle and against the unfolded engine.
+"""
+import pytest
+import torch
+
+from conftest import maxdiff
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from ucod_dpl_amd import native as N, ops  # noqa: E402
+from ucod_dpl_amd.vit_engine import ViTEngine  # noqa: E402
+from ucod_dpl_amd.data.utils.feature_extractor import random_state_dict, ARCHS  # noqa: E402
+from oracle import vit as OV  # noqa: E402
+
+DEV = "cuda"
+EPS = 1e-6
+H = 2.0 ** -11                                                  # half an ulp of fp16, relative
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rows(M, K, seed, massive=0.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 2) + torch.randn(M, 1, generator=g) * 0.3
+    if massive:
+        x[:, 7] = massive
+        x[::3, K - 5] = -0.75 * massive
+    return x.to(torch.float16)
+
+
+@pytest.mark.parametrize("M,D,massive", [(1, 256, 0), (2, 768, 0), (1371, 768, 200.0), (4384, 1024, 0), (43840, 768, 3.0e4), (333, 1536, 0)])
+def test_row_stats_h16(M, D, massive):
+    x = rows(M, D, 5 + M, massive)
+    st = ops.row_stats_h16(x.to(DEV), EPS).cpu().double()
+    xd = x.double()
+    mean, var = xd.mean(1), xd.var(1, unbiased=False)
+    rstd = (var + EPS).rsqrt()
+    assert maxdiff(st[:, 0] / rstd, torch.ones(M)) < 2e-6
+    assert maxdiff(st[:, 1], -mean * rstd) < 2e-6 * max(1.0, float((mean * rstd).abs().max()))
+
+
+def _case(M, Nn, K, seed, massive=0.0, gelu=False, scale=False):
+    g = torch.Generator().manual_seed(seed)
+    x = rows(M, K, seed + 1, massive)
+    gamma, beta = 1 + 0.3 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+    w, b = torch.randn(Nn, K, generator=g) * 0.04, torch.randn(Nn, generator=g) * 0.1
+    sc = (0.5 + torch.rand(Nn, generator=g)) if scale else None
+    wf, bf_, cs = ops.fold_layernorm_linear(gamma.to(DEV), beta.to(DEV), w.to(DEV), b.to(DEV))
+    st = ops.row_stats_h16(x.to(DEV), EPS)
+    xd = x.double()
+    mean, rstd = xd.mean(1, keepdim=True), (xd.var(1, unbiased=False, keepdim=True) + EPS).rsqrt()
+    # (a) the same rounded operands in f64
+    same = rstd * (xd @ wf.cpu().double().t() - mean * cs.cpu().double()[None, :]) + bf_.cpu().double()[None, :]
+    # (b) LayerNorm -> Linear on the unrounded weights in f64 (the reference's arithmetic)
+    ln = (xd - mean) * rstd * gamma.double() + beta.double()
+    plain = ln @ w.double().t() + b.double()
+    if scale:
+        same, plain = same * sc.double(), plain * sc.double()
+    if gelu:
+        same, plain = torch.nn.functional.gelu(same), torch.nn.functional.gelu(plain)
+    return x, st, wf, bf_, cs, (sc.to(DEV) if scale else None), same, plain
+
+
+# (M, N, K, variant): 64 x 64 and 128 x 128 tiles, the one-shot large tile (leftover tiles as patches), the mixed-height kernel at the BASELINE shapes
+SHAPES = [(200, 256, 256, 12), (200, 256, 256, 2), (1370, 2304, 768, 0), (1370, 3072, 768, 0), (4111, 768, 768, 9), (2740, 2304, 768, 9),
+          (8220, 2304, 768, 13), (8220, 3072, 768, 13), (43840, 2304, 768, 0), (43840, 3072, 768, 0), (21920, 4096, 1024, 0), (5000, 768, 768, 10)]
+
+
+@pytest.mark.parametrize("M,Nn,K,variant", SHAPES)
+@pytest.mark.parametrize("gelu", [False, True])
+def test_gemm_lnfold_matches_layernorm_then_linear(M, Nn, K, variant, gelu):
+    x, st, wf, bf_, cs, sc, same, plain = _case(M, Nn, K, M + Nn, gelu=gelu, scale=not gelu)
+    out = ops.linear_lnfold(x.to(DEV), st, wf, bf_, cs, gelu=gelu, scale=sc, variant=variant).cpu().double()
+    # (a): f32 accumulation over K plus ONE fp16 rounding of the output
+    err = (out - same).abs()
+    bound = H * same.abs() + 4e-5 * (1 + same.abs())
+    assert bool((err <= bound).all()), (float((err - bound).max()), M, Nn, K, variant)
+    # (b): the fp16 rounding of K folded weights per output on top (relative 2^-11 each, random signs)
+    assert rel_l2(out, plain) < 6e-4
+    assert maxdiff(out, plain) < 4e-3 * max(1.0, float(plain.abs().max()))
+
+
+@pytest.mark.parametrize("massive", [200.0, 3.0e4])
+@pytest.mark.parametrize("M,Nn,K,variant", [(1370, 2304, 768, 0), (8220, 3072, 768, 13), (4111, 768, 768, 9)])
+def test_lnfold_cancellation_with_massive_channels_stays_at_rounding_level(M, Nn, K, variant, massive):
+    """x W'^T and mean * colsum both carry the massive channels' contribution; their difference must come out at the f32 rounding of the LARGER terms,
+    i.e. far below one fp16 ulp of the result scale set by rstd (massive rows have rstd ~ 1 / massive: outputs stay O(1))."""
+    x, st, wf, bf_, cs, sc, same, plain = _case(M, Nn, K, M + 3, massive=massive)
+    out = ops.linear_lnfold(x.to(DEV), st, wf, bf_, cs, variant=variant).cpu().double()
+    err = (out - same).abs()
+    bound = H * same.abs() + 1e-4 * (1 + same.abs())
+    assert bool((err <= bound).all()), (float((err - bound).max()), massive)
+    assert rel_l2(out, plain) < 8e-4
+
+
+def test_gemm_lnfold_is_refused_by_the_bf16_build():
+    x = torch.zeros(128, 256, dtype=torch.float16, device=DEV)
+    w = torch.zeros(128, 256, dtype=torch.float16, device=DEV)
+    z = torch.zeros(128, dtype=torch.float32, device=DEV)
+    st = torch.zeros(128, 2, dtype=torch.float32, device=DEV)
+    out = torch.empty(128, 128, dtype=torch.float16, device=DEV)
+    args = (N.ptr(x), N.ptr(w), N.ptr(out), 128, 128, 256, N.ptr(z), N.ptr(z), N.ptr(st), None, 0, N.stream())
+    assert N.load("bf16").ucod_gemm_lnfold(N.EPI_LNFOLD_BIAS_BF16, *args) == -1
+    assert N.load("f16").ucod_gemm_lnfold(N.EPI_LNFOLD_BIAS_BF16, *args) == 0
+    assert N.load("f16").ucod_gemm_lnfold(N.EPI_BIAS_BF16, *args) == -1                 # only the two folded epilogues
+    assert N.load("f16").ucod_gemm_bf16(N.EPI_LNFOLD_BIAS_BF16, N.ptr(x), N.ptr(w), N.ptr(out), 128, 128, 256, N.ptr(z), None, None, None, 0, 0, N.stream()) == -1
+
+
+# ------------------------------------------------------------------------------------------------ the engine with the fold
+@pytest.fixture(scope="module")
+def small():
+    ARCHS["fold_vit"] = (256, 4, 5, 14, 224, True)
+    sd = random_state_dict("fold_vit", seed=4)
+    g = torch.Generator().manual_seed(8)
+    for k in sd:                                                # LayerNorm parameters away from (1, 0): the fold has something to carry
+        if "norm" in k and k.endswith("weight"):
+            sd[k] = 1 + 0.3 * torch.randn(sd[k].shape, generator=g)
+        if "norm" in k and k.endswith("bias"):
+            sd[k] = 0.2 * torch.randn(sd[k].shape, generator=g)
+    img = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        _, ref = OV.dinov2_forward(img, sd, heads=4, patch=14, eps=1e-6, full_last_layer=False)
+        layer_ref = list(OV.dinov2_forward.layer_keys)
+    return sd, img, ref, layer_ref
+
+
+def test_engine_with_the_fold_against_the_oracle_and_the_unfolded_engine(small):
+    sd, img, ref, layer_ref = small
+    fold = ViTEngine(sd, heads=4, device=DEV, half="f16", resid="f16")
+    plain = ViTEngine(sd, heads=4, device=DEV, half="f16", resid="f16", ln_fold=False)
+    assert fold.ln_fold and not plain.ln_fold and fold._desc(3, 224, 224).ln_fold == 1
+    kf, kp = fold(img.to(DEV)).cpu(), plain(img.to(DEV)).cpu()
+    fold.check_overflow(wait=True)
+    df, dp = rel_l2(kf, ref), rel_l2(kp, ref)
+    assert df < 1.5e-3 and df <= 1.25 * dp + 1e-4, (df, dp)       # no 16-bit LayerNorm output any more: at least as close as the unfolded engine
+    assert rel_l2(kf, kp) < 2e-3
+    # a truncated pass: its last layer takes the plain weights and a LayerNorm kernel, the ones before it the folded entries
+    for n in (1, 2, 4):
+        kn = fold.forward(img.to(DEV), n_layers=n).cpu()
+        assert rel_l2(kn, layer_ref[n - 1]) < 1.5e-3, n
+    # one image (small-tile kernels) against the same image inside the batch (large-tile kernels are not reached at this size; the stats / fold path is the same)
+    k1 = fold(img[:1].contiguous().to(DEV)).cpu()
+    assert rel_l2(k1, kf[:1]) < 1e-3
+
+
+def test_ln_fold_is_refused_where_it_cannot_run(small):
+    sd = small[0]
+    for kw in (dict(half="bf16"), dict(half="f16", resid="f32"), dict(half="f16", resid="auto")):
+        with pytest.raises(ValueError):
+            ViTEngine(sd, heads=4, device=DEV, ln_fold=True, **kw)
+        assert not ViTEngine(sd, heads=4, device=DEV, **kw).ln_fold
+
+
+def test_attention_variant_66_reaches_its_kernel_through_the_engine(small):
+    """the driver forwarded only 5 / 64 / 32 to ucod_attention_fwd, so attn_variant=66 silently ran the default kernel."""
+    sd, img = small[0], small[1]
+    lib = N.load()
+    qkv = (torch.randn(2 * 257, 3 * 256, generator=torch.Generator().manual_seed(1)) * 0.5).to(torch.bfloat16).to(DEV)
+    o66, o5 = ops.attention(qkv, 2, 257, 4, scale=0.0, variant=66), ops.attention(qkv, 2, 257, 4, scale=0.0, variant=5)
+    e66, e5 = ViTEngine(sd, heads=4, device=DEV, attn_variant=66), ViTEngine(sd, heads=4, device=DEV, attn_variant=5)
+    k66, k5 = e66(img.to(DEV)), e5(img.to(DEV))
+    if not torch.equal(o66, o5):                                # the two kernels differ in their last bits on this input: so must the engines
+        assert not torch.equal(k66, k5)
+    assert rel_l2(k66, k5) < 2e-2
+    assert lib.ucod_abi_version() == N.ABI_VERSION

@@ -354,10 +354,10 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
     // large tiles when either dimension is long enough to fill the chip with 256-row tiles (the key hook has M = channels = 768
     // but N = all tokens: 3 x 172 tiles)
     const bool big_enough = a.M >= 2048 || (a.M >= 512 && (long)a.M * a.N >= (1L << 24));
-    if (big_enough && a.K >= 128 && (a.N & 3) == 0 && (!(EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) || (a.N & 7) == 0)) {
+    if (big_enough && a.K >= 128 && (a.N & 3) == 0 && (!(kBiasLike<EPI> || kGeluLike<EPI>) || (a.N & 7) == 0)) {
       // two 32-MFMA barrier intervals per K-tile (variants 9/10) beat four 16-MFMA ones (5/6) by 2-4 % and the persistent
       // form (7/8) by 1-5 % on every backbone shape (tools/gemm_bench.py); the width with the shorter modelled makespan
-      variant = (big_plan(a.M, a.N, a.K, 192, kPatchEpi).cost < big_plan(a.M, a.N, a.K, 256, kPatchEpi).cost) ? 10 : 9;
+      variant = (!kFold<EPI> && big_plan(a.M, a.N, a.K, 192, kPatchEpi).cost < big_plan(a.M, a.N, a.K, 256, kPatchEpi).cost) ? 10 : 9;
       // three or more rounds with a nearly empty last one (QKV 6.05, fc1 8.06): mixed-height tiles make it whole rounds (-7 % / -8 %,
       // tools/gemm_order_sweep.py); at one or two rounds the patches above already do that at the same cost
       const MixedPlan mp = mixed_plan(a.M, a.N, 256);
@@ -368,8 +368,12 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
     if (kTrainEpi && ((a.N & 7) != 0 || a.K < 128)) return UCOD_EINVAL;
     if (variant < 3) variant = (big_plan(a.M, a.N, a.K, 192, kPatchEpi).cost < big_plan(a.M, a.N, a.K, 256, kPatchEpi).cost) ? 10 : 9;
   }
-  constexpr bool kBf16Out = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || kTrainEpi);
+  constexpr bool kBf16Out = (kBiasLike<EPI> || kGeluLike<EPI> || kTrainEpi);
   if ((variant >= 3 && variant <= 8) || variant == 11 || variant > 14 || variant < 0) return UCOD_EINVAL;   // 3-8: laboratory variants (variants/gemm_bf16_lab.hip)
+  if constexpr (kFold<EPI>) {                                    // the LayerNorm-folded drains exist for 64-column waves only: the 256-wide forms
+    if (variant == 10) variant = 9;
+    if (variant == 14) variant = 13;
+  }
   if (variant >= 9 && variant <= 10 && ((a.N & 3) != 0 || (kBf16Out && (a.N & 7) != 0))) return UCOD_EINVAL;   // 16-byte row stores
   if constexpr (kColFused<EPI>) {
     if (variant == 13 || variant == 14) {                     // mixed-height tiles; falls back to 9 / 10 when the plan is not feasible
@@ -392,8 +396,14 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
           if (aux == 2 && variant == 13) { hipLaunchKernelGGL((gemm_bf16_mixed_kernel<EPI, 4, 2>), grid, block, 0, s, a); UCOD_CHECK_LAUNCH(); return UCOD_OK; }
           if (aux == 16 && variant == 13) { hipLaunchKernelGGL((gemm_bf16_mixed_kernel<EPI, 4, 16>), grid, block, 0, s, a); UCOD_CHECK_LAUNCH(); return UCOD_OK; }
         }
-        if (variant == 13) hipLaunchKernelGGL((gemm_bf16_mixed_kernel<EPI, 4>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_bf16_mixed_kernel<EPI, 3>), grid, block, 0, s, a);
+        if constexpr (kFold<EPI>) {                               // (always 256 wide, non-temporal output stores like the unfolded forward epilogues)
+          hipLaunchKernelGGL((gemm_bf16_mixed_kernel<EPI, 4, 2>), grid, block, 0, s, a);
+          UCOD_CHECK_LAUNCH();
+          return UCOD_OK;
+        } else {
+          if (variant == 13) hipLaunchKernelGGL((gemm_bf16_mixed_kernel<EPI, 4>), grid, block, 0, s, a);
+          else hipLaunchKernelGGL((gemm_bf16_mixed_kernel<EPI, 3>), grid, block, 0, s, a);
+        }
         UCOD_CHECK_LAUNCH();
         return UCOD_OK;
       }
@@ -427,8 +437,12 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
       a.patches_per_wg = cdiv((long)pl.left * pl.ppt, a.main_tiles);
       grid.x = a.main_tiles;
     }
-    if (wide) hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4, true, 2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3, true, 2>), grid, block, 0, s, a);
+    if constexpr (kFold<EPI>) {
+      hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4, true, 2>), grid, block, 0, s, a);
+    } else {
+      if (wide) hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 4, true, 2>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 3, true, 2>), grid, block, 0, s, a);
+    }
   } else {
     // 128 x 128 tiles (two workgroups per CU), or 64 x 64 when there are fewer 128-tiles than CUs: a batch-1 backbone pass has 66 tiles of
     // proj / fc2 (29 -> 19 us per launch with the small tile; 264 tiles of fc1 are already better off with 128 x 128).  Variant 12 forces
@@ -500,12 +514,14 @@ static int launch_resid_h16(ucod::GemmArgs a, hipStream_t s) {
 
 static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int M, int N, int K, const float* bias,
                       const float* scale, const float* resid, const float* pos, int tokens_per_image, int variant,
-                      void* stream, const void* aux, void* out2) {
+                      void* stream, const void* aux, void* out2, const float* stats = nullptr, const float* colsum = nullptr) {
   using namespace ucod;
   if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0) return UCOD_EINVAL;
   GemmArgs a;
   a.aux = aux;
   a.out2 = out2;
+  a.stats = stats;
+  a.colsum = colsum;
   a.ovf = (epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16 || epilogue == UCOD_EPI_PATCH_TOKENS_H16) ? resid16_overflow_counter() : nullptr;
   a.stamps = nullptr;
 #ifdef UCOD_GEMM_STAMPS
@@ -529,7 +545,7 @@ static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int
   a.group_m = 8;
   a.col_fast = 0;
   hipStream_t s = (hipStream_t)stream;
-  UCOD_PROF(epilogue == UCOD_EPI_QKV_FP8 ? 0 : epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16 ? 2 : epilogue == UCOD_EPI_PATCH_TOKENS_H16 ? 3 : (epilogue >= 0 && epilogue <= 5 ? epilogue : (epilogue == UCOD_EPI_GELU_BWD_BF16 ? PROF_GEMM_EPI6 : PROF_GEMM_EPI7)), s);
+  UCOD_PROF(epilogue == UCOD_EPI_QKV_FP8 || epilogue == UCOD_EPI_LNFOLD_BIAS_BF16 ? 0 : epilogue == UCOD_EPI_LNFOLD_GELU_BF16 ? 1 : epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16 ? 2 : epilogue == UCOD_EPI_PATCH_TOKENS_H16 ? 3 : (epilogue >= 0 && epilogue <= 5 ? epilogue : (epilogue == UCOD_EPI_GELU_BWD_BF16 ? PROF_GEMM_EPI6 : PROF_GEMM_EPI7)), s);
   switch (epilogue) {
     case UCOD_EPI_BIAS_BF16:                                   // NULL bias (plain product) only in the large-tile kernels
       if (!bias && (variant == 1 || variant == 2 || K < 128 || (N & 3))) return UCOD_EINVAL;
@@ -550,6 +566,12 @@ static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int
       if (!bias && (variant == 1 || variant == 2 || K < 128 || (N & 3))) return UCOD_EINVAL;
       return launch<UCOD_EPI_BIAS_F32>(a, variant, s);
     case UCOD_EPI_QKV_FP8: return launch_qkv_fp8(a, s);
+    case UCOD_EPI_LNFOLD_BIAS_BF16:
+      if (!bias || !stats || !colsum || (N & 7) != 0) return UCOD_EINVAL;
+      return launch<UCOD_EPI_LNFOLD_BIAS_BF16>(a, variant, s);
+    case UCOD_EPI_LNFOLD_GELU_BF16:
+      if (!bias || !stats || !colsum || (N & 7) != 0) return UCOD_EINVAL;
+      return launch<UCOD_EPI_LNFOLD_GELU_BF16>(a, variant, s);
     case UCOD_EPI_BIAS_SCALE_RESID_H16:
       if (!bias || !scale || !resid || !a.ovf) return UCOD_EINVAL;
       // large passes: the mixed-height large-tile kernel; small ones (a batch-1 Look-Twice pass) the 128 x 128 / 64 x 64 kernel, so that the
@@ -567,6 +589,7 @@ extern "C" int ucod_gemm_bf16(int epilogue, const void* A, const void* B, void* 
                               const float* scale, const float* resid, const float* pos, int tokens_per_image, int variant,
                               void* stream) {
   if (epilogue == UCOD_EPI_GELU_BWD_BF16 || epilogue == UCOD_EPI_BIAS_GELU_SAVE_BF16) return UCOD_EINVAL;   // need ucod_gemm_bf16_train
+  if (epilogue == UCOD_EPI_LNFOLD_BIAS_BF16 || epilogue == UCOD_EPI_LNFOLD_GELU_BF16) return UCOD_EINVAL;   // need ucod_gemm_lnfold
   return gemm_entry(epilogue, A, B, out, M, N, K, bias, scale, resid, pos, tokens_per_image, variant, stream, nullptr, nullptr);
 }
 
@@ -576,6 +599,19 @@ extern "C" int ucod_gemm_bf16_train(int epilogue, const void* A, const void* B, 
   return gemm_entry(epilogue, A, B, out, M, N, K, bias, nullptr, nullptr, nullptr, 0, variant, stream, aux_bf16, out2_bf16);
 }
 
+
+// LayerNorm folded into the consumer GEMM: A = the fp16 residual stream itself (so this entry exists in the fp16-operand build only: an MFMA
+// takes both operands in one type), B = fp16(gamma (.) W), out = 16-bit [M,N].  See kFold in gemm_bf16_epilogue.h.
+extern "C" int ucod_gemm_lnfold(int epilogue, const void* x_f16, const void* w_folded, void* out, int M, int N, int K, const float* bias_folded,
+                                const float* colsum, const float* stats, const float* scale, int variant, void* stream) {
+#ifndef UCOD_HALF_F16
+  return UCOD_EINVAL;
+#else
+  if (epilogue != UCOD_EPI_LNFOLD_BIAS_BF16 && epilogue != UCOD_EPI_LNFOLD_GELU_BF16) return UCOD_EINVAL;
+  if (epilogue == UCOD_EPI_LNFOLD_GELU_BF16 && scale) return UCOD_EINVAL;
+  return gemm_entry(epilogue, x_f16, w_folded, out, M, N, K, bias_folded, scale, nullptr, nullptr, 0, variant, stream, nullptr, nullptr, stats, colsum);
+#endif
+}
 
 // Re-read the UCOD_GEMM_* tuning variables (gemm_bf16_plan.h): they are read once per process, not per launch.
 extern "C" void ucod_gemm_reload_tuning(void) { ucod::tuning() = ucod::read_gemm_tuning(); }

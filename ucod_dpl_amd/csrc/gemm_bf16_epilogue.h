@@ -19,6 +19,17 @@
 namespace ucod {
 
 constexpr int BM = 128, BN = 128, BK = 64;
+
+// LayerNorm folded into its consumer GEMM (round 5).  With x the fp16 residual stream as the A operand, W' = fp16(gamma (.) W), c[n] = sum_k W'[n][k],
+// b'[n] = sum_k beta[k] W[n][k] + b[n]:   LN(x) W^T + b = rstd[m] * (x W'^T - mean[m] * c[n]) + b'[n]   (modeling_dinov2.py:348-381: norm1 -> attention,
+// norm2 -> mlp).  The epilogue applies the two per-row scalars s = rstd, u = -mean * rstd:  out = s * acc + (u * c[n] + b'[n]).  The 16-bit
+// rounding of the LayerNorm output and the LayerNorm launch itself disappear.
+template <int EPI>
+constexpr bool kFold = (EPI == UCOD_EPI_LNFOLD_BIAS_BF16 || EPI == UCOD_EPI_LNFOLD_GELU_BF16);
+template <int EPI>
+constexpr bool kBiasLike = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_LNFOLD_BIAS_BF16);        // optional column scale, 16-bit output
+template <int EPI>
+constexpr bool kGeluLike = (EPI == UCOD_EPI_BIAS_GELU_BF16 || EPI == UCOD_EPI_LNFOLD_GELU_BF16);   // erf-GELU, 16-bit output
 // cache policy of the large-tile epilogue's output stores (aux bits of buffer_store: 0 default, 2 nt, 16 sc1 = write-through, the line
 // is dropped from the XCD's L2 instead of displacing operand panels)
 #ifndef UCOD_ST_AUX
@@ -46,6 +57,8 @@ struct GemmArgs {
   const void* aux;    // GELU_BWD: bf16 [M,N] pre-activation of the forward fc1
   void* out2;         // BIAS_GELU_SAVE: bf16 [M,N] pre-activation output
   unsigned* ovf;      // f16 residual-stream epilogues: saturation counter (common.h: resid16_overflow_counter)
+  const float* stats;   // LayerNorm-folded epilogues: per-row (rstd, -mean * rstd) of the A rows, f32 [M][2]
+  const float* colsum;  // LayerNorm-folded epilogues: c[n] = sum_k B[n][k] (of the ROUNDED folded weight), f32 [N]
   int M, N, K;
   int tok;   // tokens per image incl. CLS (PATCH / KEY epilogues)
   int tiles_m, tiles_n;
@@ -125,7 +138,13 @@ __device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& a, int m, int n, float v) {
   if (m >= a.M || n >= a.N) return;
-  if constexpr (EPI == UCOD_EPI_BIAS_BF16) {
+  if constexpr (kFold<EPI>) {
+    const float s = a.stats[2 * (size_t)m], u = a.stats[2 * (size_t)m + 1];
+    float o = fmaf(s, v, fmaf(u, a.colsum[n], a.bias[n]));
+    if constexpr (EPI == UCOD_EPI_LNFOLD_BIAS_BF16) o *= (a.scale ? a.scale[n] : 1.f);
+    else o = gelu_erf(o);
+    reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_h(o);
+  } else if constexpr (EPI == UCOD_EPI_BIAS_BF16) {
     reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_h((v + a.bias[n]) * (a.scale ? a.scale[n] : 1.f));
   } else if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) {
     reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_h(gelu_erf(v + a.bias[n]));
@@ -176,12 +195,18 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& a, int m, int n,
     }
   } else {
     const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
-    if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16) {
+    if constexpr (kBiasLike<EPI> || kGeluLike<EPI>) {
       f32x4 o = v + b;
-      if constexpr (EPI == UCOD_EPI_BIAS_BF16) {
+      if constexpr (kFold<EPI>) {
+        const float s = a.stats[2 * (size_t)m], u = a.stats[2 * (size_t)m + 1];
+        const f32x4 c = *reinterpret_cast<const f32x4*>(a.colsum + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(s, v[e], fmaf(u, c[e], b[e]));
+      }
+      if constexpr (kBiasLike<EPI>) {
         if (a.scale) o = o * *reinterpret_cast<const f32x4*>(a.scale + n);
       }
-      if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) {
+      if constexpr (kGeluLike<EPI>) {
         const f32x2 g0 = gelu_erf2((f32x2){o[0], o[1]}), g1 = gelu_erf2((f32x2){o[2], o[3]});
         o = (f32x4){g0[0], g0[1], g1[0], g1[1]};
       }
@@ -235,7 +260,17 @@ __device__ __forceinline__ void epilogue_store8_bf16(const GemmArgs& a, int m, i
   if (m >= a.M || n >= a.N) return;
   f32x4 o0 = v0 + *reinterpret_cast<const f32x4*>(a.bias + n);
   f32x4 o1 = v1 + *reinterpret_cast<const f32x4*>(a.bias + n + 4);
-  if constexpr (EPI == UCOD_EPI_BIAS_BF16) {
+  if constexpr (kFold<EPI>) {
+    const float s = a.stats[2 * (size_t)m], u = a.stats[2 * (size_t)m + 1];
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + n), b1 = *reinterpret_cast<const f32x4*>(a.bias + n + 4);
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.colsum + n), c1 = *reinterpret_cast<const f32x4*>(a.colsum + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o0[e] = fmaf(s, v0[e], fmaf(u, c0[e], b0[e]));
+      o1[e] = fmaf(s, v1[e], fmaf(u, c1[e], b1[e]));
+    }
+  }
+  if constexpr (kBiasLike<EPI>) {
     if (a.scale) {
       o0 = o0 * *reinterpret_cast<const f32x4*>(a.scale + n);
       o1 = o1 * *reinterpret_cast<const f32x4*>(a.scale + n + 4);
@@ -259,7 +294,7 @@ __device__ __forceinline__ void epilogue_store8_bf16(const GemmArgs& a, int m, i
 // by 16-byte-per-lane instructions (4-8x fewer, wider instructions than storing straight from the accumulator layout).
 template <int EPI, int WCOLS, int ROWS>
 __device__ __forceinline__ void drain_rows(const GemmArgs& a, const char* wbase, int m_first, int n_first, int lane) {
-  constexpr bool BF16_OUT = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16);
+  constexpr bool BF16_OUT = (kBiasLike<EPI> || kGeluLike<EPI>);
   if constexpr (BF16_OUT && (WCOLS % 8) == 0 && (ROWS * (WCOLS / 8)) % 64 == 0) {
     constexpr int CH = WCOLS / 8;                     // 32-byte (8 x f32) chunks per row -> 16-byte bf16 stores
     if ((a.N & 7) == 0) {
@@ -296,7 +331,7 @@ __device__ __forceinline__ void drain_rows(const GemmArgs& a, const char* wbase,
 template <int EPI>
 constexpr bool kColFused = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 ||
                             EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16 ||
-                            EPI == UCOD_EPI_QKV_FP8 || EPI == UCOD_EPI_BIAS_SCALE_RESID_H16);
+                            EPI == UCOD_EPI_QKV_FP8 || EPI == UCOD_EPI_BIAS_SCALE_RESID_H16 || kFold<EPI>);
 template <int EPI>
 constexpr bool kF32Out = (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_BIAS_F32);
 
@@ -311,20 +346,22 @@ __device__ __forceinline__ void load_col_consts(const GemmArgs& a, int ncol0, fl
       n = n < a.N ? n : a.N - 1;
       if constexpr (EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8) {
         cb[j] = (a.bias ? a.bias : reinterpret_cast<const float*>(a.B))[n];   // NULL bias = plain product (dgrad GEMMs): selected in finish_col_consts
+      } else if constexpr (kFold<EPI>) {
+        // (accumulators start at zero: the folded bias is added behind the per-row scaling, in the row-major drain)
       } else if constexpr (EPI != UCOD_EPI_GELU_BWD_BF16) {
         cb[j] = a.bias[n];
       }
       if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_BIAS_SCALE_RESID_H16) cs[j] = a.scale[n];
       // optional scale: unconditional load now (a branch here costs a vmcnt(0) at the join, ahead of the operand DMAs),
       // select at the point of use (finish_col_consts) so nothing waits on the load before the DMAs are out
-      if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8) cs[j] = (a.scale ? a.scale : reinterpret_cast<const float*>(a.B))[n];
+      if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8 || EPI == UCOD_EPI_LNFOLD_BIAS_BF16) cs[j] = (a.scale ? a.scale : reinterpret_cast<const float*>(a.B))[n];
     }
   }
 }
 
 template <int EPI, int NT>
 __device__ __forceinline__ void finish_col_consts(const GemmArgs& a, float (&cb)[NT], float (&cs)[NT]) {
-  if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8) {
+  if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8 || EPI == UCOD_EPI_LNFOLD_BIAS_BF16) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) cs[j] = a.scale ? cs[j] : 1.f;
   }
@@ -351,7 +388,7 @@ constexpr bool kFastRowMapped = kRowMapped<EPI> && NT == 4;
 // staging area, row-major.  big_epilogue() below supplies the one for 16 x 16 accumulator tiles; a kernel on 32 x 32 MFMA tiles supplies its own.
 template <int EPI>
 constexpr bool kStageScaled = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_QKV_FP8 ||
-                               EPI == UCOD_EPI_BIAS_SCALE_RESID_H16);
+                               EPI == UCOD_EPI_BIAS_SCALE_RESID_H16 || EPI == UCOD_EPI_LNFOLD_BIAS_BF16);
 
 template <int EPI, int NT, int NI, int AUX, bool FASTRM, class Stage>
 __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Stage& stage, char* wbase, int m_first, int n_first, int lane) {
@@ -606,6 +643,35 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
 #pragma unroll
         for (int it = 0; it < ITS; ++it) pre[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_2, at(it, 0), 0, 0);
       }
+      // LayerNorm-folded epilogues: the lane's eight columns are the same for every row (FAST), so u * c[n] + b'[n] needs 16 registers loaded
+      // once per tile (already multiplied by the optional column scale, which the stager applied to the accumulators); the two per-row
+      // scalars (s, u) = (rstd, -mean * rstd) of a pass are requested one pass ahead, like the residual rows of RH16: no load between two stores.
+      static_assert(!kFold<EPI> || FAST, "the LayerNorm-folded epilogues need 64-column waves");
+      float fc[kFold<EPI> ? 8 : 1], fb[kFold<EPI> ? 8 : 1];
+      u32x2 st[2][kFold<EPI> ? ITS : 1];
+      const unsigned st_rec = !kFold<EPI> || rows_left <= 0 ? 0u : (rows_left > 0x0FFFFFFFl ? 0x7FFFFFF8u : (unsigned)rows_left * 8u);   // rows past M read zeros
+      const auto rs_st = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(kFold<EPI> ? (const void*)a.stats : (const void*)a.out)) + (size_t)(m_first < a.M ? m_first : 0) * 8, 0, st_rec, 0x00020000);
+      auto st_at = [&](int it, int pass) -> unsigned { return (unsigned)(pass * PR + it * 8 + (lane >> 3)) * 8u; };
+      if constexpr (kFold<EPI>) {
+        const int n = n_first + (lane & 7) * 8, nn = n < a.N ? n : 0;          // (N % 8 == 0: a chunk is inside or outside as a whole)
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.colsum + nn), c1 = *reinterpret_cast<const f32x4*>(a.colsum + nn + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + nn), b1 = *reinterpret_cast<const f32x4*>(a.bias + nn + 4);
+        f32x4 q0 = {1.f, 1.f, 1.f, 1.f}, q1 = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (EPI == UCOD_EPI_LNFOLD_BIAS_BF16) {
+          if (a.scale) {
+            q0 = *reinterpret_cast<const f32x4*>(a.scale + nn);
+            q1 = *reinterpret_cast<const f32x4*>(a.scale + nn + 4);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          fc[e] = c0[e] * q0[e]; fc[4 + e] = c1[e] * q1[e];
+          fb[e] = b0[e] * q0[e]; fb[4 + e] = b1[e] * q1[e];
+        }
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) st[0][it] = __builtin_amdgcn_raw_buffer_load_b64(rs_st, st_at(it, 0), 0, 0);
+      }
 #pragma unroll
       for (int pass = 0; pass < NP; ++pass) {
         stage(pass);
@@ -618,12 +684,31 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
             }
           }
         }
+        if constexpr (kFold<EPI>) {
+          if (pass + 1 < NP) {
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) {
+              if (!live(it, pass + 1)) continue;
+              st[(pass + 1) & 1][it] = __builtin_amdgcn_raw_buffer_load_b64(rs_st, st_at(it, pass + 1), 0, 0);
+            }
+          }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
           if (!live(it, pass)) continue;
           f32x4 v0 = *reinterpret_cast<const f32x4*>(lds_at(it));
           f32x4 v1 = *reinterpret_cast<const f32x4*>(lds_at(it) + 16);
+          if constexpr (kFold<EPI>) {                              // out = s * acc + (u * c + b')  [* column scale, folded into all three]
+            // (the whole vector is cast, then indexed: __builtin_bit_cast of ONE ELEMENT of an ext-vector lvalue reads element 0 whatever the index -- hipcc 7.2)
+            const f32x2 su = __builtin_bit_cast(f32x2, st[pass & 1][it]);
+            const float s = su[0], u = su[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v0[e] = fmaf(s, v0[e], fmaf(u, fc[e], fb[e]));
+              v1[e] = fmaf(s, v1[e], fmaf(u, fc[4 + e], fb[4 + e]));
+            }
+          }
           if constexpr (SAVE) {                                   // pre-activation out first
             u32x4 w;
             w[0] = pack_h2(v0[0], v0[1]);
@@ -632,7 +717,7 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
             w[3] = pack_h2(v1[2], v1[3]);
             __builtin_amdgcn_raw_buffer_store_b128(w, rs_2, at(it, pass), 0, 0);
           }
-          if constexpr (SAVE || EPI == UCOD_EPI_BIAS_GELU_BF16) {  // GELU in the row-major layout (fewer live registers than in the C layout)
+          if constexpr (SAVE || kGeluLike<EPI>) {  // GELU in the row-major layout (fewer live registers than in the C layout)
             const f32x2 g0 = gelu_erf2((f32x2){v0[0], v0[1]}), g1 = gelu_erf2((f32x2){v0[2], v0[3]});
             const f32x2 g2 = gelu_erf2((f32x2){v1[0], v1[1]}), g3 = gelu_erf2((f32x2){v1[2], v1[3]});
             v0 = (f32x4){g0[0], g0[1], g1[0], g1[1]};

@@ -5,10 +5,16 @@
 #include "common.h"
 #include "../../include/ucod_dpl.h"
 
+#ifdef UCOD_HALF_F16
+#define UCOD_HALF_IS_F16 1
+#else
+#define UCOD_HALF_IS_F16 0
+#endif
+
 namespace {
 
 struct Plan {
-  size_t off_x, off_h, off_qkv, off_a, off_g, off_patch, off_qscale, off_f8, f8_bytes, total;
+  size_t off_x, off_h, off_qkv, off_a, off_g, off_patch, off_qscale, off_f8, f8_bytes, off_stats, total;
   int M, tok;
 };
 
@@ -30,6 +36,7 @@ Plan make_plan(const ucod_vit_desc* d) {
   p.off_qscale = take((size_t)3 * d->D * 4);
   p.f8_bytes = d->attn_variant == 8 ? ucod_attention_fp8_workspace_bytes(d->B, p.tok, d->heads) : 0;   // Q8 | K8 | Vt8 of the fp8 attention path
   p.off_f8 = take(p.f8_bytes);
+  p.off_stats = take(d->ln_fold ? (size_t)p.M * 8 : 0);            // (rstd, -mean * rstd) per token row of the folded LayerNorms
   p.total = o;
   return p;
 }
@@ -44,7 +51,8 @@ inline bool attn_variant_takes_prescaled_q(int av) { return av != 1; }
 bool valid(const ucod_vit_desc* d) {
   return d && d->B > 0 && d->C > 0 && d->P > 0 && d->H > 0 && d->W > 0 && d->H % d->P == 0 && d->W % d->P == 0 && d->D > 0 &&
          d->heads > 0 && d->D == d->heads * 64 && d->D % 128 == 0 && d->F % 128 == 0 && d->L >= 1 && d->Kpad % 64 == 0 &&
-         d->Kpad >= d->C * d->P * d->P && (d->resid16 == 0 || d->resid16 == 1) && attn_variant_known(d->attn_variant);
+         d->Kpad >= d->C * d->P * d->P && (d->resid16 == 0 || d->resid16 == 1) && attn_variant_known(d->attn_variant) &&
+         (d->ln_fold == 0 || (d->ln_fold == 1 && d->resid16 == 1 && d->attn_variant != 8 && UCOD_HALF_IS_F16 && d->D % 256 == 0 && d->D <= 1536));
 }
 
 }  // namespace
@@ -101,7 +109,12 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
   for (int l = 0; l < d->L; ++l) {
     const void* const* W = T + 4 + UCOD_VIT_LAYER_STRIDE * l;
     const bool last = (l == d->L - 1);
-    RUN(layernorm((const float*)W[0], (const float*)W[1]));
+    // ln_fold: LayerNorm 1 / 2 of every layer but the last live in the QKV / fc1 epilogues (ucod_gemm_lnfold: the fp16 stream x is the A operand,
+    // W[2] / W[9] hold fp16(gamma (.) W), W[3] / W[10] the folded bias, W[14] / W[15] the column sums); only the row statistics are computed here
+    const bool fold = d->ln_fold != 0 && !last;
+    float* stats = (float*)(ws + p.off_stats);
+    if (fold) RUN(ucod_row_stats_h16(x, stats, M, D, d->eps, stream));
+    else RUN(layernorm((const float*)W[0], (const float*)W[1]));
     if (last) {
       // key hook: only the K slice (rows D..2D-1) of the fused qkv weight; output written as [B,D,h,w]
       const char* wk = (const char*)W[2] + (size_t)D * D * 2;
@@ -113,12 +126,18 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
       RUN(ucod_gemm_bf16(UCOD_EPI_QKV_FP8, h, W[2], ws + p.off_f8, M, 3 * D, D, (const float*)W[3], qscale, nullptr, nullptr, tok, gv, stream));
       RUN(ucod_attention_fwd_fp8_fused(ws + p.off_f8, a, d->B, tok, d->heads, QE, KE, VE, stream));
     } else {
-      RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_BF16, h, W[2], qkv, M, 3 * D, D, (const float*)W[3], prescale ? qscale : nullptr, nullptr, nullptr, tok, gv, stream));
-      RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, prescale ? 0.f : scale, (av == 5 || av == 64 || av == 32) ? av : 0, stream));
+      if (fold) RUN(ucod_gemm_lnfold(UCOD_EPI_LNFOLD_BIAS_BF16, x, W[2], qkv, M, 3 * D, D, (const float*)W[3], (const float*)W[14], stats, prescale ? qscale : nullptr, gv, stream));
+      else RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_BF16, h, W[2], qkv, M, 3 * D, D, (const float*)W[3], prescale ? qscale : nullptr, nullptr, nullptr, tok, gv, stream));
+      RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, prescale ? 0.f : scale, (av == 5 || av == 64 || av == 32 || av == 66) ? av : 0, stream));
     }
     RUN(ucod_gemm_bf16(epi_resid, a, W[4], x, M, D, D, (const float*)W[5], (const float*)W[6], x, nullptr, tok, gv, stream));
-    RUN(layernorm((const float*)W[7], (const float*)W[8]));
-    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_GELU_BF16, h, W[9], g, M, F, D, (const float*)W[10], nullptr, nullptr, nullptr, tok, gv, stream));
+    if (fold) {
+      RUN(ucod_row_stats_h16(x, stats, M, D, d->eps, stream));
+      RUN(ucod_gemm_lnfold(UCOD_EPI_LNFOLD_GELU_BF16, x, W[9], g, M, F, D, (const float*)W[10], (const float*)W[15], stats, nullptr, gv, stream));
+    } else {
+      RUN(layernorm((const float*)W[7], (const float*)W[8]));
+      RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_GELU_BF16, h, W[9], g, M, F, D, (const float*)W[10], nullptr, nullptr, nullptr, tok, gv, stream));
+    }
     RUN(ucod_gemm_bf16(epi_resid, g, W[11], x, M, D, F, (const float*)W[12], (const float*)W[13], x, nullptr, tok, gv, stream));
   }
   return UCOD_OK;

@@ -195,6 +195,57 @@ __global__ __launch_bounds__(256) void layernorm_h16_strip_kernel(const u32x4* _
   }
 }
 
+// Row statistics of the fp16 residual stream for the LayerNorm-folded GEMM epilogues (ucod_gemm_lnfold): the strip walk of the kernel above
+// without gamma / beta and without the output -- half the bytes of a LayerNorm launch.  stats[row] = (rstd, -mean * rstd); same two-pass f32
+// arithmetic on the row held in registers.
+template <int NC>
+__global__ __launch_bounds__(256) void row_stats_h16_kernel(const u32x4* __restrict__ x, float2* __restrict__ stats, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int cpr = D >> 3;
+  bool second[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) second[i] = lane + 64 * i >= cpr;
+  const int nstrips = (rows + 1) >> 1, stride = gridDim.x * 4;
+  const float inv_d = 1.0f / (float)D;
+  for (int strip = blockIdx.x * 4 + (threadIdx.x >> 6); strip < nstrips; strip += stride) {
+    const int row0 = strip * 2;
+    const bool two = row0 + 1 < rows;
+    const u32x4* xs = x + (size_t)row0 * cpr;
+    float v[NC][8];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      const u32x4 w = xs[(second[i] && !two) ? c - cpr : c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) unpack_f16x2(w[e], v[i][2 * e], v[i][2 * e + 1]);
+    }
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const float t = ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+      s0 += second[i] ? 0.f : t;
+      s1 += second[i] ? t : 0.f;
+    }
+    const float mean0 = wave_sum(s0) * inv_d, mean1 = wave_sum(s1) * inv_d;
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const float m = second[i] ? mean1 : mean0;
+      float t = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e] - m;
+        t += d * d;
+      }
+      q0 += second[i] ? 0.f : t;
+      q1 += second[i] ? t : 0.f;
+    }
+    const float rstd0 = rsqrtf(wave_sum(q0) * inv_d + eps), rstd1 = rsqrtf(wave_sum(q1) * inv_d + eps);
+    if (lane == 0) stats[row0] = make_float2(rstd0, -mean0 * rstd0);
+    if (lane == 1 && two) stats[row0 + 1] = make_float2(rstd1, -mean1 * rstd1);
+  }
+}
+
 // LayerNorm of an IEEE-fp16 residual stream (ucod_vit_desc.resid16): the row arrives as 8-byte (4 x f16, D % 256 == 0) or 4-byte
 // (2 x f16) chunks per lane, is widened to f32 in registers, and the same two-pass f32 statistics follow; output = operand type.
 template <int NV, int W, int R = 2>                       // NV chunks of W f16 per lane: D = 64 * NV * W; R rows per wave
@@ -470,6 +521,27 @@ extern "C" int ucod_layernorm_h16(const void* x, const float* gamma, const float
 #undef LNH_CASE
       default: return UCOD_EINVAL;
     }
+  }
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_row_stats_h16(const void* x, float* stats, int rows, int D, float eps, void* stream) {
+  using namespace ucod;
+  if (!x || !stats || rows <= 0 || D <= 0 || (D % 256) != 0 || D > 1536) return UCOD_EINVAL;
+  UCOD_PROF(PROF_LN, stream);
+  hipStream_t s = (hipStream_t)stream;
+  static const int strips_env = [] { const char* e = getenv("UCOD_STATS_STRIPS"); return e ? atoi(e) : -1; }();
+  const int per_wave = strips_env > 0 ? strips_env : 4;
+  const int nstrips = (rows + 1) / 2;
+  const int want = cdiv(cdiv(nstrips, per_wave), 4);
+  const dim3 grid((unsigned)(want > 256 ? want : (cdiv(nstrips, 4) < 256 ? cdiv(nstrips, 4) : 256))), block(256);
+  switch (D / 256) {
+#define RS_CASE(n) \
+  case n: hipLaunchKernelGGL(row_stats_h16_kernel<n>, grid, block, 0, s, (const u32x4*)x, (float2*)stats, rows, D, eps); break;
+    RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6)
+#undef RS_CASE
+    default: return UCOD_EINVAL;
   }
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;

@@ -17,13 +17,14 @@ if os.environ.get("UCOD_DPL_LIB"):
                        "UCOD_DPL_ALLOW_EXPERIMENT=1 UCOD_DPL_EXPERIMENT_LIB=<path> for an experiment build")
 if os.environ.get("UCOD_DPL_EXPERIMENT_LIB") and os.environ.get("UCOD_DPL_ALLOW_EXPERIMENT") == "1":
     LIB_PATH = os.environ["UCOD_DPL_EXPERIMENT_LIB"]
-ABI_VERSION = 3                                            # include/ucod_dpl.h: UCOD_ABI_VERSION
+ABI_VERSION = 4                                            # include/ucod_dpl.h: UCOD_ABI_VERSION
 
 EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_SCALE_RESID_F32, EPI_PATCH_TOKENS_F32, EPI_KEY_NCHW_F32, EPI_BIAS_F32 = range(6)
 EPI_GELU_BWD_BF16, EPI_BIAS_GELU_SAVE_BF16 = 6, 7          # ucod_gemm_bf16_train only (backbone-backward mode)
 EPI_QKV_FP8 = 8                                            # QKV projection of the fp8 attention path
 EPI_BIAS_SCALE_RESID_H16, EPI_PATCH_TOKENS_H16 = 9, 10     # f16 residual stream (VitDesc.resid16)
-VIT_LAYER_STRIDE = 14
+EPI_LNFOLD_BIAS_BF16, EPI_LNFOLD_GELU_BF16 = 11, 12        # ucod_gemm_lnfold only (LayerNorm folded into QKV / fc1; the fp16-operand build)
+VIT_LAYER_STRIDE = 16
 VIT_TRAIN_STRIDE = 7
 LORA_AUG = 64
 
@@ -32,7 +33,7 @@ vp, ci, cf, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 class VitDesc(C.Structure):
     _fields_ = [(n, ci) for n in ("B", "C", "H", "W", "P", "D", "heads", "F", "L", "Kpad")] + [("eps", cf)] + \
-               [(n, ci) for n in ("full_last_layer", "gemm_variant", "attn_variant", "resid16")]
+               [(n, ci) for n in ("full_last_layer", "gemm_variant", "attn_variant", "resid16", "ln_fold")]
 
 
 class VitTrainDesc(C.Structure):
@@ -62,6 +63,8 @@ SIGNATURES = {
     "ucod_prof_class_name": (C.c_char_p, [ci]),
     "ucod_prof_collect": (ci, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ucod_gemm_bf16": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
+    "ucod_gemm_lnfold": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp]),
+    "ucod_row_stats_h16": (ci, [vp, vp, ci, ci, cf, vp]),
     "ucod_gemm_reload_tuning": (None, []),
     "ucod_resid16_overflow_fetch": (ci, [vp, vp]),
     "ucod_resid16_overflow_reset": (ci, [vp]),

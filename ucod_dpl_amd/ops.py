@@ -48,6 +48,33 @@ def linear_scale_resid(x, w, b, scale, resid, variant=0):
     return gemm_bf16(N.EPI_BIAS_SCALE_RESID_F32, x, w, out, M, w.shape[0], K, bias=b, scale=scale, resid=resid, variant=variant)
 
 
+def row_stats_h16(x, eps):
+    """x fp16 [rows, D] (the fp16 residual stream) -> f32 [rows, 2] = (rstd, -mean * rstd): what the LayerNorm-folded epilogues read."""
+    if x.dtype != torch.float16:
+        raise TypeError(f"expected float16, got {x.dtype}")
+    rows, D = x.shape
+    st = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    check(N.load("f16").ucod_row_stats_h16(ptr(x), ptr(st), rows, D, float(eps), stream()), "ucod_row_stats_h16")
+    return st
+
+
+def fold_layernorm_linear(gamma, beta, w, b):
+    """(w_folded fp16 [N,K], bias_folded f32 [N], colsum f32 [N]) of LayerNorm(gamma, beta) -> Linear(w, b): include/ucod_dpl.h, ucod_gemm_lnfold."""
+    wf = cast_bf16((_f32(w) * _f32(gamma)[None, :]).contiguous(), lib=N.load("f16"))
+    return wf, (w.double() @ beta.double() + b.double()).float().contiguous(), wf.double().sum(1).float().contiguous()
+
+
+def linear_lnfold(x, stats, wf, bias_f, colsum, gelu=False, scale=None, variant=0):
+    """LayerNorm + Linear (+ GELU | * scale) as ONE GEMM on the un-normalised fp16 rows (fp16-operand build): x fp16 [M,K] -> fp16 [M,N]."""
+    if x.dtype != torch.float16 or wf.dtype != torch.float16:
+        raise TypeError("linear_lnfold takes fp16 rows and fp16 folded weights")
+    M, K = x.shape
+    out = torch.empty(M, wf.shape[0], dtype=torch.float16, device=x.device)
+    check(N.load("f16").ucod_gemm_lnfold(N.EPI_LNFOLD_GELU_BF16 if gelu else N.EPI_LNFOLD_BIAS_BF16, ptr(x), ptr(wf), ptr(out), M, wf.shape[0], K,
+                                         ptr(_f32(bias_f)), ptr(_f32(colsum)), ptr(_f32(stats)), ptr(scale), variant, stream()), "ucod_gemm_lnfold")
+    return out
+
+
 def layernorm(x, gamma, beta, eps, out_f32=False):
     rows, D = x.shape
     y = torch.empty(rows, D, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)

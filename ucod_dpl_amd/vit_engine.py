@@ -101,7 +101,7 @@ class ViTEngine:
     """HIP ViT forward -> last-layer key map [B, D, H/P, W/P] (f32)."""
 
     def __init__(self, state_dict, heads, eps=1e-6, device="cuda", full_last_layer=False, gemm_variant=0, attn_variant=0, half="bf16",
-                 resid="auto"):
+                 resid="auto", ln_fold="auto"):
         """``half``: 16-bit type of the GEMM / attention operands -- "bf16" (default; BASELINE configs[1]) or "f16" (IEEE fp16, what
         the reference's fp16-autocast launcher multiplies in: 8x finer rounding, logits within 1e-3 of the f32 reference at full
         depth).  Each choice is its own build of the same kernels (native.load).
@@ -114,6 +114,9 @@ class ViTEngine:
             it is used, so it never sets the error level (logit max-abs vs the f32 oracle 3.2e-3 with either stream);
           * fp16 operands -> f32 stream: the configuration that meets the 1e-3 logit bar keeps its whole margin (3.8e-4; 6.4e-4 with
             the fp16 stream -- opt in with resid="f16").
+        ``ln_fold``: LayerNorm 1 / 2 of every layer but the last folded into the QKV / fc1 GEMMs (ucod_gemm_lnfold, include/ucod_dpl.h): the fp16
+        stream is the GEMM's A operand, the weights carry gamma, the epilogue applies the row's (rstd, -mean * rstd).  Needs fp16 operands AND the
+        fp16 stream (an MFMA takes both operands in one type); "auto" = on exactly there (UCOD_LN_FOLD=0 switches it off for A/B runs).
         The fp16 stream SATURATES at +-65504 and counts every saturation on the device; ``check_overflow`` (polled by every later
         ``forward``, synchronously with UCOD_CHECK_RESID=1) raises FloatingPointError when the count is non-zero: a checkpoint whose
         activations do not fit fp16 is reported instead of producing inf -> NaN key maps."""
@@ -125,7 +128,9 @@ class ViTEngine:
         self.resid16 = bool(resid == "f16" or (resid == "auto" and half == "bf16"))
         self._ovf_host, self._ovf_events, self._ovf_dev = None, [], None
         if attn_variant not in (0, 1, 2, 8, 5, 64, 32, 66):
-            raise ValueError(f"attn_variant must be 0, 1, 2, 5, 8, 32 or 64 (laboratory kernels are reached through ops.attention(variant=...)), got {attn_variant}")
+            raise ValueError(f"attn_variant must be 0, 1, 2, 5, 8, 32, 64 or 66 (laboratory kernels are reached through ops.attention(variant=...)), got {attn_variant}")
+        if ln_fold not in ("auto", True, False):
+            raise ValueError(f"ln_fold must be 'auto', True or False, got {ln_fold!r}")
         c = normalize_state_dict(state_dict)
         self.kind = c["kind"]
         self.device = torch.device(device)
@@ -158,13 +163,45 @@ class ViTEngine:
             self.layers.append([f32(l["ln1_g"]), f32(l["ln1_b"]), bf(l["qkv_w"]), f32(l["qkv_b"]), bf(l["proj_w"]), f32(l["proj_b"]),
                                 f32(l["ls1"]) if l["ls1"] is not None else ones, f32(l["ln2_g"]), f32(l["ln2_b"]), bf(l["fc1_w"]),
                                 f32(l["fc1_b"]), bf(l["fc2_w"]), f32(l["fc2_b"]), f32(l["ls2"]) if l["ls2"] is not None else ones])
+        for l in self.layers:
+            l += [None, None]                                      # +14 / +15: column sums of the folded weights (ln_fold tables only)
+        can_fold = half == "f16" and self.resid16 and self.D % 256 == 0 and self.D <= 1536 and attn_variant != 8
+        if ln_fold is True and not can_fold:
+            raise ValueError("ln_fold needs half='f16' with the fp16 residual stream (resid='f16'), D % 256 == 0 and a 16-bit attention path")
+        self.ln_fold = bool(can_fold and (ln_fold is True or (ln_fold == "auto" and os.environ.get("UCOD_LN_FOLD", "1") != "0")))
+        self.fold_layers = None
+        if self.ln_fold:
+            self.fold_layers = []
+            for l, src in zip(self.layers, c["layers"]):
+                qw, qb, qc = self._fold(f32(src["ln1_g"]), f32(src["ln1_b"]), f32(src["qkv_w"]), f32(src["qkv_b"]))
+                fw, fb, fc = self._fold(f32(src["ln2_g"]), f32(src["ln2_b"]), f32(src["fc1_w"]), f32(src["fc1_b"]))
+                fl = list(l)
+                fl[2], fl[3], fl[9], fl[10], fl[14], fl[15] = qw, qb, fw, fb, qc, fc
+                self.fold_layers.append(fl)
         self._ws = None
         self._ws_key = None
+
+    def _fold(self, gamma, beta, w, b):
+        """LayerNorm(gamma, beta) followed by Linear(w, b) as one GEMM on the un-normalised rows (include/ucod_dpl.h: ucod_gemm_lnfold):
+        W' = 16-bit(gamma (.) W), column sums of the ROUNDED W' (what the MFMA multiplies by), b' = W beta + b in f64."""
+        wf = ops.cast_bf16((w * gamma[None, :]).contiguous(), lib=self.lib)
+        colsum = wf.double().sum(1).float().contiguous()
+        bias = (w.double() @ beta.double() + b.double()).float().contiguous()
+        return wf, bias, colsum
+
+    def _table(self, gh, gw, L=None):
+        """(ctypes table, tensors kept alive) of a pass over the first L layers.  With ln_fold every layer but the last OF THE PASS contributes its
+        folded entries; the last keeps the plain ones (its LayerNorm 1 runs as a kernel and feeds the key hook)."""
+        L = self.L if L is None else L
+        ptrs = [self.patch_w, self.patch_b, self.cls, self._pos(gh, gw)]
+        for i, l in enumerate(self.layers):
+            ptrs += self.fold_layers[i] if (self.ln_fold and i != L - 1) else l
+        return (C.c_void_p * len(ptrs))(*[None if t is None else t.data_ptr() for t in ptrs]), ptrs
 
     def param_bytes(self):
         n = self.patch_w.numel() * 2
         for l in self.layers:
-            n += sum(t.numel() * t.element_size() for t in l)
+            n += sum(t.numel() * t.element_size() for t in l if t is not None)
         return n
 
     def _pos(self, gh, gw):
@@ -182,6 +219,7 @@ class ViTEngine:
         d.full_last_layer = int(self.full_last_layer)
         d.gemm_variant, d.attn_variant = self.gemm_variant, self.attn_variant
         d.resid16 = int(self.resid16)
+        d.ln_fold = int(getattr(self, "ln_fold", False))
         return d
 
     # ---- fp16 residual stream: saturation guard --------------------------------------------------------------------------------
@@ -254,11 +292,7 @@ class ViTEngine:
         B, Cc, H, W = img.shape
         gh, gw = H // self.P, W // self.P
         lib = self.lib
-        pos = self._pos(gh, gw)
-        ptrs = [self.patch_w, self.patch_b, self.cls, pos]
-        for l in self.layers:
-            ptrs += l
-        table = (C.c_void_p * len(ptrs))(*[t.data_ptr() for t in ptrs])
+        table, _keep = self._table(gh, gw, n_layers)
         key = out if out is not None else torch.empty(B, self.D, gh, gw, dtype=torch.float32, device=self.device)
         self.check_overflow()                                      # (non-blocking) passes that have finished since the last call
         ns = max(1, min(int(getattr(self, "streams", 1)), B))
@@ -465,7 +499,7 @@ class ViTLoRAEngine(ViTEngine):
         for i, tl in enumerate(self.train_layers):
             tptrs += tl + [self.lora[i], grad[i]]
         keep = ptrs + tptrs
-        return (C.c_void_p * len(ptrs))(*[t.data_ptr() for t in ptrs]), (C.c_void_p * len(tptrs))(*[t.data_ptr() for t in tptrs]), keep
+        return (C.c_void_p * len(ptrs))(*[None if t is None else t.data_ptr() for t in ptrs]), (C.c_void_p * len(tptrs))(*[t.data_ptr() for t in tptrs]), keep
 
     def _chunks(self, B):
         """Image-parallel sub-batches (``self.train_streams``, default 2): as in ViTEngine.forward, every kernel of both passes is
