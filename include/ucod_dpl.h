@@ -37,8 +37,8 @@ extern "C" {
  * the experiment variants of ucod_gemm_bf16 / ucod_attention_fwd left the product library.  native.load() refuses any other version. */
 /* 3 (round 4): ucod_disc_params gained `nbt`; ucod_step_loss, ucod_disc_bce, the feature-branch discriminator's backward entry points and
  * the assembly attention variants (ucod_attention_fwd variant 64 / 32 / 5) were added. */
-/* 4 (round 5): LayerNorm folded into its consumer GEMMs -- epilogues 11 / 12, ucod_gemm_lnfold, ucod_row_stats_h16, ucod_vit_desc.ln_fold,
- * UCOD_VIT_LAYER_STRIDE 14 -> 16 (two column-sum slots per layer). */
+/* 4 (round 5): LayerNorm folded into its consumer GEMMs -- epilogues 11 - 14, ucod_gemm_lnfold, ucod_gemm_bf16_stats, ucod_cls_rows_h16_stats,
+ * ucod_row_stats_h16, ucod_vit_desc.ln_fold, UCOD_VIT_LAYER_STRIDE 14 -> 16 (two column-sum slots per layer). */
 #define UCOD_ABI_VERSION 4
 int ucod_abi_version(void);
 /* 1 when a gfx950 device is visible to this process (hipGetDeviceProperties().gcnArchName) */
@@ -83,6 +83,12 @@ enum {
                                         stats[m] = (rstd, -mean * rstd) of row m:  out 16-bit [M,N] = (stats[m][0] * C + stats[m][1] * colsum[n] + bias[n]) * scale[n] */
   UCOD_EPI_LNFOLD_GELU_BF16 = 12,    /* ucod_gemm_lnfold only.  The same fold for norm2 -> fc1 -> GELU (modeling_dinov2.py:365-373,281-297):
                                         out = gelu_erf(stats[m][0] * C + stats[m][1] * colsum[n] + bias[n]) */
+  UCOD_EPI_BIAS_SCALE_RESID_H16_STATS = 13, /* ucod_gemm_bf16_stats only.  UCOD_EPI_BIAS_SCALE_RESID_H16 that also leaves, per output row and 64-column slot, the
+                                        (sum, sum of squares) of the fp16 values it has just written: row_partials f32 [M][N/64][2].  The next
+                                        ucod_gemm_lnfold sums a row's slots in its prologue instead of reading `stats`: no statistics launch.  Large passes only
+                                        (M >= 2048, N % 64 == 0); otherwise UCOD_EINVAL and nothing is launched */
+  UCOD_EPI_PATCH_TOKENS_H16_STATS = 14,     /* ucod_gemm_bf16_stats only.  UCOD_EPI_PATCH_TOKENS_H16 with the same partials, indexed by OUTPUT token row (the CLS rows'
+                                        partials come from ucod_cls_rows_h16_stats) */
   UCOD_EPI_QKV_FP8 = 8               /* QKV projection of the fp8 attention path (BASELINE configs[4]): out = e4m3 bytes
                                         [3 (q|k|v)][Bimg*heads][Npad][64], Npad = tokens rounded up to 64, value = clamp((C + bias[n]) *
                                         scale[n], +-448); N = 3*heads*64, M = Bimg*tokens_per_image; large-tile kernel only */
@@ -106,7 +112,17 @@ int ucod_gemm_bf16(int epilogue, const void* A_bf16, const void* B_bf16, void* o
  * scale: optional column scale (UCOD_EPI_LNFOLD_BIAS_BF16 only), out fp16 [M,N].  N % 8 == 0, K % 64 == 0.  variant as ucod_gemm_bf16
  * (the 192-wide forms 10 / 14 are taken as 9 / 13). */
 int ucod_gemm_lnfold(int epilogue, const void* x_f16, const void* w_folded, void* out, int M, int N, int K, const float* bias_folded,
-                     const float* colsum, const float* stats, const float* scale, int variant, void* stream);
+                     const float* colsum, const float* stats, const float* row_partials, int nslot, float eps, const float* scale,
+                     int variant, void* stream);
+/* `stats` may be NULL when `row_partials` f32 [M][nslot][2] is given (nslot even, <= 24): per-row partial (sum, sum of squares) of x left by the producer
+ * of x (ucod_gemm_bf16_stats / ucod_cls_rows_h16_stats); the kernel's prologue adds a row's slots and forms rstd = rsqrt(E[x^2] - mean^2 + eps) in f32.
+ * The large-tile kernels only (a small shape is then run on them too). */
+/* The producers of the fp16 residual stream with row partials (epilogues UCOD_EPI_*_STATS; arguments as ucod_gemm_bf16; `resid` / `out` f16 rows;
+ * nslot = N / 64).  UCOD_EINVAL (nothing launched) for shapes the large-tile kernels do not take: use the plain epilogue and ucod_row_stats_h16 then. */
+int ucod_gemm_bf16_stats(int epilogue, const void* A_bf16, const void* B_bf16, void* out, int M, int N, int K, const float* bias, const float* scale,
+                         const void* resid_f16, const float* pos, int tokens_per_image, float* row_partials, int nslot, void* stream);
+/* ucod_cls_rows_h16 that also writes the CLS rows' partials (slot 0 = the whole row, the other slots zero) */
+int ucod_cls_rows_h16_stats(void* x_f16, const float* cls, const float* pos, float* row_partials, int nslot, int B, int tok, int D, void* stream);
 /* Row statistics of the fp16 residual stream for the folded epilogues: stats[m] = (rstd, -mean * rstd), two-pass in f32 over the row held in
  * registers, biased variance + eps like nn.LayerNorm.  x f16 [rows,D], D % 256 == 0, D <= 1536. */
 int ucod_row_stats_h16(const void* x_f16, float* stats, int rows, int D, float eps, void* stream);
@@ -266,8 +282,9 @@ int ucod_lora_grad(void* dqkv_aug_bf16, const void* h_aug_bf16, const float* lor
  *     +6 ls1 [D] (LayerScale lambda1; ones for DINOv1)  +7 ln2_g  +8 ln2_b  +9 fc1_w bf16 [F,D]  +10 fc1_b [F]
  *     +11 fc2_w bf16 [D,F]  +12 fc2_b [D]  +13 ls2 [D]
  *     +14 qkv_colsum [3D]  +15 fc1_colsum [F]   (ln_fold only, else unused: with ln_fold the entries +2 / +3 / +9 / +10 of every layer BUT THE LAST
- *     of the pass hold the folded forms fp16(gamma (.) W) and W beta + b, and +14 / +15 the column sums of the folded weights; the last
- *     layer keeps plain weights -- its LayerNorm 1 runs as a kernel and feeds the key hook)
+ *     of the pass hold the folded forms fp16(gamma (.) W) and W beta + b, and +14 / +15 the column sums of the folded weights; for
+ *     attn_variant != 1 the Q rows of the folded qkv entries are also multiplied by head_dim^-0.5 * log2(e), the pre-scale the unfolded
+ *     pass applies as a column scale; the last layer keeps plain weights -- its LayerNorm 1 runs as a kernel and feeds the key hook)
  * The last layer uses only ln1 and the K slice (rows D..2D-1) of qkv_w / qkv_b: that projection, bias included and
  * before the head split, is what the reference's forward hook captures (feature_extractor.py:42,46-47).
  * key_out f32 [B, D, H/P, W/P].  full_last_layer != 0 additionally runs the rest of the last layer exactly as the

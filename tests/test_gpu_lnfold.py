@@ -107,13 +107,82 @@ def test_lnfold_cancellation_with_massive_channels_stays_at_rounding_level(M, Nn
     assert rel_l2(out, plain) < 8e-4
 
 
+# ------------------------------------------------------------------------------------------------ step B: row partials from the producers
+def _resid_case(M, Nn, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.float16)
+    w = (torch.randn(Nn, K, generator=g) * 0.05).to(torch.float16)
+    b, ls = torch.randn(Nn, generator=g) * 0.1, 0.1 + torch.rand(Nn, generator=g)
+    resid = rows(M, Nn, seed + 1, massive=150.0)
+    return a.to(DEV), w.to(DEV), b.to(DEV), ls.to(DEV), resid.to(DEV)
+
+
+@pytest.mark.parametrize("M,Nn,K", [(2313, 256, 256), (4384, 768, 768), (43840, 768, 3072), (21920, 1024, 1024), (2100, 1536, 128)])
+def test_resid_epilogue_with_row_partials(M, Nn, K):
+    """UCOD_EPI_BIAS_SCALE_RESID_H16_STATS: the stream it writes is bit-identical to the plain epilogue's, and every (row, 64-column slot) holds the sum and
+    the sum of squares of exactly those fp16 values (f32 adds of 64 terms: compared with f64 at 1e-6 relative to the slot's sum of magnitudes)."""
+    lib = N.load("f16")
+    a, w, b, ls, resid = _resid_case(M, Nn, K, M + K)
+    plain = torch.empty(M, Nn, dtype=torch.float16, device=DEV)
+    N.check(lib.ucod_gemm_bf16(N.EPI_BIAS_SCALE_RESID_H16, N.ptr(a), N.ptr(w), N.ptr(plain), M, Nn, K, N.ptr(b), N.ptr(ls), N.ptr(resid), None, 0, 0, N.stream()), "plain")
+    out, part = ops.linear_scale_resid_h16_stats(a, w, b, ls, resid)
+    assert torch.equal(out, plain)
+    xs = out.double().cpu().view(M, Nn // 64, 64)
+    ps, pq = part[:, :, 0].double().cpu(), part[:, :, 1].double().cpu()
+    assert bool(((ps - xs.sum(2)).abs() <= 1e-6 * xs.abs().sum(2) + 1e-6).all())
+    assert bool(((pq - (xs * xs).sum(2)).abs() <= 1e-6 * (xs * xs).sum(2) + 1e-6).all())
+    # the in-place form the driver uses (out aliases resid)
+    r2 = resid.clone()
+    part2 = torch.empty_like(part)
+    N.check(lib.ucod_gemm_bf16_stats(N.EPI_BIAS_SCALE_RESID_H16_STATS, N.ptr(a), N.ptr(w), N.ptr(r2), M, Nn, K, N.ptr(b), N.ptr(ls), N.ptr(r2), None, 0, N.ptr(part2), Nn // 64,
+                                     N.stream()), "in place")
+    assert torch.equal(r2, plain) and torch.equal(part2, part)
+
+
+def test_row_partial_producers_refuse_small_passes():
+    lib = N.load("f16")
+    a, w, b, ls, resid = _resid_case(1370, 768, 768, 1)
+    part = torch.empty(1370, 12, 2, dtype=torch.float32, device=DEV)
+    args = (N.ptr(a), N.ptr(w), N.ptr(resid), 1370, 768, 768, N.ptr(b), N.ptr(ls), N.ptr(resid), None, 0, N.ptr(part), 12, N.stream())
+    assert lib.ucod_gemm_bf16_stats(N.EPI_BIAS_SCALE_RESID_H16_STATS, *args) == -1
+    assert lib.ucod_gemm_bf16_stats(N.EPI_BIAS_SCALE_RESID_H16, *args) == -1                 # only the two *_STATS epilogues
+    assert lib.ucod_gemm_bf16(N.EPI_BIAS_SCALE_RESID_H16_STATS, N.ptr(a), N.ptr(w), N.ptr(resid), 1370, 768, 768, N.ptr(b), N.ptr(ls), N.ptr(resid), None, 0, 0, N.stream()) == -1
+
+
+@pytest.mark.parametrize("M,Nn,K,variant", [(2313, 768, 256, 0), (4384, 2304, 768, 0), (8220, 3072, 768, 13), (43840, 2304, 768, 0), (43840, 3072, 768, 0),
+                                            (21920, 3072, 1024, 0), (1370, 2304, 768, 0), (2500, 1024, 1536, 9)])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_gemm_lnfold_from_row_partials(M, Nn, K, variant, gelu):
+    """The consumer's prologue sums a row's slots and forms (rstd, -mean * rstd) itself (one-pass variance in f64 from f32 partial sums): same result as with
+    the two-pass statistics kernel to the rounding of the output.  The x rows come out of the producer epilogue, massive channels included."""
+    a, w, b, ls, resid = _resid_case(max(M, 2048), K, 256, M + Nn)
+    x, part = ops.linear_scale_resid_h16_stats(a, w, b, ls, resid)
+    x, part = x[:M].contiguous(), part[:M].contiguous()
+    g = torch.Generator().manual_seed(Nn)
+    gamma, beta = 1 + 0.3 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+    wl, bl = torch.randn(Nn, K, generator=g) * 0.04, torch.randn(Nn, generator=g) * 0.1
+    wf, bf_, cs = ops.fold_layernorm_linear(gamma.to(DEV), beta.to(DEV), wl.to(DEV), bl.to(DEV))
+    xd = x.double().cpu()
+    mean, rstd = xd.mean(1, keepdim=True), (xd.var(1, unbiased=False, keepdim=True) + EPS).rsqrt()
+    same = rstd * (xd @ wf.cpu().double().t() - mean * cs.cpu().double()[None, :]) + bf_.cpu().double()[None, :]
+    if gelu:
+        same = torch.nn.functional.gelu(same)
+    out_p = ops.linear_lnfold(x, None, wf, bf_, cs, gelu=gelu, variant=variant, partials=part, eps=EPS).cpu().double()
+    out_s = ops.linear_lnfold(x, ops.row_stats_h16(x, EPS), wf, bf_, cs, gelu=gelu, variant=variant).cpu().double()
+    for out in (out_p, out_s):
+        err = (out - same).abs()
+        bound = H * same.abs() + 1e-4 * (1 + same.abs())
+        assert bool((err <= bound).all()), (float((err - bound).max()), M, Nn, K, variant)
+    assert rel_l2(out_p, out_s) < 1e-4                              # at most an occasional last-bit difference of the fp16 output
+
+
 def test_gemm_lnfold_is_refused_by_the_bf16_build():
     x = torch.zeros(128, 256, dtype=torch.float16, device=DEV)
     w = torch.zeros(128, 256, dtype=torch.float16, device=DEV)
     z = torch.zeros(128, dtype=torch.float32, device=DEV)
     st = torch.zeros(128, 2, dtype=torch.float32, device=DEV)
     out = torch.empty(128, 128, dtype=torch.float16, device=DEV)
-    args = (N.ptr(x), N.ptr(w), N.ptr(out), 128, 128, 256, N.ptr(z), N.ptr(z), N.ptr(st), None, 0, N.stream())
+    args = (N.ptr(x), N.ptr(w), N.ptr(out), 128, 128, 256, N.ptr(z), N.ptr(z), N.ptr(st), None, 0, 1e-6, None, 0, N.stream())
     assert N.load("bf16").ucod_gemm_lnfold(N.EPI_LNFOLD_BIAS_BF16, *args) == -1
     assert N.load("f16").ucod_gemm_lnfold(N.EPI_LNFOLD_BIAS_BF16, *args) == 0
     assert N.load("f16").ucod_gemm_lnfold(N.EPI_BIAS_BF16, *args) == -1                 # only the two folded epilogues
@@ -155,6 +224,29 @@ def test_engine_with_the_fold_against_the_oracle_and_the_unfolded_engine(small):
     # one image (small-tile kernels) against the same image inside the batch (large-tile kernels are not reached at this size; the stats / fold path is the same)
     k1 = fold(img[:1].contiguous().to(DEV)).cpu()
     assert rel_l2(k1, kf[:1]) < 1e-3
+
+
+def test_engine_with_the_fold_on_a_large_pass_takes_the_partials_path(small):
+    """Nine images = 2313 token rows: the producers are the large-tile kernels with the *_STATS epilogues (patch embedding + CLS rows, out-projection, fc2) and no
+    statistics kernel runs; the first three images must agree with the three-image pass (small-tile kernels + ucod_row_stats_h16) and with the oracle."""
+    sd, img, ref, _ = small
+    more = torch.cat((img, torch.randn(6, 3, 224, 224, generator=torch.Generator().manual_seed(10))), 0)
+    fold = ViTEngine(sd, heads=4, device=DEV, half="f16", resid="f16")
+    lib = N.load("f16")
+    lib.ucod_prof_enable(1)
+    k9 = fold(more.to(DEV)).cpu()
+    torch.cuda.synchronize()
+    lib.ucod_prof_enable(0)
+    ncls = lib.ucod_prof_num_classes()
+    import ctypes as C
+    tot, cnt = (C.c_double * ncls)(), (C.c_longlong * ncls)()
+    lib.ucod_prof_collect(tot, cnt)
+    launches = {lib.ucod_prof_class_name(i).decode(): cnt[i] for i in range(ncls) if cnt[i]}
+    assert launches.get("layernorm", 0) == 1, launches             # the last layer's LayerNorm 1 only: no LayerNorm and no statistics launch for the folded ones
+    fold.check_overflow(wait=True)
+    k3 = fold(img.to(DEV)).cpu()
+    assert rel_l2(k9[:3], ref) < 1.5e-3
+    assert rel_l2(k9[:3], k3) < 1e-3
 
 
 def test_ln_fold_is_refused_where_it_cannot_run(small):

@@ -225,6 +225,20 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
 
   float cb[NT], cs[NT];
   load_col_consts<EPI, NT>(a, n0 + wn * 16 * NT + (lane & 15), cb, cs);
+  // LayerNorm-folded epilogues: the column sums beside the bias, and this thread's row statistics (or partial sums) for the tile's LDS table --
+  // all requested ahead of the operand DMAs (see fold_request)
+  FoldCtx<NT> fold;
+  FoldReq freq;
+  char* const fold_tab = smem + 2 * MixCfg<NT, 1>::BUF;
+  if constexpr (kFold<EPI>) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      int n = n0 + wn * 16 * NT + (lane & 15) + j * 16;
+      n = n < a.N ? n : a.N - 1;
+      fold.cc[j] = a.colsum[n];
+    }
+    fold_request(a, m0, 2 * Cfg::RG, wave, lane, freq);
+  }
   stageA(0, 0);
   stageA(0, 1);
   stageB(0);
@@ -245,6 +259,16 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
     wait_vmcnt<0>();
   }
   finish_col_consts<EPI, NT>(a, cb, cs);
+  if constexpr (kFold<EPI>) {                   // table written here, read in the epilogue: every barrier of the K loop lies in between
+    fold_finish(a, fold_tab, 2 * Cfg::RG, wave, lane, freq);
+    fold.tab = reinterpret_cast<const float*>(fold_tab) + wm * Cfg::RG;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      fold.cc[j] *= cs[j];
+      fold.cb[j] = cb[j] * cs[j];
+      cb[j] = 0.f;                              // accumulators start at zero: the folded bias is added behind the per-row scaling
+    }
+  }
   f32x4 acc[NI][NT];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -307,7 +331,7 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
     }
   }
   if (wm == 0) UCOD_MIXED_BARRIER();
-  big_epilogue<EPI, NT, NI, AUX>(a, acc, cs, smem + wave * (32 * EPI_PITCH(16 * NT)), m0 + wm * Cfg::RG, n0 + wn * 16 * NT, lane);
+  big_epilogue<EPI, NT, NI, AUX>(a, acc, cs, smem + wave * (32 * EPI_PITCH(16 * NT)), m0 + wm * Cfg::RG, n0 + wn * 16 * NT, lane, &fold);
 }
 
 // first row of row-tile tm when every `stride`-th row-tile (n_tall of them in all) is 32 rows taller
@@ -320,7 +344,7 @@ __device__ __forceinline__ int mixed_row0(int tm, int n_tall, int stride, bool& 
 
 template <int EPI, int NT, int AUX = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_mixed_kernel(const GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * MixCfg<NT, 1>::BUF];
+  __shared__ __attribute__((aligned(16))) char smem[2 * MixCfg<NT, 1>::BUF + (kFold<EPI> ? FOLD_TAB_BYTES : 0)];   // (+ the folded epilogues' row table)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwg = a.tiles_m * a.tiles_n;
@@ -347,7 +371,7 @@ static void apply_order_tuning(GemmArgs& a) {
 template <int EPI>
 static int launch(GemmArgs a, int variant, hipStream_t s) {
   constexpr bool kTrainEpi = (EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
-  constexpr bool kPatchEpi = !kTrainEpi;
+  constexpr bool kPatchEpi = !kTrainEpi && !kFold<EPI>;        // (leftover-as-patches: not for the LayerNorm-folded epilogues, whose row scalars live in the tile's LDS table)
   const bool auto_small = variant == 0;                       // only `auto` may pick the 64 x 64 tile by itself
   if (variant == 0) {
     variant = 2;
@@ -370,9 +394,10 @@ static int launch(GemmArgs a, int variant, hipStream_t s) {
   }
   constexpr bool kBf16Out = (kBiasLike<EPI> || kGeluLike<EPI> || kTrainEpi);
   if ((variant >= 3 && variant <= 8) || variant == 11 || variant > 14 || variant < 0) return UCOD_EINVAL;   // 3-8: laboratory variants (variants/gemm_bf16_lab.hip)
-  if constexpr (kFold<EPI>) {                                    // the LayerNorm-folded drains exist for 64-column waves only: the 256-wide forms
+  if constexpr (kFold<EPI>) {                                    // the LayerNorm-folded epilogues exist for 64-column waves only: the 256-wide forms
     if (variant == 10) variant = 9;
     if (variant == 14) variant = 13;
+    if (a.part_in && variant < 9) variant = 9;                    // row partials are summed by the large-tile kernels' prologue only
   }
   if (variant >= 9 && variant <= 10 && ((a.N & 3) != 0 || (kBf16Out && (a.N & 7) != 0))) return UCOD_EINVAL;   // 16-byte row stores
   if constexpr (kColFused<EPI>) {
@@ -490,9 +515,13 @@ static int launch_qkv_fp8(ucod::GemmArgs a, hipStream_t s) {
 }
 
 // Out-projection / fc2 with the f16 residual stream (UCOD_EPI_BIAS_SCALE_RESID_H16): the mixed-height large-tile kernel, 256 wide.
+template <int EPI = UCOD_EPI_BIAS_SCALE_RESID_H16>
 static int launch_resid_h16(ucod::GemmArgs a, hipStream_t s) {
   using namespace ucod;
   if ((a.N & 7) != 0 || a.K < 128 || !a.bias || !a.scale || !a.resid) return UCOD_EINVAL;
+  if constexpr (kStats<EPI>) {                                    // whole 64-column slots; the table's byte offsets fit the descriptors
+    if ((a.N & 63) != 0 || !a.part_out || a.nslot != a.N / 64 || (long)a.M * a.nslot * 8 >= (1L << 31)) return UCOD_EINVAL;
+  }
   if ((long)a.M * a.K * 2 >= (1L << 32) || (long)a.N * a.K * 2 >= (1L << 32)) return UCOD_EINVAL;      // 32-bit operand offsets
   const MixedPlan mp = mixed_plan(a.M, a.N, 256);
   a.tiles_n = cdiv(a.N, 256);
@@ -507,14 +536,36 @@ static int launch_resid_h16(ucod::GemmArgs a, hipStream_t s) {
   }
   a.col_fast = a.tiles_n <= 4;
   apply_order_tuning(a);
-  hipLaunchKernelGGL((gemm_bf16_mixed_kernel<UCOD_EPI_BIAS_SCALE_RESID_H16, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
+  hipLaunchKernelGGL((gemm_bf16_mixed_kernel<EPI, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+// Patch embedding onto the f16 residual stream WITH row partials (UCOD_EPI_PATCH_TOKENS_H16_STATS): the 256-wide one-shot large-tile kernel and its
+// offset-scheme drain only (no leftover patches: they would bypass the partial sums); anything it cannot take is refused, the caller then uses the
+// plain epilogue and ucod_row_stats_h16.
+static int launch_patch_h16_stats(ucod::GemmArgs a, hipStream_t s) {
+  using namespace ucod;
+  if (!a.bias || !a.pos || a.tok < 2 || !a.part_out || (a.N & 63) != 0 || a.nslot != a.N / 64 || a.K < 128 || a.M < 2048) return UCOD_EINVAL;
+  const int np = a.tok - 1;
+  const unsigned long out_bytes = (unsigned long)(a.M / np) * a.tok * a.N * 2ul;
+  if ((a.M % np) != 0 || out_bytes >= 0x7FFFFFF0ul || (unsigned long)a.tok * a.N * 4ul >= 0x7FFFFFF0ul ||
+      (unsigned long)(a.M / np) * a.tok * a.nslot * 8ul >= 0x7FFFFFF0ul) return UCOD_EINVAL;
+  a.tiles_m = cdiv(a.M, 256);
+  a.tiles_n = cdiv(a.N, 256);
+  a.col_fast = a.tiles_n <= 4;
+  apply_order_tuning(a);
+  a.main_tiles = 0;
+  a.patches_per_wg = 0;
+  hipLaunchKernelGGL((gemm_bf16_big_kernel<UCOD_EPI_PATCH_TOKENS_H16_STATS, 4, true, 2>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }
 
 static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int M, int N, int K, const float* bias,
                       const float* scale, const float* resid, const float* pos, int tokens_per_image, int variant,
-                      void* stream, const void* aux, void* out2, const float* stats = nullptr, const float* colsum = nullptr) {
+                      void* stream, const void* aux, void* out2, const float* stats = nullptr, const float* colsum = nullptr,
+                      const float* part_in = nullptr, float* part_out = nullptr, int nslot = 0, float eps = 0.f) {
   using namespace ucod;
   if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0) return UCOD_EINVAL;
   GemmArgs a;
@@ -522,7 +573,12 @@ static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int
   a.out2 = out2;
   a.stats = stats;
   a.colsum = colsum;
-  a.ovf = (epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16 || epilogue == UCOD_EPI_PATCH_TOKENS_H16) ? resid16_overflow_counter() : nullptr;
+  a.part_in = part_in;
+  a.part_out = part_out;
+  a.nslot = nslot;
+  a.eps = eps;
+  a.ovf = (epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16 || epilogue == UCOD_EPI_PATCH_TOKENS_H16 || epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16_STATS ||
+           epilogue == UCOD_EPI_PATCH_TOKENS_H16_STATS) ? resid16_overflow_counter() : nullptr;
   a.stamps = nullptr;
 #ifdef UCOD_GEMM_STAMPS
   a.stamps = (unsigned long long*)pos;   // diagnostic build: the (otherwise unused here) `pos` argument carries the stamp buffer
@@ -545,7 +601,7 @@ static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int
   a.group_m = 8;
   a.col_fast = 0;
   hipStream_t s = (hipStream_t)stream;
-  UCOD_PROF(epilogue == UCOD_EPI_QKV_FP8 || epilogue == UCOD_EPI_LNFOLD_BIAS_BF16 ? 0 : epilogue == UCOD_EPI_LNFOLD_GELU_BF16 ? 1 : epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16 ? 2 : epilogue == UCOD_EPI_PATCH_TOKENS_H16 ? 3 : (epilogue >= 0 && epilogue <= 5 ? epilogue : (epilogue == UCOD_EPI_GELU_BWD_BF16 ? PROF_GEMM_EPI6 : PROF_GEMM_EPI7)), s);
+  UCOD_PROF(epilogue == UCOD_EPI_QKV_FP8 || epilogue == UCOD_EPI_LNFOLD_BIAS_BF16 ? 0 : epilogue == UCOD_EPI_LNFOLD_GELU_BF16 ? 1 : (epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16 || epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16_STATS) ? 2 : (epilogue == UCOD_EPI_PATCH_TOKENS_H16 || epilogue == UCOD_EPI_PATCH_TOKENS_H16_STATS) ? 3 : (epilogue >= 0 && epilogue <= 5 ? epilogue : (epilogue == UCOD_EPI_GELU_BWD_BF16 ? PROF_GEMM_EPI6 : PROF_GEMM_EPI7)), s);
   switch (epilogue) {
     case UCOD_EPI_BIAS_BF16:                                   // NULL bias (plain product) only in the large-tile kernels
       if (!bias && (variant == 1 || variant == 2 || K < 128 || (N & 3))) return UCOD_EINVAL;
@@ -567,11 +623,18 @@ static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int
       return launch<UCOD_EPI_BIAS_F32>(a, variant, s);
     case UCOD_EPI_QKV_FP8: return launch_qkv_fp8(a, s);
     case UCOD_EPI_LNFOLD_BIAS_BF16:
-      if (!bias || !stats || !colsum || (N & 7) != 0) return UCOD_EINVAL;
-      return launch<UCOD_EPI_LNFOLD_BIAS_BF16>(a, variant, s);
     case UCOD_EPI_LNFOLD_GELU_BF16:
-      if (!bias || !stats || !colsum || (N & 7) != 0) return UCOD_EINVAL;
-      return launch<UCOD_EPI_LNFOLD_GELU_BF16>(a, variant, s);
+      if (!bias || (!stats && !part_in) || !colsum || (N & 7) != 0) return UCOD_EINVAL;
+      if (part_in && (nslot < 2 || nslot > 2 * FOLD_MAX_SLOT_PAIRS || (nslot & 1) || K < 128 || (long)M * nslot * 8 >= (1L << 32) - 16)) return UCOD_EINVAL;
+      if (!part_in && (long)M * 8 >= (1L << 32) - 16) return UCOD_EINVAL;
+      return epilogue == UCOD_EPI_LNFOLD_BIAS_BF16 ? launch<UCOD_EPI_LNFOLD_BIAS_BF16>(a, variant, s) : launch<UCOD_EPI_LNFOLD_GELU_BF16>(a, variant, s);
+    case UCOD_EPI_BIAS_SCALE_RESID_H16_STATS:
+      if (!bias || !scale || !resid || !a.ovf || !part_out) return UCOD_EINVAL;
+      if (M >= 2048 && K >= 128 && (N & 7) == 0 && (long)M * K * 2 < (1L << 32) && (long)N * K * 2 < (1L << 32)) return launch_resid_h16<UCOD_EPI_BIAS_SCALE_RESID_H16_STATS>(a, s);
+      return UCOD_EINVAL;                                          // (small passes: the caller takes the plain epilogue + ucod_row_stats_h16)
+    case UCOD_EPI_PATCH_TOKENS_H16_STATS:
+      if (!a.ovf) return UCOD_EINVAL;
+      return launch_patch_h16_stats(a, s);
     case UCOD_EPI_BIAS_SCALE_RESID_H16:
       if (!bias || !scale || !resid || !a.ovf) return UCOD_EINVAL;
       // large passes: the mixed-height large-tile kernel; small ones (a batch-1 Look-Twice pass) the 128 x 128 / 64 x 64 kernel, so that the
@@ -590,6 +653,7 @@ extern "C" int ucod_gemm_bf16(int epilogue, const void* A, const void* B, void* 
                               void* stream) {
   if (epilogue == UCOD_EPI_GELU_BWD_BF16 || epilogue == UCOD_EPI_BIAS_GELU_SAVE_BF16) return UCOD_EINVAL;   // need ucod_gemm_bf16_train
   if (epilogue == UCOD_EPI_LNFOLD_BIAS_BF16 || epilogue == UCOD_EPI_LNFOLD_GELU_BF16) return UCOD_EINVAL;   // need ucod_gemm_lnfold
+  if (epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16_STATS || epilogue == UCOD_EPI_PATCH_TOKENS_H16_STATS) return UCOD_EINVAL;   // need ucod_gemm_bf16_stats
   return gemm_entry(epilogue, A, B, out, M, N, K, bias, scale, resid, pos, tokens_per_image, variant, stream, nullptr, nullptr);
 }
 
@@ -603,14 +667,25 @@ extern "C" int ucod_gemm_bf16_train(int epilogue, const void* A, const void* B, 
 // LayerNorm folded into the consumer GEMM: A = the fp16 residual stream itself (so this entry exists in the fp16-operand build only: an MFMA
 // takes both operands in one type), B = fp16(gamma (.) W), out = 16-bit [M,N].  See kFold in gemm_bf16_epilogue.h.
 extern "C" int ucod_gemm_lnfold(int epilogue, const void* x_f16, const void* w_folded, void* out, int M, int N, int K, const float* bias_folded,
-                                const float* colsum, const float* stats, const float* scale, int variant, void* stream) {
+                                const float* colsum, const float* stats, const float* row_partials, int nslot, float eps, const float* scale,
+                                int variant, void* stream) {
 #ifndef UCOD_HALF_F16
   return UCOD_EINVAL;
 #else
   if (epilogue != UCOD_EPI_LNFOLD_BIAS_BF16 && epilogue != UCOD_EPI_LNFOLD_GELU_BF16) return UCOD_EINVAL;
   if (epilogue == UCOD_EPI_LNFOLD_GELU_BF16 && scale) return UCOD_EINVAL;
-  return gemm_entry(epilogue, x_f16, w_folded, out, M, N, K, bias_folded, scale, nullptr, nullptr, 0, variant, stream, nullptr, nullptr, stats, colsum);
+  return gemm_entry(epilogue, x_f16, w_folded, out, M, N, K, bias_folded, scale, nullptr, nullptr, 0, variant, stream, nullptr, nullptr, stats, colsum,
+                    row_partials, nullptr, nslot, eps);
 #endif
+}
+
+// The two residual-stream producers with row partials for the next LayerNorm-folded consumer (large passes only; UCOD_EINVAL otherwise, nothing launched).
+extern "C" int ucod_gemm_bf16_stats(int epilogue, const void* A, const void* B, void* out, int M, int N, int K, const float* bias, const float* scale,
+                                    const void* resid, const float* pos, int tokens_per_image, float* row_partials, int nslot, void* stream) {
+  if (epilogue != UCOD_EPI_BIAS_SCALE_RESID_H16_STATS && epilogue != UCOD_EPI_PATCH_TOKENS_H16_STATS) return UCOD_EINVAL;
+  if (!row_partials || nslot <= 0) return UCOD_EINVAL;
+  return gemm_entry(epilogue, A, B, out, M, N, K, bias, scale, (const float*)resid, pos, tokens_per_image, 0, stream, nullptr, nullptr, nullptr, nullptr,
+                    nullptr, row_partials, nslot, 0.f);
 }
 
 // Re-read the UCOD_GEMM_* tuning variables (gemm_bf16_plan.h): they are read once per process, not per launch.

@@ -26,6 +26,15 @@ constexpr int BM = 128, BN = 128, BK = 64;
 // rounding of the LayerNorm output and the LayerNorm launch itself disappear.
 template <int EPI>
 constexpr bool kFold = (EPI == UCOD_EPI_LNFOLD_BIAS_BF16 || EPI == UCOD_EPI_LNFOLD_GELU_BF16);
+// The residual-stream producers that also leave row statistics for the next LayerNorm-folded consumer (round 5, step B): every wave adds up
+// the 64 values of a row it has just rounded to fp16 -- sum and sum of squares of the ROUNDED values, what the consumer's MFMA will read -- and
+// stores the pair into slot (column / 64) of the row: no statistics launch, no atomics, one fixed order of additions.
+template <int EPI>
+constexpr bool kResidH16 = (EPI == UCOD_EPI_BIAS_SCALE_RESID_H16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_H16_STATS);
+template <int EPI>
+constexpr bool kPatchH16 = (EPI == UCOD_EPI_PATCH_TOKENS_H16 || EPI == UCOD_EPI_PATCH_TOKENS_H16_STATS);
+template <int EPI>
+constexpr bool kStats = (EPI == UCOD_EPI_BIAS_SCALE_RESID_H16_STATS || EPI == UCOD_EPI_PATCH_TOKENS_H16_STATS);
 template <int EPI>
 constexpr bool kBiasLike = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_LNFOLD_BIAS_BF16);        // optional column scale, 16-bit output
 template <int EPI>
@@ -57,8 +66,13 @@ struct GemmArgs {
   const void* aux;    // GELU_BWD: bf16 [M,N] pre-activation of the forward fc1
   void* out2;         // BIAS_GELU_SAVE: bf16 [M,N] pre-activation output
   unsigned* ovf;      // f16 residual-stream epilogues: saturation counter (common.h: resid16_overflow_counter)
-  const float* stats;   // LayerNorm-folded epilogues: per-row (rstd, -mean * rstd) of the A rows, f32 [M][2]
+  const float* stats;   // LayerNorm-folded epilogues: per-row (rstd, -mean * rstd) of the A rows, f32 [M][2] (used when part_in is NULL)
   const float* colsum;  // LayerNorm-folded epilogues: c[n] = sum_k B[n][k] (of the ROUNDED folded weight), f32 [N]
+  const float* part_in; // LayerNorm-folded epilogues: per-row partial (sum, sum of squares) of the A rows, f32 [M][nslot][2], written by the producer's
+                        // *_STATS epilogue; the consumer's prologue sums them (large-tile kernels only)
+  float* part_out;      // *_STATS epilogues: where this launch leaves its output rows' partial (sum, sum of squares), f32 [rows][nslot][2], slot = column / 64
+  int nslot;            // partial slots per row of part_in / part_out
+  float eps;            // LayerNorm eps (part_in)
   int M, N, K;
   int tok;   // tokens per image incl. CLS (PATCH / KEY epilogues)
   int tiles_m, tiles_n;
@@ -156,13 +170,13 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& a, int m, int n, 
     const int np = a.tok - 1;
     const int b = m / np, p = m - b * np;
     reinterpret_cast<float*>(a.out)[((size_t)b * a.tok + 1 + p) * a.N + n] = v + a.bias[n] + a.pos[(size_t)(1 + p) * a.N + n];
-  } else if constexpr (EPI == UCOD_EPI_PATCH_TOKENS_H16) {
+  } else if constexpr (kPatchH16<EPI>) {
     const int np = a.tok - 1;
     const int b = m / np, p = m - b * np;
     const float o = v + a.bias[n] + a.pos[(size_t)(1 + p) * a.N + n];
     if (beyond_f16(o)) atomicAdd(a.ovf, 1u);
     reinterpret_cast<unsigned short*>(a.out)[((size_t)b * a.tok + 1 + p) * a.N + n] = __builtin_bit_cast(unsigned short, (_Float16)clamp_f16(o));
-  } else if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_H16) {
+  } else if constexpr (kResidH16<EPI>) {
     const size_t i = (size_t)m * a.N + n;
     const float o = (float)reinterpret_cast<const _Float16*>(a.resid)[i] + a.scale[n] * (v + a.bias[n]);
     if (beyond_f16(o)) atomicAdd(a.ovf, 1u);
@@ -219,7 +233,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& a, int m, int n,
       const f32x4 r = *reinterpret_cast<const f32x4*>(a.resid + i);
       const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
       *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + i) = r + sc * (v + b);
-    } else if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_H16) {
+    } else if constexpr (kResidH16<EPI>) {
       const size_t i = (size_t)m * a.N + n;
       const u32x2 rw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(a.resid) + i);
       float r0, r1, r2, r3;
@@ -232,12 +246,12 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& a, int m, int n,
       w[0] = pack_f16x2(clamp_f16(o[0]), clamp_f16(o[1]));
       w[1] = pack_f16x2(clamp_f16(o[2]), clamp_f16(o[3]));
       *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(a.out) + i) = w;
-    } else if constexpr (EPI == UCOD_EPI_PATCH_TOKENS_F32 || EPI == UCOD_EPI_PATCH_TOKENS_H16) {
+    } else if constexpr (EPI == UCOD_EPI_PATCH_TOKENS_F32 || kPatchH16<EPI>) {
       const int np = a.tok - 1;
       const int bi = m / np, p = m - bi * np;
       const f32x4 ps = *reinterpret_cast<const f32x4*>(a.pos + (size_t)(1 + p) * a.N + n);
       const f32x4 o = v + b + ps;
-      if constexpr (EPI == UCOD_EPI_PATCH_TOKENS_H16) {
+      if constexpr (kPatchH16<EPI>) {
         if (beyond_f16(o[0]) || beyond_f16(o[1]) || beyond_f16(o[2]) || beyond_f16(o[3])) atomicAdd(a.ovf, 1u);
         u32x2 w;
         w[0] = pack_f16x2(clamp_f16(o[0]), clamp_f16(o[1]));
@@ -318,6 +332,108 @@ __device__ __forceinline__ void drain_rows(const GemmArgs& a, const char* wbase,
   }
 }
 
+// (sum, sum of squares) of the eight fp16 values in w, added over the 8 consecutive lanes that hold one row's 64 columns (lane & 7 = chunk):
+// three DPP steps (xor 1, xor 2 inside the quad, then the mirrored lane of the other quad); every lane of the group ends with the total.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_t(float v) {
+  const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+  return v + __builtin_bit_cast(float, o);
+}
+__device__ __forceinline__ f32x2 row_partial8(const u32x4& w) {
+  float ps = 0.f, pq = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float lo, hi;
+    unpack_f16x2(w[e], lo, hi);
+    ps += lo + hi;
+    pq = fmaf(lo, lo, fmaf(hi, hi, pq));
+  }
+  ps = dpp_add_t<0xB1>(ps);  pq = dpp_add_t<0xB1>(pq);      // quad_perm [1,0,3,2]
+  ps = dpp_add_t<0x4E>(ps);  pq = dpp_add_t<0x4E>(pq);      // quad_perm [2,3,0,1]
+  ps = dpp_add_t<0x141>(ps); pq = dpp_add_t<0x141>(pq);     // row_half_mirror: lane i <-> 7 - i of each group of 8
+  return (f32x2){ps, pq};
+}
+
+// ---- LayerNorm-folded consumers: the tile's row table and the stager's constants ----------------------------------------------------
+// Large-tile kernels keep (s, u) = (rstd, -mean * rstd) of the tile's rows in LDS (behind the two K-tile buffers): thread t of the workgroup owns
+// row m0 + t, requests either its `stats` pair or its nslot (sum, sum of squares) partials BEFORE the operand DMAs are issued (oldest in the
+// vmcnt queue: they have landed when the counted prologue wait returns), turns them into (s, u) and writes the table ahead of the K loop's first
+// barrier.  The stager then reads four rows' scalars per 16-row accumulator tile with two ds_read_b128 (requested one pass ahead) and applies
+//   out = s[row] * (acc * q[col]) + (u[row] * (c q)[col] + (b' q)[col])      (q = optional column scale)
+// in the MFMA C layout, where a lane owns one column per tile: the row-major drain behind it is the unfolded one (plus GELU for fc1).
+// (ablation builds only -- wrong results, timing: bit 0 no prologue work, bit 1 no arithmetic in the stager, bit 2 no table reads)
+#ifndef UCOD_FOLD_ABL
+#define UCOD_FOLD_ABL 0
+#endif
+constexpr int FOLD_TAB_ROWS = 288;                                 // >= rows of the tallest tile (2 x 144)
+constexpr int FOLD_TAB_BYTES = 2 * FOLD_TAB_ROWS * 4;
+constexpr int FOLD_MAX_SLOT_PAIRS = 12;                            // nslot <= 24 (D <= 1536)
+template <int NT>
+struct FoldCtx {
+  const float* tab;      // LDS: s of this wave group's rows at tab[r], u at tab[FOLD_TAB_ROWS + r]
+  float cc[NT], cb[NT];  // (colsum * q), (bias' * q) of the lane's column per 16-wide tile
+};
+struct FoldReq {
+  f32x4 p[FOLD_MAX_SLOT_PAIRS];
+  f32x2 su;
+};
+constexpr int FOLD_BASE_PAIRS = 6;                                 // slot pairs requested unconditionally (D = 768: all of them); the rest under one wave-uniform test
+// request: no wait; rows / slots that do not exist read zeros through the descriptors' range check.  Only the waves that own rows of the tile take part
+// (`wave` is a scalar: the test is a scalar branch taken before any operand DMA has been issued).
+__device__ __forceinline__ void fold_request(const GemmArgs& a, int m0, int rows, int wave, int lane, FoldReq& r) {
+  if constexpr ((UCOD_FOLD_ABL & 1) != 0) return;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  if (wave * 64 >= rows) return;
+  const int tid = wave * 64 + lane;
+  const int m = m0 + tid;
+  const bool live = tid < rows && m < a.M;
+  const bool parts = a.part_in != nullptr;
+  const unsigned prow = (unsigned)a.nslot * 8u;
+  const unsigned long pbytes = parts ? (unsigned long)a.M * prow : 0ul;
+  const auto rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(parts ? a.part_in : a.colsum), 0, pbytes > 0xFFFFFFF0ul ? 0xFFFFFFF0u : (unsigned)pbytes, 0x00020000);
+  const auto rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(parts ? a.colsum : a.stats), 0, parts ? 0u : (unsigned)a.M * 8u, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < FOLD_BASE_PAIRS; ++i)
+    r.p[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, (live && 2 * i < a.nslot) ? (unsigned)m * prow + (unsigned)i * 16u : OOB, 0, 0));
+  if (a.nslot > 2 * FOLD_BASE_PAIRS) {
+#pragma unroll
+    for (int i = FOLD_BASE_PAIRS; i < FOLD_MAX_SLOT_PAIRS; ++i)
+      r.p[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, (live && 2 * i < a.nslot) ? (unsigned)m * prow + (unsigned)i * 16u : OOB, 0, 0));
+  }
+  r.su = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_s, live ? (unsigned)m * 8u : OOB, 0, 0));
+}
+// finish: (s, u) of this thread's row into the table.  Partials: biased variance E[x^2] - mean^2 (+ eps) like nn.LayerNorm, in f32 -- the two sums
+// are f32 already, so a wider subtraction would keep nothing the sums have not lost; a residual-stream row has |mean| well below its deviation.
+__device__ __forceinline__ void fold_finish(const GemmArgs& a, char* tab_bytes, int rows, int wave, int lane, const FoldReq& r) {
+  if constexpr ((UCOD_FOLD_ABL & 1) != 0) return;
+  if (wave * 64 >= rows) return;
+  const int tid = wave * 64 + lane;
+  float S = 0.f, Q = 0.f;
+#pragma unroll
+  for (int i = 0; i < FOLD_BASE_PAIRS; ++i) {
+    S += r.p[i][0] + r.p[i][2];
+    Q += r.p[i][1] + r.p[i][3];
+  }
+  if (a.nslot > 2 * FOLD_BASE_PAIRS) {
+#pragma unroll
+    for (int i = FOLD_BASE_PAIRS; i < FOLD_MAX_SLOT_PAIRS; ++i) {
+      S += r.p[i][0] + r.p[i][2];
+      Q += r.p[i][1] + r.p[i][3];
+    }
+  }
+  const float inv_d = 1.0f / (float)a.K;
+  const float mean = S * inv_d;
+  const float var = __builtin_fmaxf(fmaf(-mean, mean, Q * inv_d), 0.f);
+  const float rstd = rsqrtf(var + a.eps);
+  const bool parts = a.part_in != nullptr;
+  const float s = parts ? rstd : r.su[0], u = parts ? -mean * rstd : r.su[1];
+  if (tid < FOLD_TAB_ROWS) {
+    float* tab = reinterpret_cast<float*>(tab_bytes);
+    tab[tid] = s;
+    tab[FOLD_TAB_ROWS + tid] = u;
+  }
+}
+
 // ---- large-tile epilogue (one-shot and persistent kernels) ------------------------------------------------------
 // s_memtime stamps (tools/gemm_stamps.py) showed the old epilogue costing 12 k (bf16 out) to 40 k (f32 residual) cycles per
 // 256-wide tile INDEPENDENT of how many CUs were active: not bandwidth, but a latency chain -- every 16-byte store was
@@ -331,7 +447,7 @@ __device__ __forceinline__ void drain_rows(const GemmArgs& a, const char* wbase,
 template <int EPI>
 constexpr bool kColFused = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 ||
                             EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16 ||
-                            EPI == UCOD_EPI_QKV_FP8 || EPI == UCOD_EPI_BIAS_SCALE_RESID_H16 || kFold<EPI>);
+                            EPI == UCOD_EPI_QKV_FP8 || kResidH16<EPI> || kFold<EPI>);
 template <int EPI>
 constexpr bool kF32Out = (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_BIAS_F32);
 
@@ -346,12 +462,10 @@ __device__ __forceinline__ void load_col_consts(const GemmArgs& a, int ncol0, fl
       n = n < a.N ? n : a.N - 1;
       if constexpr (EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8) {
         cb[j] = (a.bias ? a.bias : reinterpret_cast<const float*>(a.B))[n];   // NULL bias = plain product (dgrad GEMMs): selected in finish_col_consts
-      } else if constexpr (kFold<EPI>) {
-        // (accumulators start at zero: the folded bias is added behind the per-row scaling, in the row-major drain)
       } else if constexpr (EPI != UCOD_EPI_GELU_BWD_BF16) {
         cb[j] = a.bias[n];
       }
-      if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_BIAS_SCALE_RESID_H16) cs[j] = a.scale[n];
+      if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || kResidH16<EPI>) cs[j] = a.scale[n];
       // optional scale: unconditional load now (a branch here costs a vmcnt(0) at the join, ahead of the operand DMAs),
       // select at the point of use (finish_col_consts) so nothing waits on the load before the DMAs are out
       if constexpr (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_QKV_FP8 || EPI == UCOD_EPI_LNFOLD_BIAS_BF16) cs[j] = (a.scale ? a.scale : reinterpret_cast<const float*>(a.B))[n];
@@ -380,7 +494,7 @@ __device__ __forceinline__ void finish_col_consts(const GemmArgs& a, float (&cb)
 // and a vmcnt(0) in front of every store, one store round trip per store instruction: key hook 106 us, patch embedding 78 us per 32
 // images.  Same order of additions as the chunk-by-chunk drains, (sum + bias) + position: bitwise the same values on every tile path.)
 template <int EPI>
-constexpr bool kRowMapped = (EPI == UCOD_EPI_KEY_NCHW_F32 || EPI == UCOD_EPI_PATCH_TOKENS_F32 || EPI == UCOD_EPI_PATCH_TOKENS_H16);
+constexpr bool kRowMapped = (EPI == UCOD_EPI_KEY_NCHW_F32 || EPI == UCOD_EPI_PATCH_TOKENS_F32 || kPatchH16<EPI>);
 template <int EPI, int NT>
 constexpr bool kFastRowMapped = kRowMapped<EPI> && NT == 4;
 
@@ -388,7 +502,7 @@ constexpr bool kFastRowMapped = kRowMapped<EPI> && NT == 4;
 // staging area, row-major.  big_epilogue() below supplies the one for 16 x 16 accumulator tiles; a kernel on 32 x 32 MFMA tiles supplies its own.
 template <int EPI>
 constexpr bool kStageScaled = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 || EPI == UCOD_EPI_QKV_FP8 ||
-                               EPI == UCOD_EPI_BIAS_SCALE_RESID_H16 || EPI == UCOD_EPI_LNFOLD_BIAS_BF16);
+                               kResidH16<EPI> || EPI == UCOD_EPI_LNFOLD_BIAS_BF16);
 
 template <int EPI, int NT, int NI, int AUX, bool FASTRM, class Stage>
 __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Stage& stage, char* wbase, int m_first, int n_first, int lane) {
@@ -446,12 +560,12 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-  } else if constexpr (FASTRM && (EPI == UCOD_EPI_PATCH_TOKENS_F32 || EPI == UCOD_EPI_PATCH_TOKENS_H16)) {
+  } else if constexpr (FASTRM && (EPI == UCOD_EPI_PATCH_TOKENS_F32 || kPatchH16<EPI>)) {
     // row m = image * (tok-1) + p  ->  token row image * tok + 1 + p = m + image + 1, + position embedding of token 1 + p.  The position
     // rows of a pass are requested before its accumulators are staged; nothing else is loaded, so the wait in front of a pass's stores is
     // the only one (it also retires the previous pass's stores: four round trips per tile instead of one per store).
     static_assert(WCOLS == 64 && NI == 8, "64-column waves");
-    constexpr bool H16 = (EPI == UCOD_EPI_PATCH_TOKENS_H16);
+    constexpr bool H16 = (kPatchH16<EPI>);
     constexpr unsigned DROP = 0x80000000u;
     constexpr int EW = H16 ? 8 : 4;                               // columns per lane and store
     constexpr int CH = WCOLS / EW, RPI = 64 / CH, ITS = PR / RPI; // chunks per row, rows per wave instruction, instructions per pass
@@ -459,6 +573,8 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
     const unsigned out_bytes = (unsigned)(a.M / np) * (unsigned)a.tok * (unsigned)a.N * (H16 ? 2u : 4u);   // (launch(): < 2^31)
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out), 0, out_bytes, 0x00020000);
     const auto rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.pos)), 0, (unsigned)a.tok * (unsigned)a.N * 4u, 0x00020000);
+    const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(kStats<EPI> ? (void*)a.part_out : a.out), 0,
+                                                        kStats<EPI> ? (unsigned)(a.M / np) * (unsigned)a.tok * (unsigned)a.nslot * 8u : 0u, 0x00020000);
     const int n = n_first + (lane % CH) * EW;
     const bool col_ok = n < a.N;
     const int lrow = m_first + lane / CH;
@@ -472,6 +588,7 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       unsigned o_off[ITS];
+      unsigned q_off[kStats<EPI> ? ITS : 1];                      // *_STATS: byte offset of (output token row, slot n_first / 64) in the partial-sum table
       u32x4 pv[ITS][H16 ? 2 : 1];
 #pragma unroll
       for (int it = 0; it < ITS; ++it) {
@@ -479,6 +596,7 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
         const int bi = m / np, p = m - bi * np;
         const bool ok = col_ok && m < a.M;
         o_off[it] = ok ? ((unsigned)(m + bi + 1) * (unsigned)a.N + (unsigned)n) * (H16 ? 2u : 4u) : DROP;
+        if constexpr (kStats<EPI>) q_off[it] = (ok && (lane % CH) == 0) ? ((unsigned)(m + bi + 1) * (unsigned)a.nslot + (unsigned)(n_first >> 6)) * 8u : DROP;
         const unsigned p_off = ok ? ((unsigned)(1 + p) * (unsigned)a.N + (unsigned)n) * 4u : DROP;
         pv[it][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, p_off, 0, 0);
         if constexpr (H16) pv[it][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, p_off + 16u, 0, 0);
@@ -502,6 +620,7 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
           w[2] = pack_f16x2(clamp_f16(v1[0]), clamp_f16(v1[1]));
           w[3] = pack_f16x2(clamp_f16(v1[2]), clamp_f16(v1[3]));
           __builtin_amdgcn_raw_buffer_store_b128(w, rs_o, o_off[it], 0, 0);
+          if constexpr (kStats<EPI>) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row_partial8(w)), rs_q, q_off[it], 0, 0);
         } else {
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rs_o, o_off[it], 0, 0);
         }
@@ -607,7 +726,7 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
       }
     } else {                                                      // bf16 out: 16-byte stores (launch() guarantees N % 8 == 0)
       constexpr bool GBWD = (EPI == UCOD_EPI_GELU_BWD_BF16), SAVE = (EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16);
-      constexpr bool RH16 = (EPI == UCOD_EPI_BIAS_SCALE_RESID_H16);   // second matrix = the f16 residual stream (may alias out)
+      constexpr bool RH16 = (kResidH16<EPI>);   // second matrix = the f16 residual stream (may alias out)
       constexpr int CH = WCOLS / 8, ITS = PR * CH / 64;
       static_assert((PR * CH) % 64 == 0, "whole wave instructions");
       // second bf16 [M,N] matrix with the same geometry: the saved pre-activation, read (GELU_BWD) or written (GELU_SAVE)
@@ -638,39 +757,16 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
         return wbase + lrow(it) * EPI_PITCH(WCOLS) + lchk(it) * 32;
       };
       float amax = 0.f;                                             // RH16: largest |x_new| this lane produced (saturation test after the stores)
+      // *_STATS: this launch's rows of the partial-sum table [M][nslot][2] f32, descriptor from the wave tile's first row (rows past M are dropped)
+      const unsigned part_row_bytes = kStats<EPI> ? (unsigned)a.nslot * 8u : 0u, part_slot_off = kStats<EPI> ? (unsigned)(n_first >> 6) * 8u : 0u;
+      const unsigned long part_left = kStats<EPI> && rows_left > 0 ? (unsigned long)rows_left * part_row_bytes : 0ul;
+      const auto rs_part = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<char*>(kStats<EPI> ? (void*)a.part_out : a.out) + (kStats<EPI> ? (size_t)(m_first < a.M ? m_first : 0) * part_row_bytes : 0), 0,
+          part_left > 0x7FFFFFF0ul ? 0x7FFFFFF0u : (unsigned)part_left, 0x00020000);
       u32x4 pre[2][ITS];
       if constexpr (GBWD || RH16) {
 #pragma unroll
         for (int it = 0; it < ITS; ++it) pre[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_2, at(it, 0), 0, 0);
-      }
-      // LayerNorm-folded epilogues: the lane's eight columns are the same for every row (FAST), so u * c[n] + b'[n] needs 16 registers loaded
-      // once per tile (already multiplied by the optional column scale, which the stager applied to the accumulators); the two per-row
-      // scalars (s, u) = (rstd, -mean * rstd) of a pass are requested one pass ahead, like the residual rows of RH16: no load between two stores.
-      static_assert(!kFold<EPI> || FAST, "the LayerNorm-folded epilogues need 64-column waves");
-      float fc[kFold<EPI> ? 8 : 1], fb[kFold<EPI> ? 8 : 1];
-      u32x2 st[2][kFold<EPI> ? ITS : 1];
-      const unsigned st_rec = !kFold<EPI> || rows_left <= 0 ? 0u : (rows_left > 0x0FFFFFFFl ? 0x7FFFFFF8u : (unsigned)rows_left * 8u);   // rows past M read zeros
-      const auto rs_st = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char*>(reinterpret_cast<const char*>(kFold<EPI> ? (const void*)a.stats : (const void*)a.out)) + (size_t)(m_first < a.M ? m_first : 0) * 8, 0, st_rec, 0x00020000);
-      auto st_at = [&](int it, int pass) -> unsigned { return (unsigned)(pass * PR + it * 8 + (lane >> 3)) * 8u; };
-      if constexpr (kFold<EPI>) {
-        const int n = n_first + (lane & 7) * 8, nn = n < a.N ? n : 0;          // (N % 8 == 0: a chunk is inside or outside as a whole)
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.colsum + nn), c1 = *reinterpret_cast<const f32x4*>(a.colsum + nn + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + nn), b1 = *reinterpret_cast<const f32x4*>(a.bias + nn + 4);
-        f32x4 q0 = {1.f, 1.f, 1.f, 1.f}, q1 = {1.f, 1.f, 1.f, 1.f};
-        if constexpr (EPI == UCOD_EPI_LNFOLD_BIAS_BF16) {
-          if (a.scale) {
-            q0 = *reinterpret_cast<const f32x4*>(a.scale + nn);
-            q1 = *reinterpret_cast<const f32x4*>(a.scale + nn + 4);
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          fc[e] = c0[e] * q0[e]; fc[4 + e] = c1[e] * q1[e];
-          fb[e] = b0[e] * q0[e]; fb[4 + e] = b1[e] * q1[e];
-        }
-#pragma unroll
-        for (int it = 0; it < ITS; ++it) st[0][it] = __builtin_amdgcn_raw_buffer_load_b64(rs_st, st_at(it, 0), 0, 0);
       }
 #pragma unroll
       for (int pass = 0; pass < NP; ++pass) {
@@ -684,31 +780,12 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
             }
           }
         }
-        if constexpr (kFold<EPI>) {
-          if (pass + 1 < NP) {
-#pragma unroll
-            for (int it = 0; it < ITS; ++it) {
-              if (!live(it, pass + 1)) continue;
-              st[(pass + 1) & 1][it] = __builtin_amdgcn_raw_buffer_load_b64(rs_st, st_at(it, pass + 1), 0, 0);
-            }
-          }
-        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
           if (!live(it, pass)) continue;
           f32x4 v0 = *reinterpret_cast<const f32x4*>(lds_at(it));
           f32x4 v1 = *reinterpret_cast<const f32x4*>(lds_at(it) + 16);
-          if constexpr (kFold<EPI>) {                              // out = s * acc + (u * c + b')  [* column scale, folded into all three]
-            // (the whole vector is cast, then indexed: __builtin_bit_cast of ONE ELEMENT of an ext-vector lvalue reads element 0 whatever the index -- hipcc 7.2)
-            const f32x2 su = __builtin_bit_cast(f32x2, st[pass & 1][it]);
-            const float s = su[0], u = su[1];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v0[e] = fmaf(s, v0[e], fmaf(u, fc[e], fb[e]));
-              v1[e] = fmaf(s, v1[e], fmaf(u, fc[4 + e], fb[4 + e]));
-            }
-          }
           if constexpr (SAVE) {                                   // pre-activation out first
             u32x4 w;
             w[0] = pack_h2(v0[0], v0[1]);
@@ -751,6 +828,12 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
             for (int e = 0; e < 8; e += 2) amax = __builtin_elementwise_maximum(amax, __builtin_elementwise_maximum(__builtin_fabsf(x[e]), __builtin_fabsf(x[e + 1])));   // (v_maximum3 with |.| modifiers; NaN-propagating)
 #pragma unroll
             for (int e = 0; e < 4; ++e) w[e] = pack_f16x2(clamp_f16(x[2 * e]), clamp_f16(x[2 * e + 1]));
+            if constexpr (kStats<EPI>) {                          // (sum, sum of squares) of the row's 64 ROUNDED values of this wave -> slot n_first / 64
+              static_assert(FAST, "row partials need 64-column waves");
+              const f32x2 pq = row_partial8(w);
+              const unsigned po = (lane & 7) == 0 ? (unsigned)(pass * PR + it * 8 + (lane >> 3)) * part_row_bytes + part_slot_off : DROP;
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pq), rs_part, po, 0, 0);
+            }
           } else {
             w[0] = pack_h2(v0[0], v0[1]);
             w[1] = pack_h2(v0[2], v0[3]);
@@ -773,20 +856,42 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
 // 16 x 16 accumulator tiles (C layout: col = lane & 15, row = 4 * (lane >> 4) + reg), bias already inside, cs = per-column scale
 template <int EPI, int NT, int NI = 8, int AUX = UCOD_ST_AUX, bool FASTRM = false>
 __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI][NT], const float (&cs)[NT], char* wbase,
-                                             int m_first, int n_first, int lane) {
+                                             int m_first, int n_first, int lane, const FoldCtx<NT>* fold = nullptr) {
   constexpr int WCOLS = 16 * NT;
+  // LayerNorm-folded: (rstd, -mean * rstd) of the lane's four rows per 16-row tile, read from the tile's LDS table ONE PASS AHEAD (the reads of pass p + 1
+  // are issued behind the staging writes of pass p and land under its drain)
+  f32x4 sn[2], un[2];
+  auto fold_fetch = [&](int pass) {
+    if constexpr (kFold<EPI> && !(UCOD_FOLD_ABL & 4)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (pass * 2 + i >= NI) continue;
+        const float* t = fold->tab + (pass * 2 + i) * 16 + (lane >> 4) * 4;
+        sn[i] = *reinterpret_cast<const f32x4*>(t);
+        un[i] = *reinterpret_cast<const f32x4*>(t + FOLD_TAB_ROWS);
+      }
+    }
+  };
+  fold_fetch(0);
   auto stage = [&](int pass) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      if (pass * 2 + i >= NI) continue;
+      const f32x4 s4 = sn[i], u4 = un[i];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        if (pass * 2 + i >= NI) continue;
         f32x4 v = acc[pass * 2 + i < NI ? pass * 2 + i : 0][j];
         if constexpr (kStageScaled<EPI>) v = v * cs[j];
+        if constexpr (kFold<EPI> && !(UCOD_FOLD_ABL & 2)) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) v[rg] = fmaf(s4[rg], v[rg], fmaf(u4[rg], fold->cc[j], fold->cb[j]));
+        }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
           *reinterpret_cast<float*>(wbase + (i * 16 + (lane >> 4) * 4 + rg) * EPI_PITCH(WCOLS) + (j * 16 + (lane & 15)) * 4) = v[rg];
       }
+    }
+    if ((pass + 1) * 2 < NI) fold_fetch(pass + 1);
   };
   big_epilogue_staged<EPI, NT, NI, AUX, FASTRM>(a, stage, wbase, m_first, n_first, lane);
 }

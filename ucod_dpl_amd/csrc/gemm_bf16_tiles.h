@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   // 32-MFMA intervals instead of four 16-MFMA ones per K-tile and group) at the price of 16 more fragment registers.
   constexpr int IT = 8 / NPH;                                     // 16-row i-tiles per phase
   using Cfg = BigCfg<NT>;
-  __shared__ __attribute__((aligned(16))) char smem[2 * Cfg::BUF];
+  __shared__ __attribute__((aligned(16))) char smem[2 * Cfg::BUF + (kFold<EPI> ? FOLD_TAB_BYTES : 0)];   // (+ the LayerNorm-folded epilogues' row table)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -214,6 +214,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   float cb[NT], cs[NT];
   load_col_consts<EPI, NT>(a, n0 + wn * 16 * NT + (lane & 15), cb, cs);
   constexpr bool FASTRM = kFastRowMapped<EPI, NT>;                 // key hook / patch embedding with 64-column waves: see big_epilogue
+  FoldCtx<NT> fold;                                                // LayerNorm-folded epilogues: see gemm_bf16_epilogue.h
+  FoldReq freq;
+  char* const fold_tab = smem + 2 * Cfg::BUF;
+  if constexpr (kFold<EPI>) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      int n = n0 + wn * 16 * NT + (lane & 15) + j * 16;
+      n = n < a.N ? n : a.N - 1;
+      fold.cc[j] = a.colsum[n];
+    }
+    fold_request(a, m0, 256, wave, lane, freq);
+  }
 
   // prologue: tile 0 complete, B of tile 1 in flight
   stageA(0, 0);
@@ -227,6 +239,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   }
   if (nt > 1) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
   finish_col_consts<EPI, NT>(a, cb, cs);
+  if constexpr (kFold<EPI>) {
+    fold_finish(a, fold_tab, 256, wave, lane, freq);
+    fold.tab = reinterpret_cast<const float*>(fold_tab) + wm * 128;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      fold.cc[j] *= cs[j];
+      fold.cb[j] = cb[j] * cs[j];
+      cb[j] = 0.f;
+    }
+  }
   f32x4 acc[8][NT];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -302,7 +324,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();
 
   // epilogue through a wave-private LDS region (operand tiles are dead: last barrier passed)
-  big_epilogue<EPI, NT, 8, UCOD_ST_AUX, FASTRM>(a, acc, cs, smem + wave * (32 * EPI_PITCH(16 * NT)), m0 + wm * 128, n0 + wn * 16 * NT, lane);
+  big_epilogue<EPI, NT, 8, UCOD_ST_AUX, FASTRM>(a, acc, cs, smem + wave * (32 * EPI_PITCH(16 * NT)), m0 + wm * 128, n0 + wn * 16 * NT, lane, &fold);
 }
 
 }  // namespace ucod

@@ -2,6 +2,7 @@
 // transformers Dinov2Model / models/backbones/dino.py): one C call enqueues every kernel of the pass on the
 // caller's stream, from the NCHW image to the [B,C,h,w] last-layer key map.  No allocation, no sync: it can be
 // captured into a hipGraph by the caller.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/ucod_dpl.h"
 
@@ -14,7 +15,7 @@
 namespace {
 
 struct Plan {
-  size_t off_x, off_h, off_qkv, off_a, off_g, off_patch, off_qscale, off_f8, f8_bytes, off_stats, total;
+  size_t off_x, off_h, off_qkv, off_a, off_g, off_patch, off_qscale, off_f8, f8_bytes, off_stats, off_part, total;
   int M, tok;
 };
 
@@ -36,7 +37,8 @@ Plan make_plan(const ucod_vit_desc* d) {
   p.off_qscale = take((size_t)3 * d->D * 4);
   p.f8_bytes = d->attn_variant == 8 ? ucod_attention_fp8_workspace_bytes(d->B, p.tok, d->heads) : 0;   // Q8 | K8 | Vt8 of the fp8 attention path
   p.off_f8 = take(p.f8_bytes);
-  p.off_stats = take(d->ln_fold ? (size_t)p.M * 8 : 0);            // (rstd, -mean * rstd) per token row of the folded LayerNorms
+  p.off_stats = take(d->ln_fold ? (size_t)p.M * 8 : 0);            // (rstd, -mean * rstd) per token row of the folded LayerNorms (small passes)
+  p.off_part = take(d->ln_fold ? (size_t)p.M * (d->D / 64) * 8 : 0);   // per-row partial (sum, sum of squares) per 64-column slot (large passes)
   p.total = o;
   return p;
 }
@@ -100,11 +102,39 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
     return r16 ? ucod_layernorm_h16(x, g, b, h, M, D, d->eps, stream) : ucod_layernorm(x, g, b, h, M, D, d->eps, 0, stream);
   };
   // embeddings: patch conv as GEMM (+bias +pos), CLS rows
+  // ln_fold: the producers of x (patch embedding + CLS rows, out-projection, fc2) leave per-row partial sums for the folded consumer that follows
+  // (UCOD_EPI_*_STATS: large passes; no statistics launch at all).  `have_part` = `part` describes the current x; a producer that cannot take the
+  // shape returns UCOD_EINVAL without launching, the plain epilogue runs instead and ucod_row_stats_h16 supplies `stats` (small passes).
+  float* const stats = (float*)(ws + p.off_stats);
+  float* const part = (float*)(ws + p.off_part);
+  const int nslot = D / 64;
+  static const bool no_part = getenv("UCOD_LN_FOLD_NO_PARTIALS") != nullptr;      // measurement knob: always the statistics kernel
+  bool have_part = false;
   RUN(ucod_patch_im2col(img, patches, d->B, d->C, d->H, d->W, d->P, d->Kpad, stream));
-  RUN(ucod_gemm_bf16(epi_patch, patches, T[0], x, d->B * (tok - 1), D, d->Kpad, (const float*)T[1], nullptr, nullptr,
-                     (const float*)T[3], tok, gv, stream));
-  if (r16) RUN(ucod_cls_rows_h16(x, (const float*)T[2], (const float*)T[3], d->B, tok, D, stream));
-  else RUN(ucod_cls_rows(x, (const float*)T[2], (const float*)T[3], d->B, tok, D, stream));
+  if (d->ln_fold && d->L > 1 && !no_part) {
+    const int rc = ucod_gemm_bf16_stats(UCOD_EPI_PATCH_TOKENS_H16_STATS, patches, T[0], x, d->B * (tok - 1), D, d->Kpad, (const float*)T[1], nullptr, nullptr,
+                                        (const float*)T[3], tok, part, nslot, stream);
+    if (rc == UCOD_OK) have_part = true;
+    else if (rc != UCOD_EINVAL) return rc;
+  }
+  if (have_part) {
+    RUN(ucod_cls_rows_h16_stats(x, (const float*)T[2], (const float*)T[3], part, nslot, d->B, tok, D, stream));
+  } else {
+    RUN(ucod_gemm_bf16(epi_patch, patches, T[0], x, d->B * (tok - 1), D, d->Kpad, (const float*)T[1], nullptr, nullptr,
+                       (const float*)T[3], tok, gv, stream));
+    if (r16) RUN(ucod_cls_rows_h16(x, (const float*)T[2], (const float*)T[3], d->B, tok, D, stream));
+    else RUN(ucod_cls_rows(x, (const float*)T[2], (const float*)T[3], d->B, tok, D, stream));
+  }
+  // out-projection / fc2 (+ LayerScale + residual) into x; `want_part`: a folded consumer reads x next
+  auto resid_gemm = [&](const void* act, const void* w, const float* b, const float* ls, int K, bool want_part) -> int {
+    have_part = false;
+    if (want_part && !no_part) {
+      const int rc = ucod_gemm_bf16_stats(UCOD_EPI_BIAS_SCALE_RESID_H16_STATS, act, w, x, M, D, K, b, ls, x, nullptr, tok, part, nslot, stream);
+      if (rc == UCOD_OK) { have_part = true; return UCOD_OK; }
+      if (rc != UCOD_EINVAL) return rc;
+    }
+    return ucod_gemm_bf16(epi_resid, act, w, x, M, D, K, b, ls, x, nullptr, tok, gv, stream);
+  };
 
   for (int l = 0; l < d->L; ++l) {
     const void* const* W = T + 4 + UCOD_VIT_LAYER_STRIDE * l;
@@ -112,8 +142,8 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
     // ln_fold: LayerNorm 1 / 2 of every layer but the last live in the QKV / fc1 epilogues (ucod_gemm_lnfold: the fp16 stream x is the A operand,
     // W[2] / W[9] hold fp16(gamma (.) W), W[3] / W[10] the folded bias, W[14] / W[15] the column sums); only the row statistics are computed here
     const bool fold = d->ln_fold != 0 && !last;
-    float* stats = (float*)(ws + p.off_stats);
-    if (fold) RUN(ucod_row_stats_h16(x, stats, M, D, d->eps, stream));
+    const bool next_fold = d->ln_fold != 0 && l + 1 < d->L - 1;    // LayerNorm 1 of the next layer is folded too
+    if (fold) { if (!have_part) RUN(ucod_row_stats_h16(x, stats, M, D, d->eps, stream)); }
     else RUN(layernorm((const float*)W[0], (const float*)W[1]));
     if (last) {
       // key hook: only the K slice (rows D..2D-1) of the fused qkv weight; output written as [B,D,h,w]
@@ -126,19 +156,21 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
       RUN(ucod_gemm_bf16(UCOD_EPI_QKV_FP8, h, W[2], ws + p.off_f8, M, 3 * D, D, (const float*)W[3], qscale, nullptr, nullptr, tok, gv, stream));
       RUN(ucod_attention_fwd_fp8_fused(ws + p.off_f8, a, d->B, tok, d->heads, QE, KE, VE, stream));
     } else {
-      if (fold) RUN(ucod_gemm_lnfold(UCOD_EPI_LNFOLD_BIAS_BF16, x, W[2], qkv, M, 3 * D, D, (const float*)W[3], (const float*)W[14], stats, prescale ? qscale : nullptr, gv, stream));
+      if (fold) RUN(ucod_gemm_lnfold(UCOD_EPI_LNFOLD_BIAS_BF16, x, W[2], qkv, M, 3 * D, D, (const float*)W[3], (const float*)W[14], have_part ? nullptr : stats,
+                                     have_part ? part : nullptr, nslot, d->eps, nullptr /* the folded Q rows carry the softmax pre-scale */, gv, stream));
       else RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_BF16, h, W[2], qkv, M, 3 * D, D, (const float*)W[3], prescale ? qscale : nullptr, nullptr, nullptr, tok, gv, stream));
       RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, prescale ? 0.f : scale, (av == 5 || av == 64 || av == 32 || av == 66) ? av : 0, stream));
     }
-    RUN(ucod_gemm_bf16(epi_resid, a, W[4], x, M, D, D, (const float*)W[5], (const float*)W[6], x, nullptr, tok, gv, stream));
+    RUN(resid_gemm(a, W[4], (const float*)W[5], (const float*)W[6], D, fold));
     if (fold) {
-      RUN(ucod_row_stats_h16(x, stats, M, D, d->eps, stream));
-      RUN(ucod_gemm_lnfold(UCOD_EPI_LNFOLD_GELU_BF16, x, W[9], g, M, F, D, (const float*)W[10], (const float*)W[15], stats, nullptr, gv, stream));
+      if (!have_part) RUN(ucod_row_stats_h16(x, stats, M, D, d->eps, stream));
+      RUN(ucod_gemm_lnfold(UCOD_EPI_LNFOLD_GELU_BF16, x, W[9], g, M, F, D, (const float*)W[10], (const float*)W[15], have_part ? nullptr : stats,
+                           have_part ? part : nullptr, nslot, d->eps, nullptr, gv, stream));
     } else {
       RUN(layernorm((const float*)W[7], (const float*)W[8]));
       RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_GELU_BF16, h, W[9], g, M, F, D, (const float*)W[10], nullptr, nullptr, nullptr, tok, gv, stream));
     }
-    RUN(ucod_gemm_bf16(epi_resid, g, W[11], x, M, D, F, (const float*)W[12], (const float*)W[13], x, nullptr, tok, gv, stream));
+    RUN(resid_gemm(g, W[11], (const float*)W[12], (const float*)W[13], F, next_fold));
   }
   return UCOD_OK;
 }

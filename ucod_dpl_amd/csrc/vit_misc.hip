@@ -425,6 +425,30 @@ __global__ void cls_rows_h16_kernel(unsigned short* __restrict__ x, const float*
   x[(size_t)b * tok * D + j] = __builtin_bit_cast(unsigned short, (_Float16)clamp_f16(o));
 }
 
+// CLS rows of the fp16 stream WITH their row partials for the LayerNorm-folded consumer (gemm_bf16_epilogue.h: kStats): one workgroup per image;
+// slot 0 of the row takes (sum, sum of squares) of the rounded values, the other slots zeros.
+__global__ __launch_bounds__(256) void cls_rows_h16_stats_kernel(unsigned short* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
+                                                                 float2* __restrict__ part, int nslot, int tok, int D, unsigned* __restrict__ ovf) {
+  __shared__ float red[32];
+  const int b = blockIdx.x;
+  float s = 0.f, q = 0.f;
+  bool sat = false;
+  for (int j = threadIdx.x; j < D; j += 256) {
+    const float o = cls[j] + pos[j];
+    sat |= beyond_f16(o);
+    const _Float16 h = (_Float16)clamp_f16(o);
+    x[(size_t)b * tok * D + j] = __builtin_bit_cast(unsigned short, h);
+    const float r = (float)h;
+    s += r;
+    q = fmaf(r, r, q);
+  }
+  if (sat) atomicAdd(ovf, 1u);
+  s = block_sum(s, red);
+  q = block_sum(q, red + 16);
+  float2* row = part + (size_t)b * tok * nslot;
+  if (threadIdx.x < nslot) row[threadIdx.x] = threadIdx.x == 0 ? make_float2(s, q) : make_float2(0.f, 0.f);
+}
+
 // Saturation counter of the f16 residual stream: every kernel that rounds the stream to fp16 (patch / out-proj / fc2 epilogues, CLS rows)
 // clamps to +-65504 and adds the number of wave-lanes that had to.  One word per device, polled by the host (ucod_resid16_overflow_*).
 __device__ unsigned g_resid16_overflow = 0;
@@ -551,6 +575,15 @@ extern "C" int ucod_cls_rows_h16(void* x, const float* cls, const float* pos, in
   if (!x || !cls || !pos || B <= 0 || tok <= 0 || D <= 0) return UCOD_EINVAL;
   UCOD_PROF(ucod::PROF_CLS, stream);
   hipLaunchKernelGGL(ucod::cls_rows_h16_kernel, dim3(ucod::cdiv((long)B * D, 256)), dim3(256), 0, (hipStream_t)stream, (unsigned short*)x, cls, pos, B, tok, D, ucod::resid16_overflow_counter());
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
+
+extern "C" int ucod_cls_rows_h16_stats(void* x, const float* cls, const float* pos, float* row_partials, int nslot, int B, int tok, int D, void* stream) {
+  if (!x || !cls || !pos || !row_partials || nslot <= 0 || nslot > 256 || B <= 0 || tok <= 0 || D <= 0) return UCOD_EINVAL;
+  UCOD_PROF(ucod::PROF_CLS, stream);
+  hipLaunchKernelGGL(ucod::cls_rows_h16_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (unsigned short*)x, cls, pos, (float2*)row_partials, nslot, tok, D,
+                     ucod::resid16_overflow_counter());
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }

@@ -24,6 +24,7 @@ EPI_GELU_BWD_BF16, EPI_BIAS_GELU_SAVE_BF16 = 6, 7          # ucod_gemm_bf16_trai
 EPI_QKV_FP8 = 8                                            # QKV projection of the fp8 attention path
 EPI_BIAS_SCALE_RESID_H16, EPI_PATCH_TOKENS_H16 = 9, 10     # f16 residual stream (VitDesc.resid16)
 EPI_LNFOLD_BIAS_BF16, EPI_LNFOLD_GELU_BF16 = 11, 12        # ucod_gemm_lnfold only (LayerNorm folded into QKV / fc1; the fp16-operand build)
+EPI_BIAS_SCALE_RESID_H16_STATS, EPI_PATCH_TOKENS_H16_STATS = 13, 14   # ucod_gemm_bf16_stats only (the producers that leave row partials)
 VIT_LAYER_STRIDE = 16
 VIT_TRAIN_STRIDE = 7
 LORA_AUG = 64
@@ -63,7 +64,9 @@ SIGNATURES = {
     "ucod_prof_class_name": (C.c_char_p, [ci]),
     "ucod_prof_collect": (ci, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ucod_gemm_bf16": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
-    "ucod_gemm_lnfold": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp]),
+    "ucod_gemm_lnfold": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, cf, vp, ci, vp]),
+    "ucod_gemm_bf16_stats": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp]),
+    "ucod_cls_rows_h16_stats": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "ucod_row_stats_h16": (ci, [vp, vp, ci, ci, cf, vp]),
     "ucod_gemm_reload_tuning": (None, []),
     "ucod_resid16_overflow_fetch": (ci, [vp, vp]),

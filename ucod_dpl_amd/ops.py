@@ -64,15 +64,30 @@ def fold_layernorm_linear(gamma, beta, w, b):
     return wf, (w.double() @ beta.double() + b.double()).float().contiguous(), wf.double().sum(1).float().contiguous()
 
 
-def linear_lnfold(x, stats, wf, bias_f, colsum, gelu=False, scale=None, variant=0):
-    """LayerNorm + Linear (+ GELU | * scale) as ONE GEMM on the un-normalised fp16 rows (fp16-operand build): x fp16 [M,K] -> fp16 [M,N]."""
+def linear_lnfold(x, stats, wf, bias_f, colsum, gelu=False, scale=None, variant=0, partials=None, eps=1e-6):
+    """LayerNorm + Linear (+ GELU | * scale) as ONE GEMM on the un-normalised fp16 rows (fp16-operand build): x fp16 [M,K] -> fp16 [M,N].
+    ``stats`` f32 [M,2] (row_stats_h16) or ``partials`` f32 [M,nslot,2] (left by linear_scale_resid_h16_stats / the patch embedding)."""
     if x.dtype != torch.float16 or wf.dtype != torch.float16:
         raise TypeError("linear_lnfold takes fp16 rows and fp16 folded weights")
     M, K = x.shape
     out = torch.empty(M, wf.shape[0], dtype=torch.float16, device=x.device)
+    nslot = 0 if partials is None else partials.shape[1]
     check(N.load("f16").ucod_gemm_lnfold(N.EPI_LNFOLD_GELU_BF16 if gelu else N.EPI_LNFOLD_BIAS_BF16, ptr(x), ptr(wf), ptr(out), M, wf.shape[0], K,
-                                         ptr(_f32(bias_f)), ptr(_f32(colsum)), ptr(_f32(stats)), ptr(scale), variant, stream()), "ucod_gemm_lnfold")
+                                         ptr(_f32(bias_f)), ptr(_f32(colsum)), ptr(stats), ptr(partials), nslot, float(eps), ptr(scale), variant, stream()),
+          "ucod_gemm_lnfold")
     return out
+
+
+def linear_scale_resid_h16_stats(a, w, b, scale, resid, half="f16"):
+    """resid f16 [M,N] + scale[n] * (a w^T + b) -> (new f16 [M,N], partials f32 [M, N/64, 2]) -- the out-projection / fc2 epilogue on the fp16 stream
+    that also leaves each row's (sum, sum of squares) per 64-column slot.  Raises for shapes the large-tile kernels do not take."""
+    M, K = a.shape
+    Nn = w.shape[0]
+    out = torch.empty(M, Nn, dtype=torch.float16, device=a.device)
+    part = torch.empty(M, Nn // 64, 2, dtype=torch.float32, device=a.device)
+    check(N.load(half).ucod_gemm_bf16_stats(N.EPI_BIAS_SCALE_RESID_H16_STATS, ptr(a), ptr(w), ptr(out), M, Nn, K, ptr(_f32(b)), ptr(_f32(scale)), ptr(resid), None, 0,
+                                            ptr(part), Nn // 64, stream()), "ucod_gemm_bf16_stats")
+    return out, part
 
 
 def layernorm(x, gamma, beta, eps, out_f32=False):

@@ -173,7 +173,12 @@ class ViTEngine:
         if self.ln_fold:
             self.fold_layers = []
             for l, src in zip(self.layers, c["layers"]):
-                qw, qb, qc = self._fold(f32(src["ln1_g"]), f32(src["ln1_b"]), f32(src["qkv_w"]), f32(src["qkv_b"]))
+                # (the folded QKV entries also carry the softmax pre-scale head_dim^-0.5 * log2 e on their Q rows -- what the unfolded pass applies as
+                # a column scale in the epilogue -- so that the folded epilogue has no per-column multiply left; attn_variant 1 takes Q unscaled)
+                qs = torch.ones(3 * self.D, dtype=torch.float32, device=dev)
+                if attn_variant != 1:
+                    qs[:self.D] = 0.125 * 1.4426950408889634
+                qw, qb, qc = self._fold(f32(src["ln1_g"]), f32(src["ln1_b"]), f32(src["qkv_w"]), f32(src["qkv_b"]), row_scale=qs)
                 fw, fb, fc = self._fold(f32(src["ln2_g"]), f32(src["ln2_b"]), f32(src["fc1_w"]), f32(src["fc1_b"]))
                 fl = list(l)
                 fl[2], fl[3], fl[9], fl[10], fl[14], fl[15] = qw, qb, fw, fb, qc, fc
@@ -181,12 +186,13 @@ class ViTEngine:
         self._ws = None
         self._ws_key = None
 
-    def _fold(self, gamma, beta, w, b):
-        """LayerNorm(gamma, beta) followed by Linear(w, b) as one GEMM on the un-normalised rows (include/ucod_dpl.h: ucod_gemm_lnfold):
-        W' = 16-bit(gamma (.) W), column sums of the ROUNDED W' (what the MFMA multiplies by), b' = W beta + b in f64."""
-        wf = ops.cast_bf16((w * gamma[None, :]).contiguous(), lib=self.lib)
+    def _fold(self, gamma, beta, w, b, row_scale=None):
+        """LayerNorm(gamma, beta) followed by Linear(w, b) [* row_scale per output] as one GEMM on the un-normalised rows (include/ucod_dpl.h:
+        ucod_gemm_lnfold): W' = 16-bit(q (.) W (.) gamma), column sums of the ROUNDED W' (what the MFMA multiplies by), b' = q (W beta + b) in f64."""
+        q = torch.ones(w.shape[0], dtype=torch.float64, device=w.device) if row_scale is None else row_scale.double()
+        wf = ops.cast_bf16((w.double() * gamma.double()[None, :] * q[:, None]).float().contiguous(), lib=self.lib)
         colsum = wf.double().sum(1).float().contiguous()
-        bias = (w.double() @ beta.double() + b.double()).float().contiguous()
+        bias = ((w.double() @ beta.double() + b.double()) * q).float().contiguous()
         return wf, bias, colsum
 
     def _table(self, gh, gw, L=None):
