@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true", help="serial order: backbone pass, then decoder step, on one stream")
     ap.add_argument("--half", default="bf16", choices=["bf16", "f16"], help="16-bit operand type of the backbone (bf16 = BASELINE configs[1])")
     ap.add_argument("--ln-fold", default="auto", choices=["auto", "on", "off"], help="LayerNorm folded into the QKV / fc1 GEMMs (auto: on with fp16 operands on the fp16 stream)")
+    ap.add_argument("--look-twice", action="store_true", help="the validation leg of BASELINE configs[3]: first-stage decode + batched Look-Twice second pass "
+                    "(fallback centre box on every image); use with --arch dinov2_vitl14 --batch 16")
     ap.add_argument("--lora-resid", default="auto", choices=["auto", "f32", "f16"], help="residual stream of the backbone-backward engine (auto: fp16 with bf16 operands)")
     ap.add_argument("--lora-steps", type=int, default=4, help="steps of the separate backbone-backward (LoRA) measurement; 0 = skip")
     return ap.parse_args()
@@ -136,6 +138,8 @@ def main():
     from ucod_dpl_amd.engine.utils.seed import set_random_seed
 
     lib = native.load()
+    if a.look_twice:
+        return look_twice_leg(a, dev, lib, world, rank, host_threads, pinned_cores)
     set_random_seed(42)                                       # engine/utils/seed.py, decoder / discriminator init
     D, heads, L, P, _, _ = ARCHS[a.arch]
     cfg = make_cfg(68, D)
@@ -458,6 +462,127 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "final_loss": round(final_loss, 6),
         "backbone_backward_mode": lora_mode, "discriminator_phase": dis_phase, "f16_operands_option": f16_option,
     }
+    print(json.dumps(out))
+
+
+def look_twice_leg(a, dev, lib, world, rank, host_threads, pinned_cores):
+    """BASELINE configs[3] as SURVEY 8(d) defines C4's validation side: ViT-L/14, B = 16 per GPU, Look-Twice pass with the fallback centre box
+    [129,129,259,259] (2x zoom) on every image.  A step = one validation batch, end to end on resident inputs: backbone over the B images (what the
+    feature-cache pass does for the validation set) -> key maps -> ValLoop_Look_Twice.validate_batch (decode at 68 x 68, upsample + threshold, device CCL
+    + box tables, ONE crop launch pair over all B crops, ONE backbone pass over the crops, decode at 37 x 37, Pillow-exact resize + paste) -> resize to
+    the label size -> the nine COD measures (engine/runner/loop_UCOD_DPL.py:297-352).  The decoder's fg-head bias is set to -10 so that every first-stage
+    mask is empty and every image takes the fallback box, as C4 prescribes; the work does not depend on the mask content."""
+    import types
+    from ucod_dpl_amd import ops
+    from ucod_dpl_amd.data.utils.feature_extractor import backbone, ARCHS
+    from ucod_dpl_amd.engine.config import CfgNode
+    from ucod_dpl_amd.engine.runner import loop_look_twice as LT
+    from ucod_dpl_amd.engine.utils.metrics import statistics
+    from ucod_dpl_amd.models.uscod import baseline
+    D, heads, L, P, _, _ = ARCHS[a.arch]
+    B, S = a.batch, a.image
+    bb = backbone.random_init(a.arch, seed=0, image_size=S, device=dev, gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half=a.half, resid=a.resid,
+                              ln_fold={"auto": "auto", "on": True, "off": False}[a.ln_fold])
+    torch.manual_seed(5)
+    model = baseline(CfgNode(dict(dim=D, feature_size=68, ema_weight=0.99, dis_use_features=False))).to(dev)
+    with torch.no_grad():
+        model.decoder.conv_out_fg.bias.fill_(-10.0)
+    model.eval()
+    runner = types.SimpleNamespace(device=dev, model=model, world_size=world, rank=rank, val_dataloader=[], logger=None)
+    cfg = CfgNode(dict(train_cfg=dict(dist_train=False), model_cfg=dict(feature_size=68), val_cfg=dict(look_twice=True, look_twice_th=0.15, expand_type="dynamic"),
+                       dataset_cfg=dict(valset_cfg=dict(image_size=(S, S)))))
+    loop = LT.ValLoop_Look_Twice(cfg, runner, feature_extractor=bb)
+    g = torch.Generator().manual_seed(1234 + rank)
+    raw = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8).to(dev)            # the images as the loader's PIL path would hand them over
+    mean, std = torch.tensor([0.485, 0.456, 0.406], device=dev), torch.tensor([0.229, 0.224, 0.225], device=dev)
+    images = ((raw.float() / 255.0 - mean) / std).permute(0, 3, 1, 2).contiguous()              # first-stage input (Resize is the identity at 518 x 518)
+    labels = (torch.rand(B, S, S, generator=g) > 0.7).float().to(dev)
+    paths = [raw[i] for i in range(B)]
+    stats = statistics()
+
+    def step():
+        _, key = bb(images)
+        preds_up, boxes = loop.validate_batch(key, paths)
+        stats.step(labels, ops.bilinear_resize(preds_up.reshape(B, 1, S, S).contiguous(), S, S).reshape(B, S, S) > 0.5)
+        return preds_up, boxes
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, a.warmup)):
+        preds_up, boxes = step()
+    if not all(b == [list(LT.DEFAULT_BOX)] for b in boxes):
+        raise SystemExit("bench.py --look-twice: not every image took the fallback box")
+    stats.reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
+        dt = tdt.item()
+    # exclusive per-class durations (the step is already serial: one stream, host syncs inside the box logic)
+    libs = [lib] + ([bb.engine.lib] if bb.engine.lib is not lib else [])
+    for l_ in libs:
+        l_.ucod_prof_enable(1)
+    stats.reset()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    ncls = lib.ucod_prof_num_classes()
+    tot, cnt = (C.c_double * ncls)(), (C.c_longlong * ncls)()
+    for l_ in libs:
+        l_.ucod_prof_enable(0)
+        t_, c_ = (C.c_double * ncls)(), (C.c_longlong * ncls)()
+        l_.ucod_prof_collect(t_, c_)
+        for i in range(ncls):
+            tot[i] += t_[i]
+            cnt[i] += c_[i]
+    # the two halves alone: the first backbone pass, and everything behind it
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        _, key = bb(images)
+    barrier()
+    dt_first = time.perf_counter() - t1
+    if rank != 0:
+        return
+    gh = S // P
+    tok, F = gh * gh + 1, 4 * D
+    kernels = {}
+    for i in range(ncls):
+        if cnt[i] == 0:
+            continue
+        name = lib.ucod_prof_class_name(i).decode()
+        avg_us = tot[i] / cnt[i] * 1e3
+        k = {"launches_per_step": cnt[i] / a.steps, "avg_us": round(avg_us, 2), "ms_per_step": round(tot[i] / a.steps, 4)}
+        fl = algorithmic_work(name, B, tok, D, F, heads, bb.engine.Kpad, D, 68 * 68)
+        if name == "gemm_bf16_proj_fc2_scale_resid":
+            per_step = 2 * (L - 1) * (2.0 * B * tok * D * D + 2.0 * B * tok * D * F)      # two backbone passes per step
+            k["tflops"] = round(per_step / (tot[i] / a.steps * 1e-3) / 1e12, 1)
+        elif fl:
+            k["tflops"] = round(fl / (avg_us * 1e-6) / 1e12, 1)
+        kernels[name] = k
+    dom = max((n for n in kernels if "tflops" in kernels[n]), key=lambda n: kernels[n]["ms_per_step"])
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(kernels[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_us": kernels[dom]["avg_us"],
+                "measured_in": "the same step with HIP events around every launch (the step is serial: one stream)"}
+    out = {"metric": "validation images/sec at 3x518x518 with the Look-Twice second pass (two backbone passes per image + decode + box logic + paste + COD measures)",
+           "value": round(world * B * a.steps / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.half, "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[3] (validation side, SURVEY 8d C4): {a.arch} @{S}x{S}, batch {B}/GPU, Look-Twice second pass with the fallback centre box "
+                                  f"{LT.DEFAULT_BOX} (2x zoom) on every image", "global_batch": B * world, "parallelism": f"dp{world}", "random_init_weights": True,
+                      "residual_stream": "fp16" if bb.engine.resid16 else "f32", "ln_fold": bool(bb.engine.ln_fold),
+                      "batched": "all crops of all images in one crop launch pair, one backbone pass, one decoder pass, one paste call (loop_look_twice.py::look_twice_batch)"},
+           "first_backbone_pass_ms": round(dt_first / a.steps * 1e3, 3),
+           "second_pass_and_tail_ms": round((dt - dt_first) / a.steps * 1e3, 3),
+           "roofline": roofline, "cpu_baseline": None, "kernels": kernels,
+           "host_threads": host_threads, "host_cores_pinned": pinned_cores}
     print(json.dumps(out))
 
 

@@ -527,6 +527,12 @@ size_t ucod_paste_workspace_bytes(int nbox, int max_w, int max_h, int sh, int sw
 int ucod_paste_resized_u8(const uint8_t* masks_dev, int nbox, int sh, int sw, const int32_t* boxes_host, uint8_t* canvas_dev, int CH, int CW,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same for boxes that belong to SEVERAL canvases `canvases_dev` u8 [ncanvas,CH,CW] (the batched Look-Twice validation of BASELINE configs[3]: every
+ * image of a validation batch in one call): box_canvas_host int32 [nbox] names each box's canvas (NULL: all on canvas 0); boxes are pasted in the order
+ * given, so one canvas's boxes keep their order. */
+int ucod_paste_resized_u8_multi(const uint8_t* masks_dev, int nbox, int sh, int sw, const int32_t* boxes_host, const int32_t* box_canvas_host,
+                                uint8_t* canvases_dev, int ncanvas, int CH, int CW, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Batched crop + Pillow-BILINEAR resize + ToTensor + ImageNet Normalize on the GPU
  * (PIL crop + torchvision Resize/ToTensor/Normalize, loop_UCOD_DPL.py:282-286,341-342).
  * img u8 [H,W,3] (HWC, device); boxes_host int32 [nbox,4] = (x,y,w,h) in source pixels (regions outside the image read
@@ -534,6 +540,11 @@ int ucod_paste_resized_u8(const uint8_t* masks_dev, int nbox, int sh, int sw, co
 size_t ucod_crop_workspace_bytes(int nbox, int max_crop_h, int max_crop_w, int oh, int ow);
 int ucod_crop_resize_norm(const uint8_t* img, int H, int W, const int32_t* boxes_host, int nbox, float* out, int oh, int ow,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same for boxes cut from SEVERAL source images in one launch pair ("batch all crops of all images"): imgs_host = HOST array of nimg
+ * DEVICE pointers to u8 [H_i,W_i,3] images, hw_host int32 [nimg,2] = (H_i, W_i), box_image_host int32 [nbox] = source image of each box. */
+int ucod_crop_resize_norm_multi(const uint8_t* const* imgs_host, const int32_t* hw_host, int nimg, const int32_t* box_image_host,
+                                const int32_t* boxes_host, int nbox, float* out, int oh, int ow, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ CORAL SparseRefiner (rows R1-R4), inference */
 

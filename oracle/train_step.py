@@ -147,3 +147,32 @@ def discriminator_batch(state, features, pseudo_labels):
         state.dis_opt.step(state.disc_trainable, grads)
         state.dis_sched.step()
     return dict(loss=loss.detach(), grads=grads, probs_student=probs_student.detach(), probs_pseudo=probs_pseudo.detach())
+
+
+def run(state, loader, dis_intertrain, dis_epoch=1, merge_method="dis", on_event=None, orth="gram"):
+    """loop_UCOD_DPL.py:94-118 (TrainLoop.run) with :120-146 (run_epoch), :193-213 (decide_to_train_dis / decide_to_finetune) and :215-227
+    (Discriminator_train) -- validation and saving left out.  ``loader``: list of (features, pseudo_labels).  ``state.cfg`` carries max_epoch and
+    start_finetune.  At the finetune epoch the runner REBUILDS both optimisers and schedulers (engine/runner/runner.py:378-379 -> :276-311: fresh
+    moments, step counts and learning rates) and the loop resets ``global_step`` (:101-103); the discriminator phase runs before every
+    ``dis_intertrain``-th epoch while not finetuning.  ``on_event(tag)`` is called after every discriminator phase ("dis<epoch>") and after every
+    epoch ("epoch<epoch>", the index of the epoch just run).  Returns the per-batch losses."""
+    c = state.cfg
+    losses = []
+    while state.cur_epoch < c["max_epoch"]:
+        if state.cur_epoch == c["max_epoch"] + c["start_finetune"]:        # decide_to_finetune
+            state.finetune = True
+            state.build_optimizers()                                       # runner.start_finetune()
+            state.global_step = 0
+        if merge_method == "dis" and state.cur_epoch % dis_intertrain == 0 and not state.finetune:    # decide_to_train_dis
+            for _ in range(dis_epoch):
+                for feats, pl in loader:
+                    discriminator_batch(state, feats, pl)
+            if on_event:
+                on_event(f"dis{state.cur_epoch}")
+        for feats, pl in loader:                                           # run_epoch
+            losses.append(float(process_batch(state, feats, pl, orth=orth)["loss"]))
+            state.global_step += 1                                         # :143
+        if on_event:
+            on_event(f"epoch{state.cur_epoch}")
+        state.cur_epoch += 1
+    return losses

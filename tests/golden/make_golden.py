@@ -933,7 +933,123 @@ def g17():
     print("wrote", path)
 
 
+# ----------------------------------------------------------------------------- G18: the epoch-level schedule, from the reference's own TrainLoop.run()
+def g18():
+    """The REAL ``TrainLoop.run()`` (engine/runner/loop_UCOD_DPL.py:94-118) over 6 epochs of a 3-batch in-memory loader with
+    start_finetune = -2 (finetune switch at epoch 4: ``runner.start_finetune()`` REBUILDS both optimisers and schedulers, runner.py:378-379 -> :276-311;
+    ``global_step`` back to 0, :101-103), dis_intertrain = 2 / dis_epoch = 1 (discriminator phase before epochs 0 and 2 with the requires_grad flips,
+    :193-227; none once finetune is on), ``loss -= dis_loss`` only before finetune (:167-169), StepLR stepped per batch, EMA ramp on the doubled
+    ``global_step``.  Validation and saving are off.  ``start_finetune`` is the reference's own ``StandardRunner.start_finetune`` / ``_build_optimizer``
+    bound to the fake runner.  Recorded after every discriminator phase and every epoch: decoder, EMA decoder, discriminator (parameters + BatchNorm
+    buffers), both learning rates, ``global_step``, ``finetune``; and every batch's loss."""
+    C_, fs, B, nb = 128, 12, 4, 3
+    torch.manual_seed(18)
+    cfg = CfgNode(dict(
+        model_cfg=dict(dim=C_, feature_size=fs, ema_weight=0.99, dis_use_features=False),
+        train_cfg=dict(max_epoch=6, start_epoch=0, start_finetune=-2, lr0=6e-4, dis_lr0=1e-3, step_lr_size=2, dis_step_lr_size=2, step_lr_gamma=0.95,
+                       dis_step_lr_gamma=0.95, merge_alpha=0.5, merge_method="dis", dist_train=False, dis_epoch=1, dis_intertrain=2,
+                       save_cfg=dict(save_mode="model", save_interval=5, start_save=1000)),
+        val_cfg=dict(enable_val=False, val_interval=5, start_val=1000),
+        log_cfg=dict(log_interval=50, log_path="/tmp/ucod_g18", multi_rank=[0]),
+    ))
+    model, disc = baseline(cfg.model_cfg), Discriminator(cfg.model_cfg)
+    with torch.no_grad():
+        for p in model.decoder_ema.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    g = torch.Generator().manual_seed(1800)
+    loader = []
+    for _ in range(nb):
+        feats = torch.randn(B, C_, 14, 14, generator=g)
+        pl = (torch.rand(B, 1, 16, 16, generator=g) > 0.7).float()
+        loader.append({"pseudo_label": pl, "label_tensor": torch.zeros(1), "features": feats, "img_path": ["x"]})
+    for name in ("matplotlib", "matplotlib.pyplot", "matplotlib.patches", "torchvision.transforms.functional"):      # (what runner.py's import of loop_CORAL pulls in: as in g15)
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                mod(name)
+    sys.modules["torchvision"].transforms.functional = sys.modules["torchvision.transforms.functional"]
+    import engine.runner.runner as R                                   # the reference's runner module (accelerate is installed)
+    losses, events = [], []
+
+    class Log(NullLogger):
+        def log(self, s, *a, **k):
+            if isinstance(s, str) and s.startswith("iter") and ":loss:" in s:
+                losses.append(s)
+
+    runner = SimpleNamespace(config=cfg, model=model, discriminator=disc, logger=Log(), train_dataloader=loader, val_dataloader=[],
+                             accelerator=SimpleNamespace(backward=lambda loss: loss.backward()))
+    runner.logger.info = runner.logger.error = lambda *a, **k: None
+    runner._build_optimizer = lambda: R.StandardRunner._build_optimizer(runner)
+    runner._build_optimizer()                                           # runner.py:276-311
+    runner.start_finetune = lambda: R.StandardRunner.start_finetune(runner)   # runner.py:378-379
+    loop = L.TrainLoop.__new__(L.TrainLoop)
+    loop.cfg, loop._runner = cfg, runner
+    loop._dist_train = False
+    loop._mode = "train"
+    loop._start_epoch, loop._max_epoch = cfg.train_cfg.start_epoch, cfg.train_cfg.max_epoch
+    loop.global_step, loop._cur_epoch = 0, 0
+    loop._start_finetune, loop.finetune = cfg.train_cfg.start_finetune, False
+    loop.criterion, loop.dis_loss = nn.BCEWithLogitsLoss(), nn.BCELoss()
+    loop.merge_alpha, loop.ema_alpha = cfg.train_cfg.merge_alpha, cfg.model_cfg.ema_weight
+    L.TrainLoop._setup_validation_config(loop)
+    L.TrainLoop._setup_logging_config(loop)
+    loop.best_mae, loop.best_result = 1000.0, None
+
+    class PM:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def start_task(self, *a):
+            pass
+
+        update_task = reset_task = start_task
+
+    loop.progress_manager = PM()
+    out = {}
+    out.update(sd_flat("model0.", model))
+    out.update(sd_flat("disc0.", disc))
+    for i, b in enumerate(loader):
+        out[f"features{i}"], out[f"pl{i}"] = b["features"], b["pseudo_label"]
+
+    def snap(tag):
+        events.append(tag)
+        out.update(sd_flat(f"{tag}.model.", model))
+        out.update(sd_flat(f"{tag}.disc.", disc))
+        out[f"{tag}.lr"] = np.float64(runner.optimizer.param_groups[0]["lr"])
+        out[f"{tag}.dis_lr"] = np.float64(runner.dis_optimizer.param_groups[0]["lr"])
+        out[f"{tag}.global_step"] = np.int64(loop.global_step)
+        out[f"{tag}.finetune"] = np.int64(int(loop.finetune))
+        out[f"{tag}.decoder_requires_grad"] = np.int64(int(all(p.requires_grad for p in model.decoder.parameters())))
+        out[f"{tag}.disc_requires_grad"] = np.int64(int(any(p.requires_grad for p in disc.parameters())))
+
+    run_epoch, dis_train = loop.run_epoch, loop.Discriminator_train
+
+    def run_epoch_rec():
+        run_epoch()
+        snap(f"epoch{loop._cur_epoch}")
+
+    def dis_train_rec():
+        dis_train()
+        snap(f"dis{loop._cur_epoch}")
+
+    loop.run_epoch, loop.Discriminator_train = run_epoch_rec, dis_train_rec
+    loop.run()
+    assert events == ["dis0", "epoch0", "epoch1", "dis2", "epoch2", "epoch3", "epoch4", "epoch5"], events
+    # every batch logs twice: _process_batch's own line (global_step before its increment) and, at log_interval epochs, run_epoch's; keep the former
+    per_batch = [float(s.split(":")[-1]) for s in losses]
+    per_batch = per_batch[0:2 * nb:2] + per_batch[2 * nb:]             # epoch 0 (0 % log_interval == 0) logs every batch twice
+    assert len(per_batch) == 6 * nb
+    out["events"] = np.array(events)
+    out["loss_strings"] = np.array(losses)
+    out["losses"] = np.array(per_batch, np.float64)
+    save("g18_train_schedule", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g3b", "g4", "g5", "g6", "g6b", "g7", "g8", "g9", "g9b", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3b", "g4", "g5", "g6", "g6b", "g7", "g8", "g9", "g9b", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     for w in which:
         globals()[w]()

@@ -139,6 +139,38 @@ def test_resid_epilogue_with_row_partials(M, Nn, K):
     assert torch.equal(r2, plain) and torch.equal(part2, part)
 
 
+@pytest.mark.parametrize("B,tok,D,Kpad", [(9, 257, 256, 640), (32, 1370, 768, 640), (3, 1025, 1024, 640)])
+def test_patch_embedding_and_cls_rows_with_row_partials(B, tok, D, Kpad):
+    """UCOD_EPI_PATCH_TOKENS_H16_STATS + ucod_cls_rows_h16_stats: the token rows are bit-identical to the plain epilogue's + ucod_cls_rows_h16, and the
+    partial-sum table (indexed by OUTPUT token row, CLS rows included) adds up to each row's sum and sum of squares."""
+    lib = N.load("f16")
+    g = torch.Generator().manual_seed(B + tok)
+    Mp = B * (tok - 1)
+    a = (torch.randn(Mp, Kpad, generator=g) * 0.5).to(torch.float16).to(DEV)
+    w = (torch.randn(D, Kpad, generator=g) * 0.05).to(torch.float16).to(DEV)
+    b, cls, pos = (torch.randn(D, generator=g) * 0.1).to(DEV), torch.randn(D, generator=g).to(DEV), (torch.randn(tok, D, generator=g) * 0.5).to(DEV)
+    plain = torch.zeros(B * tok, D, dtype=torch.float16, device=DEV)
+    N.check(lib.ucod_gemm_bf16(N.EPI_PATCH_TOKENS_H16, N.ptr(a), N.ptr(w), N.ptr(plain), Mp, D, Kpad, N.ptr(b), None, None, N.ptr(pos), tok, 9, N.stream()), "plain")
+    N.check(lib.ucod_cls_rows_h16(N.ptr(plain), N.ptr(cls), N.ptr(pos), B, tok, D, N.stream()), "cls")
+    out = torch.zeros_like(plain)
+    part = torch.full((B * tok, D // 64, 2), float("nan"), dtype=torch.float32, device=DEV)
+    rc = lib.ucod_gemm_bf16_stats(N.EPI_PATCH_TOKENS_H16_STATS, N.ptr(a), N.ptr(w), N.ptr(out), Mp, D, Kpad, N.ptr(b), None, None, N.ptr(pos), tok, N.ptr(part), D // 64, N.stream())
+    assert rc == 0
+    N.check(lib.ucod_cls_rows_h16_stats(N.ptr(out), N.ptr(cls), N.ptr(pos), N.ptr(part), D // 64, B, tok, D, N.stream()), "cls stats")
+    assert torch.equal(out, plain)
+    xs = out.double().cpu()
+    ps, pq = part[:, :, 0].double().cpu().sum(1), part[:, :, 1].double().cpu().sum(1)
+    assert bool(torch.isfinite(part).all())
+    assert bool(((ps - xs.sum(1)).abs() <= 1e-6 * xs.abs().sum(1) + 1e-6).all())
+    assert bool(((pq - (xs * xs).sum(1)).abs() <= 1e-6 * (xs * xs).sum(1) + 1e-6).all())
+    # ... and the folded consumer on these partials agrees with the one on the two-pass statistics
+    wl = torch.randn(256, D, generator=g) * 0.04
+    wf, bf_, cs = ops.fold_layernorm_linear(torch.ones(D, device=DEV), torch.zeros(D, device=DEV), wl.to(DEV), torch.zeros(256, device=DEV))
+    o_p = ops.linear_lnfold(out, None, wf, bf_, cs, partials=part, eps=EPS).float()
+    o_s = ops.linear_lnfold(out, ops.row_stats_h16(out, EPS), wf, bf_, cs, variant=9).float()
+    assert rel_l2(o_p, o_s) < 1e-4
+
+
 def test_row_partial_producers_refuse_small_passes():
     lib = N.load("f16")
     a, w, b, ls, resid = _resid_case(1370, 768, 768, 1)
@@ -242,7 +274,9 @@ def test_engine_with_the_fold_on_a_large_pass_takes_the_partials_path(small):
     tot, cnt = (C.c_double * ncls)(), (C.c_longlong * ncls)()
     lib.ucod_prof_collect(tot, cnt)
     launches = {lib.ucod_prof_class_name(i).decode(): cnt[i] for i in range(ncls) if cnt[i]}
-    assert launches.get("layernorm", 0) == 1, launches             # the last layer's LayerNorm 1 only: no LayerNorm and no statistics launch for the folded ones
+    # the last layer's LayerNorm 1, plus ONE statistics launch behind the patch embedding (9 tiles on 256 CUs: the driver keeps the plain patch launch
+    # there); the 2 x 4 folded LayerNorms behind out-projection / fc2 take their statistics from the producers' partial sums
+    assert launches.get("layernorm", 0) == 2, launches
     fold.check_overflow(wait=True)
     k3 = fold(img.to(DEV)).cpu()
     assert rel_l2(k9[:3], ref) < 1.5e-3

@@ -267,3 +267,119 @@ def test_look_twice_gpu_tail_equals_host_tail():
         out[tail] = (boxes, loop.look_twice(img, boxes, preds_up).cpu())
     assert out[True][0] == out[False][0]
     assert torch.equal(out[True][1], out[False][1])
+
+
+# ------------------------------------------------------------------------------------------------ the batched second pass (BASELINE configs[3])
+def _first_stage_logits(n, seed):
+    """Logit maps with 0 - 3 blobs each (empty map -> the fallback centre box; one large blob -> no second look; several small -> several boxes)."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(n):
+        logits = torch.randn(1, 68, 68, generator=g) * 0.3 - 3.0
+        for _ in range(i % 4):
+            cy, cx, r = (int(v) for v in torch.randint(8, 60, (3,), generator=g))
+            r = 2 + r % 6
+            logits[..., max(cy - r, 0):cy + r, max(cx - r, 0):cx + r] = 4.0
+        if i % 7 == 5:
+            logits[..., 5:60, 5:60] = 4.0                      # one component above look_twice_th: boxes None
+        out.append(logits)
+    return torch.stack(out, 0)
+
+
+def test_crop_multi_image_equals_the_single_image_call():
+    loop, _, _ = make_loop()
+    imgs = [synthetic_image(427, 640, 1), synthetic_image(300, 500, 2), synthetic_image(518, 518, 3)]
+    boxes = [[[100, 50, 300, 200], [-20, -10, 90, 70]], [[0, 0, 500, 300]], [[129, 129, 259, 259], [10, 10, 37, 518], [320, 200, 1200, 900]]]
+    single = torch.cat([loop.crop_batch(im, b) for im, b in zip(imgs, boxes)], 0)
+    import ctypes as C
+    from ucod_dpl_amd import native as N
+    dev_imgs = [torch.as_tensor(im).cuda().contiguous() for im in imgs]
+    flat = np.ascontiguousarray(np.asarray([b for bs in boxes for b in bs], np.int32))
+    which = np.ascontiguousarray(np.asarray([i for i, bs in enumerate(boxes) for _ in bs], np.int32))
+    hw = np.ascontiguousarray(np.asarray([im.shape[:2] for im in imgs], np.int32))
+    lib = N.load()
+    need = lib.ucod_crop_workspace_bytes(len(flat), int(flat[:, 3].max()), int(flat[:, 2].max()), 518, 518)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    out = torch.empty(len(flat), 3, 518, 518, dtype=torch.float32, device="cuda")
+    ptrs = (C.c_void_p * 3)(*[t.data_ptr() for t in dev_imgs])
+    N.check(lib.ucod_crop_resize_norm_multi(ptrs, hw.ctypes.data, 3, which.ctypes.data, flat.ctypes.data, len(flat), N.ptr(out), 518, 518, N.ptr(ws), ws.numel(), N.stream()), "multi")
+    assert torch.equal(out, single)
+
+
+def test_batched_look_twice_equals_the_per_image_path(monkeypatch):
+    """Sixteen images of five different sizes through ``validate_batch`` (one decode, one CCL transfer, one crop launch pair, one paste call) against the
+    reference-shaped per-image path (``process_preds`` + ``look_twice``, loop_UCOD_DPL.py:297-352) on the same images: identical boxes, identical masks.
+    The encoder is made batch-invariant for this comparison -- crops go through the backbone one at a time on both sides and the decoder's 1 x 1 convolution
+    takes its exact-f32 kernel for every batch size -- because the GEMM tile path (and with it the last bits of a key map) depends on how many rows travel
+    together; what is pinned here is everything the batching touches: box tables, crop indices, resampling tables, paste order."""
+    from ucod_dpl_amd import ops
+    monkeypatch.setattr(ops, "_EXACT_F32", True)
+    loop, bb, model = make_loop()
+
+    class OneAtATime:
+        def __call__(self, crops):
+            keys = [bb(crops[i:i + 1])[1] for i in range(crops.shape[0])]
+            return None, torch.cat(keys, 0)
+
+    loop.feature_extractor = OneAtATime()
+    sizes = [(427, 640), (300, 500), (518, 518), (600, 400), (224, 224)]
+    imgs = [synthetic_image(*sizes[i % 5], seed=20 + i) for i in range(16)]
+    logits = _first_stage_logits(16, 77).cuda()
+    # per image, as the reference walks the set
+    ref_masks, ref_boxes = [], []
+    for i in range(16):
+        up, boxes = loop.process_preds(logits[i:i + 1])
+        if boxes is not None:
+            up = loop.look_twice(imgs[i], boxes, up)
+        ref_masks.append(up.reshape(518, 518).cpu())
+        ref_boxes.append(boxes)
+    assert sum(b is None for b in ref_boxes) >= 1 and sum(b == [list(LT.DEFAULT_BOX)] for b in ref_boxes) >= 1 and max(len(b) for b in ref_boxes if b) >= 2
+    assert sum(b == [] for b in ref_boxes) >= 1                 # only components below 1 % of the image: an empty box list, nothing pasted (:372-382)
+    # the batch: first-stage decode replaced by the same logits (runner.model is only used for the second pass)
+    up_b, boxes_b = loop.process_preds_batch(logits)
+    assert boxes_b == ref_boxes
+    got = loop.look_twice_batch(imgs, boxes_b, up_b).cpu()
+    for i in range(16):
+        assert torch.equal(got[i], ref_masks[i]), i
+    # second-pass backbone in several passes (max_crops_per_pass smaller than the number of crops): same result
+    loop.max_crops_per_pass = 3
+    assert torch.equal(loop.look_twice_batch(imgs, boxes_b, up_b).cpu(), got)
+
+
+def test_batched_look_twice_with_the_batched_backbone_stays_at_rounding_level():
+    """The product configuration: every crop of the batch through ONE backbone pass.  A crop's key map then differs from its batch-1 key map in the last
+    bits (tile path), so a refined mask may differ from the per-image path in the few pixels whose logit sits at the threshold: bounded here."""
+    loop, bb, model = make_loop()
+    imgs = [synthetic_image(427, 640, seed=40 + i) for i in range(16)]
+    logits = _first_stage_logits(16, 78).cuda()
+    up_b, boxes_b = loop.process_preds_batch(logits)
+    got = loop.look_twice_batch(imgs, boxes_b, up_b).cpu()
+    diff = 0
+    for i in range(16):
+        up, boxes = loop.process_preds(logits[i:i + 1])
+        assert boxes == boxes_b[i]
+        ref = loop.look_twice(imgs[i], boxes, up).reshape(518, 518).cpu() if boxes is not None else up.reshape(518, 518).cpu()
+        diff += int((got[i] != ref).sum())
+    assert diff <= 16 * 518 * 518 * 2e-4, diff
+
+
+def test_validation_run_walks_the_set_in_batches():
+    """``run()`` over a 5-image loader with look_twice_batch = 2 (groups of 2, 2, 1): the nine measures equal those of look_twice_batch = 1."""
+    loop, bb, model = make_loop()
+    g = torch.Generator().manual_seed(3)
+    items = []
+    for i in range(5):
+        img = synthetic_image(300 + 20 * i, 400, seed=60 + i)
+        label = (torch.rand(1, 300 + 20 * i, 400, generator=g) > 0.7).float()
+        feat = torch.randn(1, 128, 37, 37, generator=g)
+        items.append({"image": None, "label": label, "features": feat, "path": [img]})
+    logs = []
+    loop.runner.val_dataloader = items
+    loop.runner.logger = types.SimpleNamespace(log_table=lambda t: logs.append(t))
+    loop.cfg.val_cfg["look_twice_batch"] = 2
+    r2 = loop.run()
+    loop.cfg.val_cfg["look_twice_batch"] = 1
+    r1 = loop.run()
+    assert set(r1) == set(r2) and len(logs) == 2
+    for k in r1:
+        assert abs(r1[k] - r2[k]) <= 2e-3, (k, r1[k], r2[k])

@@ -356,3 +356,83 @@ def test_weight_gradient_run_to_run_spread_is_at_rounding_level():
     err = max(maxdiff(o.cpu(), ref.cpu()) for o in outs) / scale
     within("wgrad:run_to_run_spread_rel", spread, 2e-6)
     within("wgrad:error_vs_f64_rel", err, 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ G18: the epoch-level schedule (VERDICT r4 missing #2)
+def _g18_cfg():
+    return CfgNode(dict(
+        model_cfg=dict(dim=128, feature_size=12, ema_weight=0.99, dis_use_features=False),
+        train_cfg=dict(max_epoch=6, start_epoch=0, start_finetune=-2, lr0=6e-4, dis_lr0=1e-3, step_lr_size=2, dis_step_lr_size=2, step_lr_gamma=0.95,
+                       dis_step_lr_gamma=0.95, merge_alpha=0.5, merge_method="dis", dist_train=False, dis_epoch=1, dis_intertrain=2,
+                       save_cfg=dict(save_mode="model", save_interval=5, start_save=1000)),
+        val_cfg=dict(enable_val=False, val_interval=5, start_val=1000),
+        log_cfg=dict(log_interval=50, log_path="/tmp/ucod_g18", multi_rank=[0]),
+    ))
+
+
+def _run_g18(g, world_hook=None):
+    """The build's TrainLoop.run() on G18's data; returns {event: snapshot} in the fixture's layout plus the per-batch losses."""
+    runner = StandardRunner(_g18_cfg())
+    runner.model.load_state_dict({k: v.to(runner.device) for k, v in sub(g, "model0.").items()}, strict=True)
+    runner.discriminator.load_state_dict({k: v.to(runner.device) for k, v in sub(g, "disc0.").items()}, strict=True)
+    runner.train_dataloader = [{"pseudo_label": g[f"pl{i}"], "label_tensor": torch.zeros(1), "features": g[f"features{i}"], "img_path": ["x"]} for i in range(3)]
+    loop = TrainLoop(runner.config, runner)
+    snaps, losses, events = {}, [], []
+
+    def snap(tag):
+        events.append(tag)
+        snaps[tag] = dict(model={k: v.detach().cpu().clone() for k, v in runner.model.state_dict().items()},
+                          disc={k: v.detach().cpu().clone() for k, v in runner.discriminator.state_dict().items()},
+                          lr=runner.optimizer.param_groups[0]["lr"], dis_lr=runner.dis_optimizer.param_groups[0]["lr"], global_step=loop.global_step,
+                          finetune=int(loop.finetune), decoder_requires_grad=int(all(p.requires_grad for p in runner.model.decoder.parameters())),
+                          disc_requires_grad=int(any(p.requires_grad for p in runner.discriminator.parameters())))
+
+    run_epoch, dis_train, process = loop.run_epoch, loop.Discriminator_train, loop._process_batch
+
+    def run_epoch_rec():
+        run_epoch()
+        snap(f"epoch{loop._cur_epoch}")
+
+    def dis_train_rec():
+        dis_train()
+        snap(f"dis{loop._cur_epoch}")
+
+    def process_rec(b):
+        loss = process(b)
+        losses.append(float(loss.item()))
+        return loss
+
+    loop.run_epoch, loop.Discriminator_train, loop._process_batch = run_epoch_rec, dis_train_rec, process_rec
+    loop.run()
+    return snaps, losses, events
+
+
+def test_g18_train_schedule_matches_the_reference_run():
+    """The REAL TrainLoop.run() of the reference (engine/runner/loop_UCOD_DPL.py:94-118) over six epochs of three batches -- discriminator phases before
+    epochs 0 and 2 (:193-227), the finetune switch at epoch 4 with BOTH optimisers rebuilt (engine/runner/runner.py:378-379), global_step reset (:101-103),
+    `loss -= dis_loss` only before it (:167-169) -- against the build's TrainLoop.run() on the same data: the order of events, both learning rates,
+    global_step, the finetune flag and the requires_grad flips exactly; every batch's loss, and after every event the decoder, the EMA decoder and the
+    discriminator (BatchNorm buffers and counters included) to the tolerances below (eighteen optimiser steps of drift from G5's per-step level)."""
+    g = load_golden("g18_train_schedule")
+    snaps, losses, events = _run_g18(g)
+    assert events == [str(e) for e in g["events"]]
+    ref_losses = g["losses"].tolist()
+    assert len(losses) == len(ref_losses) == 18
+    within("g18_loss", max(abs(a - b) for a, b in zip(losses, ref_losses)), 2e-4)           # (the reference's strings carry four decimals)
+    worst = {}
+    for e in events:
+        s = snaps[e]
+        assert abs(s["lr"] - float(g[e + ".lr"])) < 1e-12 and abs(s["dis_lr"] - float(g[e + ".dis_lr"])) < 1e-12, e
+        assert s["global_step"] == int(g[e + ".global_step"]) and s["finetune"] == int(g[e + ".finetune"]), e
+        assert s["decoder_requires_grad"] == int(g[e + ".decoder_requires_grad"]) and s["disc_requires_grad"] == int(g[e + ".disc_requires_grad"]), e
+        for k, v in sub(g, e + ".model.").items():
+            if k.endswith("learnable_embedding"):
+                continue                                        # analytically frozen (see test_learnable_embedding_only_sees_weight_decay)
+            worst["model"] = max(worst.get("model", 0.0), maxdiff(s["model"][k], v))
+        for k, v in sub(g, e + ".disc.").items():
+            kind = "disc_counter" if "num_batches" in k else ("disc_bn" if "running" in k else "disc")
+            worst[kind] = max(worst.get(kind, 0.0), maxdiff(s["disc"][k], v))
+    assert worst["disc_counter"] == 0.0
+    within("g18_model_params", worst["model"], 2e-3)            # AdamW steps of lr ~ 6e-4 on noise-level gradient entries may differ by a full step (see G5)
+    within("g18_disc_params", worst["disc"], 2e-3)
+    within("g18_disc_bn", worst["disc_bn"], 2e-3)

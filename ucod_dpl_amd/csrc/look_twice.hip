@@ -64,12 +64,14 @@ __host__ __device__ static inline unsigned char clip8(long long v) {
 }
 
 // ------------------------------------------------------------------------------------------- GPU crop + resize
-struct BoxMeta { int x, y, w, h, kh, kv, off_bh, off_kh, off_bv, off_kv; };
+struct BoxMeta { const unsigned char* img; int H, W; int x, y, w, h, kh, kv, off_bh, off_kh, off_bv, off_kv; };   // (each box names its source image: boxes of many images in one launch pair)
 
 // pass 1: horizontal.  tmp[box][row < h][ox][3] u8.  grid (cdiv(ow*3,256), max_h, nbox)
-__global__ __launch_bounds__(256) void crop_hpass_kernel(const unsigned char* __restrict__ img, int H, int W, const BoxMeta* __restrict__ meta,
+__global__ __launch_bounds__(256) void crop_hpass_kernel(const BoxMeta* __restrict__ meta,
                                                          const int* __restrict__ tab, unsigned char* __restrict__ tmp, int ow, int max_h) {
   const BoxMeta m = meta[blockIdx.z];
+  const unsigned char* __restrict__ img = m.img;
+  const int H = m.H, W = m.W;
   const int row = blockIdx.y;
   if (row >= m.h) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -204,6 +206,8 @@ extern "C" int ucod_pil_resize_u8_host(const uint8_t* src, int h, int w, uint8_t
 }
 
 // workspace: [meta nbox*sizeof(BoxMeta) rounded to 256] [tables int32] [tmp u8 nbox*max_h*ow*3]
+static size_t tables_ints(int nbox, int max_dim, int oh, int ow);
+extern "C" size_t ucod_crop_workspace_bytes(int nbox, int max_crop_h, int max_crop_w, int oh, int ow);
 static size_t tables_ints(int nbox, int max_dim, int oh, int ow) {
   const int kmax = (int)std::ceil(std::max(1.0, (double)max_dim / std::min(oh, ow))) * 2 + 1;
   return (size_t)nbox * ((size_t)ow * (2 + kmax) + (size_t)oh * (2 + kmax));
@@ -214,12 +218,15 @@ extern "C" size_t ucod_crop_workspace_bytes(int nbox, int max_crop_h, int max_cr
   return meta + tabs + (size_t)nbox * max_crop_h * ow * 3;
 }
 
-extern "C" int ucod_crop_resize_norm(const uint8_t* img, int H, int W, const int32_t* boxes_host, int nbox, float* out, int oh, int ow,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
-  if (!img || !boxes_host || !out || !workspace || nbox <= 0 || H <= 0 || W <= 0 || oh <= 0 || ow <= 0) return UCOD_EINVAL;
+// boxes of SEVERAL source images in one launch pair (batched Look-Twice validation, BASELINE configs[3]): box i is cut from image box_image_host[i]
+extern "C" int ucod_crop_resize_norm_multi(const uint8_t* const* imgs_host, const int32_t* hw_host, int nimg, const int32_t* box_image_host, const int32_t* boxes_host,
+                                           int nbox, float* out, int oh, int ow, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!imgs_host || !hw_host || !box_image_host || !boxes_host || !out || !workspace || nimg <= 0 || nbox <= 0 || oh <= 0 || ow <= 0) return UCOD_EINVAL;
+  for (int i = 0; i < nimg; ++i)
+    if (!imgs_host[i] || hw_host[2 * i] <= 0 || hw_host[2 * i + 1] <= 0) return UCOD_EINVAL;
   int max_h = 0, max_w = 0;
   for (int i = 0; i < nbox; ++i) {
-    if (boxes_host[4 * i + 2] <= 0 || boxes_host[4 * i + 3] <= 0) return UCOD_EINVAL;
+    if (boxes_host[4 * i + 2] <= 0 || boxes_host[4 * i + 3] <= 0 || box_image_host[i] < 0 || box_image_host[i] >= nimg) return UCOD_EINVAL;
     max_w = std::max(max_w, boxes_host[4 * i + 2]);
     max_h = std::max(max_h, boxes_host[4 * i + 3]);
   }
@@ -230,6 +237,9 @@ extern "C" int ucod_crop_resize_norm(const uint8_t* img, int H, int W, const int
   std::vector<int> b, k;
   for (int i = 0; i < nbox; ++i) {
     BoxMeta& m = meta[i];
+    m.img = imgs_host[box_image_host[i]];
+    m.H = hw_host[2 * box_image_host[i]];
+    m.W = hw_host[2 * box_image_host[i] + 1];
     m.x = boxes_host[4 * i];
     m.y = boxes_host[4 * i + 1];
     m.w = boxes_host[4 * i + 2];
@@ -257,8 +267,16 @@ extern "C" int ucod_crop_resize_norm(const uint8_t* img, int H, int W, const int
   if (e == hipSuccess) e = hipStreamSynchronize(s);          // host tables are stack-owned: make the copies complete before returning
   if (e != hipSuccess) return (int)e;
   UCOD_PROF(PROF_CROP, s);
-  hipLaunchKernelGGL(crop_hpass_kernel, dim3(cdiv((long)ow * 3, 256), max_h, nbox), dim3(256), 0, s, img, H, W, dmeta, dtab, tmp, ow, max_h);
+  hipLaunchKernelGGL(crop_hpass_kernel, dim3(cdiv((long)ow * 3, 256), max_h, nbox), dim3(256), 0, s, dmeta, dtab, tmp, ow, max_h);
   hipLaunchKernelGGL(crop_vpass_kernel, dim3(cdiv(ow, 256), oh, nbox), dim3(256), 0, s, tmp, dmeta, dtab, out, oh, ow, max_h);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
+}
+
+extern "C" int ucod_crop_resize_norm(const uint8_t* img, int H, int W, const int32_t* boxes_host, int nbox, float* out, int oh, int ow,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  if (!img || !boxes_host || nbox <= 0 || H <= 0 || W <= 0) return UCOD_EINVAL;
+  const int32_t hw[2] = {H, W};
+  const std::vector<int32_t> which((size_t)nbox, 0);
+  return ucod_crop_resize_norm_multi(&img, hw, 1, which.data(), boxes_host, nbox, out, oh, ow, workspace, workspace_bytes, stream);
 }

@@ -232,9 +232,11 @@ extern "C" size_t ucod_paste_workspace_bytes(int nbox, int max_w, int max_h, int
   return (size_t)nbox * per_box * sizeof(int) + 256;
 }
 
-extern "C" int ucod_paste_resized_u8(const uint8_t* masks, int nbox, int sh, int sw, const int32_t* boxes_host, uint8_t* canvas, int CH, int CW,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
-  if (!masks || !boxes_host || !canvas || !workspace || nbox <= 0 || sh <= 0 || sw <= 0 || CH <= 0 || CW <= 0) return UCOD_EINVAL;
+// masks of SEVERAL canvases in one call (batched Look-Twice validation): mask i is pasted onto canvas box_canvas_host[i] of `canvases` [ncanvas][CH][CW], in
+// the order given (the boxes of one canvas keep their order: later ones overwrite earlier ones, loop_UCOD_DPL.py:346-352).  box_canvas_host NULL = one canvas.
+extern "C" int ucod_paste_resized_u8_multi(const uint8_t* masks, int nbox, int sh, int sw, const int32_t* boxes_host, const int32_t* box_canvas_host, uint8_t* canvases,
+                                           int ncanvas, int CH, int CW, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!masks || !boxes_host || !canvases || !workspace || nbox <= 0 || sh <= 0 || sw <= 0 || CH <= 0 || CW <= 0 || ncanvas <= 0) return UCOD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   std::vector<int> tab;
   std::vector<PasteMeta> metas(nbox);
@@ -246,6 +248,7 @@ extern "C" int ucod_paste_resized_u8(const uint8_t* masks, int nbox, int sh, int
     m.w = boxes_host[4 * i + 2];
     m.h = boxes_host[4 * i + 3];
     if (m.w <= 0 || m.h <= 0) return UCOD_EINVAL;                  // PIL: "height and width must be > 0"
+    if (box_canvas_host && (box_canvas_host[i] < 0 || box_canvas_host[i] >= ncanvas)) return UCOD_EINVAL;
     m.kh = bicubic_coeffs(sw, m.w, b, k);
     m.off_bh = (int)tab.size();
     tab.insert(tab.end(), b.begin(), b.end());
@@ -264,9 +267,15 @@ extern "C" int ucod_paste_resized_u8(const uint8_t* masks, int nbox, int sh, int
   if (e != hipSuccess) return (int)e;
   for (int i = 0; i < nbox; ++i) {
     const PasteMeta& m = metas[i];
+    uint8_t* canvas = canvases + (size_t)(box_canvas_host ? box_canvas_host[i] : 0) * CH * CW;
     hipLaunchKernelGGL(paste_box_kernel, dim3(cdiv(m.w, 256), m.h), dim3(256), 0, s, masks + (size_t)i * sh * sw, sh, sw, m, (const int*)workspace, canvas,
                        CH, CW);
   }
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
+}
+
+extern "C" int ucod_paste_resized_u8(const uint8_t* masks, int nbox, int sh, int sw, const int32_t* boxes_host, uint8_t* canvas, int CH, int CW,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  return ucod_paste_resized_u8_multi(masks, nbox, sh, sw, boxes_host, nullptr, canvas, 1, CH, CW, workspace, workspace_bytes, stream);
 }

@@ -4,6 +4,7 @@
 // captured into a hipGraph by the caller.
 #include <cstdlib>
 #include "common.h"
+#include "gemm_bf16_plan.h"
 #include "../../include/ucod_dpl.h"
 
 #ifdef UCOD_HALF_F16
@@ -111,7 +112,11 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
   static const bool no_part = getenv("UCOD_LN_FOLD_NO_PARTIALS") != nullptr;      // measurement knob: always the statistics kernel
   bool have_part = false;
   RUN(ucod_patch_im2col(img, patches, d->B, d->C, d->H, d->W, d->P, d->Kpad, stream));
-  if (d->ln_fold && d->L > 1 && !no_part) {
+  // (the patch embedding's *_STATS form runs without the leftover-as-patches mode: worth it only when its 256 x 256 tiles come out as nearly whole
+  // rounds of the chip; at 32 x 1369 rows -- 516 tiles on 256 CUs -- the plain launch plus one statistics launch is 11 us faster)
+  const int patch_tiles = ucod::cdiv((long)d->B * (tok - 1), 256) * ucod::cdiv(D, 256), n_cu = ucod::device_cus();
+  const bool patch_whole_rounds = patch_tiles >= n_cu && (patch_tiles % n_cu == 0 || patch_tiles % n_cu >= n_cu / 2);
+  if (d->ln_fold && d->L > 1 && !no_part && patch_whole_rounds) {
     const int rc = ucod_gemm_bf16_stats(UCOD_EPI_PATCH_TOKENS_H16_STATS, patches, T[0], x, d->B * (tok - 1), D, d->Kpad, (const float*)T[1], nullptr, nullptr,
                                         (const float*)T[3], tok, part, nslot, stream);
     if (rc == UCOD_OK) have_part = true;

@@ -161,22 +161,52 @@ class ValLoop_Look_Twice(BaseLoop):
         rows = rows[np.argsort(rows[:, 6], kind="stable")]
         return [(int(r[1]), int(r[2]), int(r[4]), int(r[3] - r[2] + 1), int(r[5] - r[4] + 1)) for r in rows]
 
-    def boxes_from_mask_gpu(self, mask_u8_dev):
-        """Integer tail of process_preds (:366-384) from a DEVICE 0/255 uint8 [h,w] mask; same result as ``boxes_from_mask``."""
+    def components_gpu_batch(self, masks_u8_dev):
+        """components_gpu for a batch [B,h,w] of device masks: every image's labelling is enqueued back to back (one workspace: the launches are
+        stream-ordered), the B component counts come back in ONE transfer, a table that overflowed is redone alone."""
+        Bn, Hh, Ww = masks_u8_dev.shape
+        lib = N.load()
+        need = lib.ucod_ccl8_workspace_bytes(Hh, Ww)
+        if getattr(self, "_ccl_ws", None) is None or self._ccl_ws.numel() < need:
+            self._ccl_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        cap = 4096
+        tables = torch.empty(Bn, cap, 7, dtype=torch.int32, device=self.device)
+        counts = torch.zeros(Bn, dtype=torch.int32, device=self.device)
+        masks_u8_dev = masks_u8_dev.contiguous()
+        for i in range(Bn):
+            N.check(lib.ucod_ccl8_components(N.ptr(masks_u8_dev[i]), Hh, Ww, N.ptr(tables[i]), cap, N.ptr(counts[i:i + 1]), N.ptr(self._ccl_ws),
+                                             self._ccl_ws.numel(), N.stream()), "ucod_ccl8_components")
+        n_host = counts.cpu().tolist()
+        biggest = max(min(n, cap) for n in n_host) if n_host else 0
+        rows_host = tables[:, :max(biggest, 1)].cpu().numpy()
+        out = []
+        for i, n in enumerate(n_host):
+            if n > cap:
+                out.append(self.components_gpu(masks_u8_dev[i]))
+                continue
+            rows = rows_host[i, :n]
+            rows = rows[np.argsort(rows[:, 6], kind="stable")]
+            out.append([(int(r[1]), int(r[2]), int(r[4]), int(r[3] - r[2] + 1), int(r[5] - r[4] + 1)) for r in rows])
+        return out
+
+    def _boxes_from_components(self, comps, npix):
+        """Integer tail of process_preds (:366-384) from one image's component list (area, x, y, w, h in cv2's label order)."""
         h, w = self.img_size
-        comps = self.components_gpu(mask_u8_dev.contiguous())
         p = [np.int64(c[0]) / (h * w) for c in comps]
         if len(p) == 0:
             return [list(DEFAULT_BOX)]
         if max(p) < self.cfg.val_cfg.look_twice_th:
             bboxes = []
-            npix = int(mask_u8_dev.shape[-2]) * int(mask_u8_dev.shape[-1])
             for (area, x, y, bw, bh), pi in zip(comps, p):
                 if pi > 0.01:
                     # the reference hands expand_bbox the one-component mask: its sum inside the component's own box IS the area
                     bboxes.append(self._expand(np.uint64(area), npix, (x, y, bw, bh), h, w, expand_type=self.cfg.val_cfg.expand_type))
             return sorted(bboxes, key=lambda b: -1 * b[2] * b[3])
         return None
+
+    def boxes_from_mask_gpu(self, mask_u8_dev):
+        """Integer tail of process_preds (:366-384) from a DEVICE 0/255 uint8 [h,w] mask; same result as ``boxes_from_mask``."""
+        return self._boxes_from_components(self.components_gpu(mask_u8_dev.contiguous()), int(mask_u8_dev.shape[-2]) * int(mask_u8_dev.shape[-1]))
 
     def process_preds(self, preds, label_tensor=None):
         """:354-384.  preds [1,1,fs,fs] logits -> (preds_up float [1,h,w] on the GPU, boxes | None)."""
@@ -187,6 +217,16 @@ class ValLoop_Look_Twice(BaseLoop):
             return preds_up, self.boxes_from_mask_gpu((preds_up[0] * 255).to(torch.uint8))
         mask = (preds_up[0].cpu().numpy() * 255).astype(np.uint8)
         return preds_up, self.boxes_from_mask(mask)
+
+    def process_preds_batch(self, preds):
+        """:354-384 for a whole validation batch: preds [B,1,fs,fs] logits -> (preds_up float [B,h,w] on the GPU, one box list | None per image).
+        One resize + threshold launch pair for the batch, every image's components enqueued back to back, one transfer of the tables; the box
+        arithmetic per image is the single-image one (``_boxes_from_components``), so every image gets exactly the boxes ``process_preds`` gives it."""
+        h, w = self.img_size
+        Bn = preds.shape[0]
+        up = ops.binarize(ops.bilinear_resize(preds.to(self.device, torch.float32), h, w), logits=True).reshape(Bn, h, w)
+        comps = self.components_gpu_batch((up * 255).to(torch.uint8))
+        return up, [self._boxes_from_components(c, h * w) for c in comps]
 
     def paste_gpu(self, masks_u8_dev, bboxes, canvas_u8_dev):
         """Pillow-BICUBIC resize of mask i to box i + paste, in order, on the device (:346-352)."""
@@ -224,12 +264,19 @@ class ValLoop_Look_Twice(BaseLoop):
         """path: image file or uint8 [H,W,3] array.  old_mask float [1,h,w] in {0,1}.  Returns ToTensor(new_mask) [1,h,w]
         (on the device with ``gpu_tail``, on the CPU with the host tail)."""
         ih, iw = self.img_size
+        if len(bboxes) == 0:
+            # process_preds returns an EMPTY list when no component reaches 1 % of the image (:372-382): the reference's loop over it pastes nothing
+            # and hands back ToTensor(ToPILImage(old_mask)) -- the old mask through an exact x 255 / 255 round trip
+            canvas = (old_mask.squeeze(0) * 255).to(torch.uint8)
+            if getattr(self, "gpu_tail", True):
+                return torch.div(canvas.to(self.device).to(torch.float32), torch.full((), 255.0, device=self.device)).unsqueeze(0)
+            return torch.from_numpy(canvas.cpu().numpy().astype(np.float32) / 255.0).unsqueeze(0)
         if isinstance(path, (str, os.PathLike)):
             from PIL import Image
             Image.MAX_IMAGE_PIXELS = None
             img = np.asarray(Image.open(path).convert("RGB"))
         else:
-            img = np.asarray(path)
+            img = np.asarray(path.cpu() if torch.is_tensor(path) else path)
         H, W = img.shape[:2]
         src_boxes = [self.resize_bbox(b, iw, ih, W, H) for b in bboxes]          # img.size = (W, H) (:335)
         crops = self.crop_batch(img, src_boxes)
@@ -255,6 +302,81 @@ class ValLoop_Look_Twice(BaseLoop):
                 canvas[y0:y1, x0:x1] = rs[y0 - by:y1 - by, x0 - bx:x1 - bx]
         return torch.from_numpy(canvas.astype(np.float32) / 255.0).unsqueeze(0)
 
+    @staticmethod
+    def _load_image(path):
+        if isinstance(path, (str, os.PathLike)):
+            from PIL import Image
+            Image.MAX_IMAGE_PIXELS = None
+            return np.asarray(Image.open(path).convert("RGB"))
+        return path if torch.is_tensor(path) else np.asarray(path)
+
+    max_crops_per_pass = 64                                                       # second-pass backbone batches (workspace ~0.3 GB per ViT-L crop)
+
+    def look_twice_batch(self, paths, boxes_list, old_masks):
+        """``look_twice`` (:326-352) for a validation batch -- SURVEY 8a row L3 "batch all crops of all images", BASELINE configs[3].
+        paths: image files or uint8 [H,W,3] arrays (any sizes); boxes_list: per image a box list or None (image keeps its first-stage mask);
+        old_masks float [B,h,w] in {0,1} on the device.  ONE crop launch pair over every crop of every image, the backbone over all crops (in passes of
+        ``max_crops_per_pass``), one decoder pass at the native grid, one paste call.  Returns float [B,h,w] on the device; every image's result is what
+        ``look_twice`` returns for it (same crop indices, same resampling tables, same paste order)."""
+        ih, iw = self.img_size
+        todo = [i for i, b in enumerate(boxes_list) if b]                          # None: no second look; []: nothing to paste (see look_twice)
+        canvases = (old_masks.to(self.device) * 255).to(torch.uint8).contiguous()
+        if not todo:
+            return torch.div(canvases.to(torch.float32), torch.full((), 255.0, device=self.device))
+        imgs, hw, box_img, src_boxes, dst_boxes, box_canvas = [], [], [], [], [], []
+        for j, i in enumerate(todo):
+            img = torch.as_tensor(self._load_image(paths[i])).to(self.device).contiguous()
+            H, W = img.shape[:2]
+            imgs.append(img)
+            hw.append((H, W))
+            for b in boxes_list[i]:
+                src_boxes.append(self.resize_bbox(b, iw, ih, W, H))                # img.size = (W, H) (:335)
+                dst_boxes.append(list(b))
+                box_img.append(j)
+                box_canvas.append(i)
+        nb = len(src_boxes)
+        lib = N.load()
+        sb = np.ascontiguousarray(np.asarray(src_boxes, np.int32).reshape(nb, 4))
+        need = lib.ucod_crop_workspace_bytes(nb, int(sb[:, 3].max()), int(sb[:, 2].max()), ih, iw)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        crops = torch.empty(nb, 3, ih, iw, dtype=torch.float32, device=self.device)
+        ptrs = (C.c_void_p * len(imgs))(*[t.data_ptr() for t in imgs])
+        hw_a = np.ascontiguousarray(np.asarray(hw, np.int32))
+        bi_a = np.ascontiguousarray(np.asarray(box_img, np.int32))
+        N.check(lib.ucod_crop_resize_norm_multi(ptrs, hw_a.ctypes.data, len(imgs), bi_a.ctypes.data, sb.ctypes.data, nb, N.ptr(crops), ih, iw, N.ptr(self._ws),
+                                                self._ws.numel(), N.stream()), "ucod_crop_resize_norm_multi")
+        keys = []
+        for c0 in range(0, nb, self.max_crops_per_pass):
+            keys.append(self.feature_extractor(crops[c0:c0 + self.max_crops_per_pass])[1])
+        key = keys[0] if len(keys) == 1 else torch.cat(keys, 0)
+        with torch.no_grad():
+            preds = self.runner.model(key)[0]                                      # decoder at the native grid, no 68x68 resize (:343-345)
+        pred01 = ops.binarize(preds.contiguous(), logits=True).reshape(nb, preds.shape[-2], preds.shape[-1])
+        masks = (pred01 * 255).to(torch.uint8).contiguous()
+        db = np.ascontiguousarray(np.asarray(dst_boxes, np.int32).reshape(nb, 4))
+        if (db[:, 2:] <= 0).any():
+            raise ValueError("height and width must be > 0")                      # what PIL's resize raises
+        bc = np.ascontiguousarray(np.asarray(box_canvas, np.int32))
+        pneed = lib.ucod_paste_workspace_bytes(nb, int(db[:, 2].max()), int(db[:, 3].max()), masks.shape[1], masks.shape[2])
+        if getattr(self, "_paste_ws", None) is None or self._paste_ws.numel() < pneed:
+            self._paste_ws = torch.empty(pneed, dtype=torch.uint8, device=self.device)
+        N.check(lib.ucod_paste_resized_u8_multi(N.ptr(masks), nb, masks.shape[1], masks.shape[2], db.ctypes.data, bc.ctypes.data, N.ptr(canvases), canvases.shape[0],
+                                                canvases.shape[1], canvases.shape[2], N.ptr(self._paste_ws), self._paste_ws.numel(), N.stream()),
+                "ucod_paste_resized_u8_multi")
+        return torch.div(canvases.to(torch.float32), torch.full((), 255.0, device=self.device))      # ToTensor's x / 255 as a true division (see look_twice)
+
+    def validate_batch(self, features, paths):
+        """First-stage decode + Look-Twice refinement of a batch: features [B,C,gh,gw] (cache items), paths: the images.  -> float [B,h,w] in {0,1}."""
+        fs = self.cfg.model_cfg.feature_size
+        features = ops.bilinear_resize(features.to(self.device, torch.float32), fs, fs)
+        with torch.no_grad():
+            preds = self.runner.model(features)[0]
+        preds_up, boxes = self.process_preds_batch(preds)
+        if self.cfg.val_cfg.look_twice and any(b is not None for b in boxes):
+            preds_up = self.look_twice_batch(paths, boxes, preds_up)
+        return preds_up, boxes
+
     # ------------------------------------------------------------------ :297-324
     def run(self):
         stats = statistics()                                                       # all nine COD measures, on the device (:299)
@@ -262,16 +384,29 @@ class ValLoop_Look_Twice(BaseLoop):
         fs = self.cfg.model_cfg.feature_size
         # Multi-rank: every rank walks ITS shard of the validation set (the reference's accelerator.prepare shards the loader) with no
         # per-image collective; the per-image records meet once, before get_result (the role of gather_for_metrics, :310).
+        # The reference walks the set one image at a time (its code assumes batch size 1, :313-317); here `look_twice_batch` images (val_cfg, default 16 =
+        # BASELINE configs[3]) are decoded, boxed, cropped, re-encoded and pasted together -- per image the same result (tests/test_gpu_look_twice.py) --
+        # and only the last step, the resize to each image's own label size + the measures, is per image as in the reference (:315-317).
+        group = int(self.cfg.val_cfg.get("look_twice_batch", 16))
+        pending = []
+
+        def flush():
+            if not pending:
+                return
+            feats = torch.cat([f.reshape(1, *f.shape[-3:]) for _, f, _ in pending], 0)
+            preds_up, _ = self.validate_batch(feats, [p for _, _, p in pending])
+            for (label_tensor, _, _), pu in zip(pending, preds_up):
+                out = ops.bilinear_resize(pu.reshape(1, 1, *pu.shape[-2:]).contiguous(), label_tensor.shape[-2], label_tensor.shape[-1])
+                stats.step(label_tensor.to(self.device), (out.reshape(1, *out.shape[-2:]) > 0.5))
+            pending.clear()
+
         for batch in parallel.shard(self.runner.val_dataloader):
             _, label_tensor, features, img_path = batch.values()
-            features = ops.bilinear_resize(features.to(self.device, torch.float32), fs, fs)
-            with torch.no_grad():
-                preds = self.runner.model(features)[0]
-            preds_up, bboxes = self.process_preds(preds, label_tensor)
-            if bboxes is not None and self.cfg.val_cfg.look_twice:
-                preds_up = self.look_twice(img_path[0], bboxes, preds_up).to(self.device)
-            out = ops.bilinear_resize(preds_up.reshape(1, 1, *preds_up.shape[-2:]).to(self.device), label_tensor.shape[-2], label_tensor.shape[-1])
-            stats.step(label_tensor.to(self.device), (out.reshape(1, *out.shape[-2:]) > 0.5))
+            for j in range(features.shape[0]):                                     # (the shipped configs use batch size 1)
+                pending.append((label_tensor[j:j + 1], features[j], img_path[j]))
+            if len(pending) >= group:
+                flush()
+        flush()
         stats.gather_records(device=self.device, dataset_len=parallel.padded_sampler_len(self.runner.val_dataloader))
         result = stats.get_result()
         self.runner.logger.log_table({k: [round(v, 4)] for k, v in result.items()})

@@ -144,6 +144,8 @@ SIGNATURES = {
     "ucod_ccl8_components": (ci, [vp, ci, ci, vp, ci, vp, vp, sz, vp]),
     "ucod_paste_workspace_bytes": (sz, [ci, ci, ci, ci, ci]),
     "ucod_paste_resized_u8": (ci, [vp, ci, ci, ci, vp, vp, ci, ci, vp, sz, vp]),
+    "ucod_paste_resized_u8_multi": (ci, [vp, ci, ci, ci, vp, vp, vp, ci, ci, ci, vp, sz, vp]),
+    "ucod_crop_resize_norm_multi": (ci, [vp, vp, ci, vp, vp, ci, vp, ci, ci, vp, sz, vp]),
     "ucod_crop_workspace_bytes": (sz, [ci, ci, ci, ci, ci]),
     "ucod_crop_resize_norm": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, vp, sz, vp]),
     "ucod_cross_attention96_fwd": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, vp]),

@@ -41,10 +41,24 @@ def cap_host_threads(world=None):
             avail = len(os.sched_getaffinity(0))                # after pin_rank_cores: this rank's own share
         except AttributeError:
             avail = os.cpu_count() or 1
-        share = avail if avail < (os.cpu_count() or 1) else max(1, (os.cpu_count() or 1) // world)
+        # pinned by pin_rank_cores: the affinity IS this rank's share.  Not pinned (UCOD_NO_PIN, too few cores, a cpuset-limited container): the
+        # affinity is shared by every rank of this host -- divide it
+        share = avail if _PINNED else max(1, avail // _local_world(world))
         n = int(os.environ.get("UCOD_RANK_THREADS") or max(1, share))
         torch.set_num_threads(n)
     return torch.get_num_threads()
+
+
+_PINNED = False                                                  # set by pin_rank_cores when it has narrowed this process's affinity
+
+
+def _local_world(world):
+    """Ranks on THIS host: LOCAL_WORLD_SIZE as torchrun exports it (two nodes x 8 ranks: 8, not 16), else the global world size."""
+    try:
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", "0"))
+    except ValueError:
+        lw = 0
+    return lw if 0 < lw <= world else world
 
 
 def pin_rank_cores(local_rank=None, world=None):
@@ -59,11 +73,14 @@ def pin_rank_cores(local_rank=None, world=None):
         cores = sorted(os.sched_getaffinity(0))
     except AttributeError:                                      # not Linux
         return os.cpu_count() or 1
-    if world <= 1 or os.environ.get("UCOD_NO_PIN") == "1" or len(cores) < world:
+    local_world = _local_world(world)                           # the host's cores are shared by the ranks of THIS host only
+    if world <= 1 or os.environ.get("UCOD_NO_PIN") == "1" or len(cores) < local_world or local_rank >= local_world:
         return len(cores)
-    per = len(cores) // world
+    per = len(cores) // local_world
     mine = cores[local_rank * per:(local_rank + 1) * per]
     os.sched_setaffinity(0, mine)
+    global _PINNED
+    _PINNED = True
     return len(mine)
 
 
@@ -189,12 +206,16 @@ def shard(loader):
         return loader
     rank = dist.get_rank()
     try:
-        from torch.utils.data import DataLoader, SequentialSampler, Subset
-        if isinstance(loader, DataLoader) and isinstance(loader.sampler, SequentialSampler) and loader.batch_sampler is not None \
-                and hasattr(loader.dataset, "__getitem__") and hasattr(loader.dataset, "__len__"):
+        from torch.utils.data import BatchSampler, DataLoader, SequentialSampler, Subset
+        # only a loader torch built itself from (dataset, batch_size): a custom batch_sampler reports batch_size None and would come back un-batched
+        if isinstance(loader, DataLoader) and isinstance(loader.sampler, SequentialSampler) and loader.batch_size is not None \
+                and type(loader.batch_sampler) is BatchSampler and hasattr(loader.dataset, "__getitem__") and hasattr(loader.dataset, "__len__"):
             sub = Subset(loader.dataset, range(rank, len(loader.dataset), world))
+            extra = {}
+            if loader.num_workers > 0:                             # (worker options are only legal with workers)
+                extra = dict(persistent_workers=loader.persistent_workers, prefetch_factor=loader.prefetch_factor, worker_init_fn=loader.worker_init_fn)
             return DataLoader(sub, batch_size=loader.batch_size, shuffle=False, num_workers=loader.num_workers, collate_fn=loader.collate_fn,
-                              pin_memory=loader.pin_memory, drop_last=False)
+                              pin_memory=loader.pin_memory, drop_last=loader.drop_last, generator=loader.generator, **extra)
     except ImportError:
         pass
     return itertools.islice(loader, rank, None, world)
