@@ -43,12 +43,16 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=4)
     ap.add_argument("--gemm-variant", type=int, default=0)
-    ap.add_argument("--attn-variant", type=int, default=2, choices=[0, 1, 2, 5, 8, 32, 64, 66], help="0 / 2 product kernel, 1 generic-scale kernel, 8 fp8 path (BASELINE configs[4]), 5 / 64 / 32 attn_fwd_v5_kernel / the assembly kernels by name")
-    ap.add_argument("--resid", default=os.environ.get("UCOD_RESID", "auto"), choices=["auto", "f32", "f16"],
-                    help="residual-stream type of the backbone (auto: fp16 for bf16 operands, f32 for fp16 operands)")
+    ap.add_argument("--attn-variant", type=int, default=2, choices=[0, 1, 2, 5, 8, 66], help="0 / 2 product kernel, 1 generic-scale kernel, 8 fp8 path (BASELINE configs[4]), 5 / 66 attn_fwd_v5_kernel / attn_fwd_v6_kernel by name")
+    ap.add_argument("--resid", default=os.environ.get("UCOD_RESID", "default"), choices=["default", "auto", "f32", "f16"],
+                    help="residual-stream type of the backbone (default: fp16 -- with fp16 operands that also folds LayerNorm into QKV / fc1; auto: the "
+                         "engine's own choice, fp16 for bf16 operands and f32 for fp16 operands)")
     ap.add_argument("--streams", type=int, default=2, help="image-parallel sub-batches of the backbone pass on independent HIP streams")
     ap.add_argument("--no-pipeline", action="store_true", help="serial order: backbone pass, then decoder step, on one stream")
-    ap.add_argument("--half", default="bf16", choices=["bf16", "f16"], help="16-bit operand type of the backbone (bf16 = BASELINE configs[1])")
+    ap.add_argument("--half", default="f16", choices=["bf16", "f16"],
+                    help="16-bit operand type of the backbone.  f16 (default since round 5): IEEE fp16 operands on the fp16 residual stream with LayerNorm folded into "
+                         "QKV / fc1 -- the configuration that meets the 1e-3 logit bar AND is the fastest; bf16: the operand type BASELINE configs[1] names, "
+                         "reported beside it")
     ap.add_argument("--ln-fold", default="auto", choices=["auto", "on", "off"], help="LayerNorm folded into the QKV / fc1 GEMMs (auto: on with fp16 operands on the fp16 stream)")
     ap.add_argument("--look-twice", action="store_true", help="the validation leg of BASELINE configs[3]: first-stage decode + batched Look-Twice second pass "
                     "(fallback centre box on every image); use with --arch dinov2_vitl14 --batch 16")
@@ -115,6 +119,8 @@ def launch_ranks(a):
 
 def main():
     a = parse()
+    if a.resid == "default":
+        a.resid = "f16" if a.half == "f16" else "auto"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
@@ -261,10 +267,9 @@ def main():
     # SEPARATELY (never part of `value`).  Measured by a CHILD process running this script with --half f16 once this process has
     # finished its own GPU work (a second engine in the same process measures 10 % low: it inherits the allocator and clock state of
     # everything that ran before it); N = 1 only.
-    f16_option = None
     del bb, pipe
     torch.cuda.empty_cache()
-    run_f16_child = a.half == "bf16" and a.lora_steps >= 0 and world == 1 and not os.environ.get("UCOD_BENCH_CHILD")
+    run_children = a.lora_steps >= 0 and world == 1 and not os.environ.get("UCOD_BENCH_CHILD")
     # Optional mode of SURVEY.md 8a row B9, reported SEPARATELY (never part of `value`): images -> LoRA backbone (student,
     # activations saved) + EMA backbone (teacher) -> the same decoder/APM/discriminator step -> backbone backward -> all-reduce
     # of decoder and LoRA gradients -> both fused optimisers.
@@ -380,65 +385,68 @@ def main():
     if not a.no_cpu_baseline and world == 1:                  # rank 0 at N = 1 only (the contract); the N > 1 lines carry null
         cpu = cpu_baseline(a, D, heads, L, P)
 
-    f16_children = []
-    if run_f16_child:
-        # Two fp16-operand configurations, each in its own process: the engine's default (resid="auto" -> f32 residual stream: the
-        # whole margin under the bar) and the fp16 residual stream (the faster one; still under the bar, with less margin).
+    # The three backbone configurations, each measured in its OWN process (a second engine in this process measures ~10 % low: it inherits the allocator and
+    # clock state of everything that ran before it): this process's is the headline, the other two are reported beside it, never part of `value`.
+    CONFIGS = {"f16_f16_stream": ("f16", "f16"), "f16_f32_stream": ("f16", "f32"), "bf16": ("bf16", "auto")}
+    PARITY_KEY = {"f16_f16_stream": "f16_operands_f16_stream" if ln_fold else "f16_operands_f16_stream_unfolded", "f16_f32_stream": "f16_operands", "bf16": "bf16"}
+    mine = "bf16" if a.half == "bf16" else ("f16_f16_stream" if resid16 else "f16_f32_stream")
+    others = {}
+    if run_children:
         import subprocess
         torch.cuda.synchronize()
-        for resid in ("auto", "f16"):
-            cmd = [sys.executable, os.path.abspath(__file__), "--half", "f16", "--resid", resid, "--steps", str(a.steps), "--warmup", str(a.warmup),
+        for name, (half, resid) in CONFIGS.items():
+            if name == mine:
+                continue
+            cmd = [sys.executable, os.path.abspath(__file__), "--half", half, "--resid", resid, "--steps", str(a.steps), "--warmup", str(a.warmup),
                    "--batch", str(B), "--arch", a.arch, "--image", str(a.image), "--streams", str(a.streams), "--attn-variant", str(a.attn_variant),
                    "--lora-steps", "-1", "--no-cpu-baseline", "--ln-fold", a.ln_fold] + (["--no-pipeline"] if a.no_pipeline else []) + (["--full-last-layer"] if a.full_last_layer else [])
             r = subprocess.run(cmd, env=dict(os.environ, UCOD_BENCH_CHILD="1"), capture_output=True, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
-                raise SystemExit("bench.py: the fp16-operand child run failed:\n" + r.stderr[-2000:])
+                raise SystemExit(f"bench.py: the child run of configuration {name} failed:\n" + r.stderr[-2000:])
             c = json.loads(line[-1])
-            f16_children.append({"resid": resid, "value": c["value"], "unit": "images/s", "ms_per_step": c["ms_per_step"],
-                                 "residual_stream": c["config"]["residual_stream"], "ln_fold": c["config"].get("ln_fold"), "serial_ms_per_step": c["roofline"]["serial_ms_per_step_without_events"],
-                                 "kernels_avg_us": {k: v["avg_us"] for k, v in c["kernels"].items()}})
-        f16_option = {k: v for k, v in f16_children[0].items() if k != "kernels_avg_us"}
-        f16_option["what"] = "the timed step with fp16 backbone operands (libucod_dpl_f16.so), same schedule, own process (python bench.py --half f16)"
+            others[name] = {"value": c["value"], "unit": "images/s", "ms_per_step": c["ms_per_step"], "dtype": half, "residual_stream": c["config"]["residual_stream"],
+                            "ln_fold": c["config"].get("ln_fold"), "serial_ms_per_step": c["roofline"]["serial_ms_per_step_without_events"],
+                            "kernels_avg_us": {k: v["avg_us"] for k, v in c["kernels"].items()},
+                            "how": f"python bench.py --half {half} --resid {resid} (own process, same schedule, same box)"}
 
-    # North-star parity bar (mask logits within 1e-3 of the f32 reference), at the top level of the line: for the dtype the line is
-    # quoted on, and -- next to it -- the configuration that meets the bar with its own throughput.
+    # North-star parity bar (mask logits within 1e-3 of the f32 reference), at the top level of the line for THIS line's configuration, and for every
+    # configuration in `configurations` with its own throughput.
     BAR = 1e-3
     par = (cpu or {}).get("parity_full_size") or {}
-    own = par if a.half == "bf16" else par.get("f16_operands") or {}
+    tl = par.get("trained_like_weights") or {}
+    own = par.get(PARITY_KEY[mine]) or {}
     logit_max_abs = own.get("logit_max_abs")
-    own_tl = (par.get("trained_like_weights") or {}).get("bf16" if a.half == "bf16" else "f16_operands") or {}
-    bar_meeting, f16_vs_bf16 = None, None
-    if par.get("f16_operands") and f16_children:
-        cands = []
-        for ch in f16_children:
-            pf = par["f16_operands"] if ch["residual_stream"] == "f32" else par.get("f16_operands_f16_stream") or {}
-            if not pf:
-                continue
-            tlw = (par.get("trained_like_weights") or {}).get("f16_operands" if ch["residual_stream"] == "f32" else "f16_operands_f16_stream") or {}
-            cands.append({"dtype": "f16", "residual_stream": ch["residual_stream"], "value": ch["value"], "unit": "images/s", "ms_per_step": ch["ms_per_step"],
-                          "logit_max_abs": pf["logit_max_abs"], "key_rel_l2": pf["key_rel_l2"], "mask_flipped_fraction": pf["mask_flipped_fraction"],
-                          "bar": BAR, "bar_met": bool(pf["logit_max_abs"] <= BAR), "margin": round(BAR / max(pf["logit_max_abs"], 1e-12), 2),
-                          # the same engine on trained-like synthetic weights (peaked attention, massive channels): the honest figure for a real checkpoint
-                          "trained_like_weights": {k: tlw.get(k) for k in ("logit_max_abs", "logit_rel_l2", "key_rel_l2", "mask_flipped_fraction")},
-                          "bar_met_on_trained_like_weights": (None if not tlw else bool(tlw["logit_max_abs"] <= BAR)),
-                          "ln_fold": ch.get("ln_fold"),
-                          "engine": f"ViTEngine(half='f16', resid='{ch['resid']}')" + (" with LayerNorm folded into the QKV / fc1 GEMMs" if ch.get("ln_fold") else "")})
-        met = [c_ for c_ in cands if c_["bar_met"]]
-        if met:
-            bar_meeting = dict(max(met, key=lambda c_: c_["value"]))       # the fastest configuration under the bar
-            bar_meeting["what"] = ("libucod_dpl_f16.so: IEEE fp16 GEMM / attention operands (what the reference's fp16-autocast launcher multiplies in, "
-                                   "scripts/launch_train_first_stage.sh:20), same kernels, same schedule, own process")
-            bar_meeting["all_f16_configurations"] = cands
-        # why the fp16-operand build is slower than the bf16 one: per kernel class, same serial pass, own processes on this box
-        ch = next((c_ for c_ in f16_children if c_["residual_stream"] == ("fp16" if resid16 else "f32")), f16_children[-1])
-        f16_vs_bf16 = {"residual_stream_of_both": ch["residual_stream"],
-                       "avg_us_bf16_vs_f16": {k: [kernels[k]["avg_us"], ch["kernels_avg_us"].get(k)] for k in kernels if k in ch["kernels_avg_us"]
-                                              and kernels[k]["ms_per_step"] > 0.05},
-                       "what": "same step, same residual-stream type, serial pass with HIP events: the fp16 MFMA kernels run longer at equal cycles (the chip "
-                               "holds a lower clock on fp16 operands: profiles/r03_f16_vs_bf16_*), the f32 residual stream costs the out-proj / fc2 "
-                               "epilogues and LayerNorm their extra bytes"}
+    own_tl = tl.get(PARITY_KEY[mine]) or {}
     ips = world * B * a.steps / dt
+
+    def describe(name, value, ms, extra):
+        pf, tlw = par.get(PARITY_KEY[name]) or {}, tl.get(PARITY_KEY[name]) or {}
+        half, resid = CONFIGS[name]
+        d_ = {"value": value, "unit": "images/s", "ms_per_step": ms, "dtype": half,
+              "engine": f"ViTEngine(half='{half}', resid='{resid}')" + (" with LayerNorm folded into the QKV / fc1 GEMMs" if extra.get("ln_fold") else ""), **extra}
+        if pf:
+            d_.update({"logit_max_abs": pf["logit_max_abs"], "key_rel_l2": pf["key_rel_l2"], "mask_flipped_fraction": pf["mask_flipped_fraction"], "bar": BAR,
+                       "bar_met": bool(pf["logit_max_abs"] <= BAR), "margin": round(BAR / max(pf["logit_max_abs"], 1e-12), 2),
+                       # the same engine on trained-like synthetic weights (peaked attention, massive channels): the honest figure for a real checkpoint
+                       "trained_like_weights": {k: tlw.get(k) for k in ("logit_max_abs", "logit_rel_l2", "key_rel_l2", "mask_flipped_fraction")},
+                       "bar_met_on_trained_like_weights": (None if not tlw else bool(tlw["logit_max_abs"] <= BAR))})
+        return d_
+
+    configurations = {mine: describe(mine, round(ips, 2), round(dt / a.steps * 1e3, 3), {"residual_stream": "fp16" if resid16 else "f32", "ln_fold": ln_fold, "this_line": True})}
+    for name, o in others.items():
+        configurations[name] = describe(name, o["value"], o["ms_per_step"], {k: o[k] for k in ("residual_stream", "ln_fold", "serial_ms_per_step", "how")})
+    met = [c_ for c_ in configurations.values() if c_.get("bar_met")]
+    bar_meeting = dict(max(met, key=lambda c_: c_["value"])) if met else None       # the fastest configuration under the bar
+    # why fp16 operands cost clock: per kernel class, same serial pass, own processes on this box (bf16 against fp16 operands on the same stream type)
+    f16_vs_bf16 = None
+    pair = ("bf16", "f16_f16_stream")
+    if all(n_ == mine or n_ in others for n_ in pair):
+        ka = {n_: ({k: v["avg_us"] for k, v in kernels.items()} if n_ == mine else others[n_]["kernels_avg_us"]) for n_ in pair}
+        f16_vs_bf16 = {"avg_us_bf16_vs_f16": {k: [ka["bf16"][k], ka["f16_f16_stream"].get(k)] for k in ka["bf16"] if k in ka["f16_f16_stream"] and ka["bf16"][k] > 20},
+                       "what": "same step on the fp16 residual stream, serial pass with HIP events: the fp16 MFMA kernels run longer at equal cycles (the chip holds a lower "
+                               "clock on fp16 operands: profiles/r03_f16_vs_bf16_*); the fp16 build has no LayerNorm launches (folded into QKV / fc1, whose "
+                               "epilogues carry the two per-row scalars instead)"}
     out = {
         "metric": "training images/sec at 3x518x518, DINOv2-B (frozen backbone fwd + DBA/APM/discriminator train step)",
         "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -450,7 +458,11 @@ def main():
         # the reference's OWN fp16-autocast forward against its f32 forward (emulated on the CPU oracle): [random-init weights, trained-like weights]
         "logit_max_abs_of_reference_fp16_autocast": [((par or {}).get("reference_fp16_autocast_emulation") or {}).get("logit_max_abs"),
                                                      (((par or {}).get("trained_like_weights") or {}).get("reference_fp16_autocast_emulation") or {}).get("logit_max_abs")],
-        "bar_meeting_config": bar_meeting, "f16_vs_bf16_per_kernel": f16_vs_bf16,
+        # throughput of the fastest configuration that MEETS the bar on the flat-init weights (None: no configuration measured / none meets it), and whether that
+        # configuration also meets it on the trained-like weights (say what the numbers mean)
+        "value_at_bar": (bar_meeting or {}).get("value"), "value_at_bar_config": (bar_meeting or {}).get("engine"),
+        "value_at_bar_met_on_trained_like_weights": (bar_meeting or {}).get("bar_met_on_trained_like_weights"),
+        "configurations": configurations, "bar_meeting_config": bar_meeting, "f16_vs_bf16_per_kernel": f16_vs_bf16,
         "host_enqueue_ms_per_step": round(host_enqueue / a.steps * 1e3, 3), "host_threads": host_threads, "host_cores_pinned": pinned_cores,
         "ranks_seen": ranks_seen,
         "config": {"workload": f"{which_config(a.arch, a.image, B, a.attn_variant)}: {a.arch} @{a.image}x{a.image}, batch {B}/GPU, full APM+DBA+discriminator step, "
@@ -460,7 +472,7 @@ def main():
                    "schedule": "serial, one stream" if a.no_pipeline else
                                f"backbone pass of step k+1 on {a.streams} side stream(s) overlapped with the decoder step of step k"},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "final_loss": round(final_loss, 6),
-        "backbone_backward_mode": lora_mode, "discriminator_phase": dis_phase, "f16_operands_option": f16_option,
+        "backbone_backward_mode": lora_mode, "discriminator_phase": dis_phase,
     }
     print(json.dumps(out))
 
@@ -655,8 +667,10 @@ def cpu_baseline(a, D, heads, L, P):
     # feature_extractor.trained_like_state_dict) -- the regime a real checkpoint puts the kernels in; the random init above is the flattest.
     from ucod_dpl_amd.data.utils.feature_extractor import trained_like_state_dict
     if v1:                                                      # (the trained-like recipe scales LayerScale and the HF key names: DINOv2 only)
+        f16s = parity("f16", "f16")
         out["parity_full_size"] = {"what": f"{n} images at {a.image}x{a.image}, {a.arch}: device backbone + f32 device decoder vs the f32 oracle "
-                                           f"(same random-init weights); north-star bar: logit max-abs <= 1e-3", **parity("bf16"), "f16_operands": parity("f16")}
+                                           f"(same random-init weights); north-star bar: logit max-abs <= 1e-3", "bf16": parity("bf16"), "f16_operands": parity("f16"),
+                                   "f16_operands_f16_stream": f16s, "f16_operands_f16_stream_unfolded": f16s if not f16s["ln_fold"] else parity("f16", "f16", ln_fold=False)}
         return out
     sd_p = trained_like_state_dict(a.arch, 0, a.image)
     with torch.no_grad():
@@ -678,7 +692,7 @@ def cpu_baseline(a, D, heads, L, P):
     out["parity_full_size"] = {
         "what": f"{n} images at {a.image}x{a.image}, {a.arch}: device backbone + f32 device decoder vs the f32 oracle (same random-init weights); "
                 f"north-star bar: logit max-abs <= 1e-3",
-        **parity("bf16"),
+        "bf16": parity("bf16"),
         "reference_fp16_autocast_emulation": autocast_deviation(sd, key, fg_ref),
         "f16_operands": parity("f16"),                            # engine default for fp16 operands: f32 residual stream
         "f16_operands_f16_stream": parity("f16", "f16"),            # (LayerNorm folded into QKV / fc1: the engine's default for this pair)

@@ -38,7 +38,9 @@ extern "C" {
 /* 3 (round 4): ucod_disc_params gained `nbt`; ucod_step_loss, ucod_disc_bce, the feature-branch discriminator's backward entry points and
  * the assembly attention variants (ucod_attention_fwd variant 64 / 32 / 5) were added. */
 /* 4 (round 5): LayerNorm folded into its consumer GEMMs -- epilogues 11 - 14, ucod_gemm_lnfold, ucod_gemm_bf16_stats, ucod_cls_rows_h16_stats,
- * ucod_row_stats_h16, ucod_vit_desc.ln_fold, UCOD_VIT_LAYER_STRIDE 14 -> 16 (two column-sum slots per layer). */
+ * ucod_row_stats_h16, ucod_vit_desc.ln_fold, UCOD_VIT_LAYER_STRIDE 14 -> 16 (two column-sum slots per layer); ucod_zero_segments,
+ * ucod_accumulators_prezeroed, the *_multi forms of the Look-Twice crop / paste; the assembly attention variants 64 / 32 of ucod_attention_fwd and the
+ * UCOD_ATTN_ASM switch LEFT the product library (laboratory: ucod_attention_fwd_asm_lab of libucod_dpl_variants.so). */
 #define UCOD_ABI_VERSION 4
 int ucod_abi_version(void);
 /* 1 when a gfx950 device is visible to this process (hipGetDeviceProperties().gcnArchName) */
@@ -152,7 +154,7 @@ int ucod_layernorm_h16(const void* x_f16, const float* gamma, const float* beta,
  * scale == 0 declares that Q already carries head_dim^-0.5 * log2(e) (ucod_fill_qscale + the QKV epilogue scale do that inside
  * ucod_vit_forward) and selects the product kernel: K/V by buffer loads to LDS, -m as the score accumulator's initial value, deferred
  * max, probabilities fed back as MFMA operands from registers, f32 row sums, 16-byte output stores; query rows and 32-key blocks past
- * the last token are not computed.  variant: 0 or 2 (the same kernels); every other number is a laboratory variant
+ * the last token are not computed.  variant: 0 or 2 (the same kernels), 5 / 66 = attn_fwd_v5_kernel / attn_fwd_v6_kernel by name; every other number is a laboratory variant
  * (ucod_attention_fwd_lab of libucod_dpl_variants.so) and is refused.  tok * heads * 384 must fit 32 bits. */
 int ucod_attention_fwd(const void* qkv_bf16, void* out_bf16, int B, int tok, int heads, float scale, int variant,
                        void* stream);
@@ -297,8 +299,8 @@ typedef struct {
   float eps;              /* LayerNorm eps (1e-6 for DINOv2 / DINO) */
   int full_last_layer;
   int gemm_variant;       /* ucod_gemm_bf16's variant for every GEMM of the pass (0 = auto) */
-  int attn_variant;       /* 0 (auto) / 2: pre-scaled-Q product kernel; 1: generic-scale kernel; 8: the fp8 path of BASELINE configs[4];
-                             anything else is refused (UCOD_EINVAL) */
+  int attn_variant;       /* 0 (auto) / 2: pre-scaled-Q product kernel; 1: generic-scale kernel; 8: the fp8 path of BASELINE configs[4]; 5 / 66: the
+                             two pre-scaled-Q kernels by name; anything else is refused (UCOD_EINVAL) */
   int resid16;            /* 1: the residual stream x lives in IEEE fp16 instead of f32 (11 significand bits: 8x finer than the bf16 GEMM
                              operands it feeds, so the bf16 build's accuracy is unchanged to its own rounding).  Halves the bytes of
                              LayerNorm's read and of the out-proj / fc2 read-modify-write epilogues.  Values saturate at +-65504 and every
@@ -444,6 +446,16 @@ int ucod_step_loss(const float* losses, const float* extra, int finetune, float*
 /* dst[q][0..n[q]) = src[q][0..n[q]) for q < count <= 4, one launch (host arrays of device pointers / element counts; f32).  What
  * loop_UCOD_DPL.py's refresh of the shared student | teacher projection needs per step instead of four device-to-device copies. */
 int ucod_copy_segments(float* const* dst, const float* const* src, const size_t* n, int count, void* stream);
+/* One launch that zeroes up to eight device regions (HOST arrays of DEVICE pointers and byte counts, 4-byte aligned): the accumulating outputs of a
+ * whole step at once.  Together with ucod_accumulators_prezeroed it replaces the memset each accumulating entry point otherwise issues in front of
+ * its kernel (round 4: seven rocclr fills among the ~125 launches of a student step). */
+int ucod_zero_segments(void* const* dst, const size_t* bytes, int count, void* stream);
+/* on != 0: for the calls issued NEXT FROM THIS HOST THREAD the caller guarantees that these outputs are already zero (ucod_zero_segments), and the entry
+ * points skip their own memset: `sdiag` of ucod_dba_heads_fwd, `losses` of ucod_apm_bce, g_head_w / g_head_b / g_dec_bias of ucod_dba_bwd, `gW` of
+ * ucod_dba_wgrad / ucod_dba_wgrad_split, and the last 112 doubles of ucod_disc_fwd's `saved` buffer (its BatchNorm sums -- which every ucod_disc_fwd call
+ * also LEAVES zero, so a saved buffer that was allocated zeroed stays valid call after call).  Host-side state, like ucod_resid16_overflow_bind: set it,
+ * issue the step, clear it. */
+int ucod_accumulators_prezeroed(int on);
 int ucod_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float ema_alpha, void* stream);
 

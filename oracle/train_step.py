@@ -85,7 +85,7 @@ def update_ema(state):
     return alpha
 
 
-def process_batch(state, features, pseudo_labels, orth="gram", extra_leaves=None):
+def process_batch(state, features, pseudo_labels, orth="gram", extra_leaves=None, grad_sync=None):
     """loop_UCOD_DPL.py:148-184.  features [B,C,h,w], pseudo_labels [B,1,ph,pw].
     Returns dict(loss, dis_loss, extra, w, merged, fg, bg, teacher, grads, alpha, lr).
     ``extra_leaves``: tensors upstream of ``features`` (backbone-backward mode, SURVEY.md 8a row B9: the LoRA matrices,
@@ -111,6 +111,8 @@ def process_batch(state, features, pseudo_labels, orth="gram", extra_leaves=None
     grads = dict(zip(p.keys(), allg[:len(p)]))
     extra_grads = [torch.zeros_like(t) if g is None else g for t, g in zip(extra_leaves, allg[len(p):])]
     lr_used = state.opt.lr
+    if grad_sync is not None:                            # data parallel: the mean over ranks of the per-rank gradients, see run()
+        grads = grad_sync(grads)
     with torch.no_grad():
         state.opt.step(state.dec, grads)
         state.sched.step()
@@ -120,7 +122,7 @@ def process_batch(state, features, pseudo_labels, orth="gram", extra_leaves=None
                 bg=bg.detach(), teacher=teacher, grads=grads, alpha=alpha, lr=lr_used, p_s=p_s, p_p=p_p, extra_grads=extra_grads)
 
 
-def discriminator_batch(state, features, pseudo_labels):
+def discriminator_batch(state, features, pseudo_labels, grad_sync=None):
     """loop_UCOD_DPL.py:232-252 for one batch (discriminator trainable, student frozen)."""
     c = state.cfg
     fs = c["feature_size"]
@@ -140,6 +142,8 @@ def discriminator_batch(state, features, pseudo_labels):
     loss = bce_mean(torch.cat((probs_student, probs_pseudo), 0), label)
     gl = torch.autograd.grad(loss, [leaf[k] for k in names])
     grads = dict(zip(names, gl))
+    if grad_sync is not None:
+        grads = grad_sync(grads)
     with torch.no_grad():
         for k in sd:                                     # carry the mutated running statistics back
             if k not in leaf:
@@ -149,13 +153,16 @@ def discriminator_batch(state, features, pseudo_labels):
     return dict(loss=loss.detach(), grads=grads, probs_student=probs_student.detach(), probs_pseudo=probs_pseudo.detach())
 
 
-def run(state, loader, dis_intertrain, dis_epoch=1, merge_method="dis", on_event=None, orth="gram"):
+def run(state, loader, dis_intertrain, dis_epoch=1, merge_method="dis", on_event=None, orth="gram", grad_sync=None):
     """loop_UCOD_DPL.py:94-118 (TrainLoop.run) with :120-146 (run_epoch), :193-213 (decide_to_train_dis / decide_to_finetune) and :215-227
     (Discriminator_train) -- validation and saving left out.  ``loader``: list of (features, pseudo_labels).  ``state.cfg`` carries max_epoch and
     start_finetune.  At the finetune epoch the runner REBUILDS both optimisers and schedulers (engine/runner/runner.py:378-379 -> :276-311: fresh
     moments, step counts and learning rates) and the loop resets ``global_step`` (:101-103); the discriminator phase runs before every
     ``dis_intertrain``-th epoch while not finetuning.  ``on_event(tag)`` is called after every discriminator phase ("dis<epoch>") and after every
-    epoch ("epoch<epoch>", the index of the epoch just run).  Returns the per-batch losses."""
+    epoch ("epoch<epoch>", the index of the epoch just run).  Returns the per-batch losses.
+    ``grad_sync(grads) -> grads``: the data-parallel form (BASELINE configs[2] is "N ranks x B == the global batch seen as N per-rank
+    BatchNorm groups"): every rank runs this function on ITS shard with its own discriminator buffers, and ``grad_sync`` replaces each gradient dict by
+    the mean over ranks before the optimiser step -- what the build's one all-reduce of the pre-scaled gradient arena does."""
     c = state.cfg
     losses = []
     while state.cur_epoch < c["max_epoch"]:
@@ -166,11 +173,11 @@ def run(state, loader, dis_intertrain, dis_epoch=1, merge_method="dis", on_event
         if merge_method == "dis" and state.cur_epoch % dis_intertrain == 0 and not state.finetune:    # decide_to_train_dis
             for _ in range(dis_epoch):
                 for feats, pl in loader:
-                    discriminator_batch(state, feats, pl)
+                    discriminator_batch(state, feats, pl, grad_sync=grad_sync)
             if on_event:
                 on_event(f"dis{state.cur_epoch}")
         for feats, pl in loader:                                           # run_epoch
-            losses.append(float(process_batch(state, feats, pl, orth=orth)["loss"]))
+            losses.append(float(process_batch(state, feats, pl, orth=orth, grad_sync=grad_sync)["loss"]))
             state.global_step += 1                                         # :143
         if on_event:
             on_event(f"epoch{state.cur_epoch}")

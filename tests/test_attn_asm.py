@@ -13,7 +13,7 @@ from tools.attn_asm import run_sim, gen_attn, gen_attn32
 from tools.attn_asm.checks import audit
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ASM = os.path.join(ROOT, "ucod_dpl_amd", "csrc", "asm")
+ASM = os.path.join(ROOT, "ucod_dpl_amd", "csrc", "variants", "asm")
 
 
 @pytest.mark.parametrize("kernel,dtype,tol", [("pw64", "bf16", 4e-3), ("pw64", "f16", 6e-4), ("pw32", "bf16", 4e-3)])
@@ -71,9 +71,8 @@ def test_simulator_flags_a_missing_wait():
 
 
 @pytest.mark.parametrize("fname,text", [("attn_fwd_pw64_bf16.s", lambda: gen_attn.kernel_text("bf16")[0]),
-                                        ("attn_fwd_pw64_f16.s", lambda: gen_attn.kernel_text("f16")[0]),
                                         ("attn_fwd_pw32_bf16.s", lambda: gen_attn32.kernel_text("bf16")[0])])
 def test_committed_assembly_is_current(fname, text):
     with open(os.path.join(ASM, fname)) as f:
         committed = f.read().split("\n", 1)[1]          # first line: the GENERATED banner
-    assert committed == text(), f"{fname} is stale: run `make -C ucod_dpl_amd/csrc`"
+    assert committed == text(), f"{fname} is stale: run `make -C ucod_dpl_amd/csrc variants`"

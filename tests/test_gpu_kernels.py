@@ -234,13 +234,20 @@ def test_attention(variant, B, tok, heads):
     assert rel_l2(out, ref) < 1e-2
 
 
-@pytest.mark.parametrize("variant", [64, 32, 66])
+def _attn(qd, B, tok, heads, variant):
+    """variant 64 / 32: the laboratory assembly kernels (ops.attention_asm form 0 / 1); anything else: ops.attention"""
+    if variant in (64, 32):
+        return ops.attention_asm(qd, B, tok, heads, form=0 if variant == 64 else 1)
+    return ops.attention(qd, B, tok, heads, scale=0.0, variant=variant)
+
+
+@pytest.mark.parametrize("variant", [lab(64), lab(32), 66])
 @pytest.mark.parametrize("B,tok,heads", [(1, 200, 3), (2, 1370, 2), (3, 129, 2), (2, 300, 12), (1, 785, 6), (9, 257, 1)])
 def test_attention_assembly_kernels(B, tok, heads, variant):
-    """The hand-placed assembly kernels (variant 64: 4 waves x 64 rows, one wave per SIMD; 32: 8 waves x 32 rows, two per SIMD; generated by
-    tools/attn_asm, simulated on the CPU in tests/test_attn_asm.py): same contract as the product kernel.  Shapes: rows past N in the only
-    item (200), the C2 token count, three tiles exactly (129), several items per workgroup (12 heads x 2 images on 8 groups; 9 images of one
-    head), 785 = ViT-S/8 at 224.  Deterministic (no atomics): a second launch is bitwise equal."""
+    """The hand-placed assembly kernels (64: 4 waves x 64 rows, one wave per SIMD; 32: 8 waves x 32 rows, two per SIMD; generated by tools/attn_asm,
+    simulated on the CPU in tests/test_attn_asm.py; laboratory library since round 5) and attn_fwd_v6_kernel (66): same contract as the product kernel.
+    Shapes: rows past N in the only item (200), the C2 token count, three tiles exactly (129), several items per workgroup (12 heads x 2 images on 8
+    groups; 9 images of one head), 785 = ViT-S/8 at 224.  Deterministic (no atomics): a second launch is bitwise equal."""
     g = torch.Generator().manual_seed(tok * 5 + heads)
     D = heads * 64
     qkv = torch.randn(B * tok, 3 * D, generator=g) * 1.5
@@ -250,10 +257,10 @@ def test_attention_assembly_kernels(B, tok, heads, variant):
     p = torch.softmax(torch.matmul(q, k.transpose(2, 3)) * math.log(2.0), dim=-1)
     ref = torch.matmul(p, v).transpose(1, 2).reshape(B * tok, D).float()
     qd = qkv.to(DEV)
-    out = ops.attention(qd, B, tok, heads, scale=0.0, variant=variant).float().cpu()
+    out = _attn(qd, B, tok, heads, variant).float().cpu()
     assert maxdiff(out, ref) < 2.5e-2, maxdiff(out, ref)
     assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)          # measured 2.0-2.3e-3 (bf16 probabilities)
-    assert torch.equal(out, ops.attention(qd, B, tok, heads, scale=0.0, variant=variant).float().cpu())
+    assert torch.equal(out, _attn(qd, B, tok, heads, variant).float().cpu())
     prod = ops.attention(qd, B, tok, heads, scale=0.0, variant=5).float().cpu()
     assert maxdiff(out, prod) < 4e-2          # two bf16 roundings of the same value: up to 2 ulp at |out| ~ 4
 
@@ -279,52 +286,39 @@ def test_attention_v6_small_and_boundary_token_counts(B, tok, heads):
     assert maxdiff(out, ops.attention(qd, B, tok, heads, scale=0.0, variant=5).float().cpu()) < 4e-2
 
 
+@pytest.mark.variants
+@_NEEDS_LAB
 def test_attention_assembly_kernels_refuse_what_they_cannot_do():
     qkv = torch.zeros(64, 192, dtype=torch.bfloat16, device=DEV)
     out = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)
+    lab_lib = N.load_lab()
+    for form in (0, 1):
+        assert lab_lib.ucod_attention_fwd_asm_lab(qkv.data_ptr(), out.data_ptr(), None, 1, 64, 1, form, None) == -1        # fewer than three key tiles
     lib = N.load()
-    for variant in (64, 32):
-        assert lib.ucod_attention_fwd(qkv.data_ptr(), out.data_ptr(), 1, 64, 1, 0.0, variant, None) == -1        # fewer than three key tiles
-        assert lib.ucod_attention_fwd(qkv.data_ptr(), out.data_ptr(), 1, 64, 1, 0.125, variant, None) == -1      # generic scale
+    for variant in (64, 32):                                       # ... and the product entry no longer knows them (round 5)
+        assert lib.ucod_attention_fwd(qkv.data_ptr(), out.data_ptr(), 1, 64, 1, 0.0, variant, None) == -1
 
 
+@pytest.mark.variants
+@_NEEDS_LAB
 def test_attention_assembly_lse_path():
-    """UCOD_ATTN_ASM is read once per process: the LSE entry (backbone-backward mode) with the assembly kernel runs in a child process"""
-    import subprocess, sys, os
-    env = dict(os.environ, UCOD_ATTN_ASM="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_asm", "gpu_check.py"), "lse"], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [x for x in r.stdout.splitlines() if x.startswith("lse path")][-1]
-    out_err, lse_err = float(line.split("out max|err|")[1].split()[0]), float(line.split("lse max|err|")[1].split()[0])
-    assert "rc 0" in line and out_err < 2.5e-2 and lse_err < 1e-3, line
-
-
-@pytest.mark.parametrize("variant", [2] + [lab(v) for v in (3, 4, 6, 7, 9, 12, 13, 14, 15, 102)])
-@pytest.mark.parametrize("B,tok,heads", [(1, 26, 2), (2, 64, 1), (1, 200, 3), (2, 1370, 2), (1, 1, 1), (3, 129, 2)])
-def test_attention_prescaled_q_kernel(B, tok, heads, variant):
-    """The product kernel (variant 2): Q carries head_dim^-0.5*log2(e) already (scale=0 in the ABI); token counts that exercise the dead-wave
-    skip (26, 129, 200, 1370: query blocks past the last token), the masked last tile and the skipped second 32-key block (1370, 200, 129, 1),
-    and a full last tile (64).  Laboratory variants: 3 (K/V through registers) and 4 (LDS-DMA) share their arithmetic and must agree bit
-    for bit; 102 = the round-2 product kernel, which the round-3 kernel must reproduce bit for bit (same arithmetic; only work that
-    cannot contribute was removed, and the output stores were widened)."""
-    g = torch.Generator().manual_seed(tok * 3 + heads)
+    """the assembly kernels' optional base-2 log-sum-exp output (what ucod_attention_fwd_lse writes in the product) against an f64 softmax"""
+    B, tok, heads = 2, 300, 3
+    g = torch.Generator().manual_seed(31)
     D = heads * 64
-    qkv = torch.randn(B * tok, 3 * D, generator=g) * 1.5
+    qkv = torch.randn(B * tok, 3 * D, generator=g)
     qkv[:, :D] *= 0.125 * math.log2(math.e)
     qkv = bf(qkv)
-    q, k, v = (qkv.float()[:, i * D:(i + 1) * D].reshape(B, tok, heads, 64).transpose(1, 2) for i in range(3))
-    p = torch.softmax(torch.matmul(q, k.transpose(2, 3)) * math.log(2.0), dim=-1)
-    ref = torch.matmul(p, v).transpose(1, 2).reshape(B * tok, D)
-    qd = qkv.to(DEV)
-    out = ops.attention(qd, B, tok, heads, scale=0.0, variant=variant).float().cpu()
-    assert maxdiff(out, ref) < 3e-2, maxdiff(out, ref)
-    assert rel_l2(out, ref) < 1e-2
-    if variant in (3, 4):
-        assert torch.equal(out, ops.attention(qd, B, tok, heads, scale=0.0, variant=7 - variant).float().cpu())
-    if variant == 102:
-        assert torch.equal(out, ops.attention(qd, B, tok, heads, scale=0.0, variant=2).float().cpu())
-
+    x = qkv.double().reshape(B, tok, 3, heads, 64)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    sc = q @ k.transpose(2, 3)
+    m = sc.max(-1, keepdim=True).values
+    pr = torch.exp2(sc - m)
+    l = pr.sum(-1, keepdim=True)
+    ref_o, ref_l = ((pr / l) @ v).transpose(1, 2).reshape(B * tok, D), (m + torch.log2(l))[..., 0]
+    for form in (0, 1):
+        out, lse = ops.attention_asm(qkv.to(DEV), B, tok, heads, form=form, want_lse=True)
+        assert maxdiff(out.float().cpu(), ref_o) < 2.5e-2 and maxdiff(lse.cpu(), ref_l) < 1e-3, form
 
 def test_attention_prescaled_deferred_max_branches():
     """Force both branches of the deferred-max logic: (a) a late key that beats the running max by far more than THR
@@ -345,8 +339,8 @@ def test_attention_prescaled_deferred_max_branches():
         q, k, v = (x.float()[:, i * D:(i + 1) * D] for i in range(3))
         p = torch.softmax((q @ k.t()) * math.log(2.0), dim=-1)
         ref = p @ v
-        for variant in (2, 64, 32) + ((6, 7, 9, 12, 13, 14, 15) if N.have_lab() else ()):          # 64 / 32: the assembly kernels
-            out = ops.attention(x.to(DEV), 1, tok, 1, scale=0.0, variant=variant).float().cpu()
+        for variant in (2,) + ((64, 32, 6, 7, 9, 12, 13, 14, 15) if N.have_lab() else ()):          # 64 / 32: the assembly kernels (laboratory)
+            out = _attn(x.to(DEV), 1, tok, 1, variant).float().cpu()
             assert maxdiff(out, ref) < 3e-2, (variant, maxdiff(out, ref))
 
 

@@ -157,7 +157,11 @@ def test_patch_embedding_and_cls_rows_with_row_partials(B, tok, D, Kpad):
     rc = lib.ucod_gemm_bf16_stats(N.EPI_PATCH_TOKENS_H16_STATS, N.ptr(a), N.ptr(w), N.ptr(out), Mp, D, Kpad, N.ptr(b), None, None, N.ptr(pos), tok, N.ptr(part), D // 64, N.stream())
     assert rc == 0
     N.check(lib.ucod_cls_rows_h16_stats(N.ptr(out), N.ptr(cls), N.ptr(pos), N.ptr(part), D // 64, B, tok, D, N.stream()), "cls stats")
-    assert torch.equal(out, plain)
+    # (the plain launch may compute its leftover tiles as 16 x 32 patches -- another order of the f32 adds over K, gemm_bf16_tiles.h -- which the *_STATS launch
+    # never does: identical up to a last-bit difference in those tiles' rows; the CLS rows are bitwise equal)
+    differs = (out != plain)
+    assert float(differs.float().mean()) < 2e-3 and maxdiff(out.float().cpu(), plain.float().cpu()) <= 2.0 ** -9 * max(1.0, float(plain.abs().max()))
+    assert torch.equal(out.view(B, tok, D)[:, 0], plain.view(B, tok, D)[:, 0])
     xs = out.double().cpu()
     ps, pq = part[:, :, 0].double().cpu().sum(1), part[:, :, 1].double().cpu().sum(1)
     assert bool(torch.isfinite(part).all())

@@ -224,3 +224,110 @@ def test_eight_ranks_on_one_gpu_first_contact(tmp_path):
     assert sorted(r_[0] for r_ in d["ranks_seen"]) == list(range(8)) and sorted(r_[1] for r_ in d["ranks_seen"]) == list(range(8))
     assert d["host_cores_pinned"] == max(1, len(os.sched_getaffinity(0)) // 8)
     assert d["backbone_backward_mode"]["value"] > 0 and d["discriminator_phase"]["value"] > 0
+
+
+# ------------------------------------------------------------------------------------------------ C3 as SURVEY 8(e) defines it, over a schedule
+def _schedule_cfg():
+    from test_gpu_train_step import _g18_cfg
+    cfg = _g18_cfg()
+    cfg.train_cfg["max_epoch"], cfg.train_cfg["start_finetune"] = 3, -1          # discriminator phase before epochs 0 and 2, finetune switch at epoch 2
+    return cfg
+
+
+def _schedule_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      UCOD_SINGLE_DEVICE="1", UCOD_DIST_BACKEND="gloo")
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ucod_dpl_amd.engine.runner import StandardRunner, TrainLoop
+    from ucod_dpl_amd import parallel
+    g = load_golden("g18_train_schedule")
+    runner = StandardRunner(_schedule_cfg())
+    dev = runner.device
+    if rank == 0:
+        runner.model.load_state_dict({k: v.to(dev) for k, v in sub(g, "model0.").items()}, strict=True)
+        runner.discriminator.load_state_dict({k: v.to(dev) for k, v in sub(g, "disc0.").items()}, strict=True)
+    bn = [b.layers[1] for b in (runner.discriminator.maskConv, runner.discriminator.convs[0], runner.discriminator.convs[1])]
+    parallel.broadcast_state([runner.arena.p, runner.arena.ema, runner.disc_arena.p] + [m.running_mean for m in bn] + [m.running_var for m in bn])
+    per = 4 // world
+    runner.train_dataloader = [{"pseudo_label": g[f"pl{i}"][rank * per:(rank + 1) * per], "label_tensor": torch.zeros(1),
+                                "features": g[f"features{i}"][rank * per:(rank + 1) * per], "img_path": ["x"]} for i in range(3)]
+    loop = TrainLoop(runner.config, runner)
+    loop.run()
+    torch.cuda.synchronize()
+    torch.save(dict(model={k: v.detach().cpu() for k, v in runner.model.state_dict().items()},
+                    disc={k: v.detach().cpu() for k, v in runner.discriminator.state_dict().items()},
+                    lr=runner.optimizer.param_groups[0]["lr"], dis_lr=runner.dis_optimizer.param_groups[0]["lr"], global_step=loop.global_step), out + str(rank))
+    torch.distributed.destroy_process_group()
+
+
+def _oracle_two_groups(g, world=2):
+    """BASELINE configs[2]'s parity definition on the CPU oracle: `world` per-rank states run oracle.train_step.run in lockstep threads,
+    each on its shard with its own BatchNorm buffers; before every optimiser step the gradient dicts are replaced by their mean over ranks."""
+    import threading
+    from oracle import train_step as OT
+    cfg = dict(feature_size=12, ema_weight=0.99, lr0=6e-4, dis_lr0=1e-3, step_lr_size=2, step_lr_gamma=0.95, dis_step_lr_size=2, dis_step_lr_gamma=0.95,
+               max_epoch=3, start_finetune=-1)
+    states = [OT.TrainState(sub(g, "model0.decoder."), sub(g, "model0.decoder_ema."), sub(g, "disc0."), cfg) for _ in range(world)]
+    per = 4 // world
+    barrier, slots, errors = threading.Barrier(world), [None] * world, []
+
+    def sync_for(r):
+        def sync(grads):
+            slots[r] = grads
+            barrier.wait()
+            mean = {k: (None if slots[0][k] is None else sum(s[k] for s in slots) / world) for k in grads}
+            barrier.wait()
+            return mean
+        return sync
+
+    def work(r):
+        try:
+            loader = [(g[f"features{i}"][r * per:(r + 1) * per], g[f"pl{i}"][r * per:(r + 1) * per]) for i in range(3)]
+            OT.run(states[r], loader, dis_intertrain=2, dis_epoch=1, grad_sync=sync_for(r))
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(e)
+            barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    return states
+
+
+def test_two_ranks_run_the_schedule_like_the_global_batch_in_two_batchnorm_groups(tmp_path):
+    """BASELINE configs[2] over a schedule: two real ranks (gloo, one GPU) x 2 images run the build's TrainLoop.run() -- a discriminator epoch, two epochs,
+    the finetune switch with rebuilt optimisers, another epoch -- and end with IDENTICAL decoder / EMA / discriminator parameters that equal the oracle's
+    "global batch of 4 seen as two per-rank BatchNorm groups" run (gradients averaged before every optimiser step); BatchNorm running statistics stay
+    per rank, in the build as in the oracle (the reference has no SyncBN and discards its DDP wrapper, engine/runner/runner.py:357-369)."""
+    out = str(tmp_path / "sched")
+    mp.start_processes(_schedule_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(out + "0"), torch.load(out + "1")
+    for k in r0["model"]:
+        assert torch.equal(r0["model"][k], r1["model"][k]), k
+    for k in r0["disc"]:
+        if "running" not in k:
+            assert torch.equal(r0["disc"][k], r1["disc"][k]), k
+    assert any(not torch.equal(r0["disc"][k], r1["disc"][k]) for k in r0["disc"] if "running" in k)        # per-rank statistics really are per rank
+    g = load_golden("g18_train_schedule")
+    states = _oracle_two_groups(g)
+    assert r0["global_step"] == states[0].global_step and abs(r0["lr"] - states[0].opt.lr) < 1e-12 and abs(r0["dis_lr"] - states[0].dis_opt.lr) < 1e-12
+    from conftest import within
+    worst = {"dec": 0.0, "disc": 0.0, "bn": 0.0}
+    for k, v in states[0].dec.items():
+        if k != "learnable_embedding":
+            worst["dec"] = max(worst["dec"], maxdiff(r0["model"]["decoder." + k], v), maxdiff(r0["model"]["decoder_ema." + k], states[0].ema[k]))
+    for r, got in enumerate((r0, r1)):
+        for k, v in states[r].disc.items():
+            if "num_batches" in k:
+                assert int(got["disc"][k]) == int(v), k
+            else:
+                kind = "bn" if "running" in k else "disc"
+                worst[kind] = max(worst[kind], maxdiff(got["disc"][k], v))
+    within("c3_schedule_decoder", worst["dec"], 2e-3)
+    within("c3_schedule_disc", worst["disc"], 2e-3)
+    within("c3_schedule_bn", worst["bn"], 2e-3)

@@ -21,9 +21,6 @@
 
 namespace ucod {
 
-#ifndef UCOD_ATTN_ASM_DEFAULT
-#define UCOD_ATTN_ASM_DEFAULT 0
-#endif
 constexpr int HD = 64;        // head dim
 constexpr int QT = 128;       // query rows per workgroup
 constexpr int KT = 64;        // keys per tile
@@ -795,21 +792,6 @@ __global__ __launch_bounds__(256, 2) void attn_cross96_kernel(const bf16_raw* __
   }
 }
 
-bool attn_asm_eligible(int B, int tok, int heads);                                                     // attention_asm.hip
-int attn_asm_launch(const void* qkv, void* out, float* lse, int B, int tok, int heads, int form, hipStream_t stream);
-
-// UCOD_ATTN_ASM (read once): 0 / unset = attn_fwd_v5_kernel serves the pre-scaled-Q calls (the default: it has no score-range limit),
-// 1 = the one-wave-per-SIMD assembly kernel, 2 = the two-waves-per-SIMD one, wherever they are eligible.  Their running max is fixed at
-// an item's first 32 keys + 64: a row whose scores (log2 units) exceed that by more than 127 overflows -- 3-4 % faster on ViT-B/14
-// (profiles/r04_attention_asm_ab.txt), so opt-in.
-static int attn_asm_default() {
-  static const int mode = [] {
-    const char* e = getenv("UCOD_ATTN_ASM");
-    return e ? atoi(e) : UCOD_ATTN_ASM_DEFAULT;
-  }();
-  return mode;
-}
-
 }  // namespace ucod
 
 // variant: 0 / 2 = the product kernels (generic-scale when scale != 0, pre-scaled-Q when scale == 0).  Every other number is an
@@ -817,22 +799,10 @@ static int attn_asm_default() {
 extern "C" int ucod_attention_fwd(const void* qkv, void* out, int B, int tok, int heads, float scale, int variant, void* stream) {
   using namespace ucod;
   if (!qkv || !out || B <= 0 || tok <= 0 || heads <= 0) return UCOD_EINVAL;
-  if (variant != 0 && variant != 2 && variant != 64 && variant != 32 && variant != 5 && variant != 66) return UCOD_EINVAL;
+  if (variant != 0 && variant != 2 && variant != 5 && variant != 66) return UCOD_EINVAL;      // 5 = attn_fwd_v5_kernel by name (what 0 / 2 select with scale == 0)
   if ((size_t)tok * heads * HD * 3 * 2 >= (1ull << 32)) return UCOD_EINVAL;       // per-image qkv rows are addressed with 32-bit byte offsets
-  // variant 64 / 32 = the assembly kernels (4 waves x 64 rows, one wave per SIMD / 8 waves x 32 rows, two per SIMD; refused where they do
-  // not apply), 5 = attn_fwd_v5_kernel whatever the default, 0 / 2 = the default
-  if ((variant == 64 || variant == 32) && (scale != 0.f || !attn_asm_eligible(B, tok, heads))) return UCOD_EINVAL;
-#ifdef UCOD_HALF_F16
-  if (variant == 32) return UCOD_EINVAL;
-#endif
   UCOD_PROF(PROF_ATTN, stream);
-  int form = variant == 64 ? 0 : variant == 32 ? 1 : -1;
   if (variant == 66 && scale != 0.f) return UCOD_EINVAL;         // 66 = attn_fwd_v6_kernel by name (64 query rows per wave)
-  if (form < 0 && variant != 5 && variant != 66 && scale == 0.f && attn_asm_default() > 0 && attn_asm_eligible(B, tok, heads)) form = attn_asm_default() == 2 ? 1 : 0;
-#ifdef UCOD_HALF_F16
-  if (form == 1) form = 0;
-#endif
-  if (form >= 0) return attn_asm_launch(qkv, out, nullptr, B, tok, heads, form, (hipStream_t)stream);
   if (scale == 0.f && variant == 66) {
     const int npairs = B * heads, nq6 = cdiv(tok, 256);
     hipLaunchKernelGGL(attn_fwd_v6_kernel, dim3(cdiv(npairs, 8) * 8 * nq6), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads,
@@ -866,13 +836,6 @@ extern "C" int ucod_attention_fwd_lse(const void* qkv, void* out, float* lse, in
   if (!qkv || !out || !lse || B <= 0 || tok <= 0 || heads <= 0) return UCOD_EINVAL;
   if ((size_t)tok * heads * HD * 3 * 2 >= (1ull << 32)) return UCOD_EINVAL;
   UCOD_PROF(PROF_ATTN, stream);
-  if (attn_asm_default() > 0 && attn_asm_eligible(B, tok, heads)) {
-    int form = attn_asm_default() == 2 ? 1 : 0;
-#ifdef UCOD_HALF_F16
-    form = 0;
-#endif
-    return attn_asm_launch(qkv, out, lse, B, tok, heads, form, (hipStream_t)stream);
-  }
   const int npairs = B * heads, nq = cdiv(tok, QT);
   hipLaunchKernelGGL(attn_fwd_v5_kernel, dim3(cdiv(npairs, 8) * 8 * nq), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)qkv, (bf16_raw*)out, tok, heads, npairs,
                      lse);

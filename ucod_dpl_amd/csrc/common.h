@@ -148,6 +148,9 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // device address of the f16-residual-stream saturation counter of the current device (vit_misc.hip)
 unsigned* resid16_overflow_counter();
+// ucod_accumulators_prezeroed (elementwise.hip): the caller has zeroed the accumulating outputs of the calls it issues next from this host thread
+// (one ucod_zero_segments launch per step instead of a memset in front of every producer)
+bool accumulators_prezeroed();
 
 // op classes for the optional event profiler (prof.hip); the first six follow the UCOD_EPI_* numbering
 enum ProfClass {

@@ -345,7 +345,7 @@ extern "C" int ucod_dba_heads_fwd(const float* d, int ld_c, int c0, const float*
   if (!d || !emb || !norm || !head_w || !head_b || !fg || B <= 0 || HW <= 0 || c0 < 0 || c0 + 128 > ld_c) return UCOD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   UCOD_PROF(PROF_DBA_HEADS, s);
-  if (sdiag) {
+  if (sdiag && !ucod::accumulators_prezeroed()) {
     hipError_t e = hipMemsetAsync(sdiag, 0, sizeof(float) * B, s);
     if (e != hipSuccess) return (int)e;
   }
@@ -386,8 +386,9 @@ extern "C" int ucod_dba_bwd(const float* d, int ld_c, int c0, const float* emb, 
   hipStream_t s = (hipStream_t)stream;
   float* gfeat = (float*)ws;
   UCOD_PROF(PROF_DBA_BWD, s);
-  hipError_t e;
-  if (g_head_w == g_dec_bias + 128 && g_head_b == g_head_w + 128) {      // the flat gradient arena (bias | head_w | head_b): one fill
+  hipError_t e = hipSuccess;
+  if (ucod::accumulators_prezeroed()) {                                  // (ucod_accumulators_prezeroed: the caller's one zero launch covered them)
+  } else if (g_head_w == g_dec_bias + 128 && g_head_b == g_head_w + 128) {      // the flat gradient arena (bias | head_w | head_b): one fill
     e = hipMemsetAsync(g_dec_bias, 0, sizeof(float) * 258, s);
   } else {
     e = hipMemsetAsync(g_head_w, 0, sizeof(float) * 128, s);

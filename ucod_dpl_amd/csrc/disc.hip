@@ -155,12 +155,16 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
 }
 
 // mean / biased variance from the f64 sums the conv kernel accumulated; writes (mean, rstd), updates the running buffers
-__global__ void bn_finalize_kernel(const double* __restrict__ gacc, int C, double n, float* __restrict__ stats,
+// (the sums are consumed here and nowhere else: they are left ZERO for the next call, so that a caller that keeps its `saved` buffer -- allocated
+// zeroed -- under ucod_accumulators_prezeroed never needs a memset in front of ucod_disc_fwd)
+__global__ void bn_finalize_kernel(double* __restrict__ gacc, int C, double n, float* __restrict__ stats,
                                    float* __restrict__ rmean, float* __restrict__ rvar, int update) {
   const int c = threadIdx.x;
   if (c >= C) return;
   const double mean = gacc[c] / n;
   double var = gacc[C + c] / n - mean * mean;
+  gacc[c] = 0.0;
+  gacc[C + c] = 0.0;
   var = var > 0.0 ? var : 0.0;
   stats[c] = (float)mean;
   stats[C + c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
@@ -214,8 +218,10 @@ extern "C" int ucod_disc_fwd(const float* mask, const ucod_disc_params* p, float
   double* ac1 = (double*)((char*)saved + acc_off_bytes(d));
   double* ac2 = ac1 + 64;
   double* ac3 = ac2 + 32;
-  hipError_t e = hipMemsetAsync(ac1, 0, 112 * sizeof(double), s);
-  if (e != hipSuccess) return (int)e;
+  if (!accumulators_prezeroed()) {
+    hipError_t e = hipMemsetAsync(ac1, 0, 112 * sizeof(double), s);
+    if (e != hipSuccess) return (int)e;
+  }
   hipLaunchKernelGGL((conv3x3_kernel<1, 32, 1, false, 8>), dim3(cdiv((long)B * d.s1 * d.s1, 256), 4), dim3(256), 0, s, mask, p->w1, nullptr, nullptr, nullptr, y1, ac1, B, fs, d.s1);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, ac1, 32, (double)B * d.s1 * d.s1, st1, p->rm1, p->rv1, update_running);
   hipLaunchKernelGGL((conv3x3_kernel<32, 16, 2, true, 4>), dim3(cdiv((long)B * d.s2 * d.s2, 256), 4), dim3(256), 0, s, y1, p->w2, st1, p->g1, p->b1, y2, ac2, B, d.s1, d.s2);

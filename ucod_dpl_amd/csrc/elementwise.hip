@@ -361,8 +361,10 @@ extern "C" int ucod_apm_bce(const float* pl, const float* teacher, const float* 
   if (!pl || !teacher || !fg || !bg || !p_s || !p_p || !w || !merged || !gfg || !gbg || !losses || B <= 0 || HW <= 0) return UCOD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   UCOD_PROF(PROF_APM, s);
-  hipError_t e = hipMemsetAsync(losses, 0, 4 * sizeof(float), s);
-  if (e != hipSuccess) return (int)e;
+  if (!ucod::accumulators_prezeroed()) {
+    hipError_t e = hipMemsetAsync(losses, 0, 4 * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+  }
   hipLaunchKernelGGL(apm_bce_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, s, pl, teacher, fg, bg, p_s, p_p, epoch_frac, gscale, w, merged, gfg, gbg, losses, B, HW);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
@@ -390,6 +392,43 @@ __global__ __launch_bounds__(256) void copy_segments_kernel(const CopySegs s, si
   }
 }
 }  // namespace ucod
+
+namespace ucod {
+static thread_local bool t_prezeroed = false;
+bool accumulators_prezeroed() { return t_prezeroed; }
+struct ZeroSegs { unsigned* dst[8]; size_t n[8]; };                  // n in 4-byte words
+__global__ __launch_bounds__(256) void zero_segments_kernel(const ZeroSegs s, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    size_t k = i;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (k < s.n[q]) { s.dst[q][k] = 0u; break; }
+      k -= s.n[q];
+    }
+  }
+}
+}  // namespace ucod
+
+extern "C" int ucod_accumulators_prezeroed(int on) {
+  ucod::t_prezeroed = on != 0;
+  return UCOD_OK;
+}
+
+extern "C" int ucod_zero_segments(void* const* dst, const size_t* bytes, int count, void* stream) {
+  if (!dst || !bytes || count < 1 || count > 8) return UCOD_EINVAL;
+  ucod::ZeroSegs s{};
+  size_t total = 0;
+  for (int q = 0; q < count; ++q) {
+    if (bytes[q] && (!dst[q] || (bytes[q] & 3) || ((size_t)dst[q] & 3))) return UCOD_EINVAL;
+    s.dst[q] = (unsigned*)dst[q];
+    s.n[q] = bytes[q] / 4;
+    total += s.n[q];
+  }
+  if (total == 0) return UCOD_OK;
+  hipLaunchKernelGGL(ucod::zero_segments_kernel, dim3(ucod::nblocks(total, 1024)), dim3(256), 0, (hipStream_t)stream, s, total);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
 
 extern "C" int ucod_copy_segments(float* const* dst, const float* const* src, const size_t* n, int count, void* stream) {
   if (!dst || !src || !n || count < 1 || count > 4) return UCOD_EINVAL;

@@ -239,8 +239,10 @@ extern "C" int ucod_dba_wgrad(const float* gd, const float* x, float* gW, int B,
   while (WG_CHUNK > 128 && (long)cdiv(C, 128) * cdiv(HW, WG_CHUNK) * B < 1024) WG_CHUNK >>= 1;
   dim3 grid(cdiv(C, 128), cdiv(HW, WG_CHUNK), B), block(256);
   UCOD_PROF(PROF_DBA_WGRAD, stream);
-  hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * 128 * (size_t)C, (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
+  if (!ucod::accumulators_prezeroed()) {
+    hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * 128 * (size_t)C, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
   if ((HW % 4) == 0 && (((uintptr_t)x) % 16) == 0 && (((uintptr_t)gd) % 16) == 0)
     hipLaunchKernelGGL((dba_wgrad_kernel<true>), grid, block, 0, (hipStream_t)stream, gd, x, gW, C, HW, WG_CHUNK, 128);
   else

@@ -458,8 +458,10 @@ extern "C" int ucod_dba_wgrad_split(const float* gd, const float* x, float* gW, 
   int chunk = cdiv(cdiv(HW, nchunk), 16) * 16;
   nchunk = cdiv(HW, chunk);
   UCOD_PROF(PROF_DBA_WGRAD, s);
-  hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * 128 * (size_t)C, s);
-  if (e != hipSuccess) return (int)e;
+  if (!ucod::accumulators_prezeroed()) {
+    hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * 128 * (size_t)C, s);
+    if (e != hipSuccess) return (int)e;
+  }
   hipLaunchKernelGGL(dba_wgrad_b3_kernel, dim3(ctiles, nchunk, B), dim3(512), 0, s, gd, x, gW, C, HW, chunk);
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;

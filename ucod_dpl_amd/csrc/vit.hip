@@ -47,8 +47,8 @@ Plan make_plan(const ucod_vit_desc* d) {
 // attn_variant of the pass: 0 (auto) and 2 = the pre-scaled-Q product kernel, 1 = the generic-scale kernel (Q as the reference holds it,
 // the scale applied inside the softmax), 8 = the fp8 path of BASELINE configs[4].  Laboratory variants (variants/attention_lab.hip) are
 // not reachable from the ViT driver: bench / tools that want to time one call ucod_attention_fwd_lab directly.
-// 5 / 64 / 32: attn_fwd_v5_kernel / the two assembly kernels by name (ucod_attention_fwd's variant), whatever UCOD_ATTN_ASM selects for 0 / 2
-inline bool attn_variant_known(int av) { return av == 0 || av == 1 || av == 2 || av == 8 || av == 5 || av == 64 || av == 32 || av == 66; }
+// 5 / 66: attn_fwd_v5_kernel / attn_fwd_v6_kernel by name (ucod_attention_fwd's variant)
+inline bool attn_variant_known(int av) { return av == 0 || av == 1 || av == 2 || av == 8 || av == 5 || av == 66; }
 inline bool attn_variant_takes_prescaled_q(int av) { return av != 1; }
 
 bool valid(const ucod_vit_desc* d) {
@@ -164,7 +164,7 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
       if (fold) RUN(ucod_gemm_lnfold(UCOD_EPI_LNFOLD_BIAS_BF16, x, W[2], qkv, M, 3 * D, D, (const float*)W[3], (const float*)W[14], have_part ? nullptr : stats,
                                      have_part ? part : nullptr, nslot, d->eps, nullptr /* the folded Q rows carry the softmax pre-scale */, gv, stream));
       else RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_BF16, h, W[2], qkv, M, 3 * D, D, (const float*)W[3], prescale ? qscale : nullptr, nullptr, nullptr, tok, gv, stream));
-      RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, prescale ? 0.f : scale, (av == 5 || av == 64 || av == 32 || av == 66) ? av : 0, stream));
+      RUN(ucod_attention_fwd(qkv, a, d->B, tok, d->heads, prescale ? 0.f : scale, (av == 5 || av == 66) ? av : 0, stream));
     }
     RUN(resid_gemm(a, W[4], (const float*)W[5], (const float*)W[6], D, fold));
     if (fold) {

@@ -183,6 +183,27 @@ class TrainLoop(BaseLoop):
         pseudo_labels = pseudo_labels.to(dev, torch.float32)
         B = features.shape[0]
         pl = ops.bilinear_resize(pseudo_labels, fs, fs)                                                               # :154
+        # ONE zero launch for every accumulating output of the step (the diagonal sums of the heads kernel, the loss cell of the APM kernel, the
+        # gradient arena behind the embedding slot: weight gradient | bias | head_w | head_b); the discriminator's BatchNorm sums live in its saved
+        # buffer and are left zero by every forward call.  Round 4: seven rocclr fills per step.
+        scratch = self._step_scratch(B, dev)
+        ops.zero_segments([scratch, A.g[A.o_W:]])
+        with ops.prezeroed():
+            return self._process_batch_zeroed(pseudo_labels, features, pl, scratch)
+
+    def _step_scratch(self, B, dev):
+        """[sdiag B | losses 4] f32, kept across steps (the step's loss tensors are views of it: read them before the next step)"""
+        if getattr(self, "_scratch", None) is None or self._scratch.numel() != B + 4 or self._scratch.device != dev:
+            self._scratch = torch.empty(B + 4, dtype=torch.float32, device=dev)
+        return self._scratch
+
+    def _process_batch_zeroed(self, pseudo_labels, features, pl, scratch):
+        r = self.runner
+        A = r.arena
+        world = r.world_size
+        dev = A.device
+        fs = self.cfg.model_cfg.feature_size
+        B = features.shape[0]
 
         # teacher (no grad) and student share one projection (:156-158).  The reference resizes the 768-channel features to
         # fs x fs first (:153) and then applies the 1x1 conv; both are linear and act on different axes, so they commute:
@@ -198,14 +219,14 @@ class TrainLoop(BaseLoop):
             d = ops.bilinear_resize(d.view(B, 256, fh, fw), fs, fs).view(B, 256, fs * fs)
         norm_s = ops.dba_colnorm(d, 0, emb_s)
         norm_t = ops.dba_colnorm(d, 128, emb_t)
-        fg, bg, sdiag = ops.dba_heads(d, 0, emb_s, norm_s, hw_s, hb_s, want_bg=True, want_sdiag=True)
+        fg, bg, sdiag = ops.dba_heads(d, 0, emb_s, norm_s, hw_s, hb_s, want_bg=True, want_sdiag=True, sdiag=scratch[:B])
         teacher, _, _ = ops.dba_heads(d, 128, emb_t, norm_t, hw_t, hb_t, want_bg=False)
         extra, gram = ops.orth_gram(d, 0, emb_s, norm_s, sdiag)
 
         # APM (:257-272) + both BCE losses and their gradients (:161-173)
         p_s, p_p = self._disc_probs(ops.binarize(fg, logits=True).view(B, 1, fs, fs), ops.binarize(pl, logits=False), features, fs)
         epoch_frac = self._cur_epoch / (self._max_epoch + self._start_finetune)
-        w, merged, gfg, gbg, losses = ops.apm_bce(pl.view(B, -1), teacher, fg, bg, p_s, p_p, epoch_frac, gscale=1.0 / world)
+        w, merged, gfg, gbg, losses = ops.apm_bce(pl.view(B, -1), teacher, fg, bg, p_s, p_p, epoch_frac, gscale=1.0 / world, losses=scratch[B:B + 4])
 
         # backward through heads / gate / normalisation / orthogonality loss, then the 1x1 conv weight gradient
         g_emb, g_W, g_b, g_hw, g_hb = A.slices(A.g)

@@ -86,7 +86,8 @@ class StandardRunner:
     def disc_saved(self, B, fs):
         key = (B, fs)
         if key not in self._saved:
-            self._saved[key] = torch.empty(native.load().ucod_disc_saved_bytes(B, fs), dtype=torch.uint8, device=self.device)
+            # zeroed: its tail holds the BatchNorm sums, which every ucod_disc_fwd leaves zero again (ucod_accumulators_prezeroed)
+            self._saved[key] = torch.zeros(native.load().ucod_disc_saved_bytes(B, fs), dtype=torch.uint8, device=self.device)
         return self._saved[key]
 
     # ------------------------------------------------------------------ checkpoints (runner.py:165-240)

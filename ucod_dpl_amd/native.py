@@ -158,6 +158,8 @@ SIGNATURES = {
     "ucod_gated_ensemble": (ci, [vp, vp, vp, vp, vp, cf, vp, vp, vp, ci, ci, ci, vp]),
     "ucod_step_loss": (ci, [vp, vp, ci, vp, vp]),
     "ucod_copy_segments": (ci, [vp, vp, vp, ci, vp]),
+    "ucod_zero_segments": (ci, [vp, vp, ci, vp]),
+    "ucod_accumulators_prezeroed": (ci, [ci]),
     "ucod_adamw_ema": (ci, [vp, vp, vp, vp, vp, sz, cf, cf, cf, cf, cf, ci, cf, vp]),
     "ucod_cod_metrics_workspace_bytes": (sz, [ci, ci, ci]),
     "ucod_cod_metrics": (ci, [vp, vp, ci, ci, ci, vp, vp, sz, vp]),
@@ -196,9 +198,10 @@ def load(half="bf16"):
 LIB_PATH_LAB = os.path.join(_HERE, "_native", "libucod_dpl_variants.so")
 LAB_SIGNATURES = {
     "ucod_attention_fwd_lab": (ci, [vp, vp, ci, ci, ci, cf, ci, vp]),
+    "ucod_attention_fwd_asm_lab": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),     # the hand-placed assembly kernels (form 0 = pw64, 1 = pw32), optional LSE
     "ucod_gemm_bf16_lab": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
 }
-ATTN_PRODUCT_VARIANTS = (0, 2, 5, 32, 64, 66)   # 64 / 32 = the hand-placed assembly kernels (4 waves x 64 rows / 8 waves x 32 rows), 5 = attn_fwd_v5_kernel whatever UCOD_ATTN_ASM says
+ATTN_PRODUCT_VARIANTS = (0, 2, 5, 66)           # 5 / 66 = attn_fwd_v5_kernel / attn_fwd_v6_kernel by name
 GEMM_PRODUCT_VARIANTS = (0, 1, 2, 9, 10, 12, 13, 14)
 
 

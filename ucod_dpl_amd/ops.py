@@ -109,6 +109,15 @@ def attention(qkv, B, tok, heads, scale=0.125, variant=0):
     return out
 
 
+def attention_asm(qkv, B, tok, heads, form=0, want_lse=False):
+    """LABORATORY (libucod_dpl_variants.so): the hand-placed gfx950 assembly kernels of round 4 -- form 0 = ucod_attn_fwd_pw64 (4 waves x 64 query rows),
+    1 = ucod_attn_fwd_pw32 (8 waves x 32 rows).  Q pre-scaled; raises for fewer than three key tiles.  -> out [, lse [B, heads, tok]]"""
+    out = torch.empty(B * tok, heads * 64, dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty(B, heads, tok, dtype=torch.float32, device=qkv.device) if want_lse else None
+    check(N.load_lab().ucod_attention_fwd_asm_lab(ptr(_bf16(qkv)), ptr(out), ptr(lse), B, tok, heads, form, stream()), "ucod_attention_fwd_asm_lab")
+    return (out, lse) if want_lse else out
+
+
 def attention_fp8(qkv, B, tok, heads, q_exp=5, k_exp=3, v_exp=3):
     """The fp8 (e4m3, block-scaled MFMA) attention path of BASELINE configs[4]; ``qkv`` bf16 with Q pre-scaled by hd^-1/2 * log2 e."""
     lib = N.load()
@@ -225,11 +234,12 @@ def dba_colnorm(d, c0, emb):
     return norm
 
 
-def dba_heads(d, c0, emb, norm, head_w, head_b, want_bg=True, want_sdiag=False):
+def dba_heads(d, c0, emb, norm, head_w, head_b, want_bg=True, want_sdiag=False, sdiag=None):
     B, ld_c, HW = d.shape
     fg = torch.empty(B, HW, dtype=torch.float32, device=d.device)
     bg = torch.empty(B, HW, dtype=torch.float32, device=d.device) if want_bg else None
-    sdiag = torch.empty(B, dtype=torch.float32, device=d.device) if want_sdiag else None
+    if sdiag is None:
+        sdiag = torch.empty(B, dtype=torch.float32, device=d.device) if want_sdiag else None
     check(N.load().ucod_dba_heads_fwd(ptr(d), ld_c, c0, ptr(emb), ptr(norm), ptr(_f32(head_w)), ptr(_f32(head_b)), ptr(fg), ptr(bg),
                                       ptr(sdiag), B, HW, stream()), "ucod_dba_heads_fwd")
     return fg, bg, sdiag
@@ -326,6 +336,29 @@ def copy_segments(pairs):
     check(N.load().ucod_copy_segments(dst, src, n, k, stream()), "ucod_copy_segments")
 
 
+def zero_segments(tensors):
+    """Zero up to eight contiguous device tensors with ONE launch (ucod_zero_segments)."""
+    k = len(tensors)
+    for t in tensors:
+        if not t.is_cuda or not t.is_contiguous() or (t.numel() * t.element_size()) % 4:
+            raise ValueError("zero_segments: contiguous device tensors of a multiple of 4 bytes")
+    dst = (C.c_void_p * k)(*[t.data_ptr() for t in tensors])
+    n = (C.c_size_t * k)(*[t.numel() * t.element_size() for t in tensors])
+    check(N.load().ucod_zero_segments(dst, n, k, stream()), "ucod_zero_segments")
+
+
+class prezeroed:
+    """Context: the accumulating outputs of the calls inside were zeroed by the caller (``zero_segments``); the entry points skip their own memsets
+    (include/ucod_dpl.h: ucod_accumulators_prezeroed)."""
+
+    def __enter__(self):
+        N.load().ucod_accumulators_prezeroed(1)
+
+    def __exit__(self, *exc):
+        N.load().ucod_accumulators_prezeroed(0)
+        return False
+
+
 def binarize(x, logits):
     x = _f32(x).contiguous()
     out = torch.empty_like(x)
@@ -333,7 +366,7 @@ def binarize(x, logits):
     return out
 
 
-def apm_bce(pl, teacher, fg, bg, p_s, p_p, epoch_frac, gscale=1.0):
+def apm_bce(pl, teacher, fg, bg, p_s, p_p, epoch_frac, gscale=1.0, losses=None):
     B = pl.shape[0]
     HW = pl.numel() // B
     dev = pl.device
@@ -341,7 +374,7 @@ def apm_bce(pl, teacher, fg, bg, p_s, p_p, epoch_frac, gscale=1.0):
     merged = torch.empty(B, HW, dtype=torch.float32, device=dev)
     gfg = torch.empty(B, HW, dtype=torch.float32, device=dev)
     gbg = torch.empty(B, HW, dtype=torch.float32, device=dev)
-    losses = torch.empty(4, dtype=torch.float32, device=dev)
+    losses = torch.empty(4, dtype=torch.float32, device=dev) if losses is None else losses
     check(N.load().ucod_apm_bce(ptr(pl), ptr(teacher), ptr(fg), ptr(bg), ptr(p_s), ptr(p_p), float(epoch_frac), float(gscale), ptr(w),
                                 ptr(merged), ptr(gfg), ptr(gbg), ptr(losses), B, HW, stream()), "ucod_apm_bce")
     return w, merged, gfg, gbg, losses

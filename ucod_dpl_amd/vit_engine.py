@@ -105,8 +105,8 @@ class ViTEngine:
         """``half``: 16-bit type of the GEMM / attention operands -- "bf16" (default; BASELINE configs[1]) or "f16" (IEEE fp16, what
         the reference's fp16-autocast launcher multiplies in: 8x finer rounding, logits within 1e-3 of the f32 reference at full
         depth).  Each choice is its own build of the same kernels (native.load).
-        ``attn_variant``: 0 / 2 the product attention kernel (UCOD_ATTN_ASM picks which), 1 the generic-scale kernel, 8 the fp8 path of
-        BASELINE configs[4]; 5 = attn_fwd_v5_kernel, 64 / 32 = the hand-placed assembly kernels (tools/attn_asm), by name.
+        ``attn_variant``: 0 / 2 the product attention kernel, 1 the generic-scale kernel, 8 the fp8 path of BASELINE configs[4]; 5 / 66 =
+        attn_fwd_v5_kernel / attn_fwd_v6_kernel by name (the hand-placed assembly kernels of round 4 are laboratory code: ops.attention_asm).
         ``resid``: type of the residual stream x between the GEMM epilogues and LayerNorm -- "f32" (what the reference holds), "f16"
         (IEEE fp16: half the bytes of LayerNorm's read and of the out-proj / fc2 read-modify-write) or "auto".  "auto" is a property of
         the ENGINE, never of the batch size (an image's key map does not depend on how many images travel with it):
@@ -127,8 +127,8 @@ class ViTEngine:
         self.resid = resid
         self.resid16 = bool(resid == "f16" or (resid == "auto" and half == "bf16"))
         self._ovf_host, self._ovf_events, self._ovf_dev = None, [], None
-        if attn_variant not in (0, 1, 2, 8, 5, 64, 32, 66):
-            raise ValueError(f"attn_variant must be 0, 1, 2, 5, 8, 32, 64 or 66 (laboratory kernels are reached through ops.attention(variant=...)), got {attn_variant}")
+        if attn_variant not in (0, 1, 2, 8, 5, 66):
+            raise ValueError(f"attn_variant must be 0, 1, 2, 5, 8 or 66 (laboratory kernels are reached through ops.attention(variant=...) / ops.attention_asm), got {attn_variant}")
         if ln_fold not in ("auto", True, False):
             raise ValueError(f"ln_fold must be 'auto', True or False, got {ln_fold!r}")
         c = normalize_state_dict(state_dict)
