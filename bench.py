@@ -352,10 +352,12 @@ def main():
     if "layernorm" in kernels:
         kernels["layernorm"]["gbs"] = round(B * tok * D * 4 / (kernels["layernorm"]["avg_us"] * 1e-6) / 1e9, 1)
         kernels["layernorm"]["moved_gbs"] = round(B * tok * D * ln_moved / (kernels["layernorm"]["avg_us"] * 1e-6) / 1e9, 1)
+    if "row_stats" in kernels:                              # LayerNorm-folded passes: the statistics launch reads the fp16 rows once (2 B / element) and writes 8 B per row
+        kernels["row_stats"]["gbs"] = round(B * tok * (D * 2 + 8) / (kernels["row_stats"]["avg_us"] * 1e-6) / 1e9, 1)
     dom = max((n for n in kernels if "tflops" in kernels[n] and n.startswith(("gemm_bf16", "attention"))),
               key=lambda n: kernels[n]["ms_per_step"])
     traffic = None                                            # HBM-side bytes per launch from committed PMC passes (see the file's "source")
-    tpath = next((t for t in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (4, 3)) if os.path.exists(t)), "")
+    tpath = next((t for t in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (5, 4, 3)) if os.path.exists(t)), "")
     if os.path.exists(tpath) and a.arch == "dinov2_vitb14" and B == 32 and a.image == 518:
         traffic = json.load(open(tpath)).get("kernels", {}).get(dom, {}).get("traffic_bytes")
     roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -374,6 +376,7 @@ def main():
                                      "peak_is": "fp8 dense (block-scaled MFMA)" if a.attn_variant == 8 else "bf16 / fp16 dense",
                                      "flops": "algorithmic: 4 * B * heads * N^2 * 64 (Q K^T + P V)"}
     if "layernorm" in kernels:
+        roofline["layernorm_launches_per_step"] = kernels["layernorm"]["launches_per_step"]     # 23 unfolded; 1 with LayerNorm folded into QKV / fc1 (the last layer's LayerNorm 1)
         roofline["hbm_row"] = {"kernel": "layernorm", "achieved": kernels["layernorm"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(kernels["layernorm"]["gbs"] / HBM_PEAK_GBS, 4),
                                "bytes": "algorithmic (SURVEY 8d): bf16 read + bf16 write = 4 B/element",

@@ -6,12 +6,13 @@ bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE under-report
 (MI355X_MICROARCH.md, HBM section)."""
 import collections, csv, glob, json, os, sys
 
-CLASSES = {                                  # bench.py kernel class -> substring of the kernel name
-    "gemm_bf16_proj_fc2_scale_resid": "gemm_bf16_mixed_kernel<9,",   # fp16 residual stream (the f32 form is gemm_bf16_big_kernel<2,)
-    "gemm_bf16_fc1_gelu": "gemm_bf16_mixed_kernel<1,",
-    "gemm_bf16_qkv_bias": "gemm_bf16_mixed_kernel<0,",
-    "attention_fwd": "attn_fwd_v5_kernel",
-    "layernorm": "layernorm",
+CLASSES = {                                  # bench.py kernel class -> substrings of the kernel name (bf16 build | fp16 build with LayerNorm folded, round 5)
+    "gemm_bf16_proj_fc2_scale_resid": ("gemm_bf16_mixed_kernel<9,", "gemm_bf16_mixed_kernel<13,"),   # fp16 residual stream (13: + row partials; the f32 form is gemm_bf16_big_kernel<2,)
+    "gemm_bf16_fc1_gelu": ("gemm_bf16_mixed_kernel<1,", "gemm_bf16_mixed_kernel<12,"),
+    "gemm_bf16_qkv_bias": ("gemm_bf16_mixed_kernel<0,", "gemm_bf16_mixed_kernel<11,"),
+    "attention_fwd": ("attn_fwd_v5_kernel",),
+    "layernorm": ("layernorm",),
+    "row_stats": ("row_stats_h16_kernel",),
 }
 
 
@@ -22,8 +23,8 @@ def mean_per_kernel(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            for cls, sub in CLASSES.items():
-                if sub in r["Kernel_Name"]:
+            for cls, subs in CLASSES.items():
+                if any(sub in r["Kernel_Name"] for sub in subs):
                     agg[cls].append(float(r["Counter_Value"]))
                     names[cls] = r["Kernel_Name"]
                     break

@@ -157,7 +157,7 @@ enum ProfClass {
   PROF_GEMM_EPI0 = 0, PROF_GEMM_EPI1, PROF_GEMM_EPI2, PROF_GEMM_EPI3, PROF_GEMM_EPI4, PROF_GEMM_EPI5, PROF_ATTN, PROF_LN,
   PROF_IM2COL, PROF_CLS, PROF_BILINEAR, PROF_DBA_PROJECT, PROF_DBA_COLNORM, PROF_DBA_HEADS, PROF_ORTH, PROF_DBA_BWD,
   PROF_DBA_WGRAD, PROF_DISC_FWD, PROF_DISC_BWD, PROF_APM, PROF_BINARIZE, PROF_ADAMW, PROF_CROP, PROF_CAST, PROF_LN_BWD, PROF_LORA,
-  PROF_ATTN_BWD, PROF_GEMM_EPI6, PROF_GEMM_EPI7, PROF_NUM
+  PROF_ATTN_BWD, PROF_GEMM_EPI6, PROF_GEMM_EPI7, PROF_ROW_STATS, PROF_NUM
 };
 struct ProfScope {
   int idx;

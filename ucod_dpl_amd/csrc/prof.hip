@@ -12,7 +12,7 @@ static const char* kNames[PROF_NUM] = {
     "gemm_bf16_bias_f32", "attention_fwd", "layernorm", "patch_im2col", "cls_rows", "bilinear_resize", "dba_project_f32",
     "dba_colnorm", "dba_heads_fwd", "orth_gram_fwd", "dba_bwd", "dba_wgrad_f32", "disc_fwd", "disc_bwd", "apm_bce", "binarize",
     "adamw_ema", "crop_resize_norm", "cast", "layernorm_bwd", "lora_rowwise", "attention_bwd", "gemm_bf16_gelu_bwd",
-    "gemm_bf16_fc1_gelu_save"};
+    "gemm_bf16_fc1_gelu_save", "row_stats"};
 
 struct Rec { int cls; hipEvent_t a, b; };
 static std::mutex g_mu;

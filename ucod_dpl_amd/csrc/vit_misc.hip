@@ -553,7 +553,7 @@ extern "C" int ucod_layernorm_h16(const void* x, const float* gamma, const float
 extern "C" int ucod_row_stats_h16(const void* x, float* stats, int rows, int D, float eps, void* stream) {
   using namespace ucod;
   if (!x || !stats || rows <= 0 || D <= 0 || (D % 256) != 0 || D > 1536) return UCOD_EINVAL;
-  UCOD_PROF(PROF_LN, stream);
+  UCOD_PROF(PROF_ROW_STATS, stream);
   hipStream_t s = (hipStream_t)stream;
   static const int strips_env = [] { const char* e = getenv("UCOD_STATS_STRIPS"); return e ? atoi(e) : -1; }();
   const int per_wave = strips_env > 0 ? strips_env : 4;

@@ -287,6 +287,11 @@ class TrainLoop(BaseLoop):
         AdamW (same hyper-parameters as the decoder's: the reference ships no loop for this mode) with the EMA update of
         the teacher's copy folded into the same launch."""
         r = self.runner
+        if getattr(r.discriminator, "use_features", False):
+            # In the reference `loss -= dis_loss` with dis_loss = BCE(D(mask, features), 0) (loop_UCOD_DPL.py:160-169, 257-272): with a TRAINED backbone that term
+            # has a gradient path into the features through featureConv, which this loop does not build (it hands the discriminator detached features).
+            raise NotImplementedError("backbone-backward mode with dis_use_features=True is not supported: d(dis_loss)/d(features) through the discriminator's "
+                                      "featureConv is not implemented (use dis_use_features=False, as every shipped config does)")
         self.lora_engine = engine
         self.lora_engine_ema = engine.clone_for_ema()
         # stream budget of the forward phase: student in `engine.train_streams` image-parallel halves + the teacher on one more

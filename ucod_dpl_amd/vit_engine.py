@@ -283,7 +283,9 @@ class ViTEngine:
             self._ovf_host.zero_()
             how = "build the engine with resid='f32'" if self.resid16 else "call forward_nograd(..., resid16=False)"
             raise FloatingPointError(f"the fp16 residual stream of this engine saturated at +-65504 (or met a NaN) in {n} wave-lane(s): the "
-                                     f"activations do not fit fp16; {how}.")
+                                     f"activations do not fit fp16; {how}.  The counter is polled without blocking: the pass (or, for a training engine, the "
+                                     f"optimiser step or steps) that consumed the clamped activations has already been applied -- discard its results "
+                                     f"(UCOD_CHECK_RESID=1 checks synchronously after every pass).")
 
     _sync_check = os.environ.get("UCOD_CHECK_RESID") == "1"    # debug: check the saturation counter synchronously after every pass
 
@@ -415,6 +417,9 @@ class ViTLoRAEngine(ViTEngine):
         super().__init__(state_dict, heads, eps=eps, device=device, full_last_layer=False, gemm_variant=gemm_variant, attn_variant=2, resid=resid)
         if not 0.0 <= lora_dropout < 1.0:
             raise ValueError("lora_dropout must be in [0, 1)")
+        if 0.0 < lora_dropout < 1.0 / 1024:
+            raise ValueError("lora_dropout below 1/1024 would be rounded to no dropout at all (the mask threshold is floor(1024 p): include/ucod_dpl.h, "
+                             "ucod_lora_dropout); use 0 or a value >= 1/1024")
         # LoRA dropout (LoraConfig.lora_dropout, full_model.py:50): active while `self.training` is True; the mask of a step is a pure
         # function of (seed, step), regenerated by the backward kernels.  `eval()` / `train()` switch it like nn.Module does.
         self.lora_dropout, self.training = float(lora_dropout), True
