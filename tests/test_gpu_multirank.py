@@ -328,6 +328,6 @@ def test_two_ranks_run_the_schedule_like_the_global_batch_in_two_batchnorm_group
             else:
                 kind = "bn" if "running" in k else "disc"
                 worst[kind] = max(worst[kind], maxdiff(got["disc"][k], v))
-    within("c3_schedule_decoder", worst["dec"], 2e-3)
-    within("c3_schedule_disc", worst["disc"], 2e-3)
-    within("c3_schedule_bn", worst["bn"], 2e-3)
+    within("c3_schedule_decoder", worst["dec"], 5e-6)           # measured 1.2e-7 / 2.5e-7 / 1.8e-7
+    within("c3_schedule_disc", worst["disc"], 5e-6)
+    within("c3_schedule_bn", worst["bn"], 5e-6)

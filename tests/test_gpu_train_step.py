@@ -418,7 +418,7 @@ def test_g18_train_schedule_matches_the_reference_run():
     assert events == [str(e) for e in g["events"]]
     ref_losses = g["losses"].tolist()
     assert len(losses) == len(ref_losses) == 18
-    within("g18_loss", max(abs(a - b) for a, b in zip(losses, ref_losses)), 2e-4)           # (the reference's strings carry four decimals)
+    within("g18_loss", max(abs(a - b) for a, b in zip(losses, ref_losses)), 1e-4)           # (the reference's strings carry four decimals: 5e-5 of rounding)
     worst = {}
     for e in events:
         s = snaps[e]
@@ -433,6 +433,7 @@ def test_g18_train_schedule_matches_the_reference_run():
             kind = "disc_counter" if "num_batches" in k else ("disc_bn" if "running" in k else "disc")
             worst[kind] = max(worst.get(kind, 0.0), maxdiff(s["disc"][k], v))
     assert worst["disc_counter"] == 0.0
-    within("g18_model_params", worst["model"], 2e-3)            # AdamW steps of lr ~ 6e-4 on noise-level gradient entries may differ by a full step (see G5)
-    within("g18_disc_params", worst["disc"], 2e-3)
-    within("g18_disc_bn", worst["disc_bn"], 2e-3)
+    # measured (MI355X, round 5): 3.3e-7 / 3.6e-7 / 1.8e-7 after eighteen optimiser steps, two discriminator epochs and the optimiser rebuild
+    within("g18_model_params", worst["model"], 5e-6)
+    within("g18_disc_params", worst["disc"], 5e-6)
+    within("g18_disc_bn", worst["disc_bn"], 5e-6)
