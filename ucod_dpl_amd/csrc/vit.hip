@@ -87,7 +87,9 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
   // attn_variant 8: the fp8 (e4m3, block-scaled MFMA) attention path of BASELINE configs[4]; same pre-scaled Q
   const bool prescale = attn_variant_takes_prescaled_q(av);
   float* qscale = (float*)(ws + p.off_qscale);
-  if (prescale) RUN(ucod_fill_qscale(qscale, D, scale * 1.4426950408889634f, stream));
+  // (with ln_fold the softmax pre-scale rides on the folded Q rows; only an unfolded QKV projection -- the last layer's, when it runs at all -- needs the vector)
+  const bool needs_qscale = prescale && !(d->ln_fold && !d->full_last_layer);
+  if (needs_qscale && av != 8) RUN(ucod_fill_qscale(qscale, D, scale * 1.4426950408889634f, stream));
   // fp8 path: the QKV epilogue writes e4m3 Q8 | K8 | V8 itself; its column scales carry 2^q_exp (times the pre-scale), 2^k_exp, 2^v_exp
   constexpr int QE = 5, KE = 3, VE = 3;
   if (av == 8) {
