@@ -120,6 +120,13 @@ class backbone(nn.Module):
                 eps = hf_cfg.get("layer_norm_eps", 1e-6 if is_v2 else 1e-12)
         if heads is None:
             raise ValueError("heads is required with an explicit state_dict")
+        if config is not None:
+            # build-only keys of dataset_cfg.feature_extractor_cfg (absent from the shipped configs: the engine's defaults apply).  The configuration bench.py
+            # quotes its headline on is  half="f16", resid="f16"  (fp16 operands on the fp16 residual stream: LayerNorm folded into QKV / fc1, logits within
+            # 1e-3 of the f32 reference on the flat init)
+            for k in ("half", "resid", "ln_fold", "attn_variant"):
+                if k in config and k not in engine_kw:
+                    engine_kw[k] = config[k]
         self.engine = ViTEngine(state_dict, heads=heads, eps=eps or 1e-6, device=device, **engine_kw)
 
     @classmethod
