@@ -287,6 +287,35 @@ def test_engine_with_the_fold_on_a_large_pass_takes_the_partials_path(small):
     assert rel_l2(k9[:3], k3) < 1e-3
 
 
+@pytest.mark.parametrize("kw", [dict(full_last_layer=True), dict(attn_variant=1), dict(attn_variant=66)])
+def test_engine_with_the_fold_in_its_other_modes(small, kw):
+    """full_last_layer: the last layer runs whole and UNFOLDED behind the folded ones (its QKV needs the pre-scale vector the folded layers no longer use);
+    attn_variant 1: the generic-scale attention kernel takes Q unscaled, so the folded Q rows must NOT carry the softmax pre-scale; 66: another kernel, same contract."""
+    sd, img, ref, _ = small
+    more = torch.cat((img, torch.randn(6, 3, 224, 224, generator=torch.Generator().manual_seed(10))), 0)       # 9 images: the large-tile kernels and the partial sums
+    for x, n in ((img, 3), (more, 3)):
+        eng = ViTEngine(sd, heads=4, device=DEV, half="f16", resid="f16", **kw)
+        assert eng.ln_fold
+        k = eng(x.to(DEV)).cpu()[:n]
+        eng.check_overflow(wait=True)
+        assert rel_l2(k, ref) < 1.5e-3, (kw, x.shape[0], rel_l2(k, ref))
+
+
+def test_engine_with_the_fold_at_vit_l_width():
+    """D = 1024: 16 partial-sum slots per row (the prologue's second group of slot pairs), 16 heads; eight images = 2056 token rows on the large-tile kernels."""
+    ARCHS["fold_vitl"] = (1024, 16, 3, 14, 224, True)
+    sd = random_state_dict("fold_vitl", seed=6)
+    img = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        _, ref = OV.dinov2_forward(img[:2], sd, heads=16, patch=14, eps=1e-6, full_last_layer=False)
+    fold = ViTEngine(sd, heads=16, device=DEV, half="f16", resid="f16")
+    plain = ViTEngine(sd, heads=16, device=DEV, half="f16", resid="f16", ln_fold=False)
+    assert fold.ln_fold and fold.fold_layers[0][14].numel() == 3072 and fold.fold_layers[0][15].numel() == 4096
+    kf, kp = fold(img.to(DEV)).cpu()[:2], plain(img.to(DEV)).cpu()[:2]
+    fold.check_overflow(wait=True)
+    assert rel_l2(kf, ref) < 1.5e-3 and rel_l2(kf, ref) <= 1.25 * rel_l2(kp, ref) + 1e-4, (rel_l2(kf, ref), rel_l2(kp, ref))
+
+
 def test_ln_fold_is_refused_where_it_cannot_run(small):
     sd = small[0]
     for kw in (dict(half="bf16"), dict(half="f16", resid="f32"), dict(half="f16", resid="auto")):
