@@ -673,9 +673,15 @@ def test_bilinear_matches_aten_semantics():
     assert torch.equal(a > 0.5, torch_bilinear(pl, 68, 68) > 0.5)
 
 
+def test_bilinear_adjoint_refuses_what_it_cannot_do():
+    y = torch.zeros(4, 68, 68, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.bilinear_resize_adjoint(y, 8, 8)                    # 8.5x: more than 16 taps per axis
+
+
 def test_bilinear_adjoint_is_the_transpose():
     g = torch.Generator().manual_seed(8)
-    for (ih, oh) in ((37, 68), (14, 28), (68, 37), (5, 12)):
+    for (ih, oh) in ((37, 68), (14, 28), (68, 37), (5, 12), (16, 68), (10, 68)):     # 16 / 10 -> 68: 4.25x / 6.8x, the 16-tap instantiation (a 224-pixel image's key map)
         x = torch.randn(3, 4, ih, ih, generator=g)
         y = torch.randn(3, 4, oh, oh, generator=g)
         xr = x.clone().requires_grad_(True)
@@ -686,7 +692,7 @@ def test_bilinear_adjoint_is_the_transpose():
         assert abs((ux * y).sum().item() - (x * got).sum().item()) < 1e-3          # <Ux, y> == <x, U^T y>
 
 
-@pytest.mark.parametrize("ih,oh,planes", [(37, 68, 256), (37, 68, 67), (24, 68, 96), (14, 28, 130), (5, 12, 64), (28, 56, 65)])
+@pytest.mark.parametrize("ih,oh,planes", [(37, 68, 256), (37, 68, 67), (24, 68, 96), (14, 28, 130), (5, 12, 64), (28, 56, 65), (16, 68, 128), (10, 68, 70)])
 def test_bilinear_lds_paths_match_the_elementwise_kernels(ih, oh, planes):
     """From 64 planes up the resize and its adjoint run the LDS-staged kernels (elementwise.hip: bilinear_up4_kernel,
     bilinear_adjoint_sep_kernel); below that the element-per-thread ones.  Same taps, same arithmetic: bit-identical results,

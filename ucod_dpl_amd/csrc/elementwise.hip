@@ -96,9 +96,13 @@ __global__ __launch_bounds__(256) void bilinear_up4_kernel(const float* __restri
 // resize commute: both are linear, one acts on channels, the other on pixels).
 // taps of source index i along one axis: the (at most MAXT) output indices whose bilinear footprint touches i, with
 // their weights.  Scans the candidate range with the SAME src_index() as the forward.
-constexpr int MAXT = 8;
+// MAXT (template parameter of the two kernels): 8 covers up-sampling up to 3.5x (the step's 37 -> 68: 5 taps) with the loops unrolled to eight
+// predicated taps; 16 takes the rare coarser grids (a 224-pixel image gives 16 x 16 keys: 16 -> 68 is 4.25x, 10 taps) up to 7.5x.
+template <int MAXT>
 __device__ __forceinline__ int adjoint_taps(int i, float scale, int in_size, int out_size, int (&idx)[MAXT], float (&w)[MAXT]) {
-  int lo = (int)floorf((float)(i - 1) / scale) - 1, hi = (int)ceilf((float)(i + 1) / scale) + 1;
+  // outputs o whose source coordinate (o + 0.5) * scale - 0.5 lies in (i - 1, i + 1), one more on each side for the rounding of the bound
+  // (round 5: the bounds (i -+ 1) / scale -+ 1 of the first version lose taps once 0.5 / scale - 0.5 exceeds that margin, i.e. beyond ~3.5x)
+  int lo = (int)floorf(((float)i - 0.5f) / scale - 0.5f) - 1, hi = (int)ceilf(((float)i + 1.5f) / scale - 0.5f) + 1;
   lo = lo < 0 ? 0 : lo;
   hi = hi > out_size - 1 ? out_size - 1 : hi;
   int n = 0;
@@ -115,6 +119,7 @@ __device__ __forceinline__ int adjoint_taps(int i, float scale, int in_size, int
 }
 
 // grid (cdiv(ih*iw,256), plane-chunks): each thread owns one source pixel, computes its taps ONCE and then sweeps planes.
+template <int MAXT>
 __global__ __launch_bounds__(256) void bilinear_adjoint_kernel(const float* __restrict__ gout, float* __restrict__ gin, long planes,
                                                                int ih, int iw, int oh, int ow, float sh, float sw) {
   const int p = blockIdx.x * 256 + threadIdx.x;
@@ -146,6 +151,7 @@ __global__ __launch_bounds__(256) void bilinear_adjoint_kernel(const float* __re
 // a workgroup walks `ppw` planes; per plane it stages gout in LDS (16-byte loads), pass 1 reduces along x with the thread's own
 // column taps held in registers, pass 2 reduces along y with the row taps read from an LDS table.  Same products, same order:
 // bit-identical to the element kernel, without its ~20 global gathers per output (it was bound by the gather rate).
+template <int MAXT>
 __global__ __launch_bounds__(256) void bilinear_adjoint_sep_kernel(const float* __restrict__ gout, float* __restrict__ gin, int planes, int ih,
                                                                    int iw, int oh, int ow, float sh, float sw, int ppw) {
   extern __shared__ __attribute__((aligned(16))) float sm[];           // G [oh*ow (padded to 4)] | R [oh*iw] | y taps
@@ -331,16 +337,20 @@ extern "C" int ucod_bilinear_resize_adjoint(const float* gout, float* gin, int p
   const float sh = (float)ih / (float)oh, sw = (float)iw / (float)ow;
   UCOD_PROF(PROF_BILINEAR, stream);
   (void)total;
-  if (ceilf(2.f / fminf(sh, sw)) + 1.f > (float)MAXT) return UCOD_EINVAL;   // more than MAXT taps per axis (upsampling beyond ~3.5x)
+  const float taps = ceilf(2.f / fminf(sh, sw)) + 1.f;
+  if (taps > 16.f) return UCOD_EINVAL;                                       // more than 16 taps per axis (up-sampling beyond 7.5x)
+  const int MAXT = taps > 8.f ? 16 : 8;
   const size_t lds = ((((size_t)oh * ow + 3) & ~(size_t)3) + (size_t)oh * iw + (size_t)ih * (2 * MAXT + 1)) * sizeof(float);
   if (!getenv("UCOD_RESIZE_ELEMENTWISE") && lds <= 60 * 1024 && planes >= 64 && iw <= 128) {
     // planes per workgroup: amortises the tap set-up, but a workgroup's planes are strictly sequential (load, barrier, pass 1, barrier,
     // pass 2) and the latencies are hidden by the other 4 workgroups on the CU -- 4096 planes: 4 per workgroup 40 us, 8: 72 us, 1: 50 us
     const int ppw = planes >= 2048 ? 4 : (planes >= 512 ? 2 : 1);
-    hipLaunchKernelGGL(bilinear_adjoint_sep_kernel, dim3(cdiv(planes, ppw)), dim3(256), lds, (hipStream_t)stream, gout, gin, planes, ih, iw, oh, ow, sh, sw, ppw);
+    if (MAXT == 8) hipLaunchKernelGGL(bilinear_adjoint_sep_kernel<8>, dim3(cdiv(planes, ppw)), dim3(256), lds, (hipStream_t)stream, gout, gin, planes, ih, iw, oh, ow, sh, sw, ppw);
+    else hipLaunchKernelGGL(bilinear_adjoint_sep_kernel<16>, dim3(cdiv(planes, ppw)), dim3(256), lds, (hipStream_t)stream, gout, gin, planes, ih, iw, oh, ow, sh, sw, ppw);
   } else {
     const int py = planes < 1024 ? planes : 1024;
-    hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(cdiv((long)ih * iw, 256), py), dim3(256), 0, (hipStream_t)stream, gout, gin, (long)planes, ih, iw, oh, ow, sh, sw);
+    if (MAXT == 8) hipLaunchKernelGGL(bilinear_adjoint_kernel<8>, dim3(cdiv((long)ih * iw, 256), py), dim3(256), 0, (hipStream_t)stream, gout, gin, (long)planes, ih, iw, oh, ow, sh, sw);
+    else hipLaunchKernelGGL(bilinear_adjoint_kernel<16>, dim3(cdiv((long)ih * iw, 256), py), dim3(256), 0, (hipStream_t)stream, gout, gin, (long)planes, ih, iw, oh, ow, sh, sw);
   }
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
