@@ -572,6 +572,48 @@ def look_twice_leg(a, dev, lib, world, rank, host_threads, pinned_cores):
     dt_first = time.perf_counter() - t1
     if rank != 0:
         return
+    cpu = None
+    if not a.no_cpu_baseline and world == 1:
+        # CPU baseline of THIS leg on a bounded sample (one image: two f32 backbone passes of the oracle + its decoder + the oracle's Look-Twice box logic, crop,
+        # resize and paste) and parity of the device path on the same image: box tables, the crop tensor bit for bit, the second pass's logits at 37 x 37
+        from oracle import vit as OV, decoder as OD, look_twice as OLT
+        from oracle.resize import torch_bilinear
+        from ucod_dpl_amd.data.utils.feature_extractor import random_state_dict
+        sd = random_state_dict(a.arch, 0, S)
+        dec = {k: v.detach().cpu().clone() for k, v in model.decoder.state_dict().items()}
+        img_u8, x1 = raw[0].cpu().numpy(), images[:1].cpu()
+        seen = {}
+
+        def encode(crop):
+            with torch.no_grad():
+                _, k2 = OV.dinov2_forward(crop, sd, heads=heads, patch=P, eps=1e-6, full_last_layer=False)
+                f2, _, _ = OD.rev_decoder_forward(k2, dec, orth="gram")
+            seen["crop"], seen["logits"] = crop, f2
+            return f2
+
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            _, key1 = OV.dinov2_forward(x1, sd, heads=heads, patch=P, eps=1e-6, full_last_layer=False)
+            fg1, _, _ = OD.rev_decoder_forward(torch_bilinear(key1, 68, 68), dec, orth="gram")
+        up1, boxes1 = OLT.process_preds(fg1, (S, S), 0.15, "dynamic")
+        new1 = OLT.look_twice(img_u8, boxes1, up1.clone(), (S, S), encode)
+        t_cpu = time.perf_counter() - t0
+        bb.engine.streams = 1
+        with torch.no_grad():
+            _, key_d = bb(images[:1])
+            mask_d, boxes_d = loop.validate_batch(key_d, [raw[0]])
+            crop_d = loop.crop_batch(raw[0], [loop.resize_bbox(b, S, S, S, S) for b in boxes_d[0]])
+            logits_d = model(bb(crop_d)[1])[0].cpu()
+        bb.engine.streams = a.streams
+        scale_ = float(seen["logits"].abs().max())
+        cpu = {"value": round(1.0 / t_cpu, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"1 image: oracle {a.arch} forward f32 twice (image, then its one crop) + oracle decoder at 68 x 68 and 37 x 37 + oracle Look-Twice box logic, "
+                         f"Pillow-exact crop / resize / paste ({t_cpu:.1f} s)",
+               "parity": {"what": "the device path on the same image against the oracle", "boxes_equal": bool(boxes_d[0] == boxes1),
+                          "crop_tensor_bit_identical": bool(torch.equal(crop_d.cpu(), seen["crop"])),
+                          "second_pass_logit_max_abs": round(float((logits_d - seen["logits"]).abs().max()), 6), "second_pass_logit_abs_max_of_reference": round(scale_, 4),
+                          "first_pass_key_rel_l2": round(float((key_d.cpu() - key1).norm() / key1.norm()), 6),
+                          "final_mask_equal": bool(torch.equal(mask_d[0].cpu(), new1.reshape(S, S)))}}
     gh = S // P
     tok, F = gh * gh + 1, 4 * D
     kernels = {}
@@ -602,7 +644,7 @@ def look_twice_leg(a, dev, lib, world, rank, host_threads, pinned_cores):
                       "schedule": f"serial steps; each backbone pass as {a.streams} image-parallel sub-batches on independent HIP streams"},
            "first_backbone_pass_ms": round(dt_first / a.steps * 1e3, 3),
            "second_pass_and_tail_ms": round((dt - dt_first) / a.steps * 1e3, 3),
-           "roofline": roofline, "cpu_baseline": None, "kernels": kernels,
+           "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
            "host_threads": host_threads, "host_cores_pinned": pinned_cores}
     print(json.dumps(out))
 
