@@ -60,8 +60,8 @@ def row_stats_h16(x, eps):
 
 def fold_layernorm_linear(gamma, beta, w, b):
     """(w_folded fp16 [N,K], bias_folded f32 [N], colsum f32 [N]) of LayerNorm(gamma, beta) -> Linear(w, b): include/ucod_dpl.h, ucod_gemm_lnfold."""
-    wf = cast_bf16((_f32(w) * _f32(gamma)[None, :]).contiguous(), lib=N.load("f16"))
-    return wf, (w.double() @ beta.double() + b.double()).float().contiguous(), wf.double().sum(1).float().contiguous()
+    from .fold import fold_layernorm_linear as _fold
+    return _fold(_f32(gamma), _f32(beta), _f32(w), _f32(b))
 
 
 def linear_lnfold(x, stats, wf, bias_f, colsum, gelu=False, scale=None, variant=0, partials=None, eps=1e-6):

@@ -189,11 +189,8 @@ class ViTEngine:
     def _fold(self, gamma, beta, w, b, row_scale=None):
         """LayerNorm(gamma, beta) followed by Linear(w, b) [* row_scale per output] as one GEMM on the un-normalised rows (include/ucod_dpl.h:
         ucod_gemm_lnfold): W' = 16-bit(q (.) W (.) gamma), column sums of the ROUNDED W' (what the MFMA multiplies by), b' = q (W beta + b) in f64."""
-        q = torch.ones(w.shape[0], dtype=torch.float64, device=w.device) if row_scale is None else row_scale.double()
-        wf = ops.cast_bf16((w.double() * gamma.double()[None, :] * q[:, None]).float().contiguous(), lib=self.lib)
-        colsum = wf.double().sum(1).float().contiguous()
-        bias = ((w.double() @ beta.double() + b.double()) * q).float().contiguous()
-        return wf, bias, colsum
+        from .fold import fold_layernorm_linear
+        return fold_layernorm_linear(gamma, beta, w, b, row_scale=row_scale, half=torch.float16)      # (the fold exists in the fp16-operand build only)
 
     def _table(self, gh, gw, L=None):
         """(ctypes table, tensors kept alive) of a pass over the first L layers.  With ln_fold every layer but the last OF THE PASS contributes its
