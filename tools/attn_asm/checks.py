@@ -36,7 +36,7 @@ def audit(prog, verbose=False):
         ws = (ins.mods.get("n", 0) + 1) if ins.klass == "nop" else 1
         k = ins.klass
         if k == "mfma":
-            t = max(t, last_mfma_issue + 8)
+            t = max(t, last_mfma_issue + (4 if ins.mods.get("passes") == 4 else 8))
             last_mfma_issue = t
 
         def need(reg, t_prod, gap, rule):
@@ -73,7 +73,7 @@ def audit(prog, verbose=False):
                 for r in ins.reads:
                     if r in last_write and last_write[r][1] == "trans":
                         need(r, last_write[r][0], 1, "R3")
-                if ins.name == "v_permlane32_swap_b32":
+                if ins.name in ("v_permlane32_swap_b32", "v_permlane16_swap_b32"):
                     for r in ins.reads + ins.writes:
                         if r in last_write and last_write[r][1] in ("valu", "trans"):
                             need(r, last_write[r][0], 2, "R4")

@@ -226,11 +226,24 @@ class Prog:
         return self._emit("v_permlane32_swap_b32", None, (a, b), "valu", text=f"v_permlane32_swap_b32 {op_t(a)}, {op_t(b)}",
                           extra_writes=a.ids() + b.ids())
 
+    def v_permlane16_swap_b32(self, a, b):
+        """16-lane rows 1 and 3 of a <-> rows 0 and 2 of b"""
+        return self._emit("v_permlane16_swap_b32", None, (a, b), "valu", text=f"v_permlane16_swap_b32 {op_t(a)}, {op_t(b)}",
+                          extra_writes=a.ids() + b.ids())
+
     # ------------------------------------------------------------------ MFMA
     def mfma(self, d, a, b, c, dtype="bf16"):
         name = f"v_mfma_f32_32x32x16_{dtype}"
         assert d.n == 16 and a.n == 4 and b.n == 4
         return self._emit(name, d, (a, b, c), "mfma")
+
+    def mfma16(self, d, a, b, c, dtype="bf16"):
+        """v_mfma_f32_16x16x32: d[m = 4 (lane >> 4) + r][n = lane & 15] = c + sum_k a[m][k] b[n][k]; a, b: lane holds row lane & 15, k = 8 (lane >> 4) .. + 7"""
+        name = f"v_mfma_f32_16x16x32_{dtype}"
+        assert d.n == 4 and a.n == 4 and b.n == 4
+        ins = self._emit(name, d, (a, b, c), "mfma")
+        ins.mods["passes"] = 4
+        return ins
 
     # ------------------------------------------------------------------ LDS
     def ds_read_b128(self, d, addr, offset=0):
@@ -293,7 +306,7 @@ class Prog:
         return self._emit(name, None, (a, b), "salu", extra_writes=[SCC_ID])
 
     def s_load(self, d, base, offset):
-        name = {1: "s_load_dword", 2: "s_load_dwordx2", 4: "s_load_dwordx4", 8: "s_load_dwordx8"}[d.n]
+        name = {1: "s_load_dword", 2: "s_load_dwordx2", 4: "s_load_dwordx4", 8: "s_load_dwordx8", 16: "s_load_dwordx16"}[d.n]
         return self._emit(name, d, (base,), "smem", mods={"offset": offset}, text=f"{name} {op_t(d)}, {op_t(base)}, {hex(offset)}")
 
     def s_memtime(self, d): return self._emit("s_memtime", d, (), "smem", mods={"offset": 0}, text=f"s_memtime {op_t(d)}")
@@ -312,6 +325,7 @@ class Prog:
         assert parts
         return self._emit("s_waitcnt", None, (), "wait", mods={"vmcnt": vmcnt, "lgkmcnt": lgkmcnt}, text="s_waitcnt " + " ".join(parts))
 
+    def s_setprio(self, n): return self._emit("s_setprio", None, (), "nop", mods={"n": 0}, text=f"s_setprio {n}")
     def s_barrier(self): return self._emit("s_barrier", None, (), "barrier", text="s_barrier")
     def s_nop(self, n): return self._emit("s_nop", None, (), "nop", mods={"n": n}, text=f"s_nop {n}")
     def s_endpgm(self): return self._emit("s_endpgm", None, (), "end", text="s_endpgm")

@@ -321,6 +321,13 @@ class Machine:
         elif n == "v_mbcnt_hi_u32_b32":
             m, add = self.rs_any(w, s[0]), rd(w, s[1])
             self.wv(w, d, np.array([bin(m & ((1 << max(l - 32, 0)) - 1)).count("1") for l in range(64)], dtype=U32) + add)
+        elif n == "v_permlane16_swap_b32":
+            a, b = rd(w, s[0]), rd(w, s[1])
+            na, nb = a.copy(), b.copy()
+            na[16:32], nb[0:16] = b[0:16], a[16:32]
+            na[48:64], nb[32:48] = b[32:48], a[48:64]
+            self.wv(w, s[0], na)
+            self.wv(w, s[1], nb)
         elif n == "v_permlane32_swap_b32":
             a, b = rd(w, s[0]), rd(w, s[1])
             na, nb = a.copy(), b.copy()
@@ -348,9 +355,27 @@ class Machine:
         el = np.stack([lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]], axis=1)   # [64][8]
         return bf16_to_f32(el) if self.dtype == "bf16" else f16_to_f32(el)
 
+    def exec_mfma16(self, w, ins):
+        """v_mfma_f32_16x16x32: D[m][n] (lane: n = lane & 15, m = 4 (lane >> 4) + r) = C + sum_k A[m][k] B[n][k]"""
+        d, (a, b, c) = ins.dst, ins.src
+        fa, fb = self.frag(w, a), self.frag(w, b)                 # [64 lanes][8]
+        Am = np.concatenate([fa[16 * g:16 * g + 16] for g in range(4)], axis=1)     # [16 rows][32 k]
+        Bm = np.concatenate([fb[16 * g:16 * g + 16] for g in range(4)], axis=1)     # [16 cols][32 k]
+        if isinstance(c, R):
+            cb = self.vblock(w, c).view(F32).copy()               # [4][64]
+        else:
+            cb = np.full((4, 64), np.array([c.bits if isinstance(c, Lit) else c], dtype=U32).view(F32)[0], dtype=F32)
+        with np.errstate(all="ignore"):
+            prod = Am.astype(np.float64) @ Bm.astype(np.float64).T                  # [m][n]
+            ll = np.arange(64)
+            out = np.stack([(cb[r].astype(np.float64) + prod[4 * (ll >> 4) + r, ll & 15]).astype(F32) for r in range(4)])
+        self.vblock(w, d)[:] = out.view(U32)
+
     def exec_mfma(self, w, ins):
         d, (a, b, c) = ins.dst, ins.src
         self.mfma_count += 1
+        if "16x16x32" in ins.name:
+            return self.exec_mfma16(w, ins)
         fa, fb = self.frag(w, a), self.frag(w, b)
         Am = np.concatenate([fa[:32], fa[32:]], axis=1)          # [32 rows][16 k]
         Bm = np.concatenate([fb[:32], fb[32:]], axis=1).T        # [16 k][32 cols]
