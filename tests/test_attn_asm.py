@@ -70,9 +70,52 @@ def test_simulator_flags_a_missing_wait():
     assert any("outstanding" in v for v in r["violations"])
 
 
+def _gemm_text():
+    from tools.attn_asm import gen_gemm
+    return gen_gemm.kernel_text(768, name="ucod_gemm_pk_k768_f0")[0]
+
+
 @pytest.mark.parametrize("fname,text", [("attn_fwd_pw64_bf16.s", lambda: gen_attn.kernel_text("bf16")[0]),
-                                        ("attn_fwd_pw32_bf16.s", lambda: gen_attn32.kernel_text("bf16")[0])])
+                                        ("attn_fwd_pw32_bf16.s", lambda: gen_attn32.kernel_text("bf16")[0]),
+                                        ("gemm_pk_k768_bf16.s", _gemm_text)])
 def test_committed_assembly_is_current(fname, text):
     with open(os.path.join(ASM, fname)) as f:
         committed = f.read().split("\n", 1)[1]          # first line: the GENERATED banner
     assert committed == text(), f"{fname} is stale: run `make -C ucod_dpl_amd/csrc variants`"
+
+
+def test_gemm_generator_simulates_correctly():
+    """the hand-placed persistent GEMM (tools/attn_asm/gen_gemm.py, laboratory): functional simulation of one workgroup (8 waves, two staggered wave groups)
+    over three output tiles incl. a ragged last row tile -- result against numpy, LDS-DMA / barrier / counted-wait protocol, static wait-state audit"""
+    import numpy as np
+    import struct
+    from tools.attn_asm.gen_gemm import GemmGen, KERNEL_NAME, KARG_BYTES
+    from tools.attn_asm.sim import Machine, bf16_round, bf16_to_f32
+    from tools.attn_asm.checks import audit
+    M, N, K = 300, 256, 256
+    g = GemmGen(K=K, stride=1, stores_per_kt=8)
+    prog = g.build()
+    assert audit(prog) == []
+    rng = np.random.default_rng(0)
+    Ab = bf16_round(rng.standard_normal((M, K)).astype(np.float32)).astype(np.uint16)
+    Wb = bf16_round((rng.standard_normal((N, K)) * 0.1).astype(np.float32)).astype(np.uint16)
+    bias = rng.standard_normal(N).astype(np.float32)
+    m = Machine(prog, nwaves=8, lds_bytes=g.lds_bytes)
+    pA, pW, pB = m.alloc(Ab.nbytes), m.alloc(Wb.nbytes), m.alloc(bias.nbytes)
+    pO = m.alloc(M * N * 2 + 4096)
+    m.write(pA, Ab); m.write(pW, Wb); m.write(pB, bias)
+    m.write(pO, np.full(M * N + 2048, 0x7FC1, dtype=np.uint16))
+    ntiles = (M + 255) // 256 * (N // 256)
+    ka = m.alloc(KARG_BYTES)
+    m.write(ka, np.frombuffer(struct.pack("<QQQQiiiiIiiiQ", pA, pW, pB, pO, M, N, N // 256, ntiles, 0, 1, ntiles, 0, 0), dtype=np.uint8))
+
+    def setup(w):
+        w.s[0], w.s[1], w.s[2] = ka & 0xFFFFFFFF, ka >> 32, 0
+        w.v[0] = np.arange(64, dtype=np.uint32) + 64 * w.wid
+    m.run(KERNEL_NAME, setup)
+    out = m.read(pO, (M * N + 2048) * 2).view(np.uint16)
+    got = bf16_to_f32(out[:M * N].astype(np.uint32)).reshape(M, N)
+    ref = bf16_to_f32(Ab.astype(np.uint32)).astype(np.float64) @ bf16_to_f32(Wb.astype(np.uint32)).astype(np.float64).T + bias
+    assert m.violations == []
+    assert np.all(out[M * N:] == 0x7FC1), "rows beyond M were written"
+    assert np.abs(got - ref).max() <= 2.0 ** -8 * np.abs(ref).max() + 1e-6          # one bf16 rounding of the result

@@ -288,6 +288,42 @@ def test_attention_v6_small_and_boundary_token_counts(B, tok, heads):
 
 @pytest.mark.variants
 @_NEEDS_LAB
+@pytest.mark.parametrize("M,Nn", [(256, 256), (300, 512), (8 * 1370, 2304), (32 * 1370, 2304), (32 * 1370, 768), (16 * 1370 + 7, 3072)])
+def test_gemm_assembly_kernel(M, Nn):
+    """The hand-placed persistent parked-tile GEMM (variants/gemm_asm_lab.hip; generated by tools/attn_asm/gen_gemm.py and simulated on the CPU in
+    tests/test_attn_asm.py): x W^T + b in bf16 at K = 768 -- against the f64 product, against the product's large-tile kernel (same K order: bitwise from
+    2 048 rows up, where the product takes its large tiles), rows past M untouched, deterministic."""
+    g = torch.Generator().manual_seed(M + Nn)
+    x = torch.randn(M, 768, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(Nn, 768, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    b = torch.randn(Nn, generator=g).to(DEV)
+    pad = torch.full((M + 32, Nn), float("nan"), dtype=torch.bfloat16, device=DEV)
+    out = ops.linear_bf16_asm(x, w, b, out=pad[:M])
+    ref = x.double() @ w.double().t() + b.double()
+    assert (out.double() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-3          # one bf16 rounding of the f32 sum
+    assert torch.isnan(pad[M:].float()).all(), "rows past M were written"
+    assert torch.equal(out, ops.linear_bf16_asm(x, w, b))
+    if M >= 2048:
+        assert torch.equal(out, ops.linear_bf16(x, w, b))
+
+
+@pytest.mark.variants
+@_NEEDS_LAB
+def test_gemm_assembly_kernel_refuses_what_it_cannot_do():
+    x = torch.zeros(256, 768, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(256, 768, dtype=torch.bfloat16, device=DEV)
+    b = torch.zeros(256, device=DEV)
+    out = torch.zeros(256, 256, dtype=torch.bfloat16, device=DEV)
+    lab_lib = N.load_lab()
+    p_ = N.ptr
+    assert lab_lib.ucod_gemm_bf16_asm_lab(p_(x), p_(w), p_(b), p_(out), 256, 256, 512, 0, None, None) == -1        # K is fixed per code object
+    assert lab_lib.ucod_gemm_bf16_asm_lab(p_(x), p_(w), p_(b), p_(out), 256, 192, 768, 0, None, None) == -1        # N % 256
+    assert lab_lib.ucod_gemm_bf16_asm_lab(p_(x), p_(w), None, p_(out), 256, 256, 768, 0, None, None) == -1         # bias is not optional
+    assert lab_lib.ucod_gemm_bf16_asm_lab(p_(x), p_(w), p_(b), p_(out), 256, 256, 768, 999, None, None) == -1      # no such form
+
+
+@pytest.mark.variants
+@_NEEDS_LAB
 def test_attention_assembly_kernels_refuse_what_they_cannot_do():
     qkv = torch.zeros(64, 192, dtype=torch.bfloat16, device=DEV)
     out = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)

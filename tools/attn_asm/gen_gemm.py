@@ -42,13 +42,13 @@ def park(s):
 
 
 v_tid = V(0)
-v_dma = [V(192 + x) for x in range(4)]
-v_ldsA = [V(196), V(197)]
-v_ldsB = [V(198), V(199)]
-v_st = V(200)
-v_bias = V(201)
-v_t = [V(202), V(203)]
-ARCH_VGPRS = 204
+v_dma = [V(192 + x) for x in range(5)]   # row sets 8 (pp0 + 4 k) + (lane >> 3), k = 0..4 (the trailing group uses 3)
+v_ldsA = [V(197), V(198)]
+v_ldsB = [V(199), V(200)]
+v_st = V(201)
+v_bias = V(202)
+v_t = [V(203), V(204)]
+ARCH_VGPRS = 208
 ACC_VGPRS = 48
 
 
@@ -74,17 +74,22 @@ s_dB = [S(32, 4), S(40, 4)]
 s_dO = [S(44, 4), S(48, 4)]       # [cur, nxt]
 s_dP = S(52, 4)                   # the parked tile's output descriptor
 s_dBias = S(56, 4)
-s_m0A = [S(60 + x) for x in range(4)]
-s_m0B = [S(64 + x) for x in range(4)]
+s_m0base = S(60)                           # LDS address of this wave's first activation piece: pp0 * 1024
+s_pp0 = S(61)
 s_row = [S(68 + i) for i in range(8)]      # i * 16 * N * 2
+s_accu = None
 s_n0x4 = [S(76), S(77)]                    # [cur, nxt]
 s_koff = S(78)
-s_t = [S(80 + k) for k in range(12)]
+s_t = [S(80 + k) for k in range(10)]
+s_now = S(90, 2)                           # diagnostic builds (stamps): s_memtime, previous stamp, 10 interval accumulators
+s_prev = S(92)
+NSTAMP = 8
+# (the accumulators reuse the registers of the prefetch experiments' scratch and sit above every live scalar of the kernel)
 DESC3 = 0x00020000
 
 
 class GemmGen:
-    def __init__(self, K=768, abl=(), stores_from=1, stores_per_kt=2, stamps=False, stride=32):
+    def __init__(self, K=768, abl=(), stores_from=1, stores_per_kt=2, stamps=False, stride=32, nk=(5, 3), g0_r0=5, g1_where="R0", pol_a="", pol_b="", pol_st="nt"):
         assert K % 128 == 0
         self.K, self.K2, self.NKT = K, 2 * K, K // 64
         self.abl = set(abl)
@@ -93,6 +98,13 @@ class GemmGen:
         self.stores_from, self.stores_per_kt = stores_from, stores_per_kt
         self.stamps = stamps
         self.stride = stride                                      # workgroups per XCD (the simulator runs one workgroup with stride 1)
+        # the 32 + 32 one-KiB DMA pieces of a K-tile: a leading-group wave owns row sets k = 0..nk[0]-1 of both operands, a trailing-group wave nk[1];
+        # the leading group issues its first g0_r0 pieces in R0 and the rest in R1, the trailing group all of its pieces in R0 (or in M intervals)
+        assert 4 * nk[0] + 4 * nk[1] == 32 and max(nk) <= 5
+        self.nk, self.g0_r0, self.g1_where = nk, g0_r0, g1_where
+        self.pol_a, self.pol_b, self.pol_st = pol_a, pol_b, pol_st     # cache policies of the activation / weight DMAs and of the output stores
+        # stamps: 0 R0 work, 1 barrier after an R interval, 2 M0 work, 3 barrier after an M interval, 4 R1 work, 5 wait for the DMAs, 6 M1 work, 7 seam
+        self.s_acc = [S(94 + k) for k in range(8)]
         # which parked stores go into which K-tile of the next tile
         self.store_plan = {}
         s = 0
@@ -150,28 +162,23 @@ class GemmGen:
             p.s_and_b32(d[1], d[1], I(0xFFFF))
         p.s_lshl_b32(s_n0x4[which], n0, 2)
 
-    def dma_group(self, kt, which, buf, pieces=range(8)):
-        """the LDS-DMAs (this wave's 4 A pieces and 4 W pieces, or a subset) of K-tile kt of the tile whose descriptors are set `which`, into buffer buf.
-        Returns a list of emitters, one per piece (each: M0 write + DMA)."""
-        p = self.p
-        out = []
+    def pieces(self, g):
+        """this wave's DMA pieces of one K-tile as (operand, k): activation and weight alternate so that both streams are requested at the same rate"""
+        return [(op, k) for k in range(self.nk[g]) for op in ("A", "B")]
 
-        def piece(x):
-            def emit():
-                isA = x < 4
-                m0s = (s_m0A if isA else s_m0B)[x & 3]
-                if buf:
-                    p.s_add_u32(M0, m0s, I(BUF))
-                else:
-                    p.s_mov_b32(M0, m0s)
-                if "nodma" in self.abl:
-                    return
-                p.s_nop(0)
-                p.buffer_load_lds_dwordx4(v_dma[x & 3], (s_dA if isA else s_dB)[which], s_koff)
-            return emit
-        for x in pieces:
-            out.append(piece(x))
-        return out
+    def dma(self, piece, which, buf):
+        """emitter of one LDS-DMA piece (M0 write, one wait state, DMA) of the K-tile whose k offset is in s_koff, tile descriptors `which`, buffer buf"""
+        p = self.p
+        op, k = piece
+
+        def emit():
+            isA = op == "A"
+            p.s_add_u32(M0, s_m0base, I(k * 4096 + (0 if isA else A_BYTES) + (BUF if buf else 0)))
+            if "nodma" in self.abl or ("noA" in self.abl and isA) or ("noB" in self.abl and not isA):
+                return
+            p.s_nop(0)
+            p.buffer_load_lds_dwordx4(v_dma[k], (s_dA if isA else s_dB)[which], s_koff, policy=self.pol_a if isA else self.pol_b)
+        return emit
 
     def set_koff(self, kt):
         self.p.s_mov_b32(s_koff, I(kt * 128))
@@ -200,6 +207,22 @@ class GemmGen:
         if "nomfma" in self.abl:
             return []
         return out
+
+    def stamp(self, k):
+        """diagnostic builds: add the cycles since the previous stamp to accumulator k (k None: only restart the clock)"""
+        if not self.stamps:
+            return
+        p = self.p
+        p.s_memtime(s_now)
+        p.s_waitcnt(lgkmcnt=0)
+        if k is not None:
+            p.s_sub_u32(s_t[9], s_now[0], s_prev)
+            p.s_add_u32(self.s_acc[k], self.s_acc[k], s_t[9])
+        p.s_mov_b32(s_prev, s_now[0])
+
+    def barrier(self):
+        if "nobar" not in self.abl:
+            self.p.s_barrier()
 
     def toggle_lds(self):
         p = self.p
@@ -231,14 +254,15 @@ class GemmGen:
         p.v_add_u32(tmp, s_row[i], v_st)
         if "nostore" in self.abl:
             return
-        p.buffer_store_dwordx4(park(s), tmp, desc, I(0), jp * 64)
+        p.buffer_store_dwordx4(park(s), tmp, desc, I(0), jp * 64, policy=self.pol_st)
 
     def seam(self):
         """top of a tile: park the finished tile (garbage before the first: its descriptor is empty), rotate the descriptor sets, bias -> row block 0"""
         p = self.p
         p.s_nop(7)
         p.s_nop(3)
-        self.convert()
+        if "noconv" not in self.abl:
+            self.convert()
         for k in range(4):
             p.s_mov_b32(s_dP[k], s_dO[0][k])
         for d in (s_dA, s_dB, s_dO):
@@ -251,41 +275,61 @@ class GemmGen:
 
     # ------------------------------------------------------------------ one tile, one wave group
     def tile_body(self, g):
-        """12 K-tiles of one output tile for wave group g (0: leading, 1: one barrier behind)"""
+        """12 K-tiles of one output tile for wave group g (0: leading, 1: one barrier behind).  Global barrier B(4T) ends the last reads of K-tile T-1 and
+        precedes the leading group's first read of K-tile T: the DMAs of K-tile T go out between B(4T-4) and B(4T), from READ intervals only (a wave that
+        issues into a full vector-memory queue stalls; in an MFMA interval that stall is matrix time) --
+          leading group:  R0(T-1) and R1(T-1), waited for at the end of M1(T-1);   trailing group: R0(T-1), waited for at the end of R1(T-1).
+        The parked stores of a K-tile are issued behind the last DMAs of the interval that ends with the wait, so the counted wait leaves exactly them."""
         p = self.p
         NKT = self.NKT
+        pc = self.pieces(g)
         for t in range(NKT):
             buf = t & 1
             first = t == 0
             stores = self.store_plan.get(t, [])
+            kt, which = (t + 1, 0) if t + 1 < NKT else (0, 1)         # the K-tile being requested: t + 1 (the next tile's K-tile 0 at the end)
             p.comment(f"---- group {g} K-tile {t}")
             # ---------------- R0
+            self.stamp(None)
             if first:
                 self.seam()
-            if g == 0:
-                # DMA of K-tile t+1 (the next tile's K-tile 0 at t = NKT-1) into the other buffer: all waves are past the barrier that ends its last reads
-                kt, which = (t + 1, 0) if t + 1 < NKT else (0, 1)
-                self.set_koff(kt)
-                for e in self.dma_group(kt, which, buf ^ 1):
-                    e()
+                self.stamp(7)
             else:
                 p.s_nop(7)
-            for n_, s in enumerate(stores):
-                self.store(s, s_dP, v_t[n_ & 1])
             for e in self.frag_reads(0):
                 e()
+            self.set_koff(kt)
+            in_r0 = pc[:self.g0_r0] if g == 0 else (pc if self.g1_where == "R0" else [])
+            for x in in_r0:
+                self.dma(x, which, buf ^ 1)()
             p.s_waitcnt(lgkmcnt=0)
-            p.s_barrier()
+            self.stamp(0)
+            self.barrier()
+            self.stamp(1)
             # ---------------- M0
             p.s_setprio(1)
-            for e in self.mfma_list(first):
+            mf = self.mfma_list(first)
+            fill = [self.dma(x, which, buf ^ 1) for x in pc] if (g == 1 and self.g1_where == "M0") else []
+            for k, e in enumerate(mf):
                 e()
+                if k % 4 == 1 and k // 4 < len(fill):
+                    fill[k // 4]()
+            if not mf:
+                for e in fill:
+                    e()
             p.s_setprio(0)
-            p.s_barrier()
+            self.stamp(2)
+            self.barrier()
+            self.stamp(3)
             # ---------------- R1
             p.s_nop(7)
             for e in self.frag_reads(1):
                 e()
+            if g == 0:
+                for x in pc[self.g0_r0:]:
+                    self.dma(x, which, buf ^ 1)()
+            for n_, s_ in enumerate(stores):
+                self.store(s_, s_dP, v_t[n_ & 1])
             if t == 2:
                 # descriptors of the tile after this one (scalar work, hidden in a read interval)
                 p.s_add_u32(s_t[8], s_idx, I(self.stride))
@@ -294,33 +338,23 @@ class GemmGen:
                 p.s_cselect_b32(s_has_next, I(1), I(0))
             self.toggle_lds()
             p.s_waitcnt(lgkmcnt=0)
-            if g == 1:
-                # this wave's DMAs of K-tile t+1 (issued in the previous M1) have landed; younger: the parked stores of this K-tile
+            self.stamp(4)
+            if g == 1 and "nowait" not in self.abl:
                 p.s_waitcnt(vmcnt=len(stores))
-            p.s_barrier()
+                self.stamp(5)
+            self.barrier()
+            self.stamp(1)
             # ---------------- M1
             p.s_setprio(1)
-            mf = self.mfma_list(False)
-            if g == 1:
-                # DMA of K-tile t+2 into THIS buffer... no: into buffer (t+2)&1 = buf, whose last reads (this K-tile's k-step 1) ended at the barrier above
-                kt2 = t + 2
-                kt, which = (kt2, 0) if kt2 < NKT else (kt2 - NKT, 1)
-                self.set_koff(kt)
-                dm = self.dma_group(kt, which, buf)
-                for k, e in enumerate(mf):
-                    e()
-                    if k % 4 == 1 and k // 4 < len(dm):
-                        dm[k // 4]()
-                if not mf:
-                    for e in dm:
-                        e()
-            else:
-                for e in mf:
-                    e()
+            for e in self.mfma_list(False):
+                e()
             p.s_setprio(0)
-            if g == 0:
+            self.stamp(6)
+            if g == 0 and "nowait" not in self.abl:
                 p.s_waitcnt(vmcnt=len(stores))
-            p.s_barrier()
+                self.stamp(5)
+            self.barrier()
+            self.stamp(3)
 
     # ------------------------------------------------------------------ whole program
     def build(self):
@@ -354,18 +388,26 @@ class GemmGen:
         p.s_cbranch("scc1", lab_go)
         p.s_endpgm()
         p.label(lab_go)
+        if self.stamps:
+            for k in range(NSTAMP):
+                p.s_mov_b32(self.s_acc[k], I(0))
         # ---- lane constants
         p.v_and_b32(l15, I(15), lane)
         p.v_lshrrev_b32(q, I(4), lane)
         p.v_lshrrev_b32(r8, I(3), lane)
         p.v_and_b32(c8, I(7), lane)
-        # DMA source offsets: row = 64 x + 8 w + r8, 16-byte chunk c8 ^ r8 (the LDS image is the swizzled one)
+        # DMA pieces: piece pp (0..31) of an operand = rows 8 pp .. 8 pp + 7 of its K-tile; this wave owns pp0 + 4 k: pp0 = w (leading group, k < nk[0]) or
+        # 4 nk[0] + (w & 3) (trailing group); source offset of a lane: row 8 pp + r8, 16-byte chunk c8 ^ r8 (the LDS image is the swizzled one)
+        p.s_and_b32(s_pp0, s_w, I(3))
+        p.s_mul_i32(s_t[4], s_wm, I(4 * self.nk[0]))
+        p.s_add_u32(s_pp0, s_pp0, s_t[4])
+        p.s_lshl_b32(s_m0base, s_pp0, 10)
         p.v_xor_b32(x0, c8, r8)
         p.v_lshlrev_b32(x0, I(4), x0)
-        p.s_lshl_b32(s_t[4], s_w, 3)
+        p.s_lshl_b32(s_t[4], s_pp0, 3)
         p.v_add_u32(x1, s_t[4], r8)
-        for x in range(4):
-            p.v_add_u32(v_t[0], I(64 * x), x1)
+        for x in range(5):
+            p.v_add_u32(v_t[0], I(32 * x), x1)
             p.v_mul_u32_u24(v_t[0], I(self.K2), v_t[0])
             p.v_add_u32(v_dma[x], v_t[0], x0)
         # fragment read addresses: row (wm 128 | wn 64) + l15, chunk (4 ks + q) ^ (l15 & 7)
@@ -397,11 +439,7 @@ class GemmGen:
         p.v_add_u32(x1, s_t[5], x1)
         p.v_lshlrev_b32(x1, I(2), x1)
         p.v_add_u32(v_bias, I(BIAS_LDS), x1)
-        # scalars: M0 bases of the DMA pieces, row-block offsets of the stores
-        for x in range(4):
-            p.s_lshl_b32(s_t[4], s_w, 10)
-            p.s_add_u32(s_m0A[x], s_t[4], I(x * 8192))
-            p.s_add_u32(s_m0B[x], s_m0A[x], I(A_BYTES))
+        # scalars: row-block offsets of the stores
         p.s_lshl_b32(s_t[4], s_N, 5)                 # 16 rows * N * 2 bytes
         p.s_mov_b32(s_row[0], I(0))
         for i in range(1, 8):
@@ -430,19 +468,16 @@ class GemmGen:
         p.s_lshl_b32(s_t[5], s_t[4], 8)              # piece * 256 floats
         p.s_cmp("lt", "u32", s_t[5], s_N)
         p.s_cbranch("scc1", nb)
-        # K-tile 0 of the first tile (both groups); the trailing group also its share of K-tile 1 (the leading group issues it in its first read interval)
+        # K-tile 0 of the first tile: every wave its own pieces
         lab_g1, lab_g1_loop, lab_g0_loop, lab_tail, lab_end = (p.newlabel(n) for n in ("g1", "g1_loop", "g0_loop", "tail", "end"))
-        self.set_koff(0)
-        for e in self.dma_group(0, 1, 0):
-            e()
-        p.s_cmp("eq", "u32", s_wm, I(0))
         lab_g0 = p.newlabel("g0")
+        self.set_koff(0)
+        p.s_cmp("eq", "u32", s_wm, I(0))
         p.s_cbranch("scc1", lab_g0)
         # ================= trailing group
-        self.set_koff(1)
-        for e in self.dma_group(1, 1, 1):
-            e()
-        p.s_waitcnt(vmcnt=8)
+        for x in self.pieces(1):
+            self.dma(x, 1, 0)()
+        p.s_waitcnt(vmcnt=0)
         p.s_barrier()
         p.s_barrier()                                # one interval behind
         p.label(lab_g1_loop)
@@ -453,6 +488,8 @@ class GemmGen:
         p.s_branch(lab_tail)
         # ================= leading group
         p.label(lab_g0)
+        for x in self.pieces(0):
+            self.dma(x, 1, 0)()
         p.s_waitcnt(vmcnt=0)
         p.s_barrier()
         p.label(lab_g0_loop)
@@ -469,6 +506,25 @@ class GemmGen:
         p.s_nop(1)
         for s in range(16):
             self.store(s, s_dO[0], v_t[s & 1])
+        if self.stamps:
+            # waves 0 and 4 of every workgroup: dbg[(wg * 2 + wm) * 8 + k] = accumulator k
+            lab_nodump = p.newlabel("nodump")
+            p.s_and_b32(s_t[0], s_w, I(3))
+            p.s_cmp("eq", "u32", s_t[0], I(0))
+            p.s_cbranch("scc0", lab_nodump)
+            p.s_lshl_b32(s_t[0], s_wg, 1)
+            p.s_add_u32(s_t[0], s_t[0], s_wm)
+            p.s_lshl_b32(s_t[0], s_t[0], 5)
+            p.s_mov_b32(s_dP[0], s_dbg[0])
+            p.s_and_b32(s_dP[1], s_dbg[1], I(0xFFFF))
+            p.s_mov_b32(s_dP[2], I(1 << 20))
+            p.v_mov_b32(v_t[0], s_t[0])
+            for k in range(NSTAMP):
+                p.v_mov_b32(v_t[1], self.s_acc[k])
+                p.s_nop(1)
+                p.buffer_store_dword(v_t[1], v_t[0], s_dP, I(0), 4 * k)
+                p.s_nop(1)
+            p.label(lab_nodump)
         p.s_waitcnt(vmcnt=0)
         p.s_endpgm()
         return p
@@ -567,6 +623,32 @@ amdhsa.version:
 ...
 \t.end_amdgpu_metadata
 """
+
+
+# the forms built into the laboratory library (variants/gemm_asm_lab.hip: `form`); 0 is the kernel, the rest are timing-only ablations (WRONG results)
+# and placement experiments
+VARIANTS = [
+    ("the kernel (parked stores non-temporal)", {}),
+    ("ablation: no parked stores (output not written)", {"abl": ["nostore"]}),
+    ("ablation: no LDS-DMA (operands not loaded)", {"abl": ["nodma"]}),
+    ("ablation: no fragment reads", {"abl": ["nolds"]}),
+    ("ablation: no MFMAs", {"abl": ["nomfma"]}),
+    ("ablation: no barriers inside the K loop", {"abl": ["nobar"]}),
+    ("ablation: no seam conversion", {"abl": ["noconv"]}),
+    ("ablation: no activation DMA", {"abl": ["noA"]}),
+    ("ablation: no weight DMA", {"abl": ["noB"]}),
+    ("diagnostic: cycle stamps per interval kind (dbg[(wg * 2 + group) * 8 + k]; needs the dbg buffer)", {"stamps": True}),
+    ("ablation: DMAs issued, never waited for (racy)", {"abl": ["nowait"]}),
+    ("placement: leading group R0 7 / R1 3 pieces", {"g0_r0": 7}),
+    ("placement: leading group R0 3 / R1 7 pieces", {"g0_r0": 3}),
+    ("placement: trailing group's pieces between the MFMAs of M0 instead of R0", {"g1_where": "M0"}),
+    ("placement: 8 + 8 pieces per wave (leading R0 4 / R1 4, trailing R0 8)", {"nk": (4, 4), "g0_r0": 4}),
+    ("placement: 4 parked stores per K-tile (K-tiles 1..4)", {"stores_per_kt": 4}),
+    ("policy: parked stores with the default policy (write-back, kept in L2)", {"pol_st": ""}),
+    ("policy: activation DMAs nt", {"pol_a": "nt"}),
+    ("policy: weight DMAs nt", {"pol_b": "nt"}),
+    ("policy: parked stores sc1", {"pol_st": "sc1"}),
+]
 
 
 def kernel_text(K=768, name=None, **kw):

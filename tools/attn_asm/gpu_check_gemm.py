@@ -58,3 +58,68 @@ elif stage == "time":
         gf = 2.0 * M * N * 768 / 1e9
         print(f"M {M} N {N} K 768 ({gf:.1f} GF): " + "  ".join(f"asm {a:.1f} us / product {p_:.1f} us" for a, p_ in rows)
               + f"   best asm {min(r[0] for r in rows):.1f} ({gf / min(r[0] for r in rows) / 1e3 * 1e3:.0f} TF/s)  best product {min(r[1] for r in rows):.1f}", flush=True)
+elif stage == "forms":
+    from ucod_dpl_amd import native as N
+    lab = N.load_lab()
+    nf = lab.ucod_gemm_bf16_asm_lab_forms()
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    which = [int(a) for a in sys.argv[3].split(",")] if len(sys.argv) > 3 and sys.argv[3] != "all" else [f for f in range(nf) if f != 9]     # (9: the stamps build writes through dbg)
+    shapes = [(43520, 2304)] if len(sys.argv) <= 4 else [tuple(int(v) for v in a.split("x")) for a in sys.argv[4].split(",")]
+    for (M, Nn) in shapes:
+        x, w, b = data(M, Nn, 768, 1)
+        out = torch.empty(M, Nn, dtype=torch.bfloat16, device=DEV)
+        ref = ops.linear_bf16(x, w, b)
+
+        def t_of(fn):
+            fn(); fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e3
+        best = {f: 1e9 for f in which}
+        bestp = 1e9
+        for rnd in range(4):
+            for f in which:
+                best[f] = min(best[f], t_of(lambda: ops.linear_bf16_asm(x, w, b, out=out, form=f)))
+            bestp = min(bestp, t_of(lambda: ops.linear_bf16(x, w, b)))
+        print(f"M {M} N {Nn}: product {bestp:.1f} us", flush=True)
+        for f in which:
+            out.zero_()
+            ops.linear_bf16_asm(x, w, b, out=out, form=f)
+            same = torch.equal(out, ref)
+            print(f"  form {f:2d} {best[f]:7.1f} us  equal-to-product {same}  {lab.ucod_gemm_bf16_asm_lab_label(f).decode()}", flush=True)
+elif stage == "stamps":
+    form = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+    M, Nn = (43520, 2304) if len(sys.argv) <= 3 else tuple(int(v) for v in sys.argv[3].split("x"))
+    x, w, b = data(M, Nn, 768, 1)
+    out = torch.empty(M, Nn, dtype=torch.bfloat16, device=DEV)
+    dbg = torch.zeros(256 * 2 * 8, dtype=torch.int32, device=DEV)
+    for _ in range(3):
+        dbg.zero_()
+        ops.linear_bf16_asm(x, w, b, out=out, dbg=dbg, form=form)
+    torch.cuda.synchronize()
+    d = dbg.cpu().view(256, 2, 8).double()
+    names = ["R0 work", "barrier after R", "M0 work", "barrier after M", "R1 work", "DMA wait", "M1 work", "seam"]
+    tiles = -(-M // 256) * (Nn // 256) / 256.0
+    for g in range(2):
+        tot = d[:, g].sum(1)
+        print(f"group {g}: cycles per workgroup mean {tot.mean():.0f} (min {tot.min():.0f} max {tot.max():.0f}); per tile ({tiles:.2f} tiles per workgroup):")
+        for k, nme in enumerate(names):
+            print(f"    {nme:18s} {d[:, g, k].mean() / tiles:9.0f}   ({100 * d[:, g, k].mean() / tot.mean():5.1f} %)  max over workgroups {d[:, g, k].max() / tiles:9.0f}")
+elif stage == "one":                      # for rocprofv3: `one <form> [reps] [MxN]` launches one form (form -1: the product kernel)
+    form = int(sys.argv[2])
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    M, Nn = (43520, 2304) if len(sys.argv) <= 4 else tuple(int(v) for v in sys.argv[4].split("x"))
+    x, w, b = data(M, Nn, 768, 1)
+    out = torch.empty(M, Nn, dtype=torch.bfloat16, device=DEV)
+    for _ in range(reps):
+        if form < 0:
+            ops.linear_bf16(x, w, b)
+        else:
+            ops.linear_bf16_asm(x, w, b, out=out, form=form)
+    torch.cuda.synchronize()
+    print("done")

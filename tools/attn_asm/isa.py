@@ -267,15 +267,21 @@ class Prog:
         return self._emit("buffer_load_dwordx4", d, (voff, rsrc, soff), "vmem", mods={"offset": offset},
                           text=f"buffer_load_dwordx4 {op_t(d)}, {op_t(voff)}, {op_t(rsrc)}, {op_t(soff)} offen" + (f" offset:{offset}" if offset else ""))
 
-    def buffer_load_lds_dwordx4(self, voff, rsrc, soff):
-        """LDS-DMA: 16 bytes per lane to LDS[M0 + 16*lane]"""
-        return self._emit("buffer_load_lds_dwordx4", None, (voff, rsrc, soff), "vmem",
-                          text=f"buffer_load_dwordx4 {op_t(voff)}, {op_t(rsrc)}, {op_t(soff)} offen lds", extra_reads=M0.ids())
+    def buffer_load_dword(self, d, voff, rsrc, soff, offset=0):
+        assert d.n == 1 and rsrc.n == 4 and 0 <= offset < 4096
+        return self._emit("buffer_load_dword", d, (voff, rsrc, soff), "vmem", mods={"offset": offset},
+                          text=f"buffer_load_dword {op_t(d)}, {op_t(voff)}, {op_t(rsrc)}, {op_t(soff)} offen" + (f" offset:{offset}" if offset else ""))
 
-    def buffer_store_dwordx4(self, data, voff, rsrc, soff, offset=0):
+    def buffer_load_lds_dwordx4(self, voff, rsrc, soff, policy=""):
+        """LDS-DMA: 16 bytes per lane to LDS[M0 + 16*lane]; policy: cache-policy bits as text ("nt", "sc1", "sc0 sc1", ...)"""
+        return self._emit("buffer_load_lds_dwordx4", None, (voff, rsrc, soff), "vmem",
+                          text=f"buffer_load_dwordx4 {op_t(voff)}, {op_t(rsrc)}, {op_t(soff)} offen {policy + ' ' if policy else ''}lds", extra_reads=M0.ids())
+
+    def buffer_store_dwordx4(self, data, voff, rsrc, soff, offset=0, policy=""):
         assert data.n == 4 and 0 <= offset < 4096
         return self._emit("buffer_store_dwordx4", None, (data, voff, rsrc, soff), "vmem", mods={"offset": offset},
-                          text=f"buffer_store_dwordx4 {op_t(data)}, {op_t(voff)}, {op_t(rsrc)}, {op_t(soff)} offen" + (f" offset:{offset}" if offset else ""))
+                          text=f"buffer_store_dwordx4 {op_t(data)}, {op_t(voff)}, {op_t(rsrc)}, {op_t(soff)} offen" + (f" offset:{offset}" if offset else "")
+                          + (f" {policy}" if policy else ""))
 
     def buffer_store_dword(self, data, voff, rsrc, soff, offset=0):
         return self._emit("buffer_store_dword", None, (data, voff, rsrc, soff), "vmem", mods={"offset": offset},

@@ -515,6 +515,13 @@ class Machine:
             w.vm_q.append({"kind": "load", "regs": regs})
             for r in regs:
                 w.pending[r] = f"`{ins.text}`"
+        elif n == "buffer_load_dword":
+            voff, rsrc, soff = s
+            addr, ok = self.buf_addr(w, rsrc, self.rd(w, voff), self.rs(w, soff), ins.mods["offset"], 4)
+            blk = self.vblock(w, d)
+            for l in range(64):
+                blk[0, l] = self.mem[addr[l]:addr[l] + 4].view(U32)[0] if ok[l] else 0
+            w.vm_q.append({"kind": "load", "regs": []})          # (the prefetch form: the destination is never read, so nothing is pending on it)
         elif n == "buffer_load_lds_dwordx4":
             voff, rsrc, soff = s
             addr, ok = self.buf_addr(w, rsrc, self.rd(w, voff), self.rs(w, soff), 0, 16)

@@ -200,7 +200,9 @@ LAB_SIGNATURES = {
     "ucod_attention_fwd_lab": (ci, [vp, vp, ci, ci, ci, cf, ci, vp]),
     "ucod_attention_fwd_asm_lab": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),     # the hand-placed assembly kernels (form 0 = pw64, 1 = pw32), optional LSE
     "ucod_gemm_bf16_lab": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
-    "ucod_gemm_bf16_asm_lab": (ci, [vp, vp, vp, vp, ci, ci, ci, vp, vp]),
+    "ucod_gemm_bf16_asm_lab": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "ucod_gemm_bf16_asm_lab_forms": (ci, []),
+    "ucod_gemm_bf16_asm_lab_label": (C.c_char_p, [ci]),
 }
 ATTN_PRODUCT_VARIANTS = (0, 2, 5, 66)           # 5 / 66 = attn_fwd_v5_kernel / attn_fwd_v6_kernel by name
 GEMM_PRODUCT_VARIANTS = (0, 1, 2, 9, 10, 12, 13, 14)

@@ -41,11 +41,11 @@ def linear_bf16(x, w, b, gelu=False, variant=0):
     return gemm_bf16(N.EPI_BIAS_GELU_BF16 if gelu else N.EPI_BIAS_BF16, x, w, out, M, w.shape[0], K, bias=_f32(b), variant=variant)
 
 
-def linear_bf16_asm(x, w, b, out=None, dbg=None):
+def linear_bf16_asm(x, w, b, out=None, dbg=None, form=0):
     """LABORATORY: the hand-placed persistent GEMM (variants/gemm_asm_lab.hip; K = 768, N % 256 == 0): x bf16 [M,K], w bf16 [N,K], b f32 [N] -> bf16 [M,N]."""
     M, K = x.shape
     out = torch.empty(M, w.shape[0], dtype=torch.bfloat16, device=x.device) if out is None else out
-    check(N.load_lab().ucod_gemm_bf16_asm_lab(ptr(_bf16(x)), ptr(_bf16(w)), ptr(_f32(b)), ptr(out), M, w.shape[0], K, ptr(dbg), stream()), "ucod_gemm_bf16_asm_lab")
+    check(N.load_lab().ucod_gemm_bf16_asm_lab(ptr(_bf16(x)), ptr(_bf16(w)), ptr(_f32(b)), ptr(out), M, w.shape[0], K, form, ptr(dbg), stream()), "ucod_gemm_bf16_asm_lab")
     return out
 
 
