@@ -292,7 +292,7 @@ def test_attention_v6_small_and_boundary_token_counts(B, tok, heads):
 def test_gemm_assembly_kernel(M, Nn):
     """The hand-placed persistent parked-tile GEMM (variants/gemm_asm_lab.hip; generated by tools/attn_asm/gen_gemm.py and simulated on the CPU in
     tests/test_attn_asm.py): x W^T + b in bf16 at K = 768 -- against the f64 product, against the product's large-tile kernel (same K order: bitwise from
-    2 048 rows up, where the product takes its large tiles), rows past M untouched, deterministic."""
+    2 048 rows and 2 304 columns up, where the product takes whole large tiles), rows past M untouched, deterministic."""
     g = torch.Generator().manual_seed(M + Nn)
     x = torch.randn(M, 768, generator=g).to(torch.bfloat16).to(DEV)
     w = (torch.randn(Nn, 768, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
@@ -303,7 +303,7 @@ def test_gemm_assembly_kernel(M, Nn):
     assert (out.double() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-3          # one bf16 rounding of the f32 sum
     assert torch.isnan(pad[M:].float()).all(), "rows past M were written"
     assert torch.equal(out, ops.linear_bf16_asm(x, w, b))
-    if M >= 2048:
+    if M >= 2048 and Nn >= 2304:                                  # (at N = 768 the product sums the leftover tiles' K range as interleaved partials: other low bits)
         assert torch.equal(out, ops.linear_bf16(x, w, b))
 
 
