@@ -1,4 +1,5 @@
 #!/bin/bash
+# (every pass under its own `timeout`: a FETCH_SIZE / WRITE_SIZE pass over this script hung a box for 25 minutes in round 5 and is not in the list)
 # PMC passes over ONE form of the assembly GEMM (or the product kernel: form -1) at the QKV shape.  Run on the GPU box from the repo root:
 #   bash tools/gemm_asm_pmc.sh "<forms>" [MxN] > profiles/rNN_gemm_asm_pmc.txt         (separate --pmc passes, kernel trace only)
 FORMS=${1:-"0 -1"}; SHAPE=${2:-43520x2304}
@@ -6,9 +7,9 @@ R=$PWD; cd /tmp; export TMPDIR=/tmp
 rm -rf $R/gpurun_out/gemm_asm_pmc
 for form in $FORMS; do
   i=0
-  for set in "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "FETCH_SIZE WRITE_SIZE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_TAG_STALL_sum" "TA_BUSY_avr TD_BUSY_avr TCP_PENDING_STALL_CYCLES_sum"; do
+  for set in "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_TAG_STALL_sum" "TA_BUSY_avr TD_BUSY_avr TCP_PENDING_STALL_CYCLES_sum"; do
     i=$((i+1))
-    rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/gemm_asm_pmc/f${form}_$i -- python3 $R/tools/attn_asm/gpu_check_gemm.py one $form 4 $SHAPE > /dev/null 2>&1
+    timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/gemm_asm_pmc/f${form}_$i -- python3 $R/tools/attn_asm/gpu_check_gemm.py one $form 4 $SHAPE > /dev/null 2>&1
   done
 done
 cd $R; python3 - <<'PY'
