@@ -648,6 +648,9 @@ VARIANTS = [
     ("policy: activation DMAs nt", {"pol_a": "nt"}),
     ("policy: weight DMAs nt", {"pol_b": "nt"}),
     ("policy: parked stores sc1", {"pol_st": "sc1"}),
+    ("ablation: LDS-DMA + barriers + fragment reads only (no MFMAs, no stores)", {"abl": ["nomfma", "nostore"]}),
+    ("ablation: LDS-DMA + barriers only (no MFMAs, no stores, no fragment reads, no seam conversion)", {"abl": ["nomfma", "nostore", "nolds", "noconv"]}),
+    ("ablation: MFMAs + fragment reads + barriers only (no DMA, no stores)", {"abl": ["nodma", "nostore"]}),
 ]
 
 
