@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Generator of the hand-placed bf16 GEMM  out[M, N] = A[M, K] W[N, K]^T + bias  (bf16 in, f32 accumulate, bf16 out) for gfx950: the
-persistent, parked-tile form of the large-tile kernel (csrc/gemm_bf16_tiles.h: gemm_bf16_big_kernel) that VERDICT r4 item 2 asks for.
+persistent, parked-tile form of the large-tile kernel (csrc/gemm_bf16_tiles.h: gemm_bf16_big_kernel) that VERDICT r4 item 2 asked for.
+LABORATORY (variants/gemm_asm_lab.hip): 4-10 % faster than the product kernel at whole rounds, the 105 us gate not met; DESIGN.md section 0 item 2 has
+the numbers and the twenty-form ablation table this generator builds (VARIANTS below).
+What it computes: transformers modeling_dinov2.py:153-179 (query / key / value projections), :348-381 (the MLP's fc1 without its activation).
 
 Shape of the kernel (K fixed at generation time, K % 128 == 0; N % 256 == 0):
   * persistent grid of 8 x 32 workgroups, 8 waves each (2 in M x 4 in N), one workgroup per CU, two waves per SIMD (252 registers);
@@ -9,18 +12,23 @@ Shape of the kernel (K fixed at generation time, K % 128 == 0; N % 256 == 0):
     block is the transposed tile -- lane (q = lane >> 4, c = lane & 15) holds row c, columns 4q .. 4q + 3 -- so that two column blocks
     make 16-byte row chunks with two v_permlane16_swap and no LDS staging;
   * the K-tiles of consecutive output tiles run as ONE pipeline: LDS = two 64-KiB K-tile buffers {A rows 0..255 | W rows 0..255} fed by
-    16-byte LDS-DMA one K-tile ahead, the seam included (the first K-tiles of the next output tile are requested during the last ones of
+    16-byte LDS-DMA one K-tile ahead, the seam included (the first K-tile of the next output tile is requested during the last one of
     this tile);
   * a K-tile is two k-steps; per k-step and wave group an interval R (12 ds_read_b128 into 48 fragment registers) and an interval M
     (32 MFMAs), separated by raw s_barriers; the wm = 1 waves run one barrier behind the wm = 0 waves, so each SIMD alternates a wave
     in M with a wave in R (the product kernel's choreography, by hand);
+  * every LDS-DMA and every store is issued from an R interval (a wave that issues into a full vector-memory queue stalls at issue: in an M
+    interval that stall is matrix time): the 32 + 32 one-KiB pieces of a K-tile are owned 10 per leading-group wave (5 in R0, 5 in R1, waited
+    for at the end of M1) and 6 per trailing-group wave (R0, waited for at the end of R1) -- tile_body() has the barrier arithmetic;
   * at the seam a wave converts its 128 accumulator registers to 64 PARKED registers of packed bf16 (64 v_cvt_pk + 32 swaps) and the 16
-    stores of 16 bytes per lane are issued two per K-tile during K-tiles 1..8 of the NEXT tile, behind counted vmcnt: the store-bound
-    drain (8.2 k cycles per tile at the CU's 16 B/clk) overlaps the next tile's main loop;
+    non-temporal stores of 16 bytes per lane are issued two per K-tile during K-tiles 1..8 of the NEXT tile, behind counted vmcnt: the
+    store-bound drain (8.2 k cycles per tile at the CU's 16 B/clk) overlaps the next tile's main loop;
   * bias: the whole vector sits in LDS (DMA, once); at the seam row block 0's accumulators are loaded with it and serve as the C operand
     of every row block's first MFMA.
 
-Registers: v0-127 accumulators, v128-191 parked tile, v192-203 addresses; a0-31 activation fragments, a32-47 weight fragments.
+Registers: v0-127 accumulators, v128-191 parked tile, v192-204 addresses; a0-31 activation fragments, a32-47 weight fragments.
+Checked on the CPU by the functional simulator (sim.py: results, LDS-DMA / barrier / counted-wait protocol) and the static wait-state audit
+(checks.py): tests/test_attn_asm.py; on the GPU bitwise against the product kernel: tests/test_gpu_kernels.py::test_gemm_assembly_kernel.
 """
 import argparse
 
