@@ -84,7 +84,8 @@ def test_committed_assembly_is_current(fname, text):
     assert committed == text(), f"{fname} is stale: run `make -C ucod_dpl_amd/csrc variants`"
 
 
-def test_gemm_generator_simulates_correctly():
+@pytest.mark.parametrize("sync", [4, 1])
+def test_gemm_generator_simulates_correctly(sync):
     """the hand-placed persistent GEMM (tools/attn_asm/gen_gemm.py, laboratory): functional simulation of one workgroup (8 waves, two staggered wave groups)
     over three output tiles incl. a ragged last row tile -- result against numpy, LDS-DMA / barrier / counted-wait protocol, static wait-state audit"""
     import numpy as np
@@ -93,7 +94,7 @@ def test_gemm_generator_simulates_correctly():
     from tools.attn_asm.sim import Machine, bf16_round, bf16_to_f32
     from tools.attn_asm.checks import audit
     M, N, K = 300, 256, 256
-    g = GemmGen(K=K, stride=1, stores_per_kt=8)
+    g = GemmGen(K=K, stride=1, sync=sync)          # sync: barriers per K-tile (4: fenced R | M intervals; 1: groups skewed by a k-step)
     prog = g.build()
     assert audit(prog) == []
     rng = np.random.default_rng(0)

@@ -97,7 +97,7 @@ DESC3 = 0x00020000
 
 
 class GemmGen:
-    def __init__(self, K=768, abl=(), stores_from=1, stores_per_kt=2, stamps=False, stride=32, nk=(5, 3), g0_r0=5, g1_where="R0", pol_a="", pol_b="", pol_st="nt"):
+    def __init__(self, K=768, abl=(), stores_from=1, stores_per_kt="spread", stamps=False, stride=32, nk=(5, 3), g0_r0=5, g1_where="R0", pol_a="", pol_b="", pol_st="nt", sync=4):
         assert K % 128 == 0
         self.K, self.K2, self.NKT = K, 2 * K, K // 64
         self.abl = set(abl)
@@ -111,17 +111,27 @@ class GemmGen:
         assert 4 * nk[0] + 4 * nk[1] == 32 and max(nk) <= 5
         self.nk, self.g0_r0, self.g1_where = nk, g0_r0, g1_where
         self.pol_a, self.pol_b, self.pol_st = pol_a, pol_b, pol_st     # cache policies of the activation / weight DMAs and of the output stores
+        self.sync = sync                                          # barriers per K-tile: 4 (R | M intervals fenced) or 1 (groups skewed by one k-step, free-running inside the K-tile)
         # stamps: 0 R0 work, 1 barrier after an R interval, 2 M0 work, 3 barrier after an M interval, 4 R1 work, 5 wait for the DMAs, 6 M1 work, 7 seam
         self.s_acc = [S(94 + k) for k in range(8)]
-        # which parked stores go into which K-tile of the next tile
+        # which parked stores go into which K-tile of the next tile: stores_per_kt from K-tile stores_from on, or (stores_per_kt = "spread") evenly over
+        # all K-tiles of the tile (the store path is then loaded at 1.33 stores per wave and K-tile instead of 2 for two thirds of the tile)
         self.store_plan = {}
-        s = 0
-        t = stores_from
-        while s < 16:
-            assert t < self.NKT - 1, "parked stores do not fit the K loop"
-            self.store_plan[t] = list(range(s, min(16, s + stores_per_kt)))
-            s += stores_per_kt
-            t += 1
+        if stores_per_kt == "spread":
+            done = 0
+            for t in range(self.NKT):
+                upto = (16 * (t + 1) + self.NKT - 1) // self.NKT
+                self.store_plan[t] = list(range(done, upto))
+                done = upto
+            assert done == 16
+        else:
+            s = 0
+            t = stores_from
+            while s < 16:
+                assert t < self.NKT, "parked stores do not fit the K loop"
+                self.store_plan[t] = list(range(s, min(16, s + stores_per_kt)))
+                s += stores_per_kt
+                t += 1
 
     # ------------------------------------------------------------------ helpers
     def ptr_add(self, dst, base, off32):
@@ -195,10 +205,9 @@ class GemmGen:
         """12 ds_read_b128 of k-step ks: 8 activation row blocks + 4 weight column blocks (into the single fragment set)"""
         p = self.p
         out = []
-        for i in range(8):
-            out.append(lambda i=i: p.ds_read_b128(fragA(i), v_ldsA[ks], i * 2048))
-        for j in range(4):
-            out.append(lambda j=j: p.ds_read_b128(fragB(j), v_ldsB[ks], j * 2048))
+        ra = [lambda i=i: p.ds_read_b128(fragA(i), v_ldsA[ks], i * 2048) for i in range(8)]
+        rb = [lambda j=j: p.ds_read_b128(fragB(j), v_ldsB[ks], j * 2048) for j in range(4)]
+        out = ra[1:7] + rb[:3] + [ra[0], ra[7], rb[3]]              # (the last MFMAs of a k-step read A block 7 -- block 0 in a tile's first k-step -- and W block 3: rewritten last)
         if "nolds" in self.abl:
             return []
         return out
@@ -364,6 +373,65 @@ class GemmGen:
             self.barrier()
             self.stamp(3)
 
+    def tile_body_1bar(self, g, entry_label=None):
+        """The same tile with ONE barrier per K-tile.  The trailing group runs one k-step behind INSIDE the K-tile instead of one barrier behind:
+            leading:   | R0(t) M0(t) R1(t) M1(t)           | barrier
+            trailing:  | M1(t-1) R0(t) M0(t) R1(t)         | barrier          (its M1 of the tile's last K-tile opens the next tile's first period)
+        so a SIMD's two waves still alternate MFMA and read phases, held together by the barrier once per K-tile.  The barrier is both hand-offs of the
+        two-buffer ring: before it every wave has waited for its own DMAs of K-tile t+1 and has finished its reads of K-tile t; behind it K-tile t+1 is read
+        and the DMAs of K-tile t+2 go out (read phases only; the trailing group's R1 is its last phase before the barrier, so it carries stores only)."""
+        p = self.p
+        NKT = self.NKT
+        pc = self.pieces(g)
+        for t in range(NKT):
+            buf = t & 1
+            first = t == 0
+            stores = self.store_plan.get(t, [])
+            kt, which = (t + 1, 0) if t + 1 < NKT else (0, 1)
+            p.comment(f"---- group {g} K-tile {t} (one barrier per K-tile)")
+            if g == 1:
+                # M1 of the previous K-tile (for t == 0: of the previous TILE; the very first period of the kernel enters behind it)
+                p.s_setprio(1)
+                for e in self.mfma_list(False):
+                    e()
+                p.s_setprio(0)
+                if first and entry_label is not None:
+                    p.label(entry_label)
+            if first:
+                self.seam()
+            for e in self.frag_reads(0):
+                e()
+            self.set_koff(kt)
+            for x in (pc[:self.g0_r0] if g == 0 else pc):
+                self.dma(x, which, buf ^ 1)()
+            p.s_waitcnt(lgkmcnt=0)
+            p.s_setprio(1)
+            for e in self.mfma_list(first):
+                e()
+            p.s_setprio(0)
+            for e in self.frag_reads(1):
+                e()
+            if g == 0:
+                for x in pc[self.g0_r0:]:
+                    self.dma(x, which, buf ^ 1)()
+            for n_, s_ in enumerate(stores):
+                self.store(s_, s_dP, v_t[n_ & 1])
+            if t == 2:
+                p.s_add_u32(s_t[8], s_idx, I(self.stride))
+                self.make_desc(s_t[8], 1)
+                p.s_cmp("lt", "u32", s_t[8], s_end)
+                p.s_cselect_b32(s_has_next, I(1), I(0))
+            self.toggle_lds()
+            p.s_waitcnt(lgkmcnt=0)
+            if g == 0:
+                p.s_setprio(1)
+                for e in self.mfma_list(False):
+                    e()
+                p.s_setprio(0)
+            if "nowait" not in self.abl:
+                p.s_waitcnt(vmcnt=len(stores))
+            self.barrier()
+
     # ------------------------------------------------------------------ whole program
     def build(self):
         p = self.p
@@ -487,12 +555,23 @@ class GemmGen:
             self.dma(x, 1, 0)()
         p.s_waitcnt(vmcnt=0)
         p.s_barrier()
-        p.s_barrier()                                # one interval behind
-        p.label(lab_g1_loop)
-        self.tile_body(1)
+        if self.sync == 1:
+            lab_entry = p.newlabel("g1_entry")
+            p.s_branch(lab_entry)                    # the first period has no M1 of a previous K-tile in front of it
+            p.label(lab_g1_loop)
+            self.tile_body_1bar(1, entry_label=lab_entry)
+        else:
+            p.s_barrier()                            # one interval behind
+            p.label(lab_g1_loop)
+            self.tile_body(1)
         p.s_add_u32(s_idx, s_idx, I(self.stride))
         p.s_cmp("eq", "u32", s_has_next, I(1))
         p.s_cbranch("scc1", lab_g1_loop)
+        if self.sync == 1:                           # M1 of the last K-tile of the last tile
+            p.s_setprio(1)
+            for e in self.mfma_list(False):
+                e()
+            p.s_setprio(0)
         p.s_branch(lab_tail)
         # ================= leading group
         p.label(lab_g0)
@@ -501,11 +580,15 @@ class GemmGen:
         p.s_waitcnt(vmcnt=0)
         p.s_barrier()
         p.label(lab_g0_loop)
-        self.tile_body(0)
+        if self.sync == 1:
+            self.tile_body_1bar(0)
+        else:
+            self.tile_body(0)
         p.s_add_u32(s_idx, s_idx, I(self.stride))
         p.s_cmp("eq", "u32", s_has_next, I(1))
         p.s_cbranch("scc1", lab_g0_loop)
-        p.s_barrier()                                # the trailing group's extra interval
+        if self.sync != 1:
+            p.s_barrier()                            # the trailing group's extra interval
         # ================= last tile: convert and store directly
         p.label(lab_tail)
         p.s_nop(7)
@@ -656,6 +739,10 @@ VARIANTS = [
     ("policy: activation DMAs nt", {"pol_a": "nt"}),
     ("policy: weight DMAs nt", {"pol_b": "nt"}),
     ("policy: parked stores sc1", {"pol_st": "sc1"}),
+    ("placement: two parked stores per K-tile in K-tiles 1-8 instead of the even spread", {"stores_per_kt": 2}),
+    ("synchronisation: ONE barrier per K-tile, groups skewed by a k-step", {"sync": 1}),
+    ("synchronisation: one barrier per K-tile + leading group R0 6 / R1 4", {"sync": 1, "g0_r0": 6}),
+    ("synchronisation: one barrier per K-tile + 8 + 8 pieces per wave", {"sync": 1, "nk": (4, 4), "g0_r0": 4}),
     ("ablation: LDS-DMA + barriers + fragment reads only (no MFMAs, no stores)", {"abl": ["nomfma", "nostore"]}),
     ("ablation: LDS-DMA + barriers only (no MFMAs, no stores, no fragment reads, no seam conversion)", {"abl": ["nomfma", "nostore", "nolds", "noconv"]}),
     ("ablation: MFMAs + fragment reads + barriers only (no DMA, no stores)", {"abl": ["nodma", "nostore"]}),

@@ -13,7 +13,8 @@ def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
     K = int(sys.argv[3]) if len(sys.argv) > 3 else 256
-    g = GemmGen(K=K, stride=1, stores_from=1, stores_per_kt=8 if K < 512 else 2)
+    import os
+    g = GemmGen(K=K, stride=1, sync=int(os.environ.get("GEMM_SYNC", "4")))
     prog = g.build()
     v = audit(prog)
     for x in v[:30]:
