@@ -32,7 +32,7 @@ Checked on the CPU by the functional simulator (sim.py: results, LDS-DMA / barri
 """
 import argparse
 
-from .isa import Prog, V, A, S, I, Lit, M0, R
+from .isa import Prog, V, A, S, I, M0
 
 KERNEL_NAME = "ucod_gemm_pk"
 BUF = 65536
@@ -85,7 +85,6 @@ s_dBias = S(56, 4)
 s_m0base = S(60)                           # LDS address of this wave's first activation piece: pp0 * 1024
 s_pp0 = S(61)
 s_row = [S(68 + i) for i in range(8)]      # i * 16 * N * 2
-s_accu = None
 s_n0x4 = [S(76), S(77)]                    # [cur, nxt]
 s_koff = S(78)
 s_t = [S(80 + k) for k in range(10)]
@@ -143,7 +142,7 @@ class GemmGen:
     def make_desc(self, idx, which):
         """descriptors of tile `idx` (SGPR) into set `which` (0 cur / 1 nxt); idx >= s_end -> empty descriptors.  Scalar only, ~35 instructions."""
         p = self.p
-        tm, tn, m0, n0, rows, valid, x, y = s_t[0], s_t[1], s_t[2], s_t[3], s_t[4], s_t[5], s_t[6], s_t[7]
+        tm, tn, m0, n0, rows, valid, x = s_t[0], s_t[1], s_t[2], s_t[3], s_t[4], s_t[5], s_t[6]
         p.s_cmp("lt", "u32", idx, s_end)
         p.s_cselect_b32(valid, I(1), I(0))
         p.s_mul_hi_u32(tm, idx, s_magic)
@@ -545,7 +544,7 @@ class GemmGen:
         p.s_cmp("lt", "u32", s_t[5], s_N)
         p.s_cbranch("scc1", nb)
         # K-tile 0 of the first tile: every wave its own pieces
-        lab_g1, lab_g1_loop, lab_g0_loop, lab_tail, lab_end = (p.newlabel(n) for n in ("g1", "g1_loop", "g0_loop", "tail", "end"))
+        lab_g1_loop, lab_g0_loop, lab_tail = (p.newlabel(n) for n in ("g1_loop", "g0_loop", "tail"))
         lab_g0 = p.newlabel("g0")
         self.set_koff(0)
         p.s_cmp("eq", "u32", s_wm, I(0))

@@ -4,7 +4,7 @@ Checks the result against numpy, the LDS-DMA / barrier / waitcnt protocol (sim.p
 import sys
 import struct
 import numpy as np
-from .gen_gemm import GemmGen, KERNEL_NAME, s_karg, s_wg, v_tid, KARG_BYTES
+from .gen_gemm import GemmGen, KERNEL_NAME, KARG_BYTES
 from .sim import Machine, bf16_round, bf16_to_f32
 from .checks import audit
 
