@@ -16,14 +16,17 @@
  *   - "bf16" buffers are raw uint16 bfloat16; "f32" are IEEE float.
  *   - tensors are dense row-major; [B,C,H,W] is NCHW exactly as the reference holds them.
  *
- * Environment switches read by the library (diagnostics; defaults are the fast paths):
+ * Environment switches read by the PRODUCT library -- three, all of them change which (deterministic) summation order a GEMM launch takes, none is a
+ * measurement knob; they are read once per process (ucod_gemm_reload_tuning re-reads them), never on the launch path:
  *   UCOD_GEMM_NO_PATCH=1       ucod_gemm_bf16*: every output through the tile path.  By default a launch that ends a few tiles past
  *                              one or two whole rounds of CUs computes those tiles as 16x32 patches on the side, which sums K in a
  *                              different order: results stay deterministic but a row's low f32 bits then depend on where the row
- *                              sits in the batch.  Set this for bitwise batch-position independence (read at every call).
+ *                              sits in the batch.  Set this for bitwise batch-position independence.
  *   UCOD_GEMM_PATCH_ROUNDS=n   largest number of whole rounds for which the patch mode is considered (default 2).
- *   UCOD_RESIZE_ELEMENTWISE=1  ucod_bilinear_resize / _adjoint: the element-per-thread kernels also for >= 64 planes (the LDS-staged
- *                              kernels produce the same bits; this is for timing comparisons).
+ *   UCOD_GEMM_NO_MIXED=1       no mixed-height launches (the one-shot large tile with a partly filled last round instead).
+ * Measurement knobs (alternative kernel forms, grid sizes, store policies: UCOD_RESIZE_ELEMENTWISE, UCOD_LN_*, UCOD_STATS_STRIPS, UCOD_RESID16_NT,
+ * UCOD_LN_FOLD_NO_PARTIALS, UCOD_GEMM_GROUP_M / _COL_FAST / _ST_AUX, UCOD_LORA_GRAD_*, UCOD_DGRAD_F32) exist only in builds made with
+ * -DUCOD_LAB_KNOBS (`make -C ucod_dpl_amd/csrc knobs`, used by tools/); libucod_dpl.so / libucod_dpl_f16.so ignore them (csrc/common.h: lab_env).
  */
 #ifndef UCOD_DPL_H
 #define UCOD_DPL_H
@@ -41,7 +44,10 @@ extern "C" {
  * ucod_row_stats_h16, ucod_vit_desc.ln_fold, UCOD_VIT_LAYER_STRIDE 14 -> 16 (two column-sum slots per layer); ucod_zero_segments,
  * ucod_accumulators_prezeroed, the *_multi forms of the Look-Twice crop / paste; the assembly attention variants 64 / 32 of ucod_attention_fwd and the
  * UCOD_ATTN_ASM switch LEFT the product library (laboratory: ucod_attention_fwd_asm_lab of libucod_dpl_variants.so). */
-#define UCOD_ABI_VERSION 4
+/* 5 (round 6): the row partials of the LayerNorm fold hold (sum, M2 about the slot mean) and are merged with Chan's formula (was: raw sums of squares);
+ * the split-operand (f32-equivalent) backbone pass: ucod_split_rows, ucod_layernorm_split, ucod_patch_im2col_split, ucod_qkv_split,
+ * ucod_attention_split_fwd, ucod_vit_forward_split (+ their size helpers); ucod_clock_probe; the measurement knobs left the product build (UCOD_LAB_KNOBS). */
+#define UCOD_ABI_VERSION 5
 int ucod_abi_version(void);
 /* 1 when a gfx950 device is visible to this process (hipGetDeviceProperties().gcnArchName) */
 int ucod_device_is_gfx950(void);
@@ -59,6 +65,10 @@ int ucod_prof_enable(int on);
 int ucod_prof_num_classes(void);
 const char* ucod_prof_class_name(int cls);
 int ucod_prof_collect(double* total_ms_host, long long* count_host);
+/* One single-wave launch that stores (s_memtime, s_memrealtime) = (shader-clock cycle counter, constant 100 MHz counter) of the CU it runs on into
+ * out_dev[0..1] (two uint64).  Two probes on the same stream bracket a region: (memtime_1 - memtime_0) / (memrealtime_1 - memrealtime_0) * 100 MHz is the
+ * mean shader clock the chip HELD over the region (bench.py --sustain-s: the roofline fraction against MFMA rate x held clock). */
+int ucod_clock_probe(unsigned long long* out_dev, void* stream);
 
 /* ------------------------------------------------------------------ ViT backbone (rows B1-B8) */
 
@@ -86,8 +96,9 @@ enum {
   UCOD_EPI_LNFOLD_GELU_BF16 = 12,    /* ucod_gemm_lnfold only.  The same fold for norm2 -> fc1 -> GELU (modeling_dinov2.py:365-373,281-297):
                                         out = gelu_erf(stats[m][0] * C + stats[m][1] * colsum[n] + bias[n]) */
   UCOD_EPI_BIAS_SCALE_RESID_H16_STATS = 13, /* ucod_gemm_bf16_stats only.  UCOD_EPI_BIAS_SCALE_RESID_H16 that also leaves, per output row and 64-column slot, the
-                                        (sum, sum of squares) of the fp16 values it has just written: row_partials f32 [M][N/64][2].  The next
-                                        ucod_gemm_lnfold sums a row's slots in its prologue instead of reading `stats`: no statistics launch.  Large passes only
+                                        (sum S, M2 = sum of squared deviations from the slot's own mean S / 64) of the fp16 values it has just written:
+                                        row_partials f32 [M][N/64][2].  The next ucod_gemm_lnfold merges a row's slots in its prologue (Chan's parallel-variance
+                                        formula: nothing cancels, whatever |mean| / sigma) instead of reading `stats`: no statistics launch.  Large passes only
                                         (M >= 2048, N % 64 == 0); otherwise UCOD_EINVAL and nothing is launched */
   UCOD_EPI_PATCH_TOKENS_H16_STATS = 14,     /* ucod_gemm_bf16_stats only.  UCOD_EPI_PATCH_TOKENS_H16 with the same partials, indexed by OUTPUT token row (the CLS rows'
                                         partials come from ucod_cls_rows_h16_stats) */
@@ -116,14 +127,16 @@ int ucod_gemm_bf16(int epilogue, const void* A_bf16, const void* B_bf16, void* o
 int ucod_gemm_lnfold(int epilogue, const void* x_f16, const void* w_folded, void* out, int M, int N, int K, const float* bias_folded,
                      const float* colsum, const float* stats, const float* row_partials, int nslot, float eps, const float* scale,
                      int variant, void* stream);
-/* `stats` may be NULL when `row_partials` f32 [M][nslot][2] is given (nslot even, <= 24): per-row partial (sum, sum of squares) of x left by the producer
- * of x (ucod_gemm_bf16_stats / ucod_cls_rows_h16_stats); the kernel's prologue adds a row's slots and forms rstd = rsqrt(E[x^2] - mean^2 + eps) in f32.
- * The large-tile kernels only (a small shape is then run on them too). */
+/* `stats` may be NULL when `row_partials` f32 [M][nslot][2] is given (nslot = K / 64, even, <= 24): per 64-column slot (S_i, M2_i) = (sum, sum of squared
+ * deviations from S_i / 64) of x's row, left by the producer of x (ucod_gemm_bf16_stats / ucod_cls_rows_h16_stats); the kernel's prologue forms
+ *   mean = sum_i S_i / K,  var = (sum_i M2_i + 64 sum_i (S_i / 64 - mean)^2) / K,  rstd = rsqrt(var + eps)   in f32
+ * (ABI 5; ABI 4 stored raw sums of squares and formed E[x^2] - mean^2, which lost the variance of rows with |mean| >> sigma).  Same value as
+ * ucod_row_stats_h16's two-pass form to f32 rounding.  The large-tile kernels only (a small shape is then run on them too). */
 /* The producers of the fp16 residual stream with row partials (epilogues UCOD_EPI_*_STATS; arguments as ucod_gemm_bf16; `resid` / `out` f16 rows;
  * nslot = N / 64).  UCOD_EINVAL (nothing launched) for shapes the large-tile kernels do not take: use the plain epilogue and ucod_row_stats_h16 then. */
 int ucod_gemm_bf16_stats(int epilogue, const void* A_bf16, const void* B_bf16, void* out, int M, int N, int K, const float* bias, const float* scale,
                          const void* resid_f16, const float* pos, int tokens_per_image, float* row_partials, int nslot, void* stream);
-/* ucod_cls_rows_h16 that also writes the CLS rows' partials (slot 0 = the whole row, the other slots zero) */
+/* ucod_cls_rows_h16 that also writes the CLS rows' partials, slot by slot like the other rows' (nslot = D / 64) */
 int ucod_cls_rows_h16_stats(void* x_f16, const float* cls, const float* pos, float* row_partials, int nslot, int B, int tok, int D, void* stream);
 /* Row statistics of the fp16 residual stream for the folded epilogues: stats[m] = (rstd, -mean * rstd), two-pass in f32 over the row held in
  * registers, biased variance + eps like nn.LayerNorm.  x f16 [rows,D], D % 256 == 0, D <= 1536. */
@@ -316,6 +329,37 @@ typedef struct {
 size_t ucod_vit_workspace_bytes(const ucod_vit_desc* d);
 int ucod_vit_forward(const ucod_vit_desc* d, const void* const* table_host, const float* img, float* key_out,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ split-operand (f32-equivalent) backbone pass (rows B1-B8 at the reference's fp32)
+ * The reference builds its cached training features with the backbone in plain fp32 (data/datasets/base_dataset.py:124-138: no autocast; only the Look-Twice
+ * extractor is autocast, engine/runner/loop_UCOD_DPL.py:289-290).  This pass computes every matrix product of the ViT with both f32 operands written as sums
+ * of `terms` bf16 values -- 2: a0 b0 + a0 b1 + a1 b0 (16 significand bits per operand, 3x the MFMA work; logits within 3e-5 of the f32 oracle on trained-like
+ * weights), 3: + a1 b1 + a0 b2 + a2 b0 (24 bits: f32-equivalent, 6x) -- each partial product exact in the MFMA's f32 accumulator, f32 residual stream, f32
+ * two-pass LayerNorm, exact-erf GELU, f32 softmax.  The partial products ride on ucod_gemm_bf16 by concatenation along K: an [M, K] operand is stored as
+ * bf16 [M, P K], P = ucod_split_products(terms) = 3 / 6, segment p of an A-side operand (role 0) holding term {0,0,1,1,0,2}[p] and of a B-side operand (role 1)
+ * term {0,1,0,1,2,0}[p].  libucod_dpl.so only (bf16 MFMA); the fp16 build returns UCOD_EINVAL.  csrc/split.hip. */
+int ucod_split_products(int terms);
+/* in f32 [M, K] with row pitch ld_in floats -> out bf16 [M, P K].  op 0: the values; 1: exact-erf GELU of them (modeling_dinov2.py:289); 2: times alpha.  K % 8 == 0 */
+int ucod_split_rows(const float* in, long ld_in, void* out_bf16, int M, int K, int terms, int role, int op, float alpha, void* stream);
+/* nn.LayerNorm (two-pass f32) of f32 rows, written as the split operand of the next GEMM: out bf16 [rows, P D].  D % 128 == 0, D <= 1536 */
+int ucod_layernorm_split(const float* x, const float* gamma, const float* beta, void* out_bf16, int rows, int D, float eps, int terms, int role, void* stream);
+/* ucod_patch_im2col with split output: patches bf16 [B gh gw, P Kpad] (A side) */
+int ucod_patch_im2col_split(const float* img, void* patches_bf16, int B, int C, int H, int W, int P, int Kpad, int terms, void* stream);
+/* f32 qkv [B tok, 3 heads 64] (the QKV projection through UCOD_EPI_BIAS_F32) -> the attention kernel's operands in `operands` (ucod_attention_split_operand_bytes):
+ * Qc | Kc bf16 [B heads][tok_pad][P 64] (Q times qscale before the split; tok_pad = tok rounded up to 32, pad rows zero) and Vt bf16 [terms][B heads][64][tok_pad] */
+size_t ucod_attention_split_operand_bytes(int B, int tok, int heads, int terms);
+int ucod_qkv_split(const float* qkv, void* operands, int B, int tok, int heads, int terms, float qscale, void* stream);
+/* softmax(Q K^T hd^-0.5) V (modeling_dinov2.py:153-179) on those operands, Q carrying head_dim^-0.5 log2 e; scores, softmax and accumulation in f32, the
+ * probabilities split into `terms` bf16 values in registers.  out bf16 [B tok, P heads 64]: the A-side split operand of the out-projection. */
+int ucod_attention_split_fwd(const void* operands, void* out_split_bf16, int B, int tok, int heads, int terms, void* stream);
+/* The whole pass, image -> last-layer key map f32 [B, D, H/P, W/P] (data/utils/feature_extractor.py:42-59), key-minimal (d->full_last_layer must be 0; resid16,
+ * ln_fold and attn_variant of the descriptor are ignored).  Table as ucod_vit_forward's with every weight matrix in its split form:
+ *   +0 patch_w bf16 [D, P Kpad] (B side)  +1 patch_b  +2 cls  +3 pos;  layer l at 4 + UCOD_VIT_LAYER_STRIDE l:  +2 qkv_w [3D, P D]  +4 proj_w [D, P D]
+ *   +9 fc1_w [F, P D]  +11 fc2_w [D, P F]  (B side),  +14 the K rows of qkv_w as an A-side operand [D, P D] (key hook; needed for the last layer of the pass),
+ *   the f32 vectors (+0 +1 +3 +5 +6 +7 +8 +10 +12 +13) as in ucod_vit_forward. */
+size_t ucod_vit_split_workspace_bytes(const ucod_vit_desc* d, int terms);
+int ucod_vit_forward_split(const ucod_vit_desc* d, int terms, const void* const* table_host, const float* img, float* key_out, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* Backbone-backward mode, whole passes (row B9; operand formats in ucod_dpl_amd/csrc/vit_train.hip).
  * T = the table of ucod_vit_forward; TT = per-layer training table (HOST array of DEVICE pointers), layer l at

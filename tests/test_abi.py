@@ -34,12 +34,20 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_argument_validation(lib):
-    assert lib.ucod_abi_version() == 4
+    assert lib.ucod_abi_version() == 5
     # rejected before any device work: null pointers / bad sizes return UCOD_EINVAL (-1)
     assert lib.ucod_gemm_bf16(0, None, None, None, 1, 1, 64, None, None, None, None, 0, 0, None) == -1
     assert lib.ucod_layernorm(None, None, None, None, 1, 100, 1e-6, 0, None) == -1
     assert lib.ucod_bilinear_resize(None, None, 1, 1, 1, 1, 1, None) == -1
     assert lib.ucod_adamw_ema(None, None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, 0.0, None) == -1
+    # the split-operand pass (ABI 5): two or three terms only, K a multiple of 8, null pointers refused
+    assert lib.ucod_split_products(2) == 3 and lib.ucod_split_products(3) == 6 and lib.ucod_split_products(4) == 0
+    assert lib.ucod_split_rows(None, 8, None, 1, 8, 2, 0, 0, 1.0, None) == -1
+    assert lib.ucod_layernorm_split(None, None, None, None, 1, 128, 1e-6, 2, 0, None) == -1
+    assert lib.ucod_attention_split_fwd(None, None, 1, 1, 1, 2, None) == -1
+    assert lib.ucod_attention_split_operand_bytes(1, 33, 2, 3) == 2 * (2 * 64 * 6 * 64 * 2) + 3 * 2 * 64 * 64 * 2
+    assert lib.ucod_attention_split_operand_bytes(1, 33, 2, 4) == 0
+    assert lib.ucod_clock_probe(None, None) == -1
 
 
 def test_workspace_size_helpers(lib):
@@ -52,6 +60,12 @@ def test_workspace_size_helpers(lib):
     assert need >= M * 768 * 4 + M * 768 * 2 * 2 + M * 2304 * 2 + M * 3072 * 2
     d.heads = 11                                           # head_dim != 64 -> rejected
     assert lib.ucod_vit_workspace_bytes(ctypes.byref(d)) == 0
+    d.heads = 12
+    assert lib.ucod_vit_split_workspace_bytes(ctypes.byref(d), 2) >= M * 768 * 4 + 2 * M * 3 * 768 * 2 + M * 2304 * 4 + M * 3072 * 4 + M * 3 * 3072 * 2
+    assert lib.ucod_vit_split_workspace_bytes(ctypes.byref(d), 3) > lib.ucod_vit_split_workspace_bytes(ctypes.byref(d), 2)
+    assert lib.ucod_vit_split_workspace_bytes(ctypes.byref(d), 4) == 0
+    d.full_last_layer = 1                                  # the split pass is key-minimal only
+    assert lib.ucod_vit_split_workspace_bytes(ctypes.byref(d), 2) == 0
     assert lib.ucod_disc_saved_bytes(32, 68) == (32 * (32 * 68 * 68 + 16 * 34 * 34 + 8 * 17 * 17) + 112) * 4 + 112 * 8
     assert lib.ucod_dba_bwd_workspace_bytes(2, 100) == 2 * 128 * 100 * 4
 

@@ -585,7 +585,7 @@ def test_vit_key_fp16_operands_against_reference_golden(name, heads, fn):
     gd = load_golden(name)
     ref = gd["key"]
     e16 = ViTEngine(sub(gd, "sd."), heads=heads, eps=1e-6, device=DEV, attn_variant=2, half="f16")
-    ebf = ViTEngine(sub(gd, "sd."), heads=heads, eps=1e-6, device=DEV, attn_variant=2)
+    ebf = ViTEngine(sub(gd, "sd."), heads=heads, eps=1e-6, device=DEV, attn_variant=2, half="bf16")
     k16, kbf = e16(gd["x"].to(DEV)).cpu(), ebf(gd["x"].to(DEV)).cpu()
     assert e16.lib.ucod_half_name() == b"f16" and ebf.lib.ucod_half_name() == b"bf16"
     assert rel_l2(k16, ref) < 1e-3, rel_l2(k16, ref)
@@ -601,8 +601,8 @@ def test_vit_key_with_fp16_residual_stream(name, heads):
     from ucod_dpl_amd.vit_engine import ViTEngine
     gd = load_golden(name)
     ref = gd["key"]
-    e32 = ViTEngine(sub(gd, "sd."), heads=heads, eps=1e-6, device=DEV, attn_variant=2, resid="f32")
-    e16 = ViTEngine(sub(gd, "sd."), heads=heads, eps=1e-6, device=DEV, attn_variant=2, resid="f16")
+    e32 = ViTEngine(sub(gd, "sd."), heads=heads, eps=1e-6, device=DEV, attn_variant=2, resid="f32", half="bf16")
+    e16 = ViTEngine(sub(gd, "sd."), heads=heads, eps=1e-6, device=DEV, attn_variant=2, resid="f16", half="bf16")
     k32, k16 = e32(gd["x"].to(DEV)).cpu(), e16(gd["x"].to(DEV)).cpu()
     assert e16._desc(2, gd["x"].shape[-2], gd["x"].shape[-1]).resid16 == 1 and e32._desc(2, 70, 70).resid16 == 0
     assert rel_l2(k16, ref) < 2e-2 and rel_l2(k16, ref) < 1.3 * rel_l2(k32, ref) + 1e-4
@@ -944,7 +944,7 @@ def test_feature_cache_pass_with_the_hip_backbone(tmp_path):
     gen = torch.Generator().manual_seed(3)
     imgs = [torch.randn(3, 70, 70, generator=gen) for _ in range(5)]
     fc = MultiCacheManager(str(tmp_path), "dinov2", "val", "T").get_features_cache()
-    assert build_feature_cache(imgs, bb, fc, batch_size=2, device=DEV) == 5
+    assert build_feature_cache(imgs, bb, fc, batch_size=2, device=DEV, precision=None) == 5     # (the extractor as given; the f32-equivalent default: tests/test_gpu_split.py)
     for i, im in enumerate(imgs):
         _, key = bb(im.unsqueeze(0).to(DEV))
         got = fc.read_file(i)

@@ -71,14 +71,16 @@ def c2():
 
 
 @pytest.mark.parametrize("half,resid,logit_tol,key_tol", [
-    ("f16", "auto", BAR, 1.5e-3),        # the bar-meeting configuration as shipped: fp16 operands, f32 residual stream (measured 3.8e-4 / 6.9e-4)
-    ("f16", "f16", BAR, 2.5e-3),         # the same with the fp16 residual stream (measured 6.4e-4 / 1.2e-3)
+    ("f16", "auto", BAR, 2.5e-3),        # the DEFAULT engine (round 6): fp16 operands on the fp16 stream, LayerNorm folded into QKV / fc1 (measured 6.0e-4 / 1.2e-3)
+    ("f16", "f16", BAR, 2.5e-3),         # the same, spelled out
+    ("f16", "f32", BAR, 1.5e-3),         # fp16 operands on the f32 residual stream (measured 3.8e-4 / 6.9e-4)
     ("bf16", "auto", 5e-3, 8e-3),        # BASELINE configs[1] dtype: asserted at its measured level (3.2e-3 / 5.5e-3), not at the bar
     ("bf16", "f32", 5e-3, 8e-3),
 ])
 def test_c2_full_size_logits_against_the_oracle(c2, half, resid, logit_tol, key_tol):
     eng = ViTEngine(c2["sd"], heads=c2["heads"], eps=1e-6, device=DEV, half=half, resid=resid)
-    assert eng.resid16 == {("f16", "auto"): False, ("f16", "f16"): True, ("bf16", "auto"): True, ("bf16", "f32"): False}[(half, resid)]
+    assert eng.resid16 == {("f16", "auto"): True, ("f16", "f16"): True, ("f16", "f32"): False, ("bf16", "auto"): True, ("bf16", "f32"): False}[(half, resid)]
+    assert eng.ln_fold == (half == "f16" and eng.resid16)
     key_dev = eng(c2["img"].to(DEV))
     eng.check_overflow(wait=True)
     fd = device_logits(key_dev, c2["dec"], c2["n"], c2["D"])
@@ -120,7 +122,8 @@ def c2_peaked():
 # (profiles/r04_parity_measured.jsonl, rows "c2_peaked"); the fp16-operand rows are ALSO held to the north-star bar where they meet it
 PEAKED = {
     # measured (MI355X, round 4; reference logits reach |2.8| here against |0.6| on the flat init):
-    ("f16", "auto", 0): (4e-3, 2e-3, 2e-4),          # 2.04e-3 / 1.06e-3 / 0      <- the bar-meeting build of the flat init does NOT meet 1e-3 here
+    ("f16", "f32", 0): (4e-3, 2e-3, 2e-4),           # 2.04e-3 / 1.06e-3 / 0      <- the bar-meeting build of the flat init does NOT meet 1e-3 here
+    ("f16", "auto", 0): (7e-3, 3.5e-3, 4.5e-4),      # the default engine = the row below (round 6)
     ("f16", "f16", 0): (7e-3, 3.5e-3, 4.5e-4),       # 3.41e-3 / 1.68e-3 / 0; round 5 (LayerNorm folded into QKV / fc1): 3.53e-3 / 1.62e-3 / 0 .. 2.2e-4 (two pixels)
     ("bf16", "auto", 0): (4e-2, 1.7e-2, 2e-3),       # 1.96e-2 / 8.57e-3 / 7.6e-4
     ("bf16", "f32", 0): (4e-2, 1.7e-2, 2e-3),        # 2.08e-2 / 8.44e-3 / 8.7e-4
@@ -150,7 +153,7 @@ def test_c2_full_size_logits_on_trained_like_weights(c2_peaked, half, resid, av)
     # launch_train_first_stage.sh:20; measured on one image: 2.95e-3 fp16, 2.3e-2 bf16).  The fp16 residual stream adds its own rounding: 1.6x.
     if av != 8:
         ref_dev = c["autocast"][torch.float16 if half == "f16" else torch.bfloat16]["logit_max_abs"]
-        assert logit_abs <= (1.6 if (half, resid) == ("f16", "f16") else 1.25) * ref_dev, (half, resid, av, logit_abs, ref_dev)
+        assert logit_abs <= (1.6 if (half == "f16" and eng.resid16) else 1.25) * ref_dev, (half, resid, av, logit_abs, ref_dev)
 
 
 def test_c5_fp8_attention_path_full_depth_against_the_oracle(c2):
@@ -158,8 +161,8 @@ def test_c5_fp8_attention_path_full_depth_against_the_oracle(c2):
     everything else bf16 -- at 518 x 518, full depth, against the f32 oracle.  A throughput-only configuration: what it costs in
     accuracy is MEASURED here and asserted at that level (key relative L2, logit max-abs, fraction of mask pixels on the other side of the
     threshold), next to the bf16 engine on the same images."""
-    e8 = ViTEngine(c2["sd"], heads=c2["heads"], eps=1e-6, device=DEV, attn_variant=8)
-    eb = ViTEngine(c2["sd"], heads=c2["heads"], eps=1e-6, device=DEV)
+    e8 = ViTEngine(c2["sd"], heads=c2["heads"], eps=1e-6, device=DEV, attn_variant=8, half="bf16")
+    eb = ViTEngine(c2["sd"], heads=c2["heads"], eps=1e-6, device=DEV, half="bf16")
     img = c2["img"].to(DEV)
     k8, kb = e8(img), eb(img)
     f8, fb = device_logits(k8, c2["dec"], c2["n"], c2["D"]), device_logits(kb, c2["dec"], c2["n"], c2["D"])
@@ -186,7 +189,8 @@ def test_c2_key_map_does_not_depend_on_the_batch(c2):
     img = torch.cat((c2["img"], torch.randn(4, 3, 518, 518, generator=torch.Generator().manual_seed(5))), 0).to(DEV)
     for half in ("bf16", "f16"):
         eng = ViTEngine(c2["sd"], heads=c2["heads"], eps=1e-6, device=DEV, half=half)
-        assert eng._desc(1, 518, 518).resid16 == eng._desc(6, 518, 518).resid16 == int(half == "bf16")
+        assert eng._desc(1, 518, 518).resid16 == eng._desc(6, 518, 518).resid16 == 1          # (round 6: both defaults run the fp16 stream; fp16 operands fold LayerNorm)
+        assert eng._desc(1, 518, 518).ln_fold == eng._desc(6, 518, 518).ln_fold == int(half == "f16")
         k6 = eng(img).clone()
         k1 = eng(img[:1].contiguous())
         r = rel_l2(k1, k6[:1])

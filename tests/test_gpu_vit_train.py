@@ -285,7 +285,7 @@ def test_forward_train_matches_inference_forward():
     from ucod_dpl_amd.vit_engine import ViTEngine
     g = load_golden("g8_dinov2_native")
     base = sub(g, "sd.")
-    inf = ViTEngine(base, heads=2, device=DEV, attn_variant=2)
+    inf = ViTEngine(base, heads=2, device=DEV, attn_variant=2, half="bf16")       # (the training engine is the bf16 build)
     eng = ViTLoRAEngine(base, heads=2, device=DEV)
     x = g["x"].to(DEV)
     k0 = inf(x)

@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+# NOTE (round 6): the environment knobs this tool sets are honoured by the -DUCOD_LAB_KNOBS builds only: `make -C ucod_dpl_amd/csrc knobs`, then run with
+#   UCOD_DPL_ALLOW_EXPERIMENT=1 UCOD_DPL_EXPERIMENT_LIB=ucod_dpl_amd/_native/libucod_dpl_knobs.so UCOD_DPL_EXPERIMENT_LIB_F16=ucod_dpl_amd/_native/libucod_dpl_f16_knobs.so
 """Tile-order / tile-height / store-policy sweep of the large-tile GEMM on the backbone's four shapes (MI355X).
 
 Every configuration = environment knobs read per launch by csrc/gemm_bf16.hip (UCOD_GEMM_GROUP_M, UCOD_GEMM_COL_FAST) + a variant

@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+# NOTE (round 6): the environment knobs this tool sets are honoured by the -DUCOD_LAB_KNOBS builds only: `make -C ucod_dpl_amd/csrc knobs`, then run with
+#   UCOD_DPL_ALLOW_EXPERIMENT=1 UCOD_DPL_EXPERIMENT_LIB=ucod_dpl_amd/_native/libucod_dpl_knobs.so UCOD_DPL_EXPERIMENT_LIB_F16=ucod_dpl_amd/_native/libucod_dpl_f16_knobs.so
 """fp16-stream LayerNorm (ucod_layernorm_h16, 16-byte strip form) at the C2 and C4 shapes with 1 / 2 / 4 / 8 strips per wave: each setting in
 its own process (UCOD_LN_STRIPS is read once).  usage: python tools/ln_strips_ab.py"""
 import os, subprocess, sys

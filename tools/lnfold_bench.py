@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+# NOTE (round 6): the environment knobs this tool sets are honoured by the -DUCOD_LAB_KNOBS builds only: `make -C ucod_dpl_amd/csrc knobs`, then run with
+#   UCOD_DPL_ALLOW_EXPERIMENT=1 UCOD_DPL_EXPERIMENT_LIB=ucod_dpl_amd/_native/libucod_dpl_knobs.so UCOD_DPL_EXPERIMENT_LIB_F16=ucod_dpl_amd/_native/libucod_dpl_f16_knobs.so
 """Isolated, interleaved timing of the LayerNorm-folded GEMMs against what they replace (BASELINE configs[1] shapes, fp16-operand build):
    LayerNorm kernel, row-statistics kernel, QKV / fc1 unfolded, folded with `stats`, folded with row partials, out-projection with and without
    the partial-sum epilogue.  Optional ablation libraries (make variant_f16 NAME=.. DEFS=-DUCOD_FOLD_ABL=n) are timed beside the product library.

@@ -4,6 +4,18 @@
 #include <stdint.h>
 #include <stddef.h>
 
+// Measurement knobs (alternative kernel forms, grid sizes, store policies: what tools/ sweeps) are read from the environment ONLY in builds made with
+// -DUCOD_LAB_KNOBS (`make knobs` -> ../_native/libucod_dpl*_knobs.so, selected by tools/ through UCOD_DPL_EXPERIMENT_LIB); in the product libraries
+// ucod::lab_env() is a constant nullptr and every knob takes its default.
+#include <cstdlib>
+namespace ucod {
+#ifdef UCOD_LAB_KNOBS
+inline const char* lab_env(const char* name) { return getenv(name); }
+#else
+inline const char* lab_env(const char*) { return nullptr; }
+#endif
+}  // namespace ucod
+
 #define UCOD_OK 0
 #define UCOD_EINVAL (-1)
 #define UCOD_ENOMEM (-2)
@@ -157,7 +169,7 @@ enum ProfClass {
   PROF_GEMM_EPI0 = 0, PROF_GEMM_EPI1, PROF_GEMM_EPI2, PROF_GEMM_EPI3, PROF_GEMM_EPI4, PROF_GEMM_EPI5, PROF_ATTN, PROF_LN,
   PROF_IM2COL, PROF_CLS, PROF_BILINEAR, PROF_DBA_PROJECT, PROF_DBA_COLNORM, PROF_DBA_HEADS, PROF_ORTH, PROF_DBA_BWD,
   PROF_DBA_WGRAD, PROF_DISC_FWD, PROF_DISC_BWD, PROF_APM, PROF_BINARIZE, PROF_ADAMW, PROF_CROP, PROF_CAST, PROF_LN_BWD, PROF_LORA,
-  PROF_ATTN_BWD, PROF_GEMM_EPI6, PROF_GEMM_EPI7, PROF_ROW_STATS, PROF_NUM
+  PROF_ATTN_BWD, PROF_GEMM_EPI6, PROF_GEMM_EPI7, PROF_ROW_STATS, PROF_SPLIT, PROF_LN_SPLIT, PROF_ATTN_SPLIT, PROF_NUM
 };
 struct ProfScope {
   int idx;

@@ -322,7 +322,7 @@ extern "C" int ucod_bilinear_resize(const float* in, float* out, int planes, int
   UCOD_PROF(PROF_BILINEAR, stream);
   constexpr int PB = 4;
   const size_t lds = (size_t)PB * ih * iw * sizeof(float);
-  if (!getenv("UCOD_RESIZE_ELEMENTWISE") && (ow & 3) == 0 && ow >= 4 && ow <= 1024 && lds <= 48 * 1024 && planes >= 64 && oh * ow >= ih * iw) {
+  if (!ucod::lab_env("UCOD_RESIZE_ELEMENTWISE") && (ow & 3) == 0 && ow >= 4 && ow <= 1024 && lds <= 48 * 1024 && planes >= 64 && oh * ow >= ih * iw) {
     hipLaunchKernelGGL(bilinear_up4_kernel<PB>, dim3(cdiv(planes, PB)), dim3(256), lds, (hipStream_t)stream, in, out, planes, ih, iw, oh, ow, sh, sw);
   } else {
     hipLaunchKernelGGL(bilinear_kernel, dim3(nblocks(total, 16384)), dim3(256), 0, (hipStream_t)stream, in, out, (long)planes, ih, iw, oh, ow, sh, sw);
@@ -341,7 +341,7 @@ extern "C" int ucod_bilinear_resize_adjoint(const float* gout, float* gin, int p
   if (taps > 16.f) return UCOD_EINVAL;                                       // more than 16 taps per axis (up-sampling beyond 7.5x)
   const int MAXT = taps > 8.f ? 16 : 8;
   const size_t lds = ((((size_t)oh * ow + 3) & ~(size_t)3) + (size_t)oh * iw + (size_t)ih * (2 * MAXT + 1)) * sizeof(float);
-  if (!getenv("UCOD_RESIZE_ELEMENTWISE") && lds <= 60 * 1024 && planes >= 64 && iw <= 128) {
+  if (!ucod::lab_env("UCOD_RESIZE_ELEMENTWISE") && lds <= 60 * 1024 && planes >= 64 && iw <= 128) {
     // planes per workgroup: amortises the tap set-up, but a workgroup's planes are strictly sequential (load, barrier, pass 1, barrier,
     // pass 2) and the latencies are hidden by the other 4 workgroups on the CU -- 4096 planes: 4 per workgroup 40 us, 8: 72 us, 1: 50 us
     const int ppw = planes >= 2048 ? 4 : (planes >= 512 ? 2 : 1);

@@ -537,7 +537,7 @@ static int launch_resid_h16(ucod::GemmArgs a, hipStream_t s) {
   a.col_fast = a.tiles_n <= 4;
   apply_order_tuning(a);
   // store policy of the new stream: default (kept in L2: the next launch reads it) or, UCOD_RESID16_NT=1, non-temporal (measurement switch, round 5)
-  static const bool nt = [] { const char* e = getenv("UCOD_RESID16_NT"); return e && e[0] == '1'; }();
+  static const bool nt = [] { const char* e = ucod::lab_env("UCOD_RESID16_NT"); return e && e[0] == '1'; }();
   if (nt) hipLaunchKernelGGL((gemm_bf16_mixed_kernel<EPI, 4, 2>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((gemm_bf16_mixed_kernel<EPI, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
   UCOD_CHECK_LAUNCH();

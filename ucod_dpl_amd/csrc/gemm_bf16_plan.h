@@ -11,7 +11,8 @@ namespace ucod {
 //   UCOD_GEMM_NO_PATCH=1      leftover tiles as a partly filled round instead of patches (bitwise batch-position independence)
 //   UCOD_GEMM_PATCH_ROUNDS=n  patches only for launches of at most n whole rounds (default 2)
 //   UCOD_GEMM_NO_MIXED=1      no mixed-height launches
-//   UCOD_GEMM_GROUP_M / UCOD_GEMM_COL_FAST / UCOD_GEMM_ST_AUX   tile order and output store policy (tools/gemm_order_sweep.py)
+//   UCOD_GEMM_GROUP_M / UCOD_GEMM_COL_FAST / UCOD_GEMM_ST_AUX   tile order and output store policy (tools/gemm_order_sweep.py): measurement knobs,
+//                             honoured by -DUCOD_LAB_KNOBS builds only (common.h: lab_env)
 struct GemmTuning {
   bool no_patch = false, no_mixed = false;
   int patch_rounds = 2, group_m = -1, col_fast = -1, st_aux = -1;      // -1: the launch's own default
@@ -20,12 +21,13 @@ inline GemmTuning read_gemm_tuning() {
   GemmTuning t;
   auto flag = [](const char* n) { const char* e = getenv(n); return e && e[0] && e[0] != '0'; };
   auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e && e[0] ? atoi(e) : dflt; };
+  auto lab_num = [](const char* n, int dflt) { const char* e = lab_env(n); return e && e[0] ? atoi(e) : dflt; };       // measurement knobs: -DUCOD_LAB_KNOBS builds only
   t.no_patch = flag("UCOD_GEMM_NO_PATCH");
   t.no_mixed = flag("UCOD_GEMM_NO_MIXED");
   t.patch_rounds = num("UCOD_GEMM_PATCH_ROUNDS", 2);
-  t.group_m = num("UCOD_GEMM_GROUP_M", -1);
-  t.col_fast = num("UCOD_GEMM_COL_FAST", -1);
-  t.st_aux = num("UCOD_GEMM_ST_AUX", -1);
+  t.group_m = lab_num("UCOD_GEMM_GROUP_M", -1);
+  t.col_fast = lab_num("UCOD_GEMM_COL_FAST", -1);
+  t.st_aux = lab_num("UCOD_GEMM_ST_AUX", -1);
   return t;
 }
 inline GemmTuning& tuning() {

@@ -12,7 +12,7 @@ static const char* kNames[PROF_NUM] = {
     "gemm_bf16_bias_f32", "attention_fwd", "layernorm", "patch_im2col", "cls_rows", "bilinear_resize", "dba_project_f32",
     "dba_colnorm", "dba_heads_fwd", "orth_gram_fwd", "dba_bwd", "dba_wgrad_f32", "disc_fwd", "disc_bwd", "apm_bce", "binarize",
     "adamw_ema", "crop_resize_norm", "cast", "layernorm_bwd", "lora_rowwise", "attention_bwd", "gemm_bf16_gelu_bwd",
-    "gemm_bf16_fc1_gelu_save", "row_stats"};
+    "gemm_bf16_fc1_gelu_save", "row_stats", "split_operands", "layernorm_split", "attention_split_fwd"};
 
 struct Rec { int cls; hipEvent_t a, b; };
 static std::mutex g_mu;
@@ -45,6 +45,22 @@ ProfScope::~ProfScope() {
 }  // namespace ucod
 
 using namespace ucod;
+
+// (s_memtime, s_memrealtime) of the CU workgroup 0 lands on: see include/ucod_dpl.h
+__global__ void clock_probe_kernel(unsigned long long* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    unsigned long long t, rt;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(rt)::"memory");
+    out[0] = t;
+    out[1] = rt;
+  }
+}
+extern "C" int ucod_clock_probe(unsigned long long* out_dev, void* stream) {
+  if (!out_dev) return UCOD_EINVAL;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_dev);
+  UCOD_CHECK_LAUNCH();
+  return UCOD_OK;
+}
 
 extern "C" int ucod_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);

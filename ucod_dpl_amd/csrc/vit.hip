@@ -39,7 +39,7 @@ Plan make_plan(const ucod_vit_desc* d) {
   p.f8_bytes = d->attn_variant == 8 ? ucod_attention_fp8_workspace_bytes(d->B, p.tok, d->heads) : 0;   // Q8 | K8 | Vt8 of the fp8 attention path
   p.off_f8 = take(p.f8_bytes);
   p.off_stats = take(d->ln_fold ? (size_t)p.M * 8 : 0);            // (rstd, -mean * rstd) per token row of the folded LayerNorms (small passes)
-  p.off_part = take(d->ln_fold ? (size_t)p.M * (d->D / 64) * 8 : 0);   // per-row partial (sum, sum of squares) per 64-column slot (large passes)
+  p.off_part = take(d->ln_fold ? (size_t)p.M * (d->D / 64) * 8 : 0);   // per-row partial (sum, M2 about the slot mean) per 64-column slot (large passes)
   p.total = o;
   return p;
 }
@@ -111,7 +111,7 @@ extern "C" int ucod_vit_forward(const ucod_vit_desc* d, const void* const* T, co
   float* const stats = (float*)(ws + p.off_stats);
   float* const part = (float*)(ws + p.off_part);
   const int nslot = D / 64;
-  static const bool no_part = getenv("UCOD_LN_FOLD_NO_PARTIALS") != nullptr;      // measurement knob: always the statistics kernel
+  static const bool no_part = ucod::lab_env("UCOD_LN_FOLD_NO_PARTIALS") != nullptr;      // measurement knob: always the statistics kernel
   bool have_part = false;
   RUN(ucod_patch_im2col(img, patches, d->B, d->C, d->H, d->W, d->P, d->Kpad, stream));
   // (the patch embedding's *_STATS form runs without the leftover-as-patches mode: worth it only when its 256 x 256 tiles come out as nearly whole

@@ -425,28 +425,26 @@ __global__ void cls_rows_h16_kernel(unsigned short* __restrict__ x, const float*
   x[(size_t)b * tok * D + j] = __builtin_bit_cast(unsigned short, (_Float16)clamp_f16(o));
 }
 
-// CLS rows of the fp16 stream WITH their row partials for the LayerNorm-folded consumer (gemm_bf16_epilogue.h: kStats): one workgroup per image;
-// slot 0 of the row takes (sum, sum of squares) of the rounded values, the other slots zeros.
+// CLS rows of the fp16 stream WITH their row partials for the LayerNorm-folded consumer (gemm_bf16_epilogue.h: kStats): one workgroup per image.  A wave's 64
+// lanes hold exactly one 64-column slot per iteration (columns wave * 64 + 256 i ..): slot (sum, M2 about the slot's own mean) of the rounded values, the
+// format row_partial8 writes for the other rows (D % 64 == 0: the launcher checks).
 __global__ __launch_bounds__(256) void cls_rows_h16_stats_kernel(unsigned short* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
                                                                  float2* __restrict__ part, int nslot, int tok, int D, unsigned* __restrict__ ovf) {
-  __shared__ float red[32];
   const int b = blockIdx.x;
-  float s = 0.f, q = 0.f;
   bool sat = false;
-  for (int j = threadIdx.x; j < D; j += 256) {
+  float2* row = part + (size_t)b * tok * nslot;
+  for (int j = threadIdx.x; j < D; j += 256) {                    // (D % 64 == 0: whole waves)
     const float o = cls[j] + pos[j];
     sat |= beyond_f16(o);
     const _Float16 h = (_Float16)clamp_f16(o);
     x[(size_t)b * tok * D + j] = __builtin_bit_cast(unsigned short, h);
     const float r = (float)h;
-    s += r;
-    q = fmaf(r, r, q);
+    const float s = wave_sum(r);
+    const float d = r - s * (1.0f / 64.0f);
+    const float m2 = wave_sum(d * d);
+    if ((threadIdx.x & 63) == 0) row[j >> 6] = make_float2(s, m2);
   }
   if (sat) atomicAdd(ovf, 1u);
-  s = block_sum(s, red);
-  q = block_sum(q, red + 16);
-  float2* row = part + (size_t)b * tok * nslot;
-  if (threadIdx.x < nslot) row[threadIdx.x] = threadIdx.x == 0 ? make_float2(s, q) : make_float2(0.f, 0.f);
 }
 
 // Saturation counter of the f16 residual stream: every kernel that rounds the stream to fp16 (patch / out-proj / fc2 epilogues, CLS rows)
@@ -510,11 +508,11 @@ extern "C" int ucod_layernorm_h16(const void* x, const float* gamma, const float
   hipStream_t s = (hipStream_t)stream;
   const unsigned* xp = (const unsigned*)x;
   bf16_raw* yp = (bf16_raw*)y;
-  static const bool no_strip = getenv("UCOD_LN_NO_STRIP") != nullptr;     // measurement knob: the 8-byte form
+  static const bool no_strip = ucod::lab_env("UCOD_LN_NO_STRIP") != nullptr;     // measurement knob: the 8-byte form
   // strips (row pairs) per wave of the 16-byte form: gamma / beta stay in registers over them.  UCOD_LN_STRIPS (read once): 0 = one strip per
   // wave (the round-3 launch); default 2 below D = 1024, 4 from there (profiles/r04_layernorm_strips.txt: 24.3 -> 23.1 us at 43840 x 768,
   // 18.6 -> 17.9 us = 0.63 of the HBM peak at 21920 x 1024, BASELINE configs[3]; 8 and more lose to the shorter tail)
-  static const int strips_env = [] { const char* e = getenv("UCOD_LN_STRIPS"); return e ? atoi(e) : -1; }();
+  static const int strips_env = [] { const char* e = ucod::lab_env("UCOD_LN_STRIPS"); return e ? atoi(e) : -1; }();
   // (round 4, late) below D = 1024: 3, not the isolated launch's optimum of 2 -- in the pipelined step, where this kernel runs beside the other stream's
   // large-tile GEMM, 3 and 4 strips give 3 381-3 398 images/s against 3 356-3 374 with 2 (three alternating runs each, one box); 3 keeps the launch at
   // 26.0 us (0.65 of the HBM peak; 2: 25.3 us, 4: 27.0 us)
@@ -555,7 +553,7 @@ extern "C" int ucod_row_stats_h16(const void* x, float* stats, int rows, int D, 
   if (!x || !stats || rows <= 0 || D <= 0 || (D % 256) != 0 || D > 1536) return UCOD_EINVAL;
   UCOD_PROF(PROF_ROW_STATS, stream);
   hipStream_t s = (hipStream_t)stream;
-  static const int strips_env = [] { const char* e = getenv("UCOD_STATS_STRIPS"); return e ? atoi(e) : -1; }();
+  static const int strips_env = [] { const char* e = ucod::lab_env("UCOD_STATS_STRIPS"); return e ? atoi(e) : -1; }();
   const int per_wave = strips_env > 0 ? strips_env : 4;
   const int nstrips = (rows + 1) / 2;
   const int want = cdiv(cdiv(nstrips, per_wave), 4);
@@ -580,7 +578,7 @@ extern "C" int ucod_cls_rows_h16(void* x, const float* cls, const float* pos, in
 }
 
 extern "C" int ucod_cls_rows_h16_stats(void* x, const float* cls, const float* pos, float* row_partials, int nslot, int B, int tok, int D, void* stream) {
-  if (!x || !cls || !pos || !row_partials || nslot <= 0 || nslot > 256 || B <= 0 || tok <= 0 || D <= 0) return UCOD_EINVAL;
+  if (!x || !cls || !pos || !row_partials || nslot <= 0 || nslot > 256 || B <= 0 || tok <= 0 || D <= 0 || (D % 64) != 0 || nslot != D / 64) return UCOD_EINVAL;
   UCOD_PROF(ucod::PROF_CLS, stream);
   hipLaunchKernelGGL(ucod::cls_rows_h16_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (unsigned short*)x, cls, pos, (float2*)row_partials, nslot, tok, D,
                      ucod::resid16_overflow_counter());

@@ -640,13 +640,13 @@ static int launch_ln_lora(const void* x, bool x_h16, const float* gamma, const f
   if (dropout && (dropout->p < 0.f || dropout->p >= 1.f)) return UCOD_EINVAL;
   UCOD_PROF(PROF_LN, stream);
   const Drop drop = make_drop(dropout);
-  static const int lnl_env = [] { const char* e = getenv("UCOD_LN_LORA_NBLK"); return e ? atoi(e) : 0; }();          // measurement knob
+  static const int lnl_env = [] { const char* e = ucod::lab_env("UCOD_LN_LORA_NBLK"); return e ? atoi(e) : 0; }();          // measurement knob
   const int lnl_max = lnl_env > 0 ? lnl_env : 2048;
   const int nblk = cdiv(rows, 8) < lnl_max ? cdiv(rows, 8) : lnl_max;   // block-stride over rows: the A rows are staged once per block
   dim3 grid(nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)3 * r * D * sizeof(float);
-  static const bool narrow = getenv("UCOD_LN_LORA_NARROW") != nullptr;     // measurement knob: the 8-byte / 4-byte form
+  static const bool narrow = ucod::lab_env("UCOD_LN_LORA_NARROW") != nullptr;     // measurement knob: the 8-byte / 4-byte form
   if ((D % 256) == 0 && D <= 1536 && !narrow) {
     switch (D / 256) {
 #define C4(n)                                                                                                                                        \
@@ -793,9 +793,9 @@ extern "C" int ucod_lora_grad(void* dqkv_aug, const void* h_aug, const float* lo
   const Drop drop = make_drop(dropout);
   hipStream_t s = (hipStream_t)stream;
   constexpr int RW = 2;                                           // ranks per pass (the reference's r = 2 is one pass)
-  static const int ns_env = [] { const char* e = getenv("UCOD_LORA_GRAD_STREAMS"); return e ? atoi(e) : 0; }();   // measurement knob: 2 or 4 row streams per block
+  static const int ns_env = [] { const char* e = ucod::lab_env("UCOD_LORA_GRAD_STREAMS"); return e ? atoi(e) : 0; }();   // measurement knob: 2 or 4 row streams per block
   const int NSr = ns_env == 2 ? 2 : ns_env == 5 ? 5 : 4;
-  static const int nb_env = [] { const char* e = getenv("UCOD_LORA_GRAD_NBLK"); return e ? atoi(e) : 0; }();       // measurement knob (<= LORA_GRAD_BLOCKS)
+  static const int nb_env = [] { const char* e = ucod::lab_env("UCOD_LORA_GRAD_NBLK"); return e ? atoi(e) : 0; }();       // measurement knob (<= LORA_GRAD_BLOCKS)
   // default: one block per CU (12 waves of 4 row streams x 3 projections), a whole round -- round 4: 512 blocks of 6 waves 158 us -> 109 us per launch at
   // ViT-B / 32 images (fewer partials to combine and to reduce; 384 blocks = 1.5 rounds: 140 us)
   static const int n_cu = [] { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); return hipGetDeviceProperties(&pr, dv) == hipSuccess ? pr.multiProcessorCount : 256; }();
@@ -803,7 +803,7 @@ extern "C" int ucod_lora_grad(void* dqkv_aug, const void* h_aug, const float* lo
   const int nblk = rows < nb_max * NSr ? cdiv(rows, NSr) : nb_max;
   const size_t lds_bytes = (size_t)6 * D * RW * sizeof(float);      // B window (3*D*RW) <= block reduction buffer (6*D*RW)
   for (int j0 = 0; j0 < r; j0 += RW) {
-    static const bool narrow = getenv("UCOD_LORA_GRAD_WIDE") == nullptr;      // default: the 4-byte-load form (88 VGPRs; the 8-byte one: 148, 4 % slower)
+    static const bool narrow = ucod::lab_env("UCOD_LORA_GRAD_WIDE") == nullptr;      // default: the 4-byte-load form (88 VGPRs; the 8-byte one: 148, 4 % slower)
 #define LG(n, vw)                                                                                                                                   \
   do {                                                                                                                                              \
     if (NSr == 2) hipLaunchKernelGGL((lora_grad_kernel<n, RW, vw, 2>), dim3(nblk), dim3(384), lds_bytes, s, (bf16_raw*)dqkv_aug, (const bf16_raw*)h_aug, lora_layer, r, j0, scaling, (float*)workspace, rows, D, drop); \

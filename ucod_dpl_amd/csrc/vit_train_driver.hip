@@ -246,7 +246,7 @@ extern "C" int ucod_vit_backward(const ucod_vit_train_desc* t, const void* const
 
   // dgrad outputs that feed a LayerNorm backward (dh) are written as bf16 (UCOD_DGRAD_F32=1: f32, the round-3 path): the GEMM's drain and the
   // LayerNorm backward's read side move half the bytes; the residual cotangent stream (dx) stays f32
-  static const bool dgrad16_env = !(getenv("UCOD_DGRAD_F32") && getenv("UCOD_DGRAD_F32")[0] == '1');
+  static const bool dgrad16_env = !(ucod::lab_env("UCOD_DGRAD_F32") && ucod::lab_env("UCOD_DGRAD_F32")[0] == '1');
   const bool r16 = d->resid16 != 0;                               // the saved residual stream is fp16 (then the dgrad outputs are bf16 whatever the variable says)
   const bool dgrad16 = dgrad16_env || r16;
   const int epi_dh = dgrad16 ? UCOD_EPI_BIAS_BF16 : UCOD_EPI_BIAS_F32;

@@ -195,11 +195,17 @@ class MultiCacheManager:
 
 
 # ------------------------------------------------------------------------------------------- the cache-building pass
-def build_feature_cache(images, feature_extractor, features_cache, batch_size=32, device="cuda", writers=8):
+def build_feature_cache(images, feature_extractor, features_cache, batch_size=32, device="cuda", writers=8, precision="f32eq"):
     """Run ``feature_extractor`` (``backbone``-like: ``(img) -> (outputs, key [B,C,h,w])``) over ``images`` -- an iterable of
     ``[3,H,W]`` f32 tensors, already transformed as base_dataset.py:133 does -- in batches, and write the features cache in
     the reference's format.  Items are streamed to disk as they are produced (the reference first collects the whole list
-    in host memory, base_dataset.py:128-143).  Returns the number of items written."""
+    in host memory, base_dataset.py:128-143).  Returns the number of items written.
+    ``precision``: the reference runs THIS pass with the backbone in plain fp32 (base_dataset.py:124-138: no autocast; the features it caches are what every
+    training epoch then reads), so by default a ``backbone`` wrapper is asked for its f32-equivalent sibling (``with_precision("f32eq")``: split-operand MFMA,
+    f32 residual stream; ~6x the matrix work of the fp16 engine, which a pass bound by pickle writes does not notice).  ``precision=None`` keeps the extractor
+    as given (any callable without ``with_precision`` -- a test double -- is used as it is)."""
+    if precision is not None and hasattr(feature_extractor, "with_precision"):
+        feature_extractor = feature_extractor.with_precision(precision)
     store = features_cache.io._store
     if store.readable:
         raise RuntimeError(f"cache at {store.dir} already exists and is valid; remove it to rebuild")

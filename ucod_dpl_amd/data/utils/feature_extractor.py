@@ -18,7 +18,7 @@ from pathlib import Path
 import torch
 from torch import nn
 
-from ...vit_engine import ViTEngine
+from ...vit_engine import ViTEngine, SplitViTEngine
 from ...engine.registry import BACKBONE_REGISTRY
 
 # name -> (width D, heads, layers, patch, pretrain image size, layerscale?)
@@ -121,13 +121,48 @@ class backbone(nn.Module):
         if heads is None:
             raise ValueError("heads is required with an explicit state_dict")
         if config is not None:
-            # build-only keys of dataset_cfg.feature_extractor_cfg (absent from the shipped configs: the engine's defaults apply).  The configuration bench.py
-            # quotes its headline on is  half="f16", resid="f16"  (fp16 operands on the fp16 residual stream: LayerNorm folded into QKV / fc1, logits within
-            # 1e-3 of the f32 reference on the flat init)
-            for k in ("half", "resid", "ln_fold", "attn_variant"):
+            # build-only keys of dataset_cfg.feature_extractor_cfg (absent from the shipped configs: the engine's defaults apply, and those ARE the
+            # configuration bench.py quotes its headline on -- fp16 operands on the fp16 residual stream with LayerNorm folded into QKV / fc1 wherever the fold
+            # exists, logits within 1e-3 of the f32 reference on the flat init; round 6)
+            for k in ("half", "resid", "ln_fold", "attn_variant", "precision"):
                 if k in config and k not in engine_kw:
                     engine_kw[k] = config[k]
-        self.engine = ViTEngine(state_dict, heads=heads, eps=eps or 1e-6, device=device, **engine_kw)
+        self._src = (state_dict, heads, eps or 1e-6, device)       # (references, not copies) what with_precision() rebuilds a sibling engine from
+        self._siblings = {}
+        self.precision, self.engine = self._make_engine(engine_kw.pop("precision", None), engine_kw)
+
+    PRECISIONS = {"split2": 2, "split3": 3, "f32eq": 3}
+
+    def _make_engine(self, precision, engine_kw):
+        """``precision``: None / "f16" / "bf16" -> the 16-bit ``ViTEngine`` (``half`` = that; None = the engine's default, fp16); "split2" / "split3" / "f32eq"
+        (= split3) -> ``SplitViTEngine``: every matrix product on split bf16 operands with an f32 residual stream -- the reference's cached-feature pass runs the
+        backbone in plain fp32 (data/datasets/base_dataset.py:124-138) and this is the engine that reproduces it to f32 rounding."""
+        state_dict, heads, eps, device = self._src
+        if precision in self.PRECISIONS:
+            extra = {k: v for k, v in engine_kw.items() if k not in ("gemm_variant",)}
+            if extra:
+                raise ValueError(f"precision={precision!r} takes no {sorted(extra)}: the split-operand engine has one residual stream (f32) and one attention path")
+            return precision, SplitViTEngine(state_dict, heads=heads, eps=eps, device=device, terms=self.PRECISIONS[precision], **engine_kw)
+        if precision not in (None, "f16", "bf16"):
+            raise ValueError(f"precision must be one of None, 'f16', 'bf16', {sorted(self.PRECISIONS)}; got {precision!r}")
+        if precision is not None:
+            if engine_kw.get("half", precision) != precision:
+                raise ValueError(f"precision={precision!r} contradicts half={engine_kw['half']!r}")
+            engine_kw = dict(engine_kw, half=precision)
+        eng = ViTEngine(state_dict, heads=heads, eps=eps, device=device, **engine_kw)
+        return eng.half, eng
+
+    def with_precision(self, precision):
+        """A ``backbone`` over the SAME checkpoint whose engine runs at ``precision`` (built once, then cached): ``build_feature_cache`` asks for "f32eq"."""
+        if precision == self.precision or (precision == "f32eq" and self.precision == "split3"):
+            return self
+        if precision not in self._siblings:
+            other = object.__new__(type(self))
+            nn.Module.__init__(other)
+            other.config, other.key, other._src, other._siblings = self.config, None, self._src, self._siblings
+            other.precision, other.engine = other._make_engine(precision, {})
+            self._siblings[precision] = other
+        return self._siblings[precision]
 
     @classmethod
     def from_state_dict(cls, state_dict, heads, eps=1e-6, device="cuda", **kw):

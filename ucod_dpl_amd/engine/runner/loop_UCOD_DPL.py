@@ -192,10 +192,15 @@ class TrainLoop(BaseLoop):
             return self._process_batch_zeroed(pseudo_labels, features, pl, scratch)
 
     def _step_scratch(self, B, dev):
-        """[sdiag B | losses 4] f32, kept across steps (the step's loss tensors are views of it: read them before the next step)"""
-        if getattr(self, "_scratch", None) is None or self._scratch.numel() != B + 4 or self._scratch.device != dev:
-            self._scratch = torch.empty(B + 4, dtype=torch.float32, device=dev)
-        return self._scratch
+        """[sdiag B | losses 4] f32.  TWO buffers used alternately: the step's loss tensors (``self.last['dis_loss']``, the diagonal sums) are views of the
+        buffer of THAT step and stay valid while the next step is enqueued and runs -- only the step after that zeroes the buffer again (with one
+        buffer a caller that read ``last`` after the next ``_process_batch`` had been enqueued saw 0 or the next step's value)."""
+        ring = getattr(self, "_scratch", None)
+        if ring is None or ring[0].numel() != B + 4 or ring[0].device != dev:
+            self._scratch = ring = [torch.empty(B + 4, dtype=torch.float32, device=dev) for _ in range(2)]
+            self._scratch_i = 0
+        self._scratch_i ^= 1
+        return ring[self._scratch_i]
 
     def _process_batch_zeroed(self, pseudo_labels, features, pl, scratch):
         r = self.runner

@@ -17,7 +17,7 @@ if os.environ.get("UCOD_DPL_LIB"):
                        "UCOD_DPL_ALLOW_EXPERIMENT=1 UCOD_DPL_EXPERIMENT_LIB=<path> for an experiment build")
 if os.environ.get("UCOD_DPL_EXPERIMENT_LIB") and os.environ.get("UCOD_DPL_ALLOW_EXPERIMENT") == "1":
     LIB_PATH = os.environ["UCOD_DPL_EXPERIMENT_LIB"]
-ABI_VERSION = 4                                            # include/ucod_dpl.h: UCOD_ABI_VERSION
+ABI_VERSION = 5                                            # include/ucod_dpl.h: UCOD_ABI_VERSION
 
 EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_SCALE_RESID_F32, EPI_PATCH_TOKENS_F32, EPI_KEY_NCHW_F32, EPI_BIAS_F32 = range(6)
 EPI_GELU_BWD_BF16, EPI_BIAS_GELU_SAVE_BF16 = 6, 7          # ucod_gemm_bf16_train only (backbone-backward mode)
@@ -63,6 +63,16 @@ SIGNATURES = {
     "ucod_prof_num_classes": (ci, []),
     "ucod_prof_class_name": (C.c_char_p, [ci]),
     "ucod_prof_collect": (ci, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "ucod_clock_probe": (ci, [vp, vp]),
+    "ucod_split_products": (ci, [ci]),
+    "ucod_split_rows": (ci, [vp, C.c_long, vp, ci, ci, ci, ci, ci, cf, vp]),
+    "ucod_layernorm_split": (ci, [vp, vp, vp, vp, ci, ci, cf, ci, ci, vp]),
+    "ucod_patch_im2col_split": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
+    "ucod_attention_split_operand_bytes": (sz, [ci, ci, ci, ci]),
+    "ucod_qkv_split": (ci, [vp, vp, ci, ci, ci, ci, cf, vp]),
+    "ucod_attention_split_fwd": (ci, [vp, vp, ci, ci, ci, ci, vp]),
+    "ucod_vit_split_workspace_bytes": (sz, [C.POINTER(VitDesc), ci]),
+    "ucod_vit_forward_split": (ci, [C.POINTER(VitDesc), ci, C.POINTER(vp), vp, vp, vp, sz, vp]),
     "ucod_gemm_bf16": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
     "ucod_gemm_lnfold": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, cf, vp, ci, vp]),
     "ucod_gemm_bf16_stats": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp]),
@@ -167,6 +177,8 @@ SIGNATURES = {
 COD_RECORD = 1032
 
 LIB_PATH_F16 = os.path.join(_HERE, "_native", "libucod_dpl_f16.so")   # same sources built with -DUCOD_HALF_F16 (fp16 forward-path operands)
+if os.environ.get("UCOD_DPL_EXPERIMENT_LIB_F16") and os.environ.get("UCOD_DPL_ALLOW_EXPERIMENT") == "1":
+    LIB_PATH_F16 = os.environ["UCOD_DPL_EXPERIMENT_LIB_F16"]          # tools/: e.g. the -DUCOD_LAB_KNOBS build (`make -C ucod_dpl_amd/csrc knobs`)
 _libs = {}
 
 

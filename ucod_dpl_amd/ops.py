@@ -56,6 +56,65 @@ def linear_scale_resid(x, w, b, scale, resid, variant=0):
     return gemm_bf16(N.EPI_BIAS_SCALE_RESID_F32, x, w, out, M, w.shape[0], K, bias=b, scale=scale, resid=resid, variant=variant)
 
 
+# ---- split-operand (f32-equivalent) pieces: include/ucod_dpl.h, "split-operand backbone pass"; csrc/split.hip
+def split_products(terms):
+    n = N.load().ucod_split_products(int(terms))
+    if n == 0:
+        raise ValueError(f"terms must be 2 or 3, got {terms}")
+    return n
+
+
+def split_rows(x, terms, role, op=0, alpha=1.0):
+    """x f32 [M,K] (rows may be strided) -> bf16 [M, P K]: segment p holds term {0,0,1,1,0,2}[p] (role 0, the A side) / {0,1,0,1,2,0}[p] (role 1, the B side)
+    of x = x0 + x1 (+ x2).  op 1: exact-erf GELU of x first; op 2: x * alpha first."""
+    _f32(x)
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("split_rows takes a 2-d tensor with contiguous rows")
+    if not x.is_cuda:
+        raise RuntimeError("ucod_dpl_amd: tensor is not on a GPU; the HIP path has no CPU fallback")
+    M, K = x.shape
+    out = torch.empty(M, split_products(terms) * K, dtype=torch.bfloat16, device=x.device)
+    check(N.load().ucod_split_rows(x.data_ptr(), x.stride(0), ptr(out), M, K, int(terms), int(role), int(op), float(alpha), stream()), "ucod_split_rows")
+    return out
+
+
+def linear_split(x, w, b, terms, variant=0):
+    """f32-equivalent x w^T + b on the bf16 matrix pipe: x f32 [M,K], w f32 [N,K], b f32 [N] -> f32 [M,N] (ucod_gemm_bf16 over the K-concatenated split operands)."""
+    M, K = x.shape
+    P = split_products(terms)
+    out = torch.empty(M, w.shape[0], dtype=torch.float32, device=x.device)
+    return gemm_bf16(N.EPI_BIAS_F32, split_rows(x, terms, 0), split_rows(w, terms, 1), out, M, w.shape[0], P * K, bias=_f32(b), variant=variant)
+
+
+def layernorm_split(x, gamma, beta, eps, terms, role=0):
+    rows, D = x.shape
+    out = torch.empty(rows, split_products(terms) * D, dtype=torch.bfloat16, device=x.device)
+    check(N.load().ucod_layernorm_split(ptr(_f32(x)), ptr(_f32(gamma)), ptr(_f32(beta)), ptr(out), rows, D, float(eps), int(terms), int(role), stream()), "ucod_layernorm_split")
+    return out
+
+
+def attention_split(qkv, B, tok, heads, terms, qscale=0.125 * 1.4426950408889634):
+    """qkv f32 [B*tok, 3*heads*64] -> the attention output as the A-side split operand bf16 [B*tok, P*heads*64] (softmax(Q K^T / 8) V, f32-equivalent)."""
+    lib = N.load()
+    need = lib.ucod_attention_split_operand_bytes(B, tok, heads, int(terms))
+    if need == 0:
+        raise ValueError("unsupported attention geometry")
+    opnd = torch.empty(need, dtype=torch.uint8, device=qkv.device)
+    out = torch.empty(B * tok, split_products(terms) * heads * 64, dtype=torch.bfloat16, device=qkv.device)
+    check(lib.ucod_qkv_split(ptr(_f32(qkv)), ptr(opnd), B, tok, heads, int(terms), float(qscale), stream()), "ucod_qkv_split")
+    check(lib.ucod_attention_split_fwd(ptr(opnd), ptr(out), B, tok, heads, int(terms), stream()), "ucod_attention_split_fwd")
+    return out
+
+
+def unsplit(xs, terms, role, K):
+    """The f32 value a split operand [M, P K] stands for (sum of its distinct terms): test helper, torch arithmetic on the device."""
+    P = split_products(terms)
+    seg = xs.view(xs.shape[0], P, K).float()
+    order = ([0, 0, 1, 1, 0, 2] if role == 0 else [0, 1, 0, 1, 2, 0])[:P]
+    first = [order.index(t) for t in range(int(terms))]
+    return sum(seg[:, i] for i in first)
+
+
 def row_stats_h16(x, eps):
     """x fp16 [rows, D] (the fp16 residual stream) -> f32 [rows, 2] = (rstd, -mean * rstd): what the LayerNorm-folded epilogues read."""
     if x.dtype != torch.float16:

@@ -111,6 +111,9 @@ def init_from_env(backend="nccl", timeout_s=None):
     import datetime
     rank, local_rank, world = env_world()
     backend = os.environ.get("UCOD_DIST_BACKEND", backend)
+    if world == 1 and os.environ.get("UCOD_FORCE_DIST") == "1":
+        force_single_rank_group(backend)
+        return rank, local_rank, world
     if world > 1 and not dist.is_initialized():
         cap_host_threads(world)
         timeout_s = float(os.environ.get("UCOD_DIST_TIMEOUT_S", timeout_s or 300))
@@ -130,19 +133,49 @@ def init_from_env(backend="nccl", timeout_s=None):
     return rank, local_rank, world
 
 
+_FORCED = False                                                  # force_single_rank_group(): collectives run although the world is one rank
+
+
+def force_single_rank_group(backend="nccl"):
+    """UCOD_FORCE_DIST=1 on ONE GPU: a real world-size-1 process group (``nccl`` = RCCL: loads librccl, creates the communicator) and NO world-size-1
+    short-circuit afterwards -- ``broadcast_state``, ``allreduce_prescaled_async`` / ``handle.wait()``, ``max_over_ranks`` and ``barrier`` issue the
+    collectives exactly as they do at 8 ranks (engine/runner/runner.py:349-372 of the reference: accelerator.prepare + DDP).  What a one-GPU box can prove
+    of the multi-GPU path: the library loads, the communicator comes up, the asynchronous all-reduce on the group's own stream is ordered against the
+    gradient kernels before it and the AdamW launch after it, and what it costs per step (tests/test_gpu_multirank.py::test_nccl_*, bench.py's
+    ``collective`` object).  Rendezvous through a file store: no port, no host name."""
+    global _FORCED
+    import datetime
+    import tempfile
+    if not dist.is_available():
+        raise RuntimeError("torch.distributed is not available in this build")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if not torch.cuda.is_available():
+                raise RuntimeError("backend nccl (= RCCL) needs a GPU; set UCOD_DIST_BACKEND=gloo on a CPU rig")
+        store = os.path.join(tempfile.mkdtemp(prefix="ucod_dist_"), "store")
+        dist.init_process_group(backend=backend, init_method=f"file://{store}", rank=0, world_size=1, timeout=datetime.timedelta(seconds=120))
+    _FORCED = True
+
+
+def collectives_on():
+    """True when the data-path collectives are to be issued: more than one rank, or a forced single-rank group (UCOD_FORCE_DIST=1)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCED)
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 def broadcast_state(tensors, src=0):
-    if world_size() > 1:
+    if collectives_on():
         for t in tensors:
             dist.broadcast(t, src=src)
 
 
 def allreduce_prescaled_(flat):
     """In-place SUM over ranks of a flat buffer whose contents were already scaled by 1/world."""
-    if world_size() > 1:
+    if collectives_on():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
@@ -157,7 +190,7 @@ class _Done:
 def allreduce_prescaled_async(flat):
     """Issue the SUM all-reduce of a pre-scaled flat buffer and return a handle; ``handle.wait()`` before the first consumer
     (the optimiser launch).  The buffer must not be written between issue and wait."""
-    if world_size() > 1:
+    if collectives_on():
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
     return _Done()
 
@@ -167,7 +200,7 @@ def grad_prescale():
 
 
 def max_over_ranks(value, device):
-    if world_size() == 1:
+    if not collectives_on():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -175,7 +208,7 @@ def max_over_ranks(value, device):
 
 
 def barrier():
-    if world_size() > 1:
+    if collectives_on():
         dist.barrier()
 
 

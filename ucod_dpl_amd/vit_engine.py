@@ -100,11 +100,12 @@ def normalize_state_dict(sd):
 class ViTEngine:
     """HIP ViT forward -> last-layer key map [B, D, H/P, W/P] (f32)."""
 
-    def __init__(self, state_dict, heads, eps=1e-6, device="cuda", full_last_layer=False, gemm_variant=0, attn_variant=0, half="bf16",
+    def __init__(self, state_dict, heads, eps=1e-6, device="cuda", full_last_layer=False, gemm_variant=0, attn_variant=0, half="f16",
                  resid="auto", ln_fold="auto"):
-        """``half``: 16-bit type of the GEMM / attention operands -- "bf16" (default; BASELINE configs[1]) or "f16" (IEEE fp16, what
-        the reference's fp16-autocast launcher multiplies in: 8x finer rounding, logits within 1e-3 of the f32 reference at full
-        depth).  Each choice is its own build of the same kernels (native.load).
+        """``half``: 16-bit type of the GEMM / attention operands -- "f16" (default since round 6: IEEE fp16, what the reference's fp16-autocast
+        launcher multiplies in; 8x finer rounding than bf16, logits within 1e-3 of the f32 reference at full depth on the flat init; the
+        configuration bench.py's headline is measured on) or "bf16" (the dtype BASELINE configs[1] names; opt-in).  Each choice is its own build of
+        the same kernels (native.load).
         ``attn_variant``: 0 / 2 the product attention kernel, 1 the generic-scale kernel, 8 the fp8 path of BASELINE configs[4]; 5 / 66 =
         attn_fwd_v5_kernel / attn_fwd_v6_kernel by name (the hand-placed assembly kernels of round 4 are laboratory code: ops.attention_asm).
         ``resid``: type of the residual stream x between the GEMM epilogues and LayerNorm -- "f32" (what the reference holds), "f16"
@@ -112,26 +113,30 @@ class ViTEngine:
         the ENGINE, never of the batch size (an image's key map does not depend on how many images travel with it):
           * bf16 operands -> fp16 stream: its 11 significand bits are 8x finer than the bf16 operands every value is rounded to before
             it is used, so it never sets the error level (logit max-abs vs the f32 oracle 3.2e-3 with either stream);
-          * fp16 operands -> f32 stream: the configuration that meets the 1e-3 logit bar keeps its whole margin (3.8e-4; 6.4e-4 with
-            the fp16 stream -- opt in with resid="f16").
+          * fp16 operands -> fp16 stream WITH LayerNorm folded into QKV / fc1 where the fold exists (D % 256 == 0, D <= 1536, a 16-bit attention
+            path: ViT-B / ViT-L; logits 6.0e-4 on the flat init, the fastest configuration), f32 stream otherwise (ViT-S; 3.8e-4).
         ``ln_fold``: LayerNorm 1 / 2 of every layer but the last folded into the QKV / fc1 GEMMs (ucod_gemm_lnfold, include/ucod_dpl.h): the fp16
         stream is the GEMM's A operand, the weights carry gamma, the epilogue applies the row's (rstd, -mean * rstd).  Needs fp16 operands AND the
-        fp16 stream (an MFMA takes both operands in one type); "auto" = on exactly there (UCOD_LN_FOLD=0 switches it off for A/B runs).
+        fp16 stream (an MFMA takes both operands in one type); "auto" = on exactly there.
         The fp16 stream SATURATES at +-65504 and counts every saturation on the device; ``check_overflow`` (polled by every later
         ``forward``, synchronously with UCOD_CHECK_RESID=1) raises FloatingPointError when the count is non-zero: a checkpoint whose
-        activations do not fit fp16 is reported instead of producing inf -> NaN key maps."""
+        activations do not fit fp16 is reported instead of producing inf -> NaN key maps.
+        No 16-bit configuration meets 1e-3 on trained-like weights (profiles/r06_error_budget_f16.json: every op class carries ~1e-3 of it);
+        ``SplitViTEngine`` (split-operand MFMA, f32 stream: f32-equivalent) is the one that does -- the feature-cache pass uses it."""
         self.half = half
         self.lib = N.load(half)
         if resid not in ("auto", "f32", "f16"):
             raise ValueError(f"resid must be 'auto', 'f32' or 'f16', got {resid!r}")
         self.resid = resid
-        self.resid16 = bool(resid == "f16" or (resid == "auto" and half == "bf16"))
+        c = normalize_state_dict(state_dict)
+        D0 = c["patch_w"].shape[0]
+        fold_shape = half == "f16" and D0 % 256 == 0 and D0 <= 1536 and attn_variant != 8       # where ucod_gemm_lnfold exists
+        self.resid16 = bool(resid == "f16" or (resid == "auto" and (half == "bf16" or (fold_shape and ln_fold is not False))))
         self._ovf_host, self._ovf_events, self._ovf_dev = None, [], None
         if attn_variant not in (0, 1, 2, 8, 5, 66):
             raise ValueError(f"attn_variant must be 0, 1, 2, 5, 8 or 66 (laboratory kernels are reached through ops.attention(variant=...) / ops.attention_asm), got {attn_variant}")
         if ln_fold not in ("auto", True, False):
             raise ValueError(f"ln_fold must be 'auto', True or False, got {ln_fold!r}")
-        c = normalize_state_dict(state_dict)
         self.kind = c["kind"]
         self.device = torch.device(device)
         self.D = c["patch_w"].shape[0]
@@ -165,21 +170,23 @@ class ViTEngine:
                                 f32(l["fc1_b"]), bf(l["fc2_w"]), f32(l["fc2_b"]), f32(l["ls2"]) if l["ls2"] is not None else ones])
         for l in self.layers:
             l += [None, None]                                      # +14 / +15: column sums of the folded weights (ln_fold tables only)
-        can_fold = half == "f16" and self.resid16 and self.D % 256 == 0 and self.D <= 1536 and attn_variant != 8
+        can_fold = fold_shape and self.resid16
         if ln_fold is True and not can_fold:
-            raise ValueError("ln_fold needs half='f16' with the fp16 residual stream (resid='f16'), D % 256 == 0 and a 16-bit attention path")
-        self.ln_fold = bool(can_fold and (ln_fold is True or (ln_fold == "auto" and os.environ.get("UCOD_LN_FOLD", "1") != "0")))
+            raise ValueError("ln_fold needs half='f16' with the fp16 residual stream (resid='f16' or 'auto'), D % 256 == 0 and a 16-bit attention path")
+        self.ln_fold = bool(can_fold and ln_fold is not False)
         self.fold_layers = None
         if self.ln_fold:
             self.fold_layers = []
             for l, src in zip(self.layers, c["layers"]):
                 # (the folded QKV entries also carry the softmax pre-scale head_dim^-0.5 * log2 e on their Q rows -- what the unfolded pass applies as
                 # a column scale in the epilogue -- so that the folded epilogue has no per-column multiply left; attn_variant 1 takes Q unscaled)
-                qs = torch.ones(3 * self.D, dtype=torch.float32, device=dev)
+                # (set-up arithmetic on the HOST in f64 -- fold.py -- then one copy per tensor: no vendor-BLAS kernel runs on the device for it)
+                cpu = lambda t: t.detach().to("cpu", torch.float32)  # noqa: E731
+                qs = torch.ones(3 * self.D, dtype=torch.float32)
                 if attn_variant != 1:
                     qs[:self.D] = 0.125 * 1.4426950408889634
-                qw, qb, qc = self._fold(f32(src["ln1_g"]), f32(src["ln1_b"]), f32(src["qkv_w"]), f32(src["qkv_b"]), row_scale=qs)
-                fw, fb, fc = self._fold(f32(src["ln2_g"]), f32(src["ln2_b"]), f32(src["fc1_w"]), f32(src["fc1_b"]))
+                qw, qb, qc = (t.to(dev) for t in self._fold(cpu(src["ln1_g"]), cpu(src["ln1_b"]), cpu(src["qkv_w"]), cpu(src["qkv_b"]), row_scale=qs))
+                fw, fb, fc = (t.to(dev) for t in self._fold(cpu(src["ln2_g"]), cpu(src["ln2_b"]), cpu(src["fc1_w"]), cpu(src["fc1_b"])))
                 fl = list(l)
                 fl[2], fl[3], fl[9], fl[10], fl[14], fl[15] = qw, qb, fw, fb, qc, fc
                 self.fold_layers.append(fl)
@@ -205,6 +212,10 @@ class ViTEngine:
         n = self.patch_w.numel() * 2
         for l in self.layers:
             n += sum(t.numel() * t.element_size() for t in l if t is not None)
+        # the folded tables are a SECOND copy of every layer's QKV / fc1 weights (+ their folded biases and column sums); the plain copies stay because
+        # the last layer of a (possibly truncated) pass runs unfolded
+        for fl, l in zip(self.fold_layers or (), self.layers):
+            n += sum(t.numel() * t.element_size() for t, t0 in zip(fl, l) if t is not None and t is not t0)
         return n
 
     def _pos(self, gh, gw):
@@ -392,6 +403,117 @@ class ViTEngine:
     __call__ = forward
 
 
+class SplitViTEngine:
+    """The frozen backbone at the REFERENCE's cached-feature precision: HIP ViT forward -> last-layer key map [B, D, H/P, W/P] (f32) with every matrix product
+    computed on split operands (include/ucod_dpl.h: "split-operand backbone pass"; csrc/split.hip) -- f32 residual stream, f32 LayerNorm, exact-erf GELU,
+    f32 softmax, each f32 GEMM / attention operand as a sum of ``terms`` bf16 values on the bf16 MFMA:
+
+    * ``terms=2``: 16 significand bits per operand, 3x the matrix work of the 16-bit engines; mask logits within ~3e-5 of the f32 oracle at full size on the
+      trained-like weights (tests/test_gpu_split.py), i.e. the configuration that meets the 1e-3 bar where the 16-bit engines do not;
+    * ``terms=3`` (default): 24 bits, f32-equivalent, 6x -- what ``build_feature_cache`` uses by default, because the reference runs that pass in plain fp32
+      (/root/reference/data/datasets/base_dataset.py:124-138: no autocast) and its speed does not matter.
+
+    Same call interface as ``ViTEngine`` (``forward`` / ``forward_async`` / ``__call__``, ``D``, ``P``, ``streams``); key-minimal pass only."""
+
+    def __init__(self, state_dict, heads, eps=1e-6, device="cuda", terms=3, gemm_variant=0):
+        if terms not in (2, 3):
+            raise ValueError(f"terms must be 2 or 3, got {terms!r}")
+        self.terms, self.half = int(terms), f"bf16x{int(terms)}"
+        self.lib = N.load("bf16")                                 # (bf16 MFMA; the fp16 build refuses the split entry points)
+        self.nprod = ops.split_products(terms)
+        c = normalize_state_dict(state_dict)
+        self.kind, self.device = c["kind"], torch.device(device)
+        self.D, self.C, self.P = c["patch_w"].shape[0], c["patch_w"].shape[1], c["patch_w"].shape[2]
+        self.heads = heads
+        if self.D != heads * 64:
+            raise ValueError(f"head_dim must be 64 (D={self.D}, heads={heads})")
+        self.L, self.F, self.eps = len(c["layers"]), c["layers"][0]["fc1_w"].shape[0], float(eps)
+        self.gemm_variant, self.streams = gemm_variant, 1
+        self.resid16 = self.ln_fold = self.full_last_layer = False
+        self.resid, self.attn_variant = "f32", 0
+        K = self.C * self.P * self.P
+        self.Kpad = (K + 63) // 64 * 64
+        dev = self.device
+        f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()  # noqa: E731
+        sw = lambda t, role=1: ops.split_rows(f32(t), self.terms, role)  # noqa: E731      (weights: the B side of y = x W^T)
+        pw = torch.zeros(self.D, self.Kpad, dtype=torch.float32, device=dev)
+        pw[:, :K] = f32(c["patch_w"]).reshape(self.D, K)
+        self._pos_src, self._pos_cache = c["pos"].detach().float().cpu(), {}
+        self.patch_w, self.patch_b, self.cls = sw(pw), f32(c["patch_b"]), f32(c["cls"])
+        ones = torch.ones(self.D, dtype=torch.float32, device=dev)
+        self.layers = []
+        D = self.D
+        for l in c["layers"]:
+            self.layers.append([f32(l["ln1_g"]), f32(l["ln1_b"]), sw(l["qkv_w"]), f32(l["qkv_b"]), sw(l["proj_w"]), f32(l["proj_b"]),
+                                f32(l["ls1"]) if l["ls1"] is not None else ones, f32(l["ln2_g"]), f32(l["ln2_b"]), sw(l["fc1_w"]),
+                                f32(l["fc1_b"]), sw(l["fc2_w"]), f32(l["fc2_b"]), f32(l["ls2"]) if l["ls2"] is not None else ones,
+                                sw(l["qkv_w"][D:2 * D], role=0), None])      # +14: the K rows as the A side of the key hook's GEMM
+        self._ws = None
+        self._side = self._side_ws = None
+
+    _pos = ViTEngine._pos
+    _desc = ViTEngine._desc
+
+    def param_bytes(self):
+        return self.patch_w.numel() * 2 + sum(t.numel() * t.element_size() for l in self.layers for t in l if t is not None)
+
+    def check_overflow(self, wait=False):
+        """(interface of ViTEngine: the f32 stream has nothing to saturate)"""
+        return None
+
+    def _table(self, gh, gw):
+        ptrs = [self.patch_w, self.patch_b, self.cls, self._pos(gh, gw)]
+        for l in self.layers:
+            ptrs += l
+        return (C.c_void_p * len(ptrs))(*[None if t is None else t.data_ptr() for t in ptrs]), ptrs
+
+    def _run(self, img, key, ws_slot, n_layers=None):
+        B, _, H, W = img.shape
+        d = self._desc(B, H, W, n_layers)
+        d.resid16 = d.ln_fold = d.full_last_layer = d.attn_variant = 0
+        need = self.lib.ucod_vit_split_workspace_bytes(C.byref(d), self.terms)
+        if need == 0:
+            raise ValueError("unsupported ViT geometry")
+        ws = ws_slot[0]
+        if ws is None or ws.numel() < need:
+            ws = ws_slot[0] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        table, _keep = self._table(H // self.P, W // self.P)
+        N.check(self.lib.ucod_vit_forward_split(C.byref(d), self.terms, table, N.ptr(img), N.ptr(key), N.ptr(ws), ws.numel(), N.stream()), "ucod_vit_forward_split")
+
+    def forward(self, img, out=None, _async=False, n_layers=None):
+        if n_layers is not None and not 1 <= n_layers <= self.L:
+            raise ValueError(f"n_layers must be in [1, {self.L}]")
+        if not img.is_cuda:
+            raise RuntimeError("SplitViTEngine needs a CUDA(ROCm) tensor; there is no CPU path")
+        img = img.to(torch.float32).contiguous()
+        B, _, H, W = img.shape
+        key = out if out is not None else torch.empty(B, self.D, H // self.P, W // self.P, dtype=torch.float32, device=self.device)
+        if not _async:
+            if self._ws is None:
+                self._ws = [None]
+            self._run(img, key, self._ws, n_layers)
+            return key
+        # forward_async: the whole pass on ONE side stream (its workspace is several GB at batch 32: no image-parallel halves here)
+        if self._side is None:
+            self._side, self._side_ws = torch.cuda.Stream(device=self.device), [None]
+        cur = torch.cuda.current_stream(self.device)
+        start = torch.cuda.Event()
+        start.record(cur)
+        self._side.wait_event(start)
+        img.record_stream(self._side)
+        key.record_stream(self._side)
+        with torch.cuda.stream(self._side):
+            self._run(img, key, self._side_ws, n_layers)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        return key, [done]
+
+    def forward_async(self, img, out=None):
+        return self.forward(img, out=out, _async=True)
+
+    __call__ = forward
+
+
 _QKV = ("query", "key", "value")
 
 
@@ -411,7 +533,8 @@ class ViTLoRAEngine(ViTEngine):
                  seed=0, resid="auto"):
         # resid: as ViTEngine ("auto" = the fp16 residual stream with bf16 operands).  Round 4: the training pass SAVES the stream in that
         # type and LayerNorm backward reads it (ucod_layernorm_bwd_ex); resid="f32" keeps the round-3 path.
-        super().__init__(state_dict, heads, eps=eps, device=device, full_last_layer=False, gemm_variant=gemm_variant, attn_variant=2, resid=resid)
+        super().__init__(state_dict, heads, eps=eps, device=device, full_last_layer=False, gemm_variant=gemm_variant, attn_variant=2, resid=resid,
+                         half="bf16")                             # (the backbone-backward entry points exist in the bf16 build only: include/ucod_dpl.h, ucod_half_name)
         if not 0.0 <= lora_dropout < 1.0:
             raise ValueError("lora_dropout must be in [0, 1)")
         if 0.0 < lora_dropout < 1.0 / 1024:
