@@ -49,10 +49,17 @@ def parse():
                          "engine's own choice, fp16 for bf16 operands and f32 for fp16 operands)")
     ap.add_argument("--streams", type=int, default=2, help="image-parallel sub-batches of the backbone pass on independent HIP streams")
     ap.add_argument("--no-pipeline", action="store_true", help="serial order: backbone pass, then decoder step, on one stream")
-    ap.add_argument("--half", default="f16", choices=["bf16", "f16"],
-                    help="16-bit operand type of the backbone.  f16 (default since round 5): IEEE fp16 operands on the fp16 residual stream with LayerNorm folded into "
-                         "QKV / fc1 -- the configuration that meets the 1e-3 logit bar AND is the fastest; bf16: the operand type BASELINE configs[1] names, "
-                         "reported beside it")
+    ap.add_argument("--half", default="f16", choices=["bf16", "f16", "split2", "split3"],
+                    help="arithmetic of the backbone.  f16 (default; the drop-in's default engine since round 6): IEEE fp16 operands on the fp16 residual stream with LayerNorm "
+                         "folded into QKV / fc1 -- meets the 1e-3 logit bar on the flat init AND is the fastest; bf16: the operand type BASELINE configs[1] names; split2 / "
+                         "split3: the split-operand pass (SplitViTEngine: two / three bf16 terms per f32 operand, f32 residual stream) -- split2 is the fastest configuration "
+                         "that meets the bar on trained-like weights, split3 is f32-equivalent (what the feature-cache pass runs); all reported beside the headline")
+    ap.add_argument("--sustain-s", type=float, default=40.0,
+                    help="after the timed region, keep running the same step for this many seconds in 10-s windows (images/s and held shader clock per window); 0 = skip. "
+                         "The reference's hot loop is 126 steps x 25 epochs (engine/runner/loop_UCOD_DPL.py:94-146), the timed region 0.2-0.4 s")
+    ap.add_argument("--pmc-traffic", action="store_true",
+                    help="measure roofline.traffic in THIS run: two child `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE) of the serial step before the timed run "
+                         "(+ ~3 min); default: the committed profiles/r0N_pmc_traffic.json, labelled as such")
     ap.add_argument("--ln-fold", default="auto", choices=["auto", "on", "off"], help="LayerNorm folded into the QKV / fc1 GEMMs (auto: on with fp16 operands on the fp16 stream)")
     ap.add_argument("--look-twice", action="store_true", help="the validation leg of BASELINE configs[3]: first-stage decode + batched Look-Twice second pass "
                     "(fallback centre box on every image); use with --arch dinov2_vitl14 --batch 16")
@@ -117,12 +124,43 @@ def launch_ranks(a):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def pmc_traffic_pass(a):
+    """`--pmc-traffic`: HBM-side bytes per launch of every kernel class, measured by THIS run -- two child `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE:
+    separate passes, counters only, as MI355X_MICROARCH.md's HBM section prescribes) over the serial form of the same step, each under `timeout`, started before
+    this process touches the GPU; tools/pmc_traffic.py applies the guide's corrections (FETCH_SIZE x 2 on gfx950, KiB units).  Returns {class: {...traffic_bytes}}
+    or None when a pass fails (the line then says so)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        print("bench.py: --pmc-traffic needs rocprofv3 on PATH; traffic left to the committed file", file=sys.stderr)
+        return None
+    tmp = tempfile.mkdtemp(prefix="ucod_pmc_", dir="/tmp")
+    args = ["--half", a.half, "--resid", a.resid, "--ln-fold", a.ln_fold, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--lora-steps", "-1", "--no-pipeline",
+            "--streams", "1", "--sustain-s", "0", "--batch", str(a.batch), "--arch", a.arch, "--image", str(a.image), "--attn-variant", str(a.attn_variant)]
+    env = dict(os.environ, TMPDIR="/tmp", UCOD_BENCH_CHILD="1")
+    for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        cmd = ["timeout", "900", "rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, sub), "--", sys.executable, os.path.abspath(__file__)] + args
+        r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True)
+        if r.returncode != 0:
+            print(f"bench.py: the {counter} pass failed or timed out (rc {r.returncode}); traffic left to the committed file\n" + r.stderr[-800:], file=sys.stderr)
+            shutil.rmtree(tmp, ignore_errors=True)
+            return None
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(tmp, "fetch"), os.path.join(tmp, "write"), "this run"], capture_output=True, text=True)
+    shutil.rmtree(tmp, ignore_errors=True)
+    if r.returncode != 0:
+        print("bench.py: tools/pmc_traffic.py failed:\n" + r.stderr[-800:], file=sys.stderr)
+        return None
+    return json.loads(r.stdout).get("kernels") or None
+
+
 def main():
     a = parse()
     if a.resid == "default":
-        a.resid = "f16" if a.half == "f16" else "auto"
+        a.resid = "auto"                                          # the engine's own choice (round 6: fp16 stream + fold for fp16 operands where the fold exists)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(a)
+    measured_traffic = pmc_traffic_pass(a) if (a.pmc_traffic and a.gpus == 1 and not os.environ.get("UCOD_BENCH_CHILD")) else None   # (before this process touches the GPU)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,9 +192,13 @@ def main():
     if world > 1 and len({(r[2], r[3]) for r in ranks_seen}) != world and os.environ.get("UCOD_SINGLE_DEVICE") != "1":
         raise SystemExit(f"bench.py: {world} ranks but the devices seen are {ranks_seen}: ranks share a GPU")
     loop = TrainLoop(cfg, runner)
-    bb = backbone.random_init(a.arch, seed=0, image_size=a.image, device=dev, full_last_layer=a.full_last_layer,
-                              gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half=a.half, resid=a.resid,
-                              ln_fold={"auto": "auto", "on": True, "off": False}[a.ln_fold])
+    split = a.half in ("split2", "split3")
+    if split:
+        bb = backbone.random_init(a.arch, seed=0, image_size=a.image, device=dev, gemm_variant=a.gemm_variant, precision=a.half)
+    else:
+        bb = backbone.random_init(a.arch, seed=0, image_size=a.image, device=dev, full_last_layer=a.full_last_layer,
+                                  gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half=a.half, resid=a.resid,
+                                  ln_fold={"auto": "auto", "on": True, "off": False}[a.ln_fold])
     ln_fold = bool(bb.engine.ln_fold)
     bb.engine.streams = a.streams
     B = a.batch
@@ -189,6 +231,7 @@ def main():
         torch.cuda.synchronize()
 
     step = serial_step if a.no_pipeline else pipelined_step
+    _STEP.update(step=step, loop=loop)                        # (the sustained run below drives the same closure)
     if not a.no_pipeline:
         pipe.submit(images)
     for _ in range(a.warmup):
@@ -244,6 +287,12 @@ def main():
         tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
         dt = tdt.item()
+    # Sustained run: the same step, back to back, for --sustain-s seconds in ~10-s windows.  The step count of a window is FIXED from the timed
+    # region (every rank runs the same number of steps: the all-reduces stay matched); the host keeps at most 16 steps in flight.
+    sustained = None
+    if a.sustain_s > 0:
+        sustained = sustain(a, lib, dev, world, B, dt / a.steps, barrier)
+        bb.engine.check_overflow(wait=True)
     # Discriminator phase (row A8, loop_UCOD_DPL.py:230-255), timed separately as SURVEY.md 8d asks: it runs one epoch in every
     # `dis_intertrain` epochs on the cached features (no backbone pass), so its unit is feature batches, not images through the ViT.
     for _ in range(3):
@@ -321,24 +370,139 @@ def main():
                      "top_kernels_measured_in": "separate serial single-stream pass of the same step (exclusive launch durations, HIP events)"}
     if rank != 0:
         return
+    classes = [(lib.ucod_prof_class_name(i).decode(), tot[i], cnt[i]) for i in range(ncls) if cnt[i]]
 
+    cpu = None
+    if not a.no_cpu_baseline and world == 1:                  # rank 0 at N = 1 only (the contract); the N > 1 lines carry null
+        cpu = cpu_baseline(a, D, heads, L, P)
+
+    # The backbone configurations, each measured in its OWN process (a second engine in this process measures ~10 % low: it inherits the allocator and
+    # clock state of everything that ran before it): this process's is the headline, the others are reported beside it, never part of `value`.
+    others = {}
+    if run_children:
+        import subprocess
+        torch.cuda.synchronize()
+        for name, (half, resid) in CONFIGS.items():
+            if name == config_name(a.half, resid16):
+                continue
+            cmd = [sys.executable, os.path.abspath(__file__), "--half", half, "--steps", str(a.steps), "--warmup", str(a.warmup),
+                   "--batch", str(B), "--arch", a.arch, "--image", str(a.image), "--streams", str(a.streams), "--attn-variant", str(a.attn_variant),
+                   "--lora-steps", "-1", "--no-cpu-baseline", "--ln-fold", a.ln_fold, "--sustain-s", "0"] + (["--resid", resid] if resid else []) + \
+                  (["--no-pipeline"] if a.no_pipeline else []) + (["--full-last-layer"] if a.full_last_layer and resid else [])
+            if half in ("split2", "split3"):                     # 3x / 6x the matrix work: a quarter of the steps keeps the whole run inside minutes
+                cmd[cmd.index("--steps") + 1], cmd[cmd.index("--warmup") + 1] = str(max(3, a.steps // 4)), str(max(1, a.warmup // 4))
+            r = subprocess.run(cmd, env=dict(os.environ, UCOD_BENCH_CHILD="1"), capture_output=True, text=True)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                raise SystemExit(f"bench.py: the child run of configuration {name} failed:\n" + r.stderr[-2000:])
+            c = json.loads(line[-1])
+            others[name] = {"value": c["value"], "unit": "images/s", "ms_per_step": c["ms_per_step"], "steps": c["steps"], "dtype": half, "residual_stream": c["config"]["residual_stream"],
+                            "ln_fold": c["config"].get("ln_fold"), "serial_ms_per_step": c["roofline"]["serial_ms_per_step_without_events"],
+                            "kernels_avg_us": {k: v["avg_us"] for k, v in c["kernels"].items()}, "roofline": {k: c["roofline"].get(k) for k in ("kernel", "achieved", "frac", "mfma_issued_tflops", "mfma_issued_frac")},
+                            "how": f"python bench.py --half {half}" + (f" --resid {resid}" if resid else "") + " (own process, same schedule, same box)"}
+
+    traffic, traffic_source = None, None
+    if measured_traffic is not None:
+        traffic, traffic_source = measured_traffic, "measured by this run: two child rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the serial step, corrected as MI355X_MICROARCH.md prescribes (tools/pmc_traffic.py)"
+    else:
+        tpath = next((t for t in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (6, 5, 4, 3)) if os.path.exists(t)), "")
+        if tpath and a.arch == "dinov2_vitb14" and B == 32 and a.image == 518 and not split:
+            traffic, traffic_source = json.load(open(tpath)).get("kernels", {}), f"committed file {os.path.relpath(tpath, ROOT)} (a --pmc pass of an earlier run of this configuration; `--pmc-traffic` measures it in the run)"
+    meas = dict(world=world, B=B, D=D, heads=heads, L=L, P=P, kpad=kpad, image=a.image, resid16=resid16, ln_fold=ln_fold, dt=dt, dt_serial=dt_serial, dt_serial_plain=dt_serial_plain,
+                classes=classes, final_loss=final_loss, dis_phase=dis_phase, lora_mode=lora_mode, host_enqueue=host_enqueue, host_threads=host_threads,
+                pinned_cores=pinned_cores, ranks_seen=ranks_seen, cpu=cpu, others=others, traffic=traffic, traffic_source=traffic_source, sustained=sustained,
+                collectives=("RCCL world-size-1 process group FORCED (UCOD_FORCE_DIST=1): broadcast at construction and every all-reduce of the step are issued on the "
+                             "group's stream" if (world == 1 and parallel.collectives_on()) else ("one asynchronous RCCL all-reduce of the flat gradient arena per step" if world > 1
+                                                                                                     else "none (world size 1: short-circuit)")))
+    print(json.dumps(build_line(a, meas)))
+
+
+MAX_CLOCK_MHZ = 2400.0                                        # MI355X_MICROARCH.md chip table: the clock the 2.5 PFLOP/s dense bf16 / fp16 peak is quoted at
+# name -> (--half, --resid or None): the configurations reported in `configurations`
+CONFIGS = {"f16_f16_stream": ("f16", "f16"), "f16_f32_stream": ("f16", "f32"), "bf16": ("bf16", "auto"), "split2": ("split2", None), "split3": ("split3", None)}
+
+
+def config_name(half, resid16):
+    return half if half in ("bf16", "split2", "split3") else ("f16_f16_stream" if resid16 else "f16_f32_stream")
+
+
+def sustain(a, lib, dev, world, B, sec_per_step, barrier):
+    """Run the module-level step (set by main) for ~a.sustain_s seconds in windows of ~10 s.  Per window: images/s over the wall clock between two
+    barrier + synchronize points, and the shader clock the chip HELD = delta s_memtime / delta s_memrealtime x 100 MHz between two single-wave probe launches
+    on the step's stream (MI355X_MICROARCH.md, in-kernel clock recipe; ucod_clock_probe)."""
+    step, loop = _STEP["step"], _STEP["loop"]
+    n_win = max(1, int(round(a.sustain_s / 10.0)))
+    per_win = max(1, int(round(a.sustain_s / n_win / sec_per_step)))
+    probes = torch.zeros(n_win, 2, 2, dtype=torch.int64, device=dev)
+    windows, ring = [], []
+    for w in range(n_win):
+        barrier()
+        lib.ucod_clock_probe(probes[w, 0].data_ptr(), torch.cuda.current_stream().cuda_stream)
+        t0 = time.perf_counter()
+        for i in range(per_win):
+            step()
+            loop.global_step += 1
+            if i % 8 == 7:                                        # bound the host's lead: at most 16 steps enqueued ahead of the device
+                ev = torch.cuda.Event()
+                ev.record()
+                ring.append(ev)
+                if len(ring) > 2:
+                    ring.pop(0).synchronize()
+        lib.ucod_clock_probe(probes[w, 1].data_ptr(), torch.cuda.current_stream().cuda_stream)
+        barrier()
+        t1 = time.perf_counter()
+        ring.clear()
+        windows.append([per_win, t1 - t0])
+    pr = probes.cpu()
+    if world > 1:                                                 # max over ranks of every window's wall time
+        tw = torch.tensor([w_[1] for w_ in windows], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
+        for w_, t_ in zip(windows, tw.tolist()):
+            w_[1] = t_
+    out = []
+    for w, (n, t) in enumerate(windows):
+        dcyc, dref = int(pr[w, 1, 0] - pr[w, 0, 0]), int(pr[w, 1, 1] - pr[w, 0, 1])
+        out.append({"steps": n, "seconds": round(t, 3), "images_per_s": round(world * B * n / t, 2), "held_clock_mhz": round(dcyc / max(dref, 1) * 100.0, 1)})
+    return {"seconds": round(sum(w_["seconds"] for w_ in out), 2), "windows": out, "value_sustained": out[-1]["images_per_s"],
+            "held_clock_mhz": round(sum(w_["held_clock_mhz"] for w_ in out) / len(out), 1),
+            "what": "the timed region's step, back to back; per ~10-s window: images/s between two barrier + synchronize points and the mean shader clock between two "
+                    "s_memtime / s_memrealtime probes on the step's stream; value_sustained = the LAST window"}
+
+
+_STEP = {}
+
+
+def build_line(a, m):
+    """The ONE JSON line of the contract from the run's measurements `m` (a plain dict: wall times, per-class HIP-event totals, the child runs' lines, the CPU leg).
+    Pure host arithmetic -- tests/test_bench_line.py calls it on canned measurements on CPU."""
+    world, B, D, heads, L, P, kpad = m["world"], m["B"], m["D"], m["heads"], m["L"], m["P"], m["kpad"]
+    resid16, ln_fold, dt, dt_serial, dt_serial_plain = m["resid16"], m["ln_fold"], m["dt"], m["dt_serial"], m["dt_serial_plain"]
+    cpu, others, sustained = m["cpu"], m["others"], m["sustained"]
+    split = a.half in ("split2", "split3")
+    nprod = {"split2": 3, "split3": 6}.get(a.half, 1)
+    gh = m["image"] // P
     tok = gh * gh + 1
     F = 4 * D
     HW = 68 * 68
+    n_layers = L if a.full_last_layer else L - 1
     kernels = {}
-    for i in range(ncls):
-        if cnt[i] == 0:
-            continue
-        name = lib.ucod_prof_class_name(i).decode()
-        avg_us = tot[i] / cnt[i] * 1e3
-        k = {"launches_per_step": cnt[i] / a.steps, "avg_us": round(avg_us, 2), "ms_per_step": round(tot[i] / a.steps, 4)}
+    for name, total_ms, count in m["classes"]:
+        avg_us = total_ms / count * 1e3
+        k = {"launches_per_step": count / a.steps, "avg_us": round(avg_us, 2), "ms_per_step": round(total_ms / a.steps, 4)}
         fl = algorithmic_work(name, B, tok, D, F, heads, kpad, D, HW)
+        per_step = None
         if name == "gemm_bf16_proj_fc2_scale_resid":
-            n_layers = L if a.full_last_layer else L - 1
             per_step = n_layers * (2.0 * B * tok * D * D + 2.0 * B * tok * D * F)
-            k["tflops"] = round(per_step / (tot[i] / a.steps * 1e-3) / 1e12, 1)
+        elif name == "gemm_bf16_bias_f32" and split:          # the split pass runs QKV and fc1 through UCOD_EPI_BIAS_F32: priced from the per-step total
+            per_step = n_layers * (2.0 * B * tok * 3 * D * D + 2.0 * B * tok * F * D)
+        elif name == "attention_split_fwd":
+            fl = 4.0 * B * heads * tok * tok * 64
+        if per_step is not None:
+            k["tflops"] = round(per_step / (total_ms / a.steps * 1e-3) / 1e12, 1)
         elif fl:
             k["tflops"] = round(fl / (avg_us * 1e-6) / 1e12, 1)
+        if split and "tflops" in k and name.startswith(("gemm_bf16", "attention_split")):
+            k["mfma_issued_tflops"] = round(k["tflops"] * nprod, 1)   # the partial products the matrix pipe actually multiplies (3 / 6 per algorithmic product)
         kernels[name] = k
     # HBM-bound representative: LayerNorm.  ALGORITHMIC bytes per SURVEY.md 8(d) / BASELINE.md section 3 = rows*D*(2 B read + 2 B write);
     # with the fp16 residual stream (default on large passes) that is also what the launch moves; with the f32 stream it moves
@@ -349,18 +513,30 @@ def main():
         kernels["layernorm"]["moved_gbs"] = round(B * tok * D * ln_moved / (kernels["layernorm"]["avg_us"] * 1e-6) / 1e9, 1)
     if "row_stats" in kernels:                              # LayerNorm-folded passes: the statistics launch reads the fp16 rows once (2 B / element) and writes 8 B per row
         kernels["row_stats"]["gbs"] = round(B * tok * (D * 2 + 8) / (kernels["row_stats"]["avg_us"] * 1e-6) / 1e9, 1)
+    if "layernorm_split" in kernels:                        # f32 row in (4 B), nprod bf16 segments out
+        kernels["layernorm_split"]["gbs"] = round(B * tok * D * (4 + 2 * nprod) / (kernels["layernorm_split"]["avg_us"] * 1e-6) / 1e9, 1)
     dom = max((n for n in kernels if "tflops" in kernels[n] and n.startswith(("gemm_bf16", "attention"))),
               key=lambda n: kernels[n]["ms_per_step"])
-    traffic = None                                            # HBM-side bytes per launch from committed PMC passes (see the file's "source")
-    tpath = next((t for t in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (5, 4, 3)) if os.path.exists(t)), "")
-    if os.path.exists(tpath) and a.arch == "dinov2_vitb14" and B == 32 and a.image == 518:
-        traffic = json.load(open(tpath)).get("kernels", {}).get(dom, {}).get("traffic_bytes")
+    traffic = m["traffic"]
+    if isinstance(traffic, dict):
+        traffic = (traffic.get(dom) or {}).get("traffic_bytes")
+    serial_ms = dt_serial / a.steps * 1e3
     roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(kernels[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                "avg_launch_us": kernels[dom]["avg_us"], "share_of_step": round(kernels[dom]["ms_per_step"] / (dt_serial / a.steps * 1e3), 3),
+                "frac": round(kernels[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": m["traffic_source"] if traffic is not None else None,
+                "avg_launch_us": kernels[dom]["avg_us"], "share_of_step": round(kernels[dom]["ms_per_step"] / serial_ms, 3),
                 "measured_in": "separate serial single-stream pass of the same step (exclusive launch durations)",
-                "serial_ms_per_step": round(dt_serial / a.steps * 1e3, 3),
+                "serial_ms_per_step": round(serial_ms, 3),
                 "serial_ms_per_step_without_events": round(dt_serial_plain / a.steps * 1e3, 3)}
+    if split:
+        roofline["flops"] = f"algorithmic (one product per f32 multiply); the matrix pipe issues {nprod} bf16 partial products per algorithmic one"
+        roofline["mfma_issued_tflops"] = kernels[dom]["mfma_issued_tflops"]
+        roofline["mfma_issued_frac"] = round(kernels[dom]["mfma_issued_tflops"] / MFMA_BF16_PEAK_TFLOPS, 4)
+    if sustained:                                           # the roofline against what the chip can do at the clock it HOLDS under this load
+        held = sustained["held_clock_mhz"]
+        roofline["held_clock_mhz"] = held
+        roofline["peak_at_held_clock"] = round(MFMA_BF16_PEAK_TFLOPS * held / MAX_CLOCK_MHZ, 1)
+        roofline["frac_at_held_clock"] = round(kernels[dom]["tflops"] / (MFMA_BF16_PEAK_TFLOPS * held / MAX_CLOCK_MHZ), 4) if held > 0 else None
+        roofline["held_clock_measured_in"] = "the sustained pipelined run (s_memtime / s_memrealtime probes around each ~10-s window); the kernel durations come from the serial pass"
     # the attention kernel's own row: on the fp8 path (BASELINE configs[4]) it is priced against the fp8 matrix peak (block-scaled
     # v_mfma_scale_f32_32x32x64_f8f6f4: 5 PFLOP/s dense), not the bf16 one
     att = next((n for n in kernels if n.startswith("attention") and "tflops" in kernels[n]), None)
@@ -370,7 +546,8 @@ def main():
                                      "frac": round(kernels[att]["tflops"] / peak_att, 4), "avg_launch_us": kernels[att]["avg_us"],
                                      "peak_is": "fp8 dense (block-scaled MFMA)" if a.attn_variant == 8 else "bf16 / fp16 dense",
                                      "flops": "algorithmic: 4 * B * heads * N^2 * 64 (Q K^T + P V)"}
-    if "layernorm" in kernels:
+    hb = "layernorm" if "layernorm" in kernels else ("layernorm_split" if "layernorm_split" in kernels else None)
+    if hb == "layernorm":
         roofline["layernorm_launches_per_step"] = kernels["layernorm"]["launches_per_step"]     # 23 unfolded; 1 with LayerNorm folded into QKV / fc1 (the last layer's LayerNorm 1)
         roofline["hbm_row"] = {"kernel": "layernorm", "achieved": kernels["layernorm"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(kernels["layernorm"]["gbs"] / HBM_PEAK_GBS, 4),
@@ -378,35 +555,13 @@ def main():
                                "moved": {"achieved": kernels["layernorm"]["moved_gbs"], "frac": round(kernels["layernorm"]["moved_gbs"] / HBM_PEAK_GBS, 4),
                                          "bytes": "fp16 residual read + 16-bit write = 4 B/element: the launch moves exactly the algorithmic bytes (PMC 135 MB)" if resid16
                                          else "f32 residual read + bf16 write = 6 B/element (what the launch moves; PMC 202 MB)"}}
+    elif hb == "layernorm_split":
+        roofline["hbm_row"] = {"kernel": "layernorm_split", "achieved": kernels[hb]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kernels[hb]["gbs"] / HBM_PEAK_GBS, 4),
+                               "bytes": f"what the launch moves: f32 row in (4 B/element) + {nprod} bf16 segments out ({2 * nprod} B/element)"}
 
-    cpu = None
-    if not a.no_cpu_baseline and world == 1:                  # rank 0 at N = 1 only (the contract); the N > 1 lines carry null
-        cpu = cpu_baseline(a, D, heads, L, P)
-
-    # The three backbone configurations, each measured in its OWN process (a second engine in this process measures ~10 % low: it inherits the allocator and
-    # clock state of everything that ran before it): this process's is the headline, the other two are reported beside it, never part of `value`.
-    CONFIGS = {"f16_f16_stream": ("f16", "f16"), "f16_f32_stream": ("f16", "f32"), "bf16": ("bf16", "auto")}
-    PARITY_KEY = {"f16_f16_stream": "f16_operands_f16_stream" if ln_fold else "f16_operands_f16_stream_unfolded", "f16_f32_stream": "f16_operands", "bf16": "bf16"}
-    mine = "bf16" if a.half == "bf16" else ("f16_f16_stream" if resid16 else "f16_f32_stream")
-    others = {}
-    if run_children:
-        import subprocess
-        torch.cuda.synchronize()
-        for name, (half, resid) in CONFIGS.items():
-            if name == mine:
-                continue
-            cmd = [sys.executable, os.path.abspath(__file__), "--half", half, "--resid", resid, "--steps", str(a.steps), "--warmup", str(a.warmup),
-                   "--batch", str(B), "--arch", a.arch, "--image", str(a.image), "--streams", str(a.streams), "--attn-variant", str(a.attn_variant),
-                   "--lora-steps", "-1", "--no-cpu-baseline", "--ln-fold", a.ln_fold] + (["--no-pipeline"] if a.no_pipeline else []) + (["--full-last-layer"] if a.full_last_layer else [])
-            r = subprocess.run(cmd, env=dict(os.environ, UCOD_BENCH_CHILD="1"), capture_output=True, text=True)
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode != 0 or not line:
-                raise SystemExit(f"bench.py: the child run of configuration {name} failed:\n" + r.stderr[-2000:])
-            c = json.loads(line[-1])
-            others[name] = {"value": c["value"], "unit": "images/s", "ms_per_step": c["ms_per_step"], "dtype": half, "residual_stream": c["config"]["residual_stream"],
-                            "ln_fold": c["config"].get("ln_fold"), "serial_ms_per_step": c["roofline"]["serial_ms_per_step_without_events"],
-                            "kernels_avg_us": {k: v["avg_us"] for k, v in c["kernels"].items()},
-                            "how": f"python bench.py --half {half} --resid {resid} (own process, same schedule, same box)"}
+    PARITY_KEY = {"f16_f16_stream": "f16_operands_f16_stream" if (ln_fold or a.half != "f16") else "f16_operands_f16_stream_unfolded", "f16_f32_stream": "f16_operands", "bf16": "bf16",
+                  "split2": "split2", "split3": "split3"}
+    mine = config_name(a.half, resid16)
 
     # North-star parity bar (mask logits within 1e-3 of the f32 reference), at the top level of the line for THIS line's configuration, and for every
     # configuration in `configurations` with its own throughput.
@@ -417,12 +572,13 @@ def main():
     logit_max_abs = own.get("logit_max_abs")
     own_tl = tl.get(PARITY_KEY[mine]) or {}
     ips = world * B * a.steps / dt
+    ENGINE = {"f16_f16_stream": "ViTEngine() [the default: half='f16', resid='auto' -> fp16 stream]", "f16_f32_stream": "ViTEngine(half='f16', resid='f32')",
+              "bf16": "ViTEngine(half='bf16')", "split2": "SplitViTEngine(terms=2)", "split3": "SplitViTEngine(terms=3) [backbone.with_precision('f32eq'): the feature-cache pass]"}
 
     def describe(name, value, ms, extra):
         pf, tlw = par.get(PARITY_KEY[name]) or {}, tl.get(PARITY_KEY[name]) or {}
-        half, resid = CONFIGS[name]
-        d_ = {"value": value, "unit": "images/s", "ms_per_step": ms, "dtype": half,
-              "engine": f"ViTEngine(half='{half}', resid='{resid}')" + (" with LayerNorm folded into the QKV / fc1 GEMMs" if extra.get("ln_fold") else ""), **extra}
+        d_ = {"value": value, "unit": "images/s", "ms_per_step": ms, "dtype": CONFIGS[name][0],
+              "engine": ENGINE[name] + (" with LayerNorm folded into the QKV / fc1 GEMMs" if extra.get("ln_fold") else ""), **extra}
         if pf:
             d_.update({"logit_max_abs": pf["logit_max_abs"], "key_rel_l2": pf["key_rel_l2"], "mask_flipped_fraction": pf["mask_flipped_fraction"], "bar": BAR,
                        "bar_met": bool(pf["logit_max_abs"] <= BAR), "margin": round(BAR / max(pf["logit_max_abs"], 1e-12), 2),
@@ -433,9 +589,11 @@ def main():
 
     configurations = {mine: describe(mine, round(ips, 2), round(dt / a.steps * 1e3, 3), {"residual_stream": "fp16" if resid16 else "f32", "ln_fold": ln_fold, "this_line": True})}
     for name, o in others.items():
-        configurations[name] = describe(name, o["value"], o["ms_per_step"], {k: o[k] for k in ("residual_stream", "ln_fold", "serial_ms_per_step", "how")})
+        configurations[name] = describe(name, o["value"], o["ms_per_step"], {k: o[k] for k in ("residual_stream", "ln_fold", "serial_ms_per_step", "steps", "roofline", "how") if k in o})
     met = [c_ for c_ in configurations.values() if c_.get("bar_met")]
-    bar_meeting = dict(max(met, key=lambda c_: c_["value"])) if met else None       # the fastest configuration under the bar
+    bar_meeting = dict(max(met, key=lambda c_: c_["value"])) if met else None       # the fastest configuration under the bar on the flat init
+    met_tl = [c_ for c_ in configurations.values() if c_.get("bar_met") and c_.get("bar_met_on_trained_like_weights")]
+    bar_meeting_tl = dict(max(met_tl, key=lambda c_: c_["value"])) if met_tl else None  # ... and the fastest one that ALSO meets it on the trained-like weights
     # why fp16 operands cost clock: per kernel class, same serial pass, own processes on this box (bf16 against fp16 operands on the same stream type)
     f16_vs_bf16 = None
     pair = ("bf16", "f16_f16_stream")
@@ -445,34 +603,42 @@ def main():
                        "what": "same step on the fp16 residual stream, serial pass with HIP events: the fp16 MFMA kernels run longer at equal cycles (the chip holds a lower "
                                "clock on fp16 operands: profiles/r03_f16_vs_bf16_*); the fp16 build has no LayerNorm launches (folded into QKV / fc1, whose "
                                "epilogues carry the two per-row scalars instead)"}
+    value, value_is = round(ips, 2), "the timed region"
+    if sustained and sustained["value_sustained"] < 0.97 * ips:      # a burst figure the chip does not hold is not the headline
+        value, value_is = sustained["value_sustained"], "the LAST ~10-s window of the sustained run (below 0.97 of the timed region's figure, reported as value_timed_region)"
+    arith = {"bf16": "bf16 MFMA", "f16": "fp16 MFMA", "split2": "two-term split bf16 MFMA (16 significand bits per operand), f32 residual stream",
+             "split3": "three-term split bf16 MFMA (f32-equivalent), f32 residual stream"}[a.half]
     out = {
         "metric": "training images/sec at 3x518x518, DINOv2-B (frozen backbone fwd + DBA/APM/discriminator train step)",
-        "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": value, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": a.half, "data": "synthetic",
+        "dtype": {"split2": "bf16x2", "split3": "bf16x3"}.get(a.half, a.half), "data": "synthetic",
+        "value_is": value_is, "value_timed_region": round(ips, 2), "value_sustained": (sustained or {}).get("value_sustained"), "sustained": sustained,
         "logit_max_abs": logit_max_abs, "bar": BAR, "bar_met": (None if logit_max_abs is None else bool(logit_max_abs <= BAR)),
         "logit_max_abs_trained_like_weights": own_tl.get("logit_max_abs"),
         "bar_met_trained_like_weights": (None if not own_tl else bool(own_tl["logit_max_abs"] <= BAR)),
         # the reference's OWN fp16-autocast forward against its f32 forward (emulated on the CPU oracle): [random-init weights, trained-like weights]
         "logit_max_abs_of_reference_fp16_autocast": [((par or {}).get("reference_fp16_autocast_emulation") or {}).get("logit_max_abs"),
                                                      (((par or {}).get("trained_like_weights") or {}).get("reference_fp16_autocast_emulation") or {}).get("logit_max_abs")],
-        # throughput of the fastest configuration that MEETS the bar on the flat-init weights (None: no configuration measured / none meets it), and whether that
-        # configuration also meets it on the trained-like weights (say what the numbers mean)
+        # throughput of the fastest configuration that MEETS the bar on the flat-init weights (None: no configuration measured / none meets it), and of the fastest one
+        # that also meets it on the trained-like weights (the split-operand pass: the precision the reference caches its features at)
         "value_at_bar": (bar_meeting or {}).get("value"), "value_at_bar_config": (bar_meeting or {}).get("engine"),
         "value_at_bar_met_on_trained_like_weights": (bar_meeting or {}).get("bar_met_on_trained_like_weights"),
-        "configurations": configurations, "bar_meeting_config": bar_meeting, "f16_vs_bf16_per_kernel": f16_vs_bf16,
-        "host_enqueue_ms_per_step": round(host_enqueue / a.steps * 1e3, 3), "host_threads": host_threads, "host_cores_pinned": pinned_cores,
-        "ranks_seen": ranks_seen,
-        "config": {"workload": f"{which_config(a.arch, a.image, B, a.attn_variant)}: {a.arch} @{a.image}x{a.image}, batch {B}/GPU, full APM+DBA+discriminator step, "
-                               f"decoder path f32 (1x1 conv as a three-way bf16 split on the matrix pipe: f32-equivalent), backbone {a.half} MFMA", "global_batch": B * world, "parallelism": f"dp{world}",
+        "value_at_bar_on_trained_like_weights": (bar_meeting_tl or {}).get("value"), "value_at_bar_on_trained_like_weights_config": (bar_meeting_tl or {}).get("engine"),
+        "drop_in_default_engine": ENGINE["f16_f16_stream"] + " = the configuration of this line" if mine == "f16_f16_stream" else ENGINE["f16_f16_stream"],
+        "configurations": configurations, "bar_meeting_config": bar_meeting, "bar_meeting_config_on_trained_like_weights": bar_meeting_tl, "f16_vs_bf16_per_kernel": f16_vs_bf16,
+        "host_enqueue_ms_per_step": round(m["host_enqueue"] / a.steps * 1e3, 3), "host_threads": m["host_threads"], "host_cores_pinned": m["pinned_cores"],
+        "ranks_seen": m["ranks_seen"], "collectives": m.get("collectives"),
+        "config": {"workload": f"{which_config(a.arch, m['image'], B, a.attn_variant)}: {a.arch} @{m['image']}x{m['image']}, batch {B}/GPU, full APM+DBA+discriminator step, "
+                               f"decoder path f32 (1x1 conv as a three-way bf16 split on the matrix pipe: f32-equivalent), backbone {arith}", "global_batch": B * world, "parallelism": f"dp{world}",
                    "backbone_last_layer": "full (as reference)" if a.full_last_layer else "key-minimal (identical key output; 279.6 of 303.1 GFLOP/img)",
                    "random_init_weights": True, "residual_stream": "fp16" if resid16 else "f32", "ln_fold": ln_fold,
                    "schedule": "serial, one stream" if a.no_pipeline else
-                               f"backbone pass of step k+1 on {a.streams} side stream(s) overlapped with the decoder step of step k"},
-        "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "final_loss": round(final_loss, 6),
-        "backbone_backward_mode": lora_mode, "discriminator_phase": dis_phase,
+                               f"backbone pass of step k+1 on {1 if split else a.streams} side stream(s) overlapped with the decoder step of step k"},
+        "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "final_loss": round(m["final_loss"], 6),
+        "backbone_backward_mode": m["lora_mode"], "discriminator_phase": m["dis_phase"],
     }
-    print(json.dumps(out))
+    return out
 
 
 def look_twice_leg(a, dev, lib, world, rank, host_threads, pinned_cores):
@@ -491,8 +657,11 @@ def look_twice_leg(a, dev, lib, world, rank, host_threads, pinned_cores):
     from ucod_dpl_amd.models.uscod import baseline
     D, heads, L, P, _, _ = ARCHS[a.arch]
     B, S = a.batch, a.image
-    bb = backbone.random_init(a.arch, seed=0, image_size=S, device=dev, gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half=a.half, resid=a.resid,
-                              ln_fold={"auto": "auto", "on": True, "off": False}[a.ln_fold])
+    if a.half in ("split2", "split3"):
+        bb = backbone.random_init(a.arch, seed=0, image_size=S, device=dev, gemm_variant=a.gemm_variant, precision=a.half)
+    else:
+        bb = backbone.random_init(a.arch, seed=0, image_size=S, device=dev, gemm_variant=a.gemm_variant, attn_variant=a.attn_variant, half=a.half, resid=a.resid,
+                                  ln_fold={"auto": "auto", "on": True, "off": False}[a.ln_fold])
     bb.engine.streams = a.streams                             # both backbone passes as image-parallel halves on two HIP streams, like the training step's
     torch.manual_seed(5)
     model = baseline(CfgNode(dict(dim=D, feature_size=68, ema_weight=0.99, dis_use_features=False))).to(dev)
@@ -693,7 +862,12 @@ def cpu_baseline(a, D, heads, L, P):
         return ops.dba_heads(d, 0, emb, ops.dba_colnorm(d, 0, emb), hw, hb, want_bg=False)[0].view(n, 1, 68, 68).cpu()
 
     def parity(half, resid="auto", sd=sd, img=img, key=key, fg_ref=fg_ref, layer_ref=layer_ref, ln_fold="auto"):
-        eng = ViTEngine(sd, heads=heads, eps=1e-6, device=dev, attn_variant=a.attn_variant, half=half, resid=resid, ln_fold=ln_fold)
+        if half in ("split2", "split3"):
+            from ucod_dpl_amd.vit_engine import SplitViTEngine
+            eng = SplitViTEngine(sd, heads=heads, eps=1e-6, device=dev, terms=int(half[-1]))
+            layer_ref = None                                        # (the per-layer table is the 16-bit engines' error budget)
+        else:
+            eng = ViTEngine(sd, heads=heads, eps=1e-6, device=dev, attn_variant=a.attn_variant, half=half, resid=resid, ln_fold=ln_fold)
         key_dev = eng(img.to(dev))
         kd, fd = key_dev.cpu(), device_logits(key_dev)
         per_layer = []
@@ -702,8 +876,8 @@ def cpu_baseline(a, D, heads, L, P):
             per_layer.append(round(float((kl - layer_ref[li - 1]).norm() / layer_ref[li - 1].norm()), 6))
         eng.check_overflow(wait=True)
         res = {"residual_stream": "fp16" if eng.resid16 else "f32", "ln_fold": bool(eng.ln_fold),
-               "key_rel_l2": round(float((kd - key).norm() / key.norm()), 6), "key_max_abs": round(float((kd - key).abs().max()), 5),
-               "logit_max_abs": round(float((fd - fg_ref).abs().max()), 6), "logit_rel_l2": round(float((fd - fg_ref).norm() / fg_ref.norm()), 6),
+               "key_rel_l2": round(float((kd - key).norm() / key.norm()), 8), "key_max_abs": round(float((kd - key).abs().max()), 7),
+               "logit_max_abs": round(float((fd - fg_ref).abs().max()), 8), "logit_rel_l2": round(float((fd - fg_ref).norm() / fg_ref.norm()), 8),
                "mask_flipped_fraction": round(float(((fd > 0) != (fg_ref > 0)).float().mean()), 6)}
         if per_layer:
             res["key_rel_l2_after_layer"] = per_layer
@@ -715,7 +889,7 @@ def cpu_baseline(a, D, heads, L, P):
     if v1:                                                      # (the trained-like recipe scales LayerScale and the HF key names: DINOv2 only)
         f16s = parity("f16", "f16")
         out["parity_full_size"] = {"what": f"{n} images at {a.image}x{a.image}, {a.arch}: device backbone + f32 device decoder vs the f32 oracle "
-                                           f"(same random-init weights); north-star bar: logit max-abs <= 1e-3", "bf16": parity("bf16"), "f16_operands": parity("f16"),
+                                           f"(same random-init weights); north-star bar: logit max-abs <= 1e-3", "bf16": parity("bf16"), "f16_operands": parity("f16", "f32"),
                                    "f16_operands_f16_stream": f16s, "f16_operands_f16_stream_unfolded": f16s if not f16s["ln_fold"] else parity("f16", "f16", ln_fold=False)}
         return out
     sd_p = trained_like_state_dict(a.arch, 0, a.image)
@@ -740,14 +914,16 @@ def cpu_baseline(a, D, heads, L, P):
                 f"north-star bar: logit max-abs <= 1e-3",
         "bf16": parity("bf16"),
         "reference_fp16_autocast_emulation": autocast_deviation(sd, key, fg_ref),
-        "f16_operands": parity("f16"),                            # engine default for fp16 operands: f32 residual stream
+        "f16_operands": parity("f16", "f32"),                      # fp16 operands on the f32 residual stream
         "f16_operands_f16_stream": parity("f16", "f16"),            # (LayerNorm folded into QKV / fc1: the engine's default for this pair)
         "f16_operands_f16_stream_unfolded": parity("f16", "f16", ln_fold=False),
+        "split2": parity("split2"), "split3": parity("split3"),    # the split-operand pass (SplitViTEngine): two / three bf16 terms per f32 operand, f32 residual stream
         "trained_like_weights": {
             "what": "same images, trained_like_state_dict (pre-softmax score std ~4, row entropy ~3.7 of ln 1370 = 7.2, LayerScale 0.1 .. 1, "
                     "massive channels +-200); reference logits reach |%.2f| (flat init: |%.2f|)" % (float(fg_p.abs().max()), float(fg_ref.abs().max())),
-            "bf16": parity("bf16", **peaked), "f16_operands": parity("f16", **peaked), "f16_operands_f16_stream": parity("f16", "f16", **peaked),
+            "bf16": parity("bf16", **peaked), "f16_operands": parity("f16", "f32", **peaked), "f16_operands_f16_stream": parity("f16", "f16", **peaked),
             "f16_operands_f16_stream_unfolded": parity("f16", "f16", ln_fold=False, **peaked),
+            "split2": parity("split2", **peaked), "split3": parity("split3", **peaked),
             "reference_fp16_autocast_emulation": autocast_deviation(sd_p, key_p, fg_p)}}
     return out
 

@@ -139,7 +139,10 @@ int ucod_gemm_bf16_stats(int epilogue, const void* A_bf16, const void* B_bf16, v
 /* ucod_cls_rows_h16 that also writes the CLS rows' partials, slot by slot like the other rows' (nslot = D / 64) */
 int ucod_cls_rows_h16_stats(void* x_f16, const float* cls, const float* pos, float* row_partials, int nslot, int B, int tok, int D, void* stream);
 /* Row statistics of the fp16 residual stream for the folded epilogues: stats[m] = (rstd, -mean * rstd), two-pass in f32 over the row held in
- * registers, biased variance + eps like nn.LayerNorm.  x f16 [rows,D], D % 256 == 0, D <= 1536. */
+ * registers, biased variance + eps like nn.LayerNorm.  x f16 [rows,D], D % 256 == 0, D <= 1536.
+ * Range of the fold: x W'^T and mean * colsum cancel in f32, which costs ~2^-24 sqrt(K) |mean| / sigma of the output scale (0.2 fp16 ulp at 100 sigma).  Both
+ * statistics paths (this kernel and the prologue of ucod_gemm_lnfold on row partials) COUNT every row with |mean| > 256 sigma into the saturation counter of the
+ * fp16 stream (ucod_resid16_overflow_*): such a checkpoint is reported by ViTEngine.check_overflow, never folded silently; use ln_fold = 0 for it. */
 int ucod_row_stats_h16(const void* x_f16, float* stats, int rows, int D, float eps, void* stream);
 /* The UCOD_GEMM_* tuning variables (csrc/gemm_bf16_plan.h) are read once per process; this re-reads them (tests, sweep tools). */
 void ucod_gemm_reload_tuning(void);

@@ -41,7 +41,7 @@ def rel_l2(a, b):
 
 def test_library_is_native_and_device_is_gfx950():
     lib = N.load()
-    assert lib.ucod_abi_version() == N.ABI_VERSION == 4
+    assert lib.ucod_abi_version() == N.ABI_VERSION == 5
     assert lib.ucod_device_is_gfx950() == 1
 
 

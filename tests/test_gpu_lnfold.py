@@ -41,6 +41,18 @@ def chan_merge(part):
     return mean, (M2.sum(1) + 64 * ((S / 64 - mean[:, None]) ** 2).sum(1)) / K
 
 
+def fold_guard_count():
+    """Events counted by the fp16-operand build into its per-device word since the last call (saturations of the fp16 stream + rows outside the fold's range)."""
+    lib = N.load("f16")
+    host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    N.check(lib.ucod_resid16_overflow_fetch(host.data_ptr(), N.stream()), "fetch")
+    torch.cuda.synchronize()
+    n = int(host[0])
+    N.check(lib.ucod_resid16_overflow_reset(N.stream()), "reset")
+    torch.cuda.synchronize()
+    return n
+
+
 def rows(M, K, seed, massive=0.0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 2) + torch.randn(M, 1, generator=g) * 0.3
@@ -230,8 +242,11 @@ def test_gemm_lnfold_from_row_partials_with_a_common_mode_offset(M, Nn, K, varia
     the producer epilogue's partials and the folded consumer, against LayerNorm -> Linear in f64 on the same fp16 rows.  ABI 4 formed E[x^2] - mean^2 in f32 and
     lost sigma^2 to ~6e-4 relative at 100 sigma (silently wrong beyond); the Chan merge keeps the statistics at f32 rounding: (1) the prologue's (rstd, -mean rstd)
     agree with the two-pass kernel's at every offset, checked through bit-comparable outputs; (2) the outputs meet the bounds of
-    test_gemm_lnfold_matches_layernorm_then_linear, widened only by the term the fold itself (not its statistics) owes to a large mean: x W'^T and mean * colsum are
-    summed in f32 at magnitude |mean| |colsum| before they cancel -- 2^-22 of that, times rstd."""
+    test_gemm_lnfold_matches_layernorm_then_linear, widened only by the term the fold ITSELF (not its statistics) owes to a large mean: x W'^T and mean * colsum are
+    summed over K in f32 at magnitude |mean| |colsum| before they cancel -- 2^-24 sqrt(K) of that, times rstd: 0.2 fp16 ulp of the outputs at 100 sigma, ~2 ulps at
+    1000 sigma; (3) that range is GUARDED: both statistics paths count every row with |mean| > 256 sigma into the fp16 stream's device counter (the engine raises),
+    and count nothing at 10 / 100 sigma."""
+    assert fold_guard_count() == 0
     g = torch.Generator().manual_seed(int(offset) + M)
     Mp = max(M, 2048)
     x0 = (torch.randn(Mp, K, generator=g) + offset * (1 + 0.1 * torch.rand(Mp, 1, generator=g))).to(torch.float16)
@@ -255,12 +270,15 @@ def test_gemm_lnfold_from_row_partials_with_a_common_mode_offset(M, Nn, K, varia
         same, plain = torch.nn.functional.gelu(same), torch.nn.functional.gelu(plain)
     out_p = ops.linear_lnfold(x, None, wf, bf_, cs, gelu=gelu, variant=variant, partials=part, eps=EPS).cpu().double()
     out_s = ops.linear_lnfold(x, ops.row_stats_h16(x, EPS), wf, bf_, cs, gelu=gelu, variant=variant).cpu().double()
-    cancel = 2.0 ** -22 * (mean.abs()[:, None] * cs.cpu().double().abs()[None, :] + (xd.abs() @ wf.cpu().double().abs().t()) * K ** -0.5) * rstd
+    tripped = fold_guard_count()
+    assert (tripped > 0) == (offset > 256.0), (tripped, offset)    # reported beyond 256 sigma, silent (and accurate) below
+    # the f32 MFMA chain adds K products of magnitude ~|mean| |w| in sequence: a random walk of roundings at the scale of the running sum
+    cancel = 2.0 ** -24 * K ** 0.5 * (mean.abs()[:, None] * cs.cpu().double().abs()[None, :] + (xd.abs() @ wf.cpu().double().abs().t()) * K ** -0.5) * rstd
     for out in (out_p, out_s):
         err = (out - same).abs()
-        bound = H * same.abs() + 4e-5 * (1 + same.abs()) + cancel
+        bound = H * same.abs() + 4e-5 * (1 + same.abs()) + 3 * cancel
         assert bool((err <= bound).all()), (float((err - bound).max()), offset, M, Nn, K)
-        assert rel_l2(out, plain) < 6e-4 + 2.0 ** -20 * offset
+        assert rel_l2(out, plain) < 6e-4 + 2.0 ** -24 * K ** 0.5 * offset
     assert rel_l2(out_p, out_s) < 1e-4 + 2.0 ** -22 * offset      # the two statistics paths give the same outputs: a key map does not depend on the pass size
 
 

@@ -581,7 +581,8 @@ static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int
   a.nslot = nslot;
   a.eps = eps;
   a.ovf = (epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16 || epilogue == UCOD_EPI_PATCH_TOKENS_H16 || epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16_STATS ||
-           epilogue == UCOD_EPI_PATCH_TOKENS_H16_STATS) ? resid16_overflow_counter() : nullptr;
+           epilogue == UCOD_EPI_PATCH_TOKENS_H16_STATS || epilogue == UCOD_EPI_LNFOLD_BIAS_BF16 || epilogue == UCOD_EPI_LNFOLD_GELU_BF16)
+              ? resid16_overflow_counter() : nullptr;           // (the folded consumers count rows outside the fold's range into the same word: fold_finish)
   a.stamps = nullptr;
 #ifdef UCOD_GEMM_STAMPS
   a.stamps = (unsigned long long*)pos;   // diagnostic build: the (otherwise unused here) `pos` argument carries the stamp buffer

@@ -373,6 +373,7 @@ __device__ __forceinline__ f32x2 row_partial8(const u32x4& w) {
 #ifndef UCOD_FOLD_ABL
 #define UCOD_FOLD_ABL 0
 #endif
+constexpr float kFoldMeanGuard = 65536.0f;                         // (|mean| / sigma)^2 above which a row is reported (fold_finish, row_stats_h16_kernel)
 constexpr int FOLD_TAB_ROWS = 288;                                 // >= rows of the tallest tile (2 x 144)
 constexpr int FOLD_TAB_BYTES = 2 * FOLD_TAB_ROWS * 4;
 constexpr int FOLD_MAX_SLOT_PAIRS = 12;                            // nslot <= 24 (D <= 1536)
@@ -451,6 +452,10 @@ __device__ __forceinline__ void fold_finish(const GemmArgs& a, char* tab_bytes, 
   const float var = fmaf(64.0f, dev, Q) * inv_d;
   const float rstd = rsqrtf(var + a.eps);
   const bool parts = a.part_in != nullptr;
+  // Range guard of the fold ITSELF (not of its statistics, which are exact to rounding): x W'^T and mean * colsum are summed in f32 at magnitude |mean| |colsum|
+  // before they cancel, which costs ~2^-24 sqrt(K) |mean| / sigma of the output scale -- 0.2 fp16 ulp at |mean| = 100 sigma, 2 ulps at 1000 sigma.  A live row with
+  // |mean| > 256 sigma is COUNTED into the engine's device word (the fp16 stream's saturation counter: ViTEngine.check_overflow raises) instead of passing silently.
+  if (parts && tid < rows && a.ovf && mean * mean > kFoldMeanGuard * (var + a.eps)) atomicAdd(a.ovf, 1u);
   const float s = parts ? rstd : r.su[0], u = parts ? -mean * rstd : r.su[1];
   if (tid < FOLD_TAB_ROWS) {
     float* tab = reinterpret_cast<float*>(tab_bytes);

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void layernorm_h16_strip_kernel(const u32x4* _
 // without gamma / beta and without the output -- half the bytes of a LayerNorm launch.  stats[row] = (rstd, -mean * rstd); same two-pass f32
 // arithmetic on the row held in registers.
 template <int NC>
-__global__ __launch_bounds__(256) void row_stats_h16_kernel(const u32x4* __restrict__ x, float2* __restrict__ stats, int rows, int D, float eps) {
+__global__ __launch_bounds__(256) void row_stats_h16_kernel(const u32x4* __restrict__ x, float2* __restrict__ stats, int rows, int D, float eps, unsigned* __restrict__ ovf) {
   const int lane = threadIdx.x & 63;
   const int cpr = D >> 3;
   bool second[NC];
@@ -243,6 +243,8 @@ __global__ __launch_bounds__(256) void row_stats_h16_kernel(const u32x4* __restr
     const float rstd0 = rsqrtf(wave_sum(q0) * inv_d + eps), rstd1 = rsqrtf(wave_sum(q1) * inv_d + eps);
     if (lane == 0) stats[row0] = make_float2(rstd0, -mean0 * rstd0);
     if (lane == 1 && two) stats[row0 + 1] = make_float2(rstd1, -mean1 * rstd1);
+    // the fold's range guard (gemm_bf16_epilogue.h: fold_finish): a row with |mean| > 256 sigma is counted, mean^2 rstd^2 = mean^2 / (var + eps)
+    if (ovf && ((lane == 0 && mean0 * mean0 * rstd0 * rstd0 > 65536.0f) || (lane == 1 && two && mean1 * mean1 * rstd1 * rstd1 > 65536.0f))) atomicAdd(ovf, 1u);
   }
 }
 
@@ -560,7 +562,7 @@ extern "C" int ucod_row_stats_h16(const void* x, float* stats, int rows, int D, 
   const dim3 grid((unsigned)(want > 256 ? want : (cdiv(nstrips, 4) < 256 ? cdiv(nstrips, 4) : 256))), block(256);
   switch (D / 256) {
 #define RS_CASE(n) \
-  case n: hipLaunchKernelGGL(row_stats_h16_kernel<n>, grid, block, 0, s, (const u32x4*)x, (float2*)stats, rows, D, eps); break;
+  case n: hipLaunchKernelGGL(row_stats_h16_kernel<n>, grid, block, 0, s, (const u32x4*)x, (float2*)stats, rows, D, eps, ucod::resid16_overflow_counter()); break;
     RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6)
 #undef RS_CASE
     default: return UCOD_EINVAL;

@@ -290,8 +290,9 @@ class ViTEngine:
             torch.cuda.current_stream(self.device).synchronize()
             self._ovf_host.zero_()
             how = "build the engine with resid='f32'" if self.resid16 else "call forward_nograd(..., resid16=False)"
-            raise FloatingPointError(f"the fp16 residual stream of this engine saturated at +-65504 (or met a NaN) in {n} wave-lane(s): the "
-                                     f"activations do not fit fp16; {how}.  The counter is polled without blocking: the pass (or, for a training engine, the "
+            raise FloatingPointError(f"the fp16 residual stream of this engine saturated at +-65504 (or met a NaN) in {n} wave-lane(s)"
+                                     + (" -- or a folded LayerNorm met a row with |mean| > 256 sigma (outside the fold's range)" if getattr(self, "ln_fold", False) else "")
+                                     + f": the activations do not fit this configuration; {how}.  The counter is polled without blocking: the pass (or, for a training engine, the "
                                      f"optimiser step or steps) that consumed the clamped activations has already been applied -- discard its results "
                                      f"(UCOD_CHECK_RESID=1 checks synchronously after every pass).")
 
