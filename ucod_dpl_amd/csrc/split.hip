@@ -227,31 +227,82 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict_
 }
 
 // ---- attention on split operands (eager_attention_forward, modeling_dinov2.py:153-179: softmax(Q K^T hd^-0.5) V), f32-equivalent.
-// A wave owns 32 queries and walks the keys in blocks of 32 with an online softmax; four waves per workgroup share nothing (no LDS, no barrier: the K / V^T
-// blocks are read straight from global memory, where the four waves' identical requests meet in the L1 / L2).
-//   S^T[key][query] = sum over the P 64 concatenated columns  Kc[key][.] Qc[query][.]        v_mfma_f32_32x32x16_bf16, A = Kc rows, B = Qc rows (in registers)
+// A wave owns 32 queries and walks the keys in blocks of 32 with an online softmax; the four waves of a workgroup (128 queries of one (image, head)) SHARE every
+// K / V^T block through LDS: the 256 threads copy block kb + 1 from global memory into registers while block kb is being multiplied, store it into the other LDS
+// stage behind the MFMAs and meet at one barrier per block (round 6, second form: the first read K / V^T straight from global memory in every wave -- four
+// copies of every request and a load -> MFMA latency chain per block: 1.74 ms per launch at 32 x 12 x 1370 tokens).
+//   S^T[key][query] = sum over the P 64 concatenated columns  Kc[key][.] Qc[query][.]        v_mfma_f32_32x32x16_bf16, A = Kc rows (LDS), B = Qc rows (registers)
 // Both operands take their 16-element k slices from the same places of a row (lane half h of MFMA step 2 j + u reads elements 32 j + 16 h + 8 u .. + 7: 32
-// contiguous bytes per lane and chunk), which is a permutation of the contraction index common to A and B.  The key rows of a block are loaded in the order
+// contiguous bytes per lane and chunk), which is a permutation of the contraction index common to A and B.  The key rows of a block are read in the order
 // pi(m) = m with bits 2 and 3 swapped, so that the C layout (lane (n, h), register i -> row 8 (i / 4) + 4 h + i % 4) hands lane half h of PV step s the EIGHT
 // CONSECUTIVE keys 16 s + 8 h .. + 7 in registers 8 s .. 8 s + 7: the probabilities are split into bf16 terms where they sit and become the B operand of
 //   O^T[d][query] += sum_key Vt[d][key] P^T[key][query]
-// whose A operand is one 16-byte read of a V^T row.  Softmax statistics per query = per lane column (+ one exchange with the other lane half).
+// whose A operand is one 16-byte LDS read of a V^T row.  Softmax statistics per query = per lane column (+ one exchange with the other lane half).
+// LDS rows are padded by 16 bytes (K rows: P 128 + 16 B, V^T rows: 64 + 16 B): the 16 lanes of a ds_read_b128 group then start at 16 different multiples of
+// four banks (strides of 100 / 20 banks) -- conflict-free by the 64-bank / 16-lane-group rule.
+template <int TERMS>
+struct AttnSplitLds {
+  static constexpr int P = products_of(TERMS);
+  static constexpr int KROW = P * 64 + 8;                        // bf16 elements per staged K row
+  static constexpr int VROW = 32 + 8;                            // bf16 elements per staged V^T row (32 keys)
+  static constexpr int K_ELEMS = 32 * KROW, V_ELEMS = TERMS * 64 * VROW;
+  static constexpr int STAGE = K_ELEMS + V_ELEMS;                // bf16 elements per stage
+  static constexpr int K_PIECES = 32 * P * 8, V_PIECES = TERMS * 64 * 4;   // 16-byte pieces per block
+  static constexpr int KPT = K_PIECES / 256, VPT = V_PIECES / 256;         // per thread
+};
+
 template <int TERMS>
 __global__ __launch_bounds__(256) void attn_split_kernel(const bf16_raw* __restrict__ Qc, const bf16_raw* __restrict__ Kc, const bf16_raw* __restrict__ Vt,
                                                          bf16_raw* __restrict__ out, int tok, int tok_pad, int heads, int D) {
-  constexpr int P = products_of(TERMS);
+  using L = AttnSplitLds<TERMS>;
+  constexpr int P = L::P;
   constexpr int NCH = P * 2;                                     // 32-element chunks of a P * 64 row
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  static_assert(L::K_PIECES % 256 == 0 && L::V_PIECES % 256 == 0, "whole pieces per thread");
+  extern __shared__ __attribute__((aligned(16))) bf16_raw lds[];  // two stages of [K block | V^T block]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q0 = (blockIdx.x * 4 + wave) * 32;
-  if (q0 >= tok_pad) return;
+  const bool active = q0 < tok_pad;                              // (a wave past the padded queries still copies its share of every block and meets the barriers)
   const int bh = blockIdx.y;
   const int b = bh / heads, hd = bh - b * heads;
   const int n = lane & 31, h = lane >> 5;
   const size_t rowlen = (size_t)P * 64;
+  const size_t plane = (size_t)gridDim.y * 64 * tok_pad;
+  // ---- this thread's pieces of a block: global source offsets (block 0) and LDS destinations
+  const bf16_raw* ksrc[L::KPT];
+  int kdst[L::KPT];
+#pragma unroll
+  for (int i = 0; i < L::KPT; ++i) {
+    const int piece = tid + 256 * i, row = piece / (P * 8), c = piece - row * (P * 8);
+    ksrc[i] = Kc + ((size_t)bh * tok_pad + row) * rowlen + c * 8;
+    kdst[i] = row * L::KROW + c * 8;
+  }
+  const bf16_raw* vsrc[L::VPT];
+  int vdst[L::VPT];
+#pragma unroll
+  for (int i = 0; i < L::VPT; ++i) {
+    const int piece = tid + 256 * i, row = piece >> 2, c = piece & 3;        // row = term * 64 + d
+    const int t = row >> 6, d = row & 63;
+    vsrc[i] = Vt + t * plane + ((size_t)bh * 64 + d) * tok_pad + c * 8;
+    vdst[i] = L::K_ELEMS + row * L::VROW + c * 8;
+  }
+  u32x4 kreg[L::KPT], vreg[L::VPT];
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < L::KPT; ++i) kreg[i] = *reinterpret_cast<const u32x4*>(ksrc[i] + (size_t)kb * 32 * rowlen);
+#pragma unroll
+    for (int i = 0; i < L::VPT; ++i) vreg[i] = *reinterpret_cast<const u32x4*>(vsrc[i] + (size_t)kb * 32);
+  };
+  auto stash = [&](int stage) {
+    bf16_raw* base = lds + stage * L::STAGE;
+#pragma unroll
+    for (int i = 0; i < L::KPT; ++i) *reinterpret_cast<u32x4*>(base + kdst[i]) = kreg[i];
+#pragma unroll
+    for (int i = 0; i < L::VPT; ++i) *reinterpret_cast<u32x4*>(base + vdst[i]) = vreg[i];
+  };
   // Q operand of this wave's 32 queries: registers for the whole pass
   sb16x8 qreg[NCH][2];
   {
-    const bf16_raw* qrow = Qc + ((size_t)bh * tok_pad + q0 + n) * rowlen + h * 16;
+    const bf16_raw* qrow = Qc + ((size_t)bh * tok_pad + (active ? q0 + n : n)) * rowlen + h * 16;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       qreg[j][0] = *reinterpret_cast<const sb16x8*>(qrow + j * 32);
@@ -259,79 +310,87 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const bf16_raw* __restr
     }
   }
   const int pin = (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1);   // pi(n)
-  const bf16_raw* kbase = Kc + ((size_t)bh * tok_pad + pin) * rowlen + h * 16;
-  const size_t plane = (size_t)gridDim.y * 64 * tok_pad;
-  const bf16_raw* vbase = Vt + ((size_t)bh * 64 + n) * tok_pad + 8 * h;
+  const int koff = pin * L::KROW + h * 16;                       // this lane's K row in a stage
+  const int voff = L::K_ELEMS + n * L::VROW + 8 * h;             // this lane's V^T row (term 0, channel n) in a stage
   f32x16 o0 = {0}, o1 = {0};
   float m_run = -INFINITY, l_run = 0.f;
   const int nkb = tok_pad >> 5;
+  fetch(0);
+  stash(0);
+  __syncthreads();
   for (int kb = 0; kb < nkb; ++kb) {
-    f32x16 s = {0};
-    const bf16_raw* krow = kbase + (size_t)kb * 32 * rowlen;
+    const bf16_raw* st_base = lds + (kb & 1) * L::STAGE;
+    if (kb + 1 < nkb) fetch(kb + 1);                             // in flight under this block's MFMAs
+    if (active) {
+      f32x16 s = {0};
+      const bf16_raw* krow = st_base + koff;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      const sb16x8 ka = *reinterpret_cast<const sb16x8*>(krow + j * 32);
-      const sb16x8 kb2 = *reinterpret_cast<const sb16x8*>(krow + j * 32 + 8);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qreg[j][0], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2, qreg[j][1], s, 0, 0, 0);
-    }
-    // register i of lane (n, h) = key kb * 32 + 16 (i / 8) + 8 h + (i % 8)
-    if (kb == nkb - 1) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        if (kb * 32 + 16 * (i >> 3) + 8 * h + (i & 7) >= tok) s[i] = -INFINITY;
-    }
-    float mx = s[0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float p[16], rs = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      p[i] = __builtin_amdgcn_exp2f(s[i] - m_new);
-      rs += p[i];
-    }
-    rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-    // probabilities -> TERMS bf16 operands per PV step
-    sb16x8 pb[TERMS][2];
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      unsigned w[TERMS][4];
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        bf16_raw a[TERMS], c[TERMS];
-        split_terms<TERMS>(p[8 * st + e], a);
-        split_terms<TERMS>(p[8 * st + e + 1], c);
-#pragma unroll
-        for (int t = 0; t < TERMS; ++t) w[t][e >> 1] = (unsigned)a[t] | ((unsigned)c[t] << 16);
+      for (int j = 0; j < NCH; ++j) {
+        const sb16x8 ka = *reinterpret_cast<const sb16x8*>(krow + j * 32);
+        const sb16x8 kb2 = *reinterpret_cast<const sb16x8*>(krow + j * 32 + 8);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qreg[j][0], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2, qreg[j][1], s, 0, 0, 0);
       }
+      // register i of lane (n, h) = key kb * 32 + 16 (i / 8) + 8 h + (i % 8)
+      if (kb == nkb - 1) {
 #pragma unroll
-      for (int t = 0; t < TERMS; ++t) pb[t][st] = __builtin_bit_cast(sb16x8, (u32x4){w[t][0], w[t][1], w[t][2], w[t][3]});
-    }
-    const bf16_raw* vrow = vbase + (size_t)kb * 32;
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      sb16x8 va[TERMS][2];
-#pragma unroll
-      for (int t = 0; t < TERMS; ++t) {
-        va[t][0] = *reinterpret_cast<const sb16x8*>(vrow + t * plane + 16 * st);
-        va[t][1] = *reinterpret_cast<const sb16x8*>(vrow + t * plane + (size_t)32 * tok_pad + 16 * st);
+        for (int i = 0; i < 16; ++i)
+          if (kb * 32 + 16 * (i >> 3) + 8 * h + (i & 7) >= tok) s[i] = -INFINITY;
       }
+      float mx = s[0];
 #pragma unroll
-      for (int pr = 0; pr < P; ++pr) {
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][0], pb[B_TERM(pr)][st], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][1], pb[B_TERM(pr)][st], o1, 0, 0, 0);
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float p[16], rs = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        p[i] = __builtin_amdgcn_exp2f(s[i] - m_new);
+        rs += p[i];
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+      // probabilities -> TERMS bf16 operands per PV step
+      sb16x8 pb[TERMS][2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        unsigned w[TERMS][4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          bf16_raw a[TERMS], c[TERMS];
+          split_terms<TERMS>(p[8 * st + e], a);
+          split_terms<TERMS>(p[8 * st + e + 1], c);
+#pragma unroll
+          for (int t = 0; t < TERMS; ++t) w[t][e >> 1] = (unsigned)a[t] | ((unsigned)c[t] << 16);
+        }
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t) pb[t][st] = __builtin_bit_cast(sb16x8, (u32x4){w[t][0], w[t][1], w[t][2], w[t][3]});
+      }
+      const bf16_raw* vrow = st_base + voff;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        sb16x8 va[TERMS][2];
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t) {
+          va[t][0] = *reinterpret_cast<const sb16x8*>(vrow + (t * 64) * L::VROW + 16 * st);
+          va[t][1] = *reinterpret_cast<const sb16x8*>(vrow + (t * 64 + 32) * L::VROW + 16 * st);
+        }
+#pragma unroll
+        for (int pr = 0; pr < P; ++pr) {
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][0], pb[B_TERM(pr)][st], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][1], pb[B_TERM(pr)][st], o1, 0, 0, 0);
+        }
       }
     }
+    if (kb + 1 < nkb) stash((kb + 1) & 1);                       // the other stage: every wave left it at the previous barrier
+    __syncthreads();
   }
   const int q = q0 + n;
-  if (q >= tok) return;
+  if (!active || q >= tok) return;
   const float inv = 1.0f / l_run;
   // O^T register i of lane (n, h): channel 32 dt + 8 (i / 4) + 4 h + i % 4 of query q -> the A-side split operand of the out-projection, row b tok + q
   bf16_raw* orow = out + ((size_t)b * tok + q) * (size_t)P * D + hd * 64;
@@ -450,8 +509,15 @@ extern "C" int ucod_attention_split_fwd(const void* operands, void* out_split, i
   const bf16_raw* Vt = Kc + qk;
   UCOD_PROF(PROF_ATTN_SPLIT, stream);
   dim3 grid(cdiv(tok_pad, 128), bh), block(256);
-  if (terms == 2) hipLaunchKernelGGL(attn_split_kernel<2>, grid, block, 0, (hipStream_t)stream, Qc, Kc, Vt, (bf16_raw*)out_split, tok, tok_pad, heads, heads * 64);
-  else hipLaunchKernelGGL(attn_split_kernel<3>, grid, block, 0, (hipStream_t)stream, Qc, Kc, Vt, (bf16_raw*)out_split, tok, tok_pad, heads, heads * 64);
+  if (terms == 2) {
+    constexpr size_t lds = 2 * AttnSplitLds<2>::STAGE * sizeof(bf16_raw);
+    hipLaunchKernelGGL(attn_split_kernel<2>, grid, block, lds, (hipStream_t)stream, Qc, Kc, Vt, (bf16_raw*)out_split, tok, tok_pad, heads, heads * 64);
+  } else {
+    constexpr size_t lds = 2 * AttnSplitLds<3>::STAGE * sizeof(bf16_raw);
+    static const int once = [] { return (int)hipFuncSetAttribute((const void*)attn_split_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }();
+    if (once != 0) return once;
+    hipLaunchKernelGGL(attn_split_kernel<3>, grid, block, lds, (hipStream_t)stream, Qc, Kc, Vt, (bf16_raw*)out_split, tok, tok_pad, heads, heads * 64);
+  }
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
 }
