@@ -251,7 +251,10 @@ struct AttnSplitLds {
   static constexpr int KPT = K_PIECES / 256, VPT = V_PIECES / 256;         // per thread
 };
 
-template <int TERMS>
+// QT = 32-query tiles per wave; the product uses ONE.  Two tiles (64 queries per wave, 256 per workgroup) halve the LDS reads per MFMA -- every K / V^T fragment
+// feeds two independent chains -- but need 332 registers, i.e. one wave per SIMD instead of two, and the softmax between the two MFMA groups then has no other
+// wave to hide behind: measured 992 us against 869 us per launch (two-term form, 32 x 12 x 1370 tokens; gpurun_out/r06_split_bench_t2.txt).
+template <int TERMS, int QT>
 __global__ __launch_bounds__(256) void attn_split_kernel(const bf16_raw* __restrict__ Qc, const bf16_raw* __restrict__ Kc, const bf16_raw* __restrict__ Vt,
                                                          bf16_raw* __restrict__ out, int tok, int tok_pad, int heads, int D) {
   using L = AttnSplitLds<TERMS>;
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const bf16_raw* __restr
   static_assert(L::K_PIECES % 256 == 0 && L::V_PIECES % 256 == 0, "whole pieces per thread");
   extern __shared__ __attribute__((aligned(16))) bf16_raw lds[];  // two stages of [K block | V^T block]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int q0 = (blockIdx.x * 4 + wave) * 32 * QT;
   const bool active = q0 < tok_pad;                              // (a wave past the padded queries still copies its share of every block and meets the barriers)
   const int bh = blockIdx.y;
   const int b = bh / heads, hd = bh - b * heads;
@@ -299,21 +302,31 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const bf16_raw* __restr
 #pragma unroll
     for (int i = 0; i < L::VPT; ++i) *reinterpret_cast<u32x4*>(base + vdst[i]) = vreg[i];
   };
-  // Q operand of this wave's 32 queries: registers for the whole pass
-  sb16x8 qreg[NCH][2];
-  {
-    const bf16_raw* qrow = Qc + ((size_t)bh * tok_pad + (active ? q0 + n : n)) * rowlen + h * 16;
+  // Q operand of this wave's queries: registers for the whole pass (a tile that starts past the padded rows re-reads the last padded row: never stored)
+  sb16x8 qreg[QT][NCH][2];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    int qr = q0 + 32 * t + n;
+    qr = qr < tok_pad ? qr : tok_pad - 1;
+    const bf16_raw* qrow = Qc + ((size_t)bh * tok_pad + qr) * rowlen + h * 16;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-      qreg[j][0] = *reinterpret_cast<const sb16x8*>(qrow + j * 32);
-      qreg[j][1] = *reinterpret_cast<const sb16x8*>(qrow + j * 32 + 8);
+      qreg[t][j][0] = *reinterpret_cast<const sb16x8*>(qrow + j * 32);
+      qreg[t][j][1] = *reinterpret_cast<const sb16x8*>(qrow + j * 32 + 8);
     }
   }
   const int pin = (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1);   // pi(n)
   const int koff = pin * L::KROW + h * 16;                       // this lane's K row in a stage
   const int voff = L::K_ELEMS + n * L::VROW + 8 * h;             // this lane's V^T row (term 0, channel n) in a stage
-  f32x16 o0 = {0}, o1 = {0};
-  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 o0[QT], o1[QT];
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    o0[t] = (f32x16){0};
+    o1[t] = (f32x16){0};
+    m_run[t] = -INFINITY;
+    l_run[t] = 0.f;
+  }
   const int nkb = tok_pad >> 5;
   fetch(0);
   stash(0);
@@ -322,100 +335,117 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const bf16_raw* __restr
     const bf16_raw* st_base = lds + (kb & 1) * L::STAGE;
     if (kb + 1 < nkb) fetch(kb + 1);                             // in flight under this block's MFMAs
     if (active) {
-      f32x16 s = {0};
+      f32x16 s[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) s[t] = (f32x16){0};
       const bf16_raw* krow = st_base + koff;
 #pragma unroll
       for (int j = 0; j < NCH; ++j) {
         const sb16x8 ka = *reinterpret_cast<const sb16x8*>(krow + j * 32);
         const sb16x8 kb2 = *reinterpret_cast<const sb16x8*>(krow + j * 32 + 8);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qreg[j][0], s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2, qreg[j][1], s, 0, 0, 0);
-      }
-      // register i of lane (n, h) = key kb * 32 + 16 (i / 8) + 8 h + (i % 8)
-      if (kb == nkb - 1) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          if (kb * 32 + 16 * (i >> 3) + 8 * h + (i & 7) >= tok) s[i] = -INFINITY;
-      }
-      float mx = s[0];
-#pragma unroll
-      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      float p[16], rs = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        p[i] = __builtin_amdgcn_exp2f(s[i] - m_new);
-        rs += p[i];
-      }
-      rs += __shfl_xor(rs, 32, 64);
-      l_run = l_run * alpha + rs;
-      m_run = m_new;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-      // probabilities -> TERMS bf16 operands per PV step
-      sb16x8 pb[TERMS][2];
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        unsigned w[TERMS][4];
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          bf16_raw a[TERMS], c[TERMS];
-          split_terms<TERMS>(p[8 * st + e], a);
-          split_terms<TERMS>(p[8 * st + e + 1], c);
-#pragma unroll
-          for (int t = 0; t < TERMS; ++t) w[t][e >> 1] = (unsigned)a[t] | ((unsigned)c[t] << 16);
+        for (int t = 0; t < QT; ++t) {
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qreg[t][j][0], s[t], 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2, qreg[t][j][1], s[t], 0, 0, 0);
         }
+      }
+      sb16x8 pb[QT][TERMS][2];
 #pragma unroll
-        for (int t = 0; t < TERMS; ++t) pb[t][st] = __builtin_bit_cast(sb16x8, (u32x4){w[t][0], w[t][1], w[t][2], w[t][3]});
+      for (int t = 0; t < QT; ++t) {
+        // register i of lane (n, h) = key kb * 32 + 16 (i / 8) + 8 h + (i % 8)
+        if (kb == nkb - 1) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (kb * 32 + 16 * (i >> 3) + 8 * h + (i & 7) >= tok) s[t][i] = -INFINITY;
+        }
+        float mx = s[t][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[t][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[t], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+        float p[16], rs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          p[i] = __builtin_amdgcn_exp2f(s[t][i] - m_new);
+          rs += p[i];
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        l_run[t] = l_run[t] * alpha + rs;
+        m_run[t] = m_new;
+        if (__any(alpha != 1.0f)) {                              // (wave-uniform) the running maximum moved for some query of the tile: rare after the first blocks
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { o0[t][i] *= alpha; o1[t][i] *= alpha; }
+        }
+        // probabilities -> TERMS bf16 operands per PV step
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          unsigned w[TERMS][4];
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            bf16_raw a[TERMS], c[TERMS];
+            split_terms<TERMS>(p[8 * st + e], a);
+            split_terms<TERMS>(p[8 * st + e + 1], c);
+#pragma unroll
+            for (int tt = 0; tt < TERMS; ++tt) w[tt][e >> 1] = (unsigned)a[tt] | ((unsigned)c[tt] << 16);
+          }
+#pragma unroll
+          for (int tt = 0; tt < TERMS; ++tt) pb[t][tt][st] = __builtin_bit_cast(sb16x8, (u32x4){w[tt][0], w[tt][1], w[tt][2], w[tt][3]});
+        }
       }
       const bf16_raw* vrow = st_base + voff;
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
         sb16x8 va[TERMS][2];
 #pragma unroll
-        for (int t = 0; t < TERMS; ++t) {
-          va[t][0] = *reinterpret_cast<const sb16x8*>(vrow + (t * 64) * L::VROW + 16 * st);
-          va[t][1] = *reinterpret_cast<const sb16x8*>(vrow + (t * 64 + 32) * L::VROW + 16 * st);
+        for (int tt = 0; tt < TERMS; ++tt) {
+          va[tt][0] = *reinterpret_cast<const sb16x8*>(vrow + (tt * 64) * L::VROW + 16 * st);
+          va[tt][1] = *reinterpret_cast<const sb16x8*>(vrow + (tt * 64 + 32) * L::VROW + 16 * st);
         }
 #pragma unroll
         for (int pr = 0; pr < P; ++pr) {
-          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][0], pb[B_TERM(pr)][st], o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][1], pb[B_TERM(pr)][st], o1, 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < QT; ++t) {
+            o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][0], pb[t][B_TERM(pr)][st], o0[t], 0, 0, 0);
+            o1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][1], pb[t][B_TERM(pr)][st], o1[t], 0, 0, 0);
+          }
         }
       }
     }
     if (kb + 1 < nkb) stash((kb + 1) & 1);                       // the other stage: every wave left it at the previous barrier
     __syncthreads();
   }
-  const int q = q0 + n;
-  if (!active || q >= tok) return;
-  const float inv = 1.0f / l_run;
-  // O^T register i of lane (n, h): channel 32 dt + 8 (i / 4) + 4 h + i % 4 of query q -> the A-side split operand of the out-projection, row b tok + q
-  bf16_raw* orow = out + ((size_t)b * tok + q) * (size_t)P * D + hd * 64;
+  if (!active) return;
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt) {
+  for (int t = 0; t < QT; ++t) {
+    const int q = q0 + 32 * t + n;
+    if (q >= tok) continue;
+    const float inv = 1.0f / l_run[t];
+    // O^T register i of lane (n, h): channel 32 dt + 8 (i / 4) + 4 h + i % 4 of query q -> the A-side split operand of the out-projection, row b tok + q
+    bf16_raw* orow = out + ((size_t)b * tok + q) * (size_t)P * D + hd * 64;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      unsigned w[TERMS][2];
+    for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
-      for (int e = 0; e < 4; e += 2) {
-        const float x0 = (dt ? o1[4 * g + e] : o0[4 * g + e]) * inv, x1 = (dt ? o1[4 * g + e + 1] : o0[4 * g + e + 1]) * inv;
-        bf16_raw a[TERMS], c[TERMS];
-        split_terms<TERMS>(x0, a);
-        split_terms<TERMS>(x1, c);
+      for (int g = 0; g < 4; ++g) {
+        unsigned w[TERMS][2];
 #pragma unroll
-        for (int t = 0; t < TERMS; ++t) w[t][e >> 1] = (unsigned)a[t] | ((unsigned)c[t] << 16);
-      }
-      const int d = 32 * dt + 8 * g + 4 * h;
+        for (int e = 0; e < 4; e += 2) {
+          const float x0 = (dt ? o1[t][4 * g + e] : o0[t][4 * g + e]) * inv, x1 = (dt ? o1[t][4 * g + e + 1] : o0[t][4 * g + e + 1]) * inv;
+          bf16_raw a[TERMS], c[TERMS];
+          split_terms<TERMS>(x0, a);
+          split_terms<TERMS>(x1, c);
 #pragma unroll
-      for (int pr = 0; pr < P; ++pr) {
-        u32x2 ow = {0u, 0u};
+          for (int tt = 0; tt < TERMS; ++tt) w[tt][e >> 1] = (unsigned)a[tt] | ((unsigned)c[tt] << 16);
+        }
+        const int d = 32 * dt + 8 * g + 4 * h;
 #pragma unroll
-        for (int t = 0; t < TERMS; ++t)
-          if (t == A_TERM(pr)) ow = (u32x2){w[t][0], w[t][1]};
-        *reinterpret_cast<u32x2*>(orow + (size_t)pr * D + d) = ow;
+        for (int pr = 0; pr < P; ++pr) {
+          u32x2 ow = {0u, 0u};
+#pragma unroll
+          for (int tt = 0; tt < TERMS; ++tt)
+            if (tt == A_TERM(pr)) ow = (u32x2){w[tt][0], w[tt][1]};
+          *reinterpret_cast<u32x2*>(orow + (size_t)pr * D + d) = ow;
+        }
       }
     }
   }
@@ -508,15 +538,15 @@ extern "C" int ucod_attention_split_fwd(const void* operands, void* out_split, i
   const bf16_raw* Kc = Qc + qk;
   const bf16_raw* Vt = Kc + qk;
   UCOD_PROF(PROF_ATTN_SPLIT, stream);
-  dim3 grid(cdiv(tok_pad, 128), bh), block(256);
+  dim3 block(256);
   if (terms == 2) {
     constexpr size_t lds = 2 * AttnSplitLds<2>::STAGE * sizeof(bf16_raw);
-    hipLaunchKernelGGL(attn_split_kernel<2>, grid, block, lds, (hipStream_t)stream, Qc, Kc, Vt, (bf16_raw*)out_split, tok, tok_pad, heads, heads * 64);
+    hipLaunchKernelGGL((attn_split_kernel<2, 1>), dim3(cdiv(tok_pad, 128), bh), block, lds, (hipStream_t)stream, Qc, Kc, Vt, (bf16_raw*)out_split, tok, tok_pad, heads, heads * 64);
   } else {
     constexpr size_t lds = 2 * AttnSplitLds<3>::STAGE * sizeof(bf16_raw);
-    static const int once = [] { return (int)hipFuncSetAttribute((const void*)attn_split_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }();
+    static const int once = [] { return (int)hipFuncSetAttribute((const void*)attn_split_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }();
     if (once != 0) return once;
-    hipLaunchKernelGGL(attn_split_kernel<3>, grid, block, lds, (hipStream_t)stream, Qc, Kc, Vt, (bf16_raw*)out_split, tok, tok_pad, heads, heads * 64);
+    hipLaunchKernelGGL((attn_split_kernel<3, 1>), dim3(cdiv(tok_pad, 128), bh), block, lds, (hipStream_t)stream, Qc, Kc, Vt, (bf16_raw*)out_split, tok, tok_pad, heads, heads * 64);
   }
   UCOD_CHECK_LAUNCH();
   return UCOD_OK;
