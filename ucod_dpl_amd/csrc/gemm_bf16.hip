@@ -259,11 +259,13 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
     wait_vmcnt<0>();
   }
   finish_col_consts<EPI, NT>(a, cb, cs);
+  float craw[NT];                                // the folded epilogues' column sums as loaded (the rank-one MFMA runs before the column scale)
   if constexpr (kFold<EPI>) {                   // table written here, read in the epilogue: every barrier of the K loop lies in between
     fold_finish(a, fold_tab, 2 * Cfg::RG, wave, lane, freq);
     fold.tab = reinterpret_cast<const float*>(fold_tab) + wm * Cfg::RG;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
+      craw[j] = fold.cc[j];
       fold.cc[j] *= cs[j];
       fold.cb[j] = cb[j] * cs[j];
       cb[j] = 0.f;                              // accumulators start at zero: the folded bias is added behind the per-row scaling
@@ -331,6 +333,7 @@ __device__ __forceinline__ void mixed_body(const GemmArgs& a, char* smem, int m0
     }
   }
   if (wm == 0) UCOD_MIXED_BARRIER();
+  if constexpr (kFold<EPI> && UCOD_FOLD_RANK1) fold_rank_one<NT, NI>(acc, fold.tab, craw, lane);
   big_epilogue<EPI, NT, NI, AUX>(a, acc, cs, smem + wave * (32 * EPI_PITCH(16 * NT)), m0 + wm * Cfg::RG, n0 + wn * 16 * NT, lane, &fold);
 }
 

@@ -375,7 +375,15 @@ __device__ __forceinline__ f32x2 row_partial8(const u32x4& w) {
 #endif
 constexpr float kFoldMeanGuard = 65536.0f;                         // (|mean| / sigma)^2 above which a row is reported (fold_finish, row_stats_h16_kernel)
 constexpr int FOLD_TAB_ROWS = 288;                                 // >= rows of the tallest tile (2 x 144)
-constexpr int FOLD_TAB_BYTES = 2 * FOLD_TAB_ROWS * 4;
+// Round 6 experiment, NOT the product form: -DUCOD_FOLD_RANK1=1 sends the rank-one term  -mean[m] * c[n]  of the fold through the MATRIX pipe
+// (fold_rank_one below: one extra 16 x 16 x 32 MFMA per accumulator tile behind the K loop, 32 against the loop's 768), so that the stager applies ONE FMA per
+// element -- s * acc + b' -- and reads one table column instead of two.  Correct (tests/test_gpu_lnfold.py passes on it) and SLOWER: the 32 MFMAs, their operand
+// conversions and table reads run serially between the K loop and the drain, while the stager's second FMA hides under its own LDS writes -- QKV 153.1 vs 149.8 us,
+// fc1 213.4 vs 210.5 isolated; 158.1 vs 153.7 and 221.2 vs 216.8 in the step (profiles/r06_lnfold_ab.txt: gate of 149 / 211 us missed, experiment closed).
+#ifndef UCOD_FOLD_RANK1
+#define UCOD_FOLD_RANK1 0
+#endif
+constexpr int FOLD_TAB_BYTES = 3 * FOLD_TAB_ROWS * 4;              // s | u | -mean
 constexpr int FOLD_MAX_SLOT_PAIRS = 12;                            // nslot <= 24 (D <= 1536)
 template <int NT>
 struct FoldCtx {
@@ -461,6 +469,38 @@ __device__ __forceinline__ void fold_finish(const GemmArgs& a, char* tab_bytes, 
     float* tab = reinterpret_cast<float*>(tab_bytes);
     tab[tid] = s;
     tab[FOLD_TAB_ROWS + tid] = u;
+    tab[2 * FOLD_TAB_ROWS + tid] = parts ? -mean : (r.su[0] != 0.f ? r.su[1] / r.su[0] : 0.f);   // (rows past M read zeros: s = 0)
+  }
+}
+
+// The fold's rank-one term on the matrix pipe:  acc[i][j] += (-mean[row]) * c[col]  as one v_mfma_f32_16x16x32 per accumulator tile whose 32-deep K slice holds
+//   A[row][0..2] = (mh, mh, ml * 2^11)      B[col][0..2] = (ch, cl, ch * 2^-11)      everything else zero,
+// mh + ml = -mean and ch + cl = c split into two fp16 terms (22 significand bits each; the second-order term ml * cl is below 2^-22 of the product and is dropped;
+// the powers of two keep ml away from fp16's subnormal range whatever |mean| is and are exact).  The three products are exact in the f32 accumulator; what the
+// MFMA adds is what `fmaf(u, c, .)` added in the stager, to 2^-22 instead of 2^-24 of |mean c| -- far below the f32 rounding of the K-long sum it cancels against.
+// Lane l supplies row / column (l & 15) and the k slice 8 (l >> 4) .. + 7: only the lanes of slice 0 carry values.
+template <int NT, int NI>
+__device__ __forceinline__ void fold_rank_one(f32x4 (&acc)[NI][NT], const float* tab, const float (&craw)[NT], int lane) {
+  const bool k0 = (lane >> 4) == 0;
+  hx8 fbx[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const float c = k0 ? craw[j] : 0.f;
+    const half_t ch = (half_t)c;
+    const half_t cl = (half_t)(c - (float)ch);
+    const half_t chs = (half_t)((float)ch * 0.00048828125f);
+    const half_t z = (half_t)0.f;
+    fbx[j] = (hx8){ch, cl, chs, z, z, z, z, z};
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const float nm = k0 ? tab[2 * FOLD_TAB_ROWS + i * 16 + (lane & 15)] : 0.f;
+    const half_t mh = (half_t)nm;
+    const half_t ml = (half_t)((nm - (float)mh) * 2048.0f);
+    const half_t z = (half_t)0.f;
+    const hx8 fax = (hx8){mh, mh, ml, z, z, z, z, z};
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = UCOD_MFMA16(fax, fbx[j], acc[i][j]);
   }
 }
 
@@ -898,7 +938,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
         if (pass * 2 + i >= NI) continue;
         const float* t = fold->tab + (pass * 2 + i) * 16 + (lane >> 4) * 4;
         sn[i] = *reinterpret_cast<const f32x4*>(t);
-        un[i] = *reinterpret_cast<const f32x4*>(t + FOLD_TAB_ROWS);
+        if constexpr (!UCOD_FOLD_RANK1) un[i] = *reinterpret_cast<const f32x4*>(t + FOLD_TAB_ROWS);
       }
     }
   };
@@ -914,7 +954,10 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, f32x4 (&acc)[NI]
         if constexpr (kStageScaled<EPI>) v = v * cs[j];
         if constexpr (kFold<EPI> && !(UCOD_FOLD_ABL & 2)) {
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) v[rg] = fmaf(s4[rg], v[rg], fmaf(u4[rg], fold->cc[j], fold->cb[j]));
+          for (int rg = 0; rg < 4; ++rg) {
+            if constexpr (UCOD_FOLD_RANK1) v[rg] = fmaf(s4[rg], v[rg], fold->cb[j]);          // (-mean c is inside the accumulator: fold_rank_one)
+            else v[rg] = fmaf(s4[rg], v[rg], fmaf(u4[rg], fold->cc[j], fold->cb[j]));
+          }
         }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)

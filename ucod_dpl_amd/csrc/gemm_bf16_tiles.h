@@ -239,11 +239,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   }
   if (nt > 1) wait_vmcnt<Cfg::NB>(); else wait_vmcnt<0>();
   finish_col_consts<EPI, NT>(a, cb, cs);
+  float craw[NT];
   if constexpr (kFold<EPI>) {
     fold_finish(a, fold_tab, 256, wave, lane, freq);
     fold.tab = reinterpret_cast<const float*>(fold_tab) + wm * 128;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
+      craw[j] = fold.cc[j];
       fold.cc[j] *= cs[j];
       fold.cb[j] = cb[j] * cs[j];
       cb[j] = 0.f;
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs a) {
   }
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();
 
+  if constexpr (kFold<EPI> && UCOD_FOLD_RANK1) fold_rank_one<NT, 8>(acc, fold.tab, craw, lane);
   // epilogue through a wave-private LDS region (operand tiles are dead: last barrier passed)
   big_epilogue<EPI, NT, 8, UCOD_ST_AUX, FASTRM>(a, acc, cs, smem + wave * (32 * EPI_PITCH(16 * NT)), m0 + wm * 128, n0 + wn * 16 * NT, lane, &fold);
 }
