@@ -102,6 +102,9 @@ enum {
                                         (M >= 2048, N % 64 == 0); otherwise UCOD_EINVAL and nothing is launched */
   UCOD_EPI_PATCH_TOKENS_H16_STATS = 14,     /* ucod_gemm_bf16_stats only.  UCOD_EPI_PATCH_TOKENS_H16 with the same partials, indexed by OUTPUT token row (the CLS rows'
                                         partials come from ucod_cls_rows_h16_stats) */
+  UCOD_EPI_BIAS_GELU_SPLIT2 = 15,    /* split-operand pass, two terms (csrc/split.hip): out bf16 [M, 3 N] = the A-side split operand (segments hi | hi | lo) of
+                                        gelu_erf(C + bias[n]) -- fc1 + GELU + the split in ONE launch instead of UCOD_EPI_BIAS_F32 + ucod_split_rows(op 1): no f32
+                                        round trip of the MLP hidden.  bf16 library; N % 8 == 0 */
   UCOD_EPI_QKV_FP8 = 8               /* QKV projection of the fp8 attention path (BASELINE configs[4]): out = e4m3 bytes
                                         [3 (q|k|v)][Bimg*heads][Npad][64], Npad = tokens rounded up to 64, value = clamp((C + bias[n]) *
                                         scale[n], +-448); N = 3*heads*64, M = Bimg*tokens_per_image; large-tile kernel only */

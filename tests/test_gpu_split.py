@@ -85,6 +85,27 @@ def test_linear_split_against_f64(M, Nn, K, terms, tol):
         assert rel_l2(out, ref) < 10 * rel_l2(x @ w.t() + b, ref) + 2e-7
 
 
+@pytest.mark.parametrize("M,Nn,K,variant", [(200, 256, 256, 0), (200, 256, 256, 12), (1370, 3072, 768, 0), (4111, 1024, 256, 9), (8220, 3072, 768, 13), (43840, 3072, 768, 0)])
+def test_fc1_gelu_split2_epilogue(M, Nn, K, variant):
+    """UCOD_EPI_BIAS_GELU_SPLIT2: fc1 + GELU + the two-term split of the result in one launch (what ucod_vit_forward_split runs for terms = 2): the output is the
+    A-side split operand [M, 3 N] = (hi | hi | lo) of gelu(x w^T + b), on every tile path (64 x 64, 128 x 128, one-shot large tile, mixed-height)."""
+    g = torch.Generator().manual_seed(M + Nn)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(Nn, K, generator=g) * 0.05, torch.randn(Nn, generator=g) * 0.2
+    ref = torch.nn.functional.gelu(x.double() @ w.double().t() + b.double())
+    xs, ws = ops.split_rows(x.to(DEV), 2, 0), ops.split_rows(w.to(DEV), 2, 1)
+    out = torch.full((M + 3, 3 * Nn), -7.0, dtype=torch.bfloat16, device=DEV)          # three guard rows behind the matrix
+    ops.gemm_bf16(N.EPI_BIAS_GELU_SPLIT2, xs, ws, out, M, Nn, 3 * K, bias=b.to(DEV), variant=variant)
+    assert bool((out[M:] == -7.0).all())
+    seg = out[:M].view(M, 3, Nn)
+    assert torch.equal(seg[:, 0], seg[:, 1])                        # hi | hi
+    got = ops.unsplit(out[:M].contiguous(), 2, 0, Nn).cpu().double()
+    assert rel_l2(got, ref) < 2e-5, rel_l2(got, ref)
+    assert maxdiff(got, ref) < 6e-4 * max(1.0, float(ref.abs().max()))
+    # the same values as the two-launch form (f32 GEMM, then exact-erf GELU + split) to the two forms' GELU difference
+    two = ops.unsplit(ops.split_rows(ops.linear_split(x.to(DEV), w.to(DEV), b.to(DEV), 2), 2, 0, op=1), 2, 0, Nn).cpu().double()
+    assert maxdiff(got, two) < 3e-5 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("terms", [2, 3])
 @pytest.mark.parametrize("rows,D", [(5, 128), (777, 384), (1371, 768), (333, 1024), (64, 1536)])
 def test_layernorm_split(rows, D, terms):

@@ -5,16 +5,17 @@
 #   * launch order of one serial step (rocclr fills / copies), LoRA-mode stats
 #   * side configurations: C4 first stage, C4 Look-Twice leg, C5 fp8, C1; next-rows bench
 set -u
+# (round 6, ADVICE r5: every rocprofv3 pass runs under `timeout` -- a FETCH_SIZE / WRITE_SIZE pass once hung a box for 25 minutes; a pass that times out is skipped)
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 bash tools/refresh_evidence.sh r05 > $O/r05_refresh.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 SERIAL="--steps 5 --warmup 2 --no-cpu-baseline --lora-steps -1 --no-pipeline --streams 1"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r05_bf16_serial -- python3 $R/bench.py --half bf16 $SERIAL > $O/prof_r05_bf16_serial_bench.json 2> $O/prof_r05_bf16_serial.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r05_bf16_serial -- python3 $R/bench.py --half bf16 $SERIAL > $O/prof_r05_bf16_serial_bench.json 2> $O/prof_r05_bf16_serial.err
 find $O/prof_r05_bf16_serial -name '*kernel_trace.csv' -delete
-rocprofv3 --kernel-trace --output-format csv -d $O/trace_r05 -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --lora-steps -1 --no-pipeline --streams 1 > /dev/null 2> $O/trace_r05.err
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/trace_r05 -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --lora-steps -1 --no-pipeline --streams 1 > /dev/null 2> $O/trace_r05.err
 python3 $R/tools/step_trace.py $O/trace_r05 > $O/r05_step_trace.txt 2>&1
 rm -rf $O/trace_r05
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r05_lora -- python3 $R/tools/lora_bench.py 32 2 1 0.05 > $O/prof_r05_lora_bench.txt 2> $O/prof_r05_lora.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r05_lora -- python3 $R/tools/lora_bench.py 32 2 1 0.05 > $O/prof_r05_lora_bench.txt 2> $O/prof_r05_lora.err
 find $O/prof_r05_lora -name '*kernel_trace.csv' -delete
 cd $R
 python bench.py --arch dinov2_vitl14 --batch 16 --lora-steps 0 --cpu-images 1 > $O/bench_r05_c4_vitl14_b16.json 2> $O/bench_r05_c4.err

@@ -608,7 +608,7 @@ static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int
   a.group_m = 8;
   a.col_fast = 0;
   hipStream_t s = (hipStream_t)stream;
-  UCOD_PROF(epilogue == UCOD_EPI_QKV_FP8 || epilogue == UCOD_EPI_LNFOLD_BIAS_BF16 ? 0 : epilogue == UCOD_EPI_LNFOLD_GELU_BF16 ? 1 : (epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16 || epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16_STATS) ? 2 : (epilogue == UCOD_EPI_PATCH_TOKENS_H16 || epilogue == UCOD_EPI_PATCH_TOKENS_H16_STATS) ? 3 : (epilogue >= 0 && epilogue <= 5 ? epilogue : (epilogue == UCOD_EPI_GELU_BWD_BF16 ? PROF_GEMM_EPI6 : PROF_GEMM_EPI7)), s);
+  UCOD_PROF(epilogue == UCOD_EPI_QKV_FP8 || epilogue == UCOD_EPI_LNFOLD_BIAS_BF16 ? 0 : (epilogue == UCOD_EPI_LNFOLD_GELU_BF16 || epilogue == UCOD_EPI_BIAS_GELU_SPLIT2) ? 1 : (epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16 || epilogue == UCOD_EPI_BIAS_SCALE_RESID_H16_STATS) ? 2 : (epilogue == UCOD_EPI_PATCH_TOKENS_H16 || epilogue == UCOD_EPI_PATCH_TOKENS_H16_STATS) ? 3 : (epilogue >= 0 && epilogue <= 5 ? epilogue : (epilogue == UCOD_EPI_GELU_BWD_BF16 ? PROF_GEMM_EPI6 : PROF_GEMM_EPI7)), s);
   switch (epilogue) {
     case UCOD_EPI_BIAS_BF16:                                   // NULL bias (plain product) only in the large-tile kernels
       if (!bias && (variant == 1 || variant == 2 || K < 128 || (N & 3))) return UCOD_EINVAL;
@@ -616,6 +616,9 @@ static int gemm_entry(int epilogue, const void* A, const void* B, void* out, int
     case UCOD_EPI_GELU_BWD_BF16: if (!aux) return UCOD_EINVAL; return launch<UCOD_EPI_GELU_BWD_BF16>(a, variant, s);
     case UCOD_EPI_BIAS_GELU_SAVE_BF16: if (!bias || !out2) return UCOD_EINVAL; return launch<UCOD_EPI_BIAS_GELU_SAVE_BF16>(a, variant, s);
     case UCOD_EPI_BIAS_GELU_BF16: if (!bias) return UCOD_EINVAL; return launch<UCOD_EPI_BIAS_GELU_BF16>(a, variant, s);
+    case UCOD_EPI_BIAS_GELU_SPLIT2:                                 // rows of 3 N bf16: the drains address them with 31-bit byte offsets
+      if (!bias || (N & 7) != 0 || (long)M * 3 * N * 2 >= (1L << 31) - 16) return UCOD_EINVAL;
+      return launch<UCOD_EPI_BIAS_GELU_SPLIT2>(a, variant, s);
     case UCOD_EPI_BIAS_SCALE_RESID_F32:
       if (!bias || !scale || !resid) return UCOD_EINVAL;
       return launch<UCOD_EPI_BIAS_SCALE_RESID_F32>(a, variant, s);

@@ -37,8 +37,18 @@ template <int EPI>
 constexpr bool kStats = (EPI == UCOD_EPI_BIAS_SCALE_RESID_H16_STATS || EPI == UCOD_EPI_PATCH_TOKENS_H16_STATS);
 template <int EPI>
 constexpr bool kBiasLike = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_LNFOLD_BIAS_BF16);        // optional column scale, 16-bit output
+// fc1 of the two-term split-operand pass: GELU, then the result as the A-side split operand of fc2 -- three bf16 segments (hi | hi | lo) of a row 3 N wide
 template <int EPI>
-constexpr bool kGeluLike = (EPI == UCOD_EPI_BIAS_GELU_BF16 || EPI == UCOD_EPI_LNFOLD_GELU_BF16);   // erf-GELU, 16-bit output
+constexpr bool kSplit2Out = (EPI == UCOD_EPI_BIAS_GELU_SPLIT2);
+template <int EPI>
+constexpr int kOutPitchMul = kSplit2Out<EPI> ? 3 : 1;              // output row pitch in units of N elements
+template <int EPI>
+constexpr bool kGeluLike = (EPI == UCOD_EPI_BIAS_GELU_BF16 || EPI == UCOD_EPI_LNFOLD_GELU_BF16 || kSplit2Out<EPI>);   // erf-GELU, 16-bit output
+// (hi, lo) bf16 terms of two f32 values, packed pairwise: v = hi + lo up to 2^-17 |v|
+__device__ __forceinline__ u32x2 split2_pack(float a, float b) {   // -> (hi pair, lo pair)
+  const unsigned hi = pack_bf16x2(a, b);
+  return (u32x2){hi, pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u))};
+}
 // cache policy of the large-tile epilogue's output stores (aux bits of buffer_store: 0 default, 2 nt, 16 sc1 = write-through, the line
 // is dropped from the XCD's L2 instead of displacing operand panels)
 #ifndef UCOD_ST_AUX
@@ -160,6 +170,13 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& a, int m, int n, 
     reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_h(o);
   } else if constexpr (EPI == UCOD_EPI_BIAS_BF16) {
     reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_h((v + a.bias[n]) * (a.scale ? a.scale[n] : 1.f));
+  } else if constexpr (kSplit2Out<EPI>) {
+    const float o = gelu_erf(v + a.bias[n]);
+    const bf16_raw hi = f32_to_bf16(o), lo = f32_to_bf16(o - bf16_to_f32(hi));
+    bf16_raw* row = reinterpret_cast<bf16_raw*>(a.out) + (size_t)m * 3 * a.N + n;
+    row[0] = hi;
+    row[a.N] = hi;
+    row[2 * (size_t)a.N] = lo;
   } else if constexpr (EPI == UCOD_EPI_BIAS_GELU_BF16) {
     reinterpret_cast<bf16_raw*>(a.out)[(size_t)m * a.N + n] = f32_to_h(gelu_erf(v + a.bias[n]));
   } else if constexpr (EPI == UCOD_EPI_BIAS_SCALE_RESID_F32) {
@@ -223,6 +240,16 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& a, int m, int n,
       if constexpr (kGeluLike<EPI>) {
         const f32x2 g0 = gelu_erf2((f32x2){o[0], o[1]}), g1 = gelu_erf2((f32x2){o[2], o[3]});
         o = (f32x4){g0[0], g0[1], g1[0], g1[1]};
+      }
+      if constexpr (kSplit2Out<EPI>) {
+        u32x2 hi, lo;
+        { const u32x2 t2 = split2_pack(o[0], o[1]); hi[0] = t2[0]; lo[0] = t2[1]; }
+        { const u32x2 t2 = split2_pack(o[2], o[3]); hi[1] = t2[0]; lo[1] = t2[1]; }
+        bf16_raw* row = reinterpret_cast<bf16_raw*>(a.out) + (size_t)m * 3 * a.N + n;
+        *reinterpret_cast<u32x2*>(row) = hi;
+        *reinterpret_cast<u32x2*>(row + a.N) = hi;
+        *reinterpret_cast<u32x2*>(row + 2 * (size_t)a.N) = lo;
+        return;
       }
       u32x2 w;
       w[0] = pack_h2(o[0], o[1]);
@@ -294,6 +321,18 @@ __device__ __forceinline__ void epilogue_store8_bf16(const GemmArgs& a, int m, i
     const f32x2 g2 = gelu_erf2((f32x2){o1[0], o1[1]}), g3 = gelu_erf2((f32x2){o1[2], o1[3]});
     o0 = (f32x4){g0[0], g0[1], g1[0], g1[1]};
     o1 = (f32x4){g2[0], g2[1], g3[0], g3[1]};
+  }
+  if constexpr (kSplit2Out<EPI>) {
+    u32x4 hi, lo;
+    { const u32x2 t2 = split2_pack(o0[0], o0[1]); hi[0] = t2[0]; lo[0] = t2[1]; }
+    { const u32x2 t2 = split2_pack(o0[2], o0[3]); hi[1] = t2[0]; lo[1] = t2[1]; }
+    { const u32x2 t2 = split2_pack(o1[0], o1[1]); hi[2] = t2[0]; lo[2] = t2[1]; }
+    { const u32x2 t2 = split2_pack(o1[2], o1[3]); hi[3] = t2[0]; lo[3] = t2[1]; }
+    bf16_raw* row = reinterpret_cast<bf16_raw*>(a.out) + (size_t)m * 3 * a.N + n;
+    *reinterpret_cast<u32x4*>(row) = hi;
+    *reinterpret_cast<u32x4*>(row + a.N) = hi;
+    *reinterpret_cast<u32x4*>(row + 2 * (size_t)a.N) = lo;
+    return;
   }
   u32x4 w;
   w[0] = pack_h2(o0[0], o0[1]);
@@ -515,7 +554,7 @@ __device__ __forceinline__ void fold_rank_one(f32x4 (&acc)[NI][NT], const float*
 //   * the f32 residual is double buffered: the loads of pass p+1 are issued BEFORE the stores of pass p, and vmcnt retires
 //     in order, so the wait for them leaves pass p's stores in flight.  (out may alias resid: passes touch disjoint rows.)
 template <int EPI>
-constexpr bool kColFused = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 ||
+constexpr bool kColFused = (EPI == UCOD_EPI_BIAS_BF16 || EPI == UCOD_EPI_BIAS_GELU_BF16 || kSplit2Out<EPI> || EPI == UCOD_EPI_BIAS_SCALE_RESID_F32 ||
                             EPI == UCOD_EPI_BIAS_F32 || EPI == UCOD_EPI_GELU_BWD_BF16 || EPI == UCOD_EPI_BIAS_GELU_SAVE_BF16 ||
                             EPI == UCOD_EPI_QKV_FP8 || kResidH16<EPI> || kFold<EPI>);
 template <int EPI>
@@ -713,7 +752,7 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
     // buffer descriptors over [first row of this wave's tile, end of the matrix) -- rows past M fail the range check and
     // are dropped (loads return 0) -- and columns past N get an offset beyond any descriptor.
     constexpr unsigned OOB = 0xFFFFFFF0u;
-    constexpr int ELT = kF32Out<EPI> ? 4 : 2;
+    constexpr int ELT = (kF32Out<EPI> ? 4 : 2) * kOutPitchMul<EPI>;   // bytes per output column of a row's pitch (the split epilogue's rows are 3 N wide)
     const long rows_left = (long)a.M - m_first;
     const unsigned long left = rows_left > 0 ? (unsigned long)rows_left * a.N * ELT : 0ul;
     const unsigned records = left > 0xFFFFFFFFul ? 0xFFFFFFFFu : (unsigned)left;
@@ -904,6 +943,15 @@ __device__ __forceinline__ void big_epilogue_staged(const GemmArgs& a, const Sta
               const unsigned po = (lane & 7) == 0 ? (unsigned)(pass * PR + it * 8 + (lane >> 3)) * part_row_bytes + part_slot_off : DROP;
               __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pq), rs_part, po, 0, 0);
             }
+          } else if constexpr (kSplit2Out<EPI>) {                  // segments hi | hi | lo, N elements apart in a row of 3 N
+            u32x4 lo;
+            { const u32x2 t2 = split2_pack(v0[0], v0[1]); w[0] = t2[0]; lo[0] = t2[1]; }
+            { const u32x2 t2 = split2_pack(v0[2], v0[3]); w[1] = t2[0]; lo[1] = t2[1]; }
+            { const u32x2 t2 = split2_pack(v1[0], v1[1]); w[2] = t2[0]; lo[2] = t2[1]; }
+            { const u32x2 t2 = split2_pack(v1[2], v1[3]); w[3] = t2[0]; lo[3] = t2[1]; }
+            const unsigned o = at(it, pass);
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs_o, o + (unsigned)a.N * 2u, 0, AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(lo, rs_o, o + (unsigned)a.N * 4u, 0, AUX);
           } else {
             w[0] = pack_h2(v0[0], v0[1]);
             w[1] = pack_h2(v0[2], v0[3]);

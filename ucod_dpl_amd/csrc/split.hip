@@ -255,7 +255,7 @@ struct AttnSplitLds {
 // feeds two independent chains -- but need 332 registers, i.e. one wave per SIMD instead of two, and the softmax between the two MFMA groups then has no other
 // wave to hide behind: measured 992 us against 869 us per launch (two-term form, 32 x 12 x 1370 tokens; gpurun_out/r06_split_bench_t2.txt).
 template <int TERMS, int QT>
-__global__ __launch_bounds__(256) void attn_split_kernel(const bf16_raw* __restrict__ Qc, const bf16_raw* __restrict__ Kc, const bf16_raw* __restrict__ Vt,
+__global__ __launch_bounds__(256, (TERMS == 2 && QT == 1) ? 2 : 1) void attn_split_kernel(const bf16_raw* __restrict__ Qc, const bf16_raw* __restrict__ Kc, const bf16_raw* __restrict__ Vt,
                                                          bf16_raw* __restrict__ out, int tok, int tok_pad, int heads, int D) {
   using L = AttnSplitLds<TERMS>;
   constexpr int P = L::P;
@@ -288,19 +288,30 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const bf16_raw* __restr
     vsrc[i] = Vt + t * plane + ((size_t)bh * 64 + d) * tok_pad + c * 8;
     vdst[i] = L::K_ELEMS + row * L::VROW + c * 8;
   }
+  // Software pipeline (round 6, third form): iteration kb issues the score MFMAs of block kb + 1 AND the P V MFMAs of block kb - 1 -- three independent accumulator
+  // chains, none of which depends on this iteration's vector work -- around the softmax of block kb (maximum, 17 v_exp_f32, row sum, term split), so that the matrix
+  // pipe works under the wave's own exponentials instead of waiting for them.  An LDS stage therefore holds [K(kb + 1) | V^T(kb - 1)]; one basic block per iteration
+  // (the last block's key mask is a select, the rescale is unconditional) with scheduling hints that spread the MFMAs through the vector instructions.
   u32x4 kreg[L::KPT], vreg[L::VPT];
-  auto fetch = [&](int kb) {
+  const int nkb = tok_pad >> 5;
+  auto fetch = [&](int kk, int vk) {                             // K block kk (if it exists) and V^T block vk (if >= 0) into registers
+    if (kk < nkb) {
 #pragma unroll
-    for (int i = 0; i < L::KPT; ++i) kreg[i] = *reinterpret_cast<const u32x4*>(ksrc[i] + (size_t)kb * 32 * rowlen);
+      for (int i = 0; i < L::KPT; ++i) kreg[i] = *reinterpret_cast<const u32x4*>(ksrc[i] + (size_t)kk * 32 * rowlen);
+    }
+    if (vk >= 0) {
 #pragma unroll
-    for (int i = 0; i < L::VPT; ++i) vreg[i] = *reinterpret_cast<const u32x4*>(vsrc[i] + (size_t)kb * 32);
+      for (int i = 0; i < L::VPT; ++i) vreg[i] = *reinterpret_cast<const u32x4*>(vsrc[i] + (size_t)vk * 32);
+    }
   };
-  auto stash = [&](int stage) {
+  auto stash = [&](int stage, bool with_v) {
     bf16_raw* base = lds + stage * L::STAGE;
 #pragma unroll
     for (int i = 0; i < L::KPT; ++i) *reinterpret_cast<u32x4*>(base + kdst[i]) = kreg[i];
+    if (with_v) {
 #pragma unroll
-    for (int i = 0; i < L::VPT; ++i) *reinterpret_cast<u32x4*>(base + vdst[i]) = vreg[i];
+      for (int i = 0; i < L::VPT; ++i) *reinterpret_cast<u32x4*>(base + vdst[i]) = vreg[i];
+    }
   };
   // Q operand of this wave's queries: registers for the whole pass (a tile that starts past the padded rows re-reads the last padded row: never stored)
   sb16x8 qreg[QT][NCH][2];
@@ -320,64 +331,91 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const bf16_raw* __restr
   const int voff = L::K_ELEMS + n * L::VROW + 8 * h;             // this lane's V^T row (term 0, channel n) in a stage
   f32x16 o0[QT], o1[QT];
   float m_run[QT], l_run[QT];
+  sb16x8 pb[QT][TERMS][2];                                       // probabilities of the PREVIOUS block as P V operands (zero before the first)
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     o0[t] = (f32x16){0};
     o1[t] = (f32x16){0};
     m_run[t] = -INFINITY;
     l_run[t] = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < TERMS; ++tt) pb[t][tt][0] = pb[t][tt][1] = __builtin_bit_cast(sb16x8, (u32x4){0u, 0u, 0u, 0u});
   }
-  const int nkb = tok_pad >> 5;
-  fetch(0);
-  stash(0);
-  __syncthreads();
-  for (int kb = 0; kb < nkb; ++kb) {
-    const bf16_raw* st_base = lds + (kb & 1) * L::STAGE;
-    if (kb + 1 < nkb) fetch(kb + 1);                             // in flight under this block's MFMAs
-    if (active) {
-      f32x16 s[QT];
+  auto scores = [&](const bf16_raw* stage_base, f32x16 (&s)[QT]) {
 #pragma unroll
-      for (int t = 0; t < QT; ++t) s[t] = (f32x16){0};
-      const bf16_raw* krow = st_base + koff;
+    for (int t = 0; t < QT; ++t) s[t] = (f32x16){0};
+    const bf16_raw* krow = stage_base + koff;
 #pragma unroll
-      for (int j = 0; j < NCH; ++j) {
-        const sb16x8 ka = *reinterpret_cast<const sb16x8*>(krow + j * 32);
-        const sb16x8 kb2 = *reinterpret_cast<const sb16x8*>(krow + j * 32 + 8);
+    for (int j = 0; j < NCH; ++j) {
+      const sb16x8 ka = *reinterpret_cast<const sb16x8*>(krow + j * 32);
+      const sb16x8 kb2 = *reinterpret_cast<const sb16x8*>(krow + j * 32 + 8);
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qreg[t][j][0], s[t], 0, 0, 0);
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2, qreg[t][j][1], s[t], 0, 0, 0);
+      }
+    }
+  };
+  auto pv = [&](const bf16_raw* stage_base) {                     // o += V^T(block in the stage) P^T(pb)
+    const bf16_raw* vrow = stage_base + voff;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      sb16x8 va[TERMS][2];
+#pragma unroll
+      for (int tt = 0; tt < TERMS; ++tt) {
+        va[tt][0] = *reinterpret_cast<const sb16x8*>(vrow + (tt * 64) * L::VROW + 16 * st);
+        va[tt][1] = *reinterpret_cast<const sb16x8*>(vrow + (tt * 64 + 32) * L::VROW + 16 * st);
+      }
+#pragma unroll
+      for (int pr = 0; pr < P; ++pr) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qreg[t][j][0], s[t], 0, 0, 0);
-          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2, qreg[t][j][1], s[t], 0, 0, 0);
+          o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][0], pb[t][B_TERM(pr)][st], o0[t], 0, 0, 0);
+          o1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][1], pb[t][B_TERM(pr)][st], o1[t], 0, 0, 0);
         }
       }
-      sb16x8 pb[QT][TERMS][2];
+    }
+  };
+  f32x16 s_cur[QT];
+  fetch(0, -1);
+  stash(1, false);                                               // K(0) alone, in the K area of stage 1
+  fetch(1, -1);
+  stash(0, false);                                               // stage 0 = [K(1) | zeros: there is no block -1]
+  for (int i = tid; i < L::V_ELEMS / 8; i += 256) *reinterpret_cast<u32x4*>(lds + L::K_ELEMS + i * 8) = (u32x4){0u, 0u, 0u, 0u};
+  __syncthreads();
+  if (active) scores(lds + L::STAGE, s_cur);
+  __syncthreads();                                               // every wave has read K(0) before iteration 0 overwrites stage 1
+  for (int kb = 0; kb < nkb; ++kb) {
+    const bf16_raw* st_base = lds + (kb & 1) * L::STAGE;
+    fetch(kb + 2, kb);                                           // for the next iteration's stage [K(kb + 2) | V^T(kb)]; in flight under this block's MFMAs
+    if (active) {
+      f32x16 s_next[QT];
+      scores(st_base, s_next);                                   // K(kb + 1) (in the last iteration: a stale block, result unused)
+      pv(st_base);                                               // V^T(kb - 1) with the previous block's probabilities
+      const int lim = tok - kb * 32;                             // keys of this block that exist
+      float alpha[QT];
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
         // register i of lane (n, h) = key kb * 32 + 16 (i / 8) + 8 h + (i % 8)
-        if (kb == nkb - 1) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i)
-            if (kb * 32 + 16 * (i >> 3) + 8 * h + (i & 7) >= tok) s[t][i] = -INFINITY;
-        }
-        float mx = s[t][0];
+        for (int i = 0; i < 16; ++i) s_cur[t][i] = (16 * (i >> 3) + 8 * h + (i & 7) < lim) ? s_cur[t][i] : -INFINITY;
+        float mx = s_cur[t][0];
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[t][i]);
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s_cur[t][i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run[t], mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+        alpha[t] = __builtin_amdgcn_exp2f(m_run[t] - m_new);
         float p[16], rs = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          p[i] = __builtin_amdgcn_exp2f(s[t][i] - m_new);
+          p[i] = __builtin_amdgcn_exp2f(s_cur[t][i] - m_new);
           rs += p[i];
         }
         rs += __shfl_xor(rs, 32, 64);
-        l_run[t] = l_run[t] * alpha + rs;
+        l_run[t] = l_run[t] * alpha[t] + rs;
         m_run[t] = m_new;
-        if (__any(alpha != 1.0f)) {                              // (wave-uniform) the running maximum moved for some query of the tile: rare after the first blocks
-#pragma unroll
-          for (int i = 0; i < 16; ++i) { o0[t][i] *= alpha; o1[t][i] *= alpha; }
-        }
-        // probabilities -> TERMS bf16 operands per PV step
+        // probabilities -> TERMS bf16 operands per PV step (consumed by the NEXT iteration's pv)
+        sb16x8 pn[TERMS][2];
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
           unsigned w[TERMS][4];
@@ -390,31 +428,26 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const bf16_raw* __restr
             for (int tt = 0; tt < TERMS; ++tt) w[tt][e >> 1] = (unsigned)a[tt] | ((unsigned)c[tt] << 16);
           }
 #pragma unroll
-          for (int tt = 0; tt < TERMS; ++tt) pb[t][tt][st] = __builtin_bit_cast(sb16x8, (u32x4){w[tt][0], w[tt][1], w[tt][2], w[tt][3]});
+          for (int tt = 0; tt < TERMS; ++tt) pn[tt][st] = __builtin_bit_cast(sb16x8, (u32x4){w[tt][0], w[tt][1], w[tt][2], w[tt][3]});
         }
-      }
-      const bf16_raw* vrow = st_base + voff;
+        // hints: one MFMA, then a handful of vector instructions, over the iteration's 8 P MFMAs (LLVM's IGroupLP; groups it cannot fill are skipped)
 #pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        sb16x8 va[TERMS][2];
-#pragma unroll
-        for (int tt = 0; tt < TERMS; ++tt) {
-          va[tt][0] = *reinterpret_cast<const sb16x8*>(vrow + (tt * 64) * L::VROW + 16 * st);
-          va[tt][1] = *reinterpret_cast<const sb16x8*>(vrow + (tt * 64 + 32) * L::VROW + 16 * st);
+        for (int g = 0; g < 8 * P; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
         }
+        // everything above was independent of this iteration's MFMAs; the rescale and the hand-over of the operands are not
 #pragma unroll
-        for (int pr = 0; pr < P; ++pr) {
+        for (int i = 0; i < 16; ++i) { o0[t][i] *= alpha[t]; o1[t][i] *= alpha[t]; }
 #pragma unroll
-          for (int t = 0; t < QT; ++t) {
-            o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][0], pb[t][B_TERM(pr)][st], o0[t], 0, 0, 0);
-            o1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][1], pb[t][B_TERM(pr)][st], o1[t], 0, 0, 0);
-          }
-        }
+        for (int tt = 0; tt < TERMS; ++tt) { pb[t][tt][0] = pn[tt][0]; pb[t][tt][1] = pn[tt][1]; }
+        s_cur[t] = s_next[t];
       }
     }
-    if (kb + 1 < nkb) stash((kb + 1) & 1);                       // the other stage: every wave left it at the previous barrier
+    stash((kb + 1) & 1, true);                                   // the other stage = [K(kb + 2) | V^T(kb)]: every wave left it at the previous barrier
     __syncthreads();
   }
+  if (active) pv(lds + (nkb & 1) * L::STAGE);                    // the last block's P V (its V^T was staged by the last iteration)
   if (!active) return;
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
@@ -627,8 +660,14 @@ extern "C" int ucod_vit_forward_split(const ucod_vit_desc* d, int terms, const v
     RUN(ucod_attention_split_fwd(att, a, d->B, tok, d->heads, terms, stream));
     RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_SCALE_RESID_F32, a, W[4], x, M, D, P * D, (const float*)W[5], (const float*)W[6], x, nullptr, tok, gv, stream));
     RUN(ucod_layernorm_split(x, (const float*)W[7], (const float*)W[8], h, M, D, d->eps, terms, 0, stream));
-    RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_F32, h, W[9], f1, M, F, P * D, (const float*)W[10], nullptr, nullptr, nullptr, tok, gv, stream));
-    RUN(ucod_split_rows(f1, F, g, M, F, terms, 0, 1, 1.f, stream));
+    if (terms == 2) {
+      // two terms: fc1 + GELU + the split of its result in ONE launch (UCOD_EPI_BIAS_GELU_SPLIT2: the epilogue's minimax erf-GELU, |err| <= 7.1e-7, is an order of
+      // magnitude below the 2^-17 of a two-term operand); three terms keep the exact-erf kernel behind an f32 round trip
+      RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_GELU_SPLIT2, h, W[9], g, M, F, P * D, (const float*)W[10], nullptr, nullptr, nullptr, tok, gv, stream));
+    } else {
+      RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_F32, h, W[9], f1, M, F, P * D, (const float*)W[10], nullptr, nullptr, nullptr, tok, gv, stream));
+      RUN(ucod_split_rows(f1, F, g, M, F, terms, 0, 1, 1.f, stream));
+    }
     RUN(ucod_gemm_bf16(UCOD_EPI_BIAS_SCALE_RESID_F32, g, W[11], x, M, D, P * F, (const float*)W[12], (const float*)W[13], x, nullptr, tok, gv, stream));
   }
   return UCOD_OK;

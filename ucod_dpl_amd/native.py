@@ -25,6 +25,7 @@ EPI_QKV_FP8 = 8                                            # QKV projection of t
 EPI_BIAS_SCALE_RESID_H16, EPI_PATCH_TOKENS_H16 = 9, 10     # f16 residual stream (VitDesc.resid16)
 EPI_LNFOLD_BIAS_BF16, EPI_LNFOLD_GELU_BF16 = 11, 12        # ucod_gemm_lnfold only (LayerNorm folded into QKV / fc1; the fp16-operand build)
 EPI_BIAS_SCALE_RESID_H16_STATS, EPI_PATCH_TOKENS_H16_STATS = 13, 14   # ucod_gemm_bf16_stats only (the producers that leave row partials)
+EPI_BIAS_GELU_SPLIT2 = 15                                  # fc1 + GELU + two-term split of the result in one launch (the split-operand pass; bf16 library)
 VIT_LAYER_STRIDE = 16
 VIT_TRAIN_STRIDE = 7
 LORA_AUG = 64
