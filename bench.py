@@ -287,8 +287,8 @@ def main():
         tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
         dt = tdt.item()
-    # Sustained run: the same step, back to back, for --sustain-s seconds in ~10-s windows.  The step count of a window is FIXED from the timed
-    # region (every rank runs the same number of steps: the all-reduces stay matched); the host keeps at most 16 steps in flight.
+    # Sustained run: the same step, back to back, for --sustain-s seconds in ~10-s windows; with several ranks they agree every 16 steps on the
+    # slowest rank's clock, so that all leave a window after the same number of steps (the all-reduces stay matched); the host keeps at most 16 steps in flight.
     sustained = None
     if a.sustain_s > 0:
         sustained = sustain(a, lib, dev, world, B, dt / a.steps, barrier)
@@ -427,32 +427,43 @@ def config_name(half, resid16):
 
 
 def sustain(a, lib, dev, world, B, sec_per_step, barrier):
-    """Run the module-level step (set by main) for ~a.sustain_s seconds in windows of ~10 s.  Per window: images/s over the wall clock between two
+    """Run the module-level step (set by main) for ~a.sustain_s seconds in windows of ~10 s (time-bounded: a window ends at the first multiple of 16 steps past its length).  Per window: images/s over the wall clock between two
     barrier + synchronize points, and the shader clock the chip HELD = delta s_memtime / delta s_memrealtime x 100 MHz between two single-wave probe launches
     on the step's stream (MI355X_MICROARCH.md, in-kernel clock recipe; ucod_clock_probe)."""
     step, loop = _STEP["step"], _STEP["loop"]
     n_win = max(1, int(round(a.sustain_s / 10.0)))
-    per_win = max(1, int(round(a.sustain_s / n_win / sec_per_step)))
+    win_s = a.sustain_s / n_win
     probes = torch.zeros(n_win, 2, 2, dtype=torch.int64, device=dev)
     windows, ring = [], []
+    CHUNK = 16                                                    # steps between two looks at the clock (and, with several ranks, two agreements on it)
     for w in range(n_win):
         barrier()
         lib.ucod_clock_probe(probes[w, 0].data_ptr(), torch.cuda.current_stream().cuda_stream)
         t0 = time.perf_counter()
-        for i in range(per_win):
-            step()
-            loop.global_step += 1
-            if i % 8 == 7:                                        # bound the host's lead: at most 16 steps enqueued ahead of the device
-                ev = torch.cuda.Event()
-                ev.record()
-                ring.append(ev)
-                if len(ring) > 2:
-                    ring.pop(0).synchronize()
+        n = 0
+        while True:
+            for i in range(CHUNK):
+                step()
+                loop.global_step += 1
+                if i % 8 == 7:                                    # bound the host's lead: at most 16 steps enqueued ahead of the device
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    ring.append(ev)
+                    if len(ring) > 2:
+                        ring.pop(0).synchronize()
+            n += CHUNK
+            elapsed = time.perf_counter() - t0
+            if world > 1:                                         # every rank must leave the window after the SAME number of steps (the all-reduces stay matched):
+                te = torch.tensor([elapsed], dtype=torch.float64, device=dev)   # they agree on the slowest rank's clock
+                torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
+                elapsed = te.item()
+            if elapsed >= win_s:
+                break
         lib.ucod_clock_probe(probes[w, 1].data_ptr(), torch.cuda.current_stream().cuda_stream)
         barrier()
         t1 = time.perf_counter()
         ring.clear()
-        windows.append([per_win, t1 - t0])
+        windows.append([n, t1 - t0])
     pr = probes.cpu()
     if world > 1:                                                 # max over ranks of every window's wall time
         tw = torch.tensor([w_[1] for w_ in windows], dtype=torch.float64, device=dev)

@@ -300,7 +300,7 @@ def test_bench_launches_two_ranks_itself(tmp_path):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--lora-steps", "1",
-                        "--no-cpu-baseline", "--image", "224", "--arch", "dino_vits8"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--image", "224", "--arch", "dino_vits8", "--sustain-s", "2"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -308,6 +308,7 @@ def test_bench_launches_two_ranks_itself(tmp_path):
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
     assert d["backbone_backward_mode"]["value"] > 0 and d["discriminator_phase"]["value"] > 0
     assert sorted(r[0] for r in d["ranks_seen"]) == [0, 1] and d["host_cores_pinned"] >= 1
+    assert d["sustained"]["windows"][0]["steps"] % 16 == 0 and d["sustained"]["value_sustained"] > 0 and d["sustained"]["held_clock_mhz"] > 100     # the sustained leg with two ranks
 
 
 def test_eight_ranks_on_one_gpu_first_contact(tmp_path):
@@ -322,7 +323,7 @@ def test_eight_ranks_on_one_gpu_first_contact(tmp_path):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "2", "--lora-steps", "1",
-                        "--no-cpu-baseline", "--image", "224", "--arch", "dino_vits8"], env=env, capture_output=True, text=True, timeout=1500)
+                        "--no-cpu-baseline", "--image", "224", "--arch", "dino_vits8", "--sustain-s", "2"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
