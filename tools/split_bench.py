@@ -60,5 +60,7 @@ ls = torch.ones(D, device=dev)
 oq = torch.empty(M, 3 * D, device=dev)
 timed("GEMM qkv  (BIAS_F32)", lambda: ops.gemm_bf16(N.EPI_BIAS_F32, hs, wq, oq, M, 3 * D, P * D, bias=bq), flops=2.0 * M * 3 * D * D)
 timed("GEMM fc1  (BIAS_F32)", lambda: ops.gemm_bf16(N.EPI_BIAS_F32, hs, w1, f1, M, F, P * D, bias=b1), flops=2.0 * M * F * D)
+if T == 2:
+    timed("GEMM fc1  (GELU_SPLIT2: fused)", lambda: ops.gemm_bf16(N.EPI_BIAS_GELU_SPLIT2, hs, w1, gs, M, F, P * D, bias=b1), flops=2.0 * M * F * D)
 timed("GEMM proj (SCALE_RESID_F32)", lambda: ops.gemm_bf16(N.EPI_BIAS_SCALE_RESID_F32, aout, wp, x, M, D, P * D, bias=bp, scale=ls, resid=x), flops=2.0 * M * D * D)
 timed("GEMM fc2  (SCALE_RESID_F32)", lambda: ops.gemm_bf16(N.EPI_BIAS_SCALE_RESID_F32, gs, w2, x, M, D, P * F, bias=bp, scale=ls, resid=x), flops=2.0 * M * D * F)
