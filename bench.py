@@ -414,7 +414,7 @@ def main():
                 collectives=("RCCL world-size-1 process group FORCED (UCOD_FORCE_DIST=1): broadcast at construction and every all-reduce of the step are issued on the "
                              "group's stream" if (world == 1 and parallel.collectives_on()) else ("one asynchronous RCCL all-reduce of the flat gradient arena per step" if world > 1
                                                                                                      else "none (world size 1: short-circuit)")))
-    print(json.dumps(build_line(a, meas)))
+    print(json.dumps(build_line(a, meas)), flush=True)
 
 
 MAX_CLOCK_MHZ = 2400.0                                        # MI355X_MICROARCH.md chip table: the clock the 2.5 PFLOP/s dense bf16 / fp16 peak is quoted at
@@ -821,7 +821,7 @@ def look_twice_leg(a, dev, lib, world, rank, host_threads, pinned_cores):
            "second_pass_and_tail_ms": round((dt - dt_first) / a.steps * 1e3, 3),
            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
            "host_threads": host_threads, "host_cores_pinned": pinned_cores}
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(a, D, heads, L, P):
@@ -940,4 +940,14 @@ def cpu_baseline(a, D, heads, L, P):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        sys.stdout.flush()
+        # leave the process group in order (RCCL's communicator teardown at interpreter exit can take the process down before a block-buffered line is written:
+        # the UCOD_FORCE_DIST=1 run of round 6 lost its line that way)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            try:
+                torch.distributed.destroy_process_group()
+            except Exception:                                   # noqa: BLE001
+                pass

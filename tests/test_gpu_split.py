@@ -249,3 +249,22 @@ def test_split_entry_points_are_refused_by_the_fp16_build():
     assert N.load("bf16").ucod_split_rows(N.ptr(x), 64, N.ptr(out), 8, 64, 2, 0, 0, 1.0, N.stream()) == 0
     assert N.load("bf16").ucod_split_rows(N.ptr(x), 64, N.ptr(out), 8, 60, 2, 0, 0, 1.0, N.stream()) == -1     # K % 8
     assert N.load("bf16").ucod_split_rows(N.ptr(x), 64, N.ptr(out), 8, 64, 4, 0, 0, 1.0, N.stream()) == -1     # terms
+
+
+def test_split_engine_at_the_other_baseline_geometries():
+    """BASELINE configs[0] (DINOv1 ViT-S/8, 224 x 224, batch 2: D = 384 -- three 128-column chunks per LayerNorm lane, 6 heads, 785 tokens, no LayerScale) and
+    configs[3] (DINOv2 ViT-L/14, 518 x 518, one image: D = 1024, 16 heads, 24 layers) through the f32-equivalent engine against the f32 CPU oracle at full depth."""
+    from test_gpu_kernels import _dino_v1_state_dict
+    sd = _dino_v1_state_dict(384, 12, 8, 224, seed=5)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        _, ref = OV.dinov1_forward(x, sd, heads=6, patch=8, eps=1e-6, full_last_layer=False)
+    key = SplitViTEngine(sd, heads=6, eps=1e-6, device=DEV, terms=3)(x.to(DEV))
+    assert key.shape == (2, 384, 28, 28) and rel_l2(key, ref) < 5e-6, rel_l2(key, ref)
+    assert rel_l2(SplitViTEngine(sd, heads=6, eps=1e-6, device=DEV, terms=2)(x.to(DEV)), ref) < 5e-5
+    sd = random_state_dict("dinov2_vitl14", seed=11, image_size=518)
+    x = torch.randn(1, 3, 518, 518, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        _, ref = OV.dinov2_forward(x, sd, heads=16, patch=14, eps=1e-6, full_last_layer=False)
+    key = SplitViTEngine(sd, heads=16, eps=1e-6, device=DEV, terms=3)(x.to(DEV))
+    assert key.shape == (1, 1024, 37, 37) and rel_l2(key, ref) < 8e-6, rel_l2(key, ref)      # (the 16-bit engines: 6.4e-3 bf16 here, tests/test_gpu_kernels.py)

@@ -25,8 +25,15 @@ t0 = time.perf_counter(); k = bb(x)[1].to("cpu"); torch.cuda.synchronize(); td2h
 tmp = tempfile.mkdtemp(prefix="ucod_cache_")
 try:
     mc = MultiCacheManager(tmp, "dinov2_vitb14", "train", "SYNTH")
+    eq = bb.with_precision("f32eq")                                    # what the pass uses by default since round 6 (the reference's fp32: base_dataset.py:124-138)
+    teq = sync_time(lambda: eq(x), 2)
     t0 = time.perf_counter(); n = build_feature_cache(imgs, bb, mc.get_features_cache(), batch_size=32, device=dev); t1 = time.perf_counter() - t0
     size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(tmp) for f in fs)
+    tmp2 = tempfile.mkdtemp(prefix="ucod_cache16_")
+    t0 = time.perf_counter(); build_feature_cache(imgs, bb, MultiCacheManager(tmp2, "dinov2_vitb14", "train", "SYNTH").get_features_cache(), batch_size=32, device=dev, precision=None); t16 = time.perf_counter() - t0
+    shutil.rmtree(tmp2, ignore_errors=True)
+    print(f"N1 (round 6) the pass runs the f32-equivalent split-operand engine by default: {32 / teq:.0f} img/s for the pass alone ({teq * 1e3:.1f} ms per 32 images); end to end "
+          f"{n / t1:.0f} img/s against {n / t16:.0f} with the fp16 engine (precision=None): the on-disk format, not the device, sets the pace")
     print(f"N1 feature cache: {n} images at 518x518 in {t1:.2f} s = {n / t1:.0f} img/s end to end, {size / 1e6:.0f} MB of per-item pickles written "
           f"({size / 1e6 / t1:.0f} MB/s: host-side stacking, D2H and file I/O bound -- one 32-image batch: pass {tb * 1e3:.1f} ms, pass + copy of the "
           f"134 MB key maps to the host {td2h * 1e3:.0f} ms); the batched backbone pass alone {32 / tb:.0f} img/s (the reference runs it one image per call)")
