@@ -414,7 +414,18 @@ def main():
                 collectives=("RCCL world-size-1 process group FORCED (UCOD_FORCE_DIST=1): broadcast at construction and every all-reduce of the step are issued on the "
                              "group's stream" if (world == 1 and parallel.collectives_on()) else ("one asynchronous RCCL all-reduce of the flat gradient arena per step" if world > 1
                                                                                                      else "none (world size 1: short-circuit)")))
+    _flush_c_stdio()
     print(json.dumps(build_line(a, meas)), flush=True)
+
+
+def _flush_c_stdio():
+    """RCCL prints its version banner through C stdio when the communicator comes up; with stdout redirected that text sits in libc's buffer until exit and would
+    land BEHIND the JSON line.  Push it out first: the line is the last thing this process writes to stdout."""
+    sys.stdout.flush()
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:                                           # noqa: BLE001
+        pass
 
 
 MAX_CLOCK_MHZ = 2400.0                                        # MI355X_MICROARCH.md chip table: the clock the 2.5 PFLOP/s dense bf16 / fp16 peak is quoted at
@@ -821,6 +832,7 @@ def look_twice_leg(a, dev, lib, world, rank, host_threads, pinned_cores):
            "second_pass_and_tail_ms": round((dt - dt_first) / a.steps * 1e3, 3),
            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
            "host_threads": host_threads, "host_cores_pinned": pinned_cores}
+    _flush_c_stdio()
     print(json.dumps(out), flush=True)
 
 
