@@ -84,3 +84,18 @@ def test_graft_entry_build_assertions_hold():
     """__graft_entry__.build() = make + these assertions; the driver runs it every round (a stale ABI number there fails the round's build check)."""
     import __graft_entry__ as G
     G.check_build()
+
+
+def test_product_libraries_read_only_the_documented_environment_variables():
+    """measurement knobs are compiled out of the product libraries (csrc/common.h: lab_env; `make knobs` builds them in for tools/).  The only
+    UCOD_* names left in the binaries are the three GEMM summation-order switches include/ucod_dpl.h documents; the Python side reads no UCOD_LN_FOLD / UCOD_FOLD_* knob."""
+    import subprocess
+    from ucod_dpl_amd import native
+    documented = {"UCOD_GEMM_NO_PATCH", "UCOD_GEMM_PATCH_ROUNDS", "UCOD_GEMM_NO_MIXED"}
+    header = open(os.path.join(ROOT, "include", "ucod_dpl.h")).read()
+    for path in (native.LIB_PATH, native.LIB_PATH_F16):
+        names = {l.strip() for l in subprocess.run(["strings", path], capture_output=True, text=True, check=True).stdout.splitlines() if re.fullmatch(r"UCOD_[A-Z0-9_]+", l.strip())}
+        assert names == documented, (path, names)
+    assert all(n in header for n in documented)
+    src = open(os.path.join(ROOT, "ucod_dpl_amd", "vit_engine.py")).read()
+    assert "UCOD_LN_FOLD" not in src and "UCOD_FOLD_ABL" not in src
