@@ -253,7 +253,7 @@ struct AttnSplitLds {
 
 // QT = 32-query tiles per wave; the product uses ONE.  Two tiles (64 queries per wave, 256 per workgroup) halve the LDS reads per MFMA -- every K / V^T fragment
 // feeds two independent chains -- but need 332 registers, i.e. one wave per SIMD instead of two, and the softmax between the two MFMA groups then has no other
-// wave to hide behind: measured 992 us against 869 us per launch (two-term form, 32 x 12 x 1370 tokens; gpurun_out/r06_split_bench_t2.txt).
+// wave to hide behind: measured 992 us against 869 us per launch before the software pipeline below, 1 006 against 813 with it (two-term form, 32 x 12 x 1370 tokens).
 template <int TERMS, int QT>
 __global__ __launch_bounds__(256, (TERMS == 2 && QT == 1) ? 2 : 1) void attn_split_kernel(const bf16_raw* __restrict__ Qc, const bf16_raw* __restrict__ Kc, const bf16_raw* __restrict__ Vt,
                                                          bf16_raw* __restrict__ out, int tok, int tok_pad, int heads, int D) {
