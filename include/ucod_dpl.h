@@ -352,7 +352,8 @@ int ucod_layernorm_split(const float* x, const float* gamma, const float* beta, 
 /* ucod_patch_im2col with split output: patches bf16 [B gh gw, P Kpad] (A side) */
 int ucod_patch_im2col_split(const float* img, void* patches_bf16, int B, int C, int H, int W, int P, int Kpad, int terms, void* stream);
 /* f32 qkv [B tok, 3 heads 64] (the QKV projection through UCOD_EPI_BIAS_F32) -> the attention kernel's operands in `operands` (ucod_attention_split_operand_bytes):
- * Qc | Kc bf16 [B heads][tok_pad][P 64] (Q times qscale before the split; tok_pad = tok rounded up to 32, pad rows zero) and Vt bf16 [terms][B heads][64][tok_pad] */
+ * Qc | Kc bf16 [B heads][tok_pad][terms 64] (one 64-wide segment per term; Q times qscale before the split; tok_pad = tok rounded up to 32, pad rows zero)
+ * and Vt bf16 [terms][B heads][64][tok_pad] */
 size_t ucod_attention_split_operand_bytes(int B, int tok, int heads, int terms);
 int ucod_qkv_split(const float* qkv, void* operands, int B, int tok, int heads, int terms, float qscale, void* stream);
 /* softmax(Q K^T hd^-0.5) V (modeling_dinov2.py:153-179) on those operands, Q carrying head_dim^-0.5 log2 e; scores, softmax and accumulation in f32, the

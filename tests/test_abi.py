@@ -45,7 +45,7 @@ def test_abi_version_and_argument_validation(lib):
     assert lib.ucod_split_rows(None, 8, None, 1, 8, 2, 0, 0, 1.0, None) == -1
     assert lib.ucod_layernorm_split(None, None, None, None, 1, 128, 1e-6, 2, 0, None) == -1
     assert lib.ucod_attention_split_fwd(None, None, 1, 1, 1, 2, None) == -1
-    assert lib.ucod_attention_split_operand_bytes(1, 33, 2, 3) == 2 * (2 * 64 * 6 * 64 * 2) + 3 * 2 * 64 * 64 * 2
+    assert lib.ucod_attention_split_operand_bytes(1, 33, 2, 3) == 2 * (2 * 64 * 3 * 64 * 2) + 3 * 2 * 64 * 64 * 2
     assert lib.ucod_attention_split_operand_bytes(1, 33, 2, 4) == 0
     assert lib.ucod_clock_probe(None, None) == -1
 

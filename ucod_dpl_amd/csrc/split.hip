@@ -65,6 +65,23 @@ __device__ __forceinline__ void store_split8(const float (&v)[8], bf16_raw* __re
   }
 }
 
+// 8 consecutive f32 values -> one 16-byte bf16 store per TERM, segments in term order (the attention operands: the kernel pairs the terms itself, so a term is
+// stored once -- the K-concatenated GEMM layout above repeats term 0 two or three times)
+template <int TERMS>
+__device__ __forceinline__ void store_terms8(const float (&v)[8], bf16_raw* __restrict__ seg0, long seg_stride) {
+  unsigned w[TERMS][4];
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    bf16_raw a[TERMS], b[TERMS];
+    split_terms<TERMS>(v[e], a);
+    split_terms<TERMS>(v[e + 1], b);
+#pragma unroll
+    for (int s = 0; s < TERMS; ++s) w[s][e >> 1] = (unsigned)a[s] | ((unsigned)b[s] << 16);
+  }
+#pragma unroll
+  for (int s = 0; s < TERMS; ++s) *reinterpret_cast<u32x4*>(seg0 + (long)s * seg_stride) = (u32x4){w[s][0], w[s][1], w[s][2], w[s][3]};
+}
+
 // ---- f32 [M, K] (row pitch ld_in) -> bf16 [M, P K]; op 0: the values, 1: exact-erf GELU of them, 2: times `alpha`
 template <int TERMS>
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ in, long ld_in, bf16_raw* __restrict__ out, int M, int K, int role, int op, float alpha) {
@@ -175,14 +192,13 @@ __global__ __launch_bounds__(256) void im2col_split_kernel(const float* __restri
 }
 
 // ---- f32 qkv [B tok, 3 D] -> the attention kernel's operands, per (image, head) and padded to tok_pad = 32-row blocks (pad rows are zeros):
-//   Qc [BH][tok_pad][P 64]  B side of S^T = K Q^T, Q times head_dim^-0.5 log2 e (in f32, before the split)
-//   Kc [BH][tok_pad][P 64]  A side
+//   Qc [BH][tok_pad][TERMS 64]  the terms of Q times head_dim^-0.5 log2 e (scaled in f32, before the split), one 64-wide segment per term
+//   Kc [BH][tok_pad][TERMS 64]  the terms of K likewise (the attention kernel forms the P partial products of S^T = K Q^T from them)
 //   Vt [TERMS][BH][64][tok_pad]  V transposed, one plane per term (the A side of O^T = V^T P^T takes 8 consecutive keys of one channel)
 // One workgroup per (32-token block, image * head).
 template <int TERMS>
 __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict__ qkv, bf16_raw* __restrict__ Qc, bf16_raw* __restrict__ Kc, bf16_raw* __restrict__ Vt,
                                                         int tok, int tok_pad, int heads, int D, float qscale) {
-  constexpr int P = products_of(TERMS);
   __shared__ float vs[32][65];
   const int tb = blockIdx.x, bh = blockIdx.y;
   const int b = bh / heads, hd = bh - b * heads;
@@ -204,9 +220,9 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) q[e] = k[e] = v[e] = 0.f;
   }
-  const size_t orow = ((size_t)bh * tok_pad + t) * (P * 64) + d8;
-  store_split8<TERMS>(q, Qc + orow, 64, 1);
-  store_split8<TERMS>(k, Kc + orow, 64, 0);
+  const size_t orow = ((size_t)bh * tok_pad + t) * (TERMS * 64) + d8;
+  store_terms8<TERMS>(q, Qc + orow, 64);
+  store_terms8<TERMS>(k, Kc + orow, 64);
 #pragma unroll
   for (int e = 0; e < 8; ++e) vs[tl][d8 + e] = v[e];
   __syncthreads();
@@ -238,16 +254,17 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict_
 // CONSECUTIVE keys 16 s + 8 h .. + 7 in registers 8 s .. 8 s + 7: the probabilities are split into bf16 terms where they sit and become the B operand of
 //   O^T[d][query] += sum_key Vt[d][key] P^T[key][query]
 // whose A operand is one 16-byte LDS read of a V^T row.  Softmax statistics per query = per lane column (+ one exchange with the other lane half).
-// LDS rows are padded by 16 bytes (K rows: P 128 + 16 B, V^T rows: 64 + 16 B): the 16 lanes of a ds_read_b128 group then start at 16 different multiples of
-// four banks (strides of 100 / 20 banks) -- conflict-free by the 64-bank / 16-lane-group rule.
+// LDS rows are padded by 16 bytes (K rows: TERMS 128 + 16 B, V^T rows: 64 + 16 B): the 16 lanes of a ds_read_b128 group then start at 16 different multiples of
+// four banks (strides of 68 / 100 and 20 banks) -- conflict-free by the 64-bank / 16-lane-group rule.  K and Q are held as TERMS segments (a term once), the
+// kernel pairs them: S^T = sum over the P (A term, B term) pairs of K_a Q_b^T -- a third / half fewer K bytes staged and read than the GEMM layout's P segments.
 template <int TERMS>
 struct AttnSplitLds {
   static constexpr int P = products_of(TERMS);
-  static constexpr int KROW = P * 64 + 8;                        // bf16 elements per staged K row
+  static constexpr int KROW = TERMS * 64 + 8;                    // bf16 elements per staged K row (one 64-wide segment per TERM + 16 bytes of padding)
   static constexpr int VROW = 32 + 8;                            // bf16 elements per staged V^T row (32 keys)
   static constexpr int K_ELEMS = 32 * KROW, V_ELEMS = TERMS * 64 * VROW;
   static constexpr int STAGE = K_ELEMS + V_ELEMS;                // bf16 elements per stage
-  static constexpr int K_PIECES = 32 * P * 8, V_PIECES = TERMS * 64 * 4;   // 16-byte pieces per block
+  static constexpr int K_PIECES = 32 * TERMS * 8, V_PIECES = TERMS * 64 * 4;   // 16-byte pieces per block
   static constexpr int KPT = K_PIECES / 256, VPT = V_PIECES / 256;         // per thread
 };
 
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(256, (TERMS == 2 && QT == 1) ? 2 : 1) void attn_spl
                                                          bf16_raw* __restrict__ out, int tok, int tok_pad, int heads, int D) {
   using L = AttnSplitLds<TERMS>;
   constexpr int P = L::P;
-  constexpr int NCH = P * 2;                                     // 32-element chunks of a P * 64 row
+  constexpr int NCH = TERMS * 2;                                 // 32-element chunks of a TERMS * 64 row: chunk 2 t + c = half c of term t
   static_assert(L::K_PIECES % 256 == 0 && L::V_PIECES % 256 == 0, "whole pieces per thread");
   extern __shared__ __attribute__((aligned(16))) bf16_raw lds[];  // two stages of [K block | V^T block]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -268,14 +285,14 @@ __global__ __launch_bounds__(256, (TERMS == 2 && QT == 1) ? 2 : 1) void attn_spl
   const int bh = blockIdx.y;
   const int b = bh / heads, hd = bh - b * heads;
   const int n = lane & 31, h = lane >> 5;
-  const size_t rowlen = (size_t)P * 64;
+  const size_t rowlen = (size_t)TERMS * 64;
   const size_t plane = (size_t)gridDim.y * 64 * tok_pad;
   // ---- this thread's pieces of a block: global source offsets (block 0) and LDS destinations
   const bf16_raw* ksrc[L::KPT];
   int kdst[L::KPT];
 #pragma unroll
   for (int i = 0; i < L::KPT; ++i) {
-    const int piece = tid + 256 * i, row = piece / (P * 8), c = piece - row * (P * 8);
+    const int piece = tid + 256 * i, row = piece / (TERMS * 8), c = piece - row * (TERMS * 8);
     ksrc[i] = Kc + ((size_t)bh * tok_pad + row) * rowlen + c * 8;
     kdst[i] = row * L::KROW + c * 8;
   }
@@ -345,14 +362,21 @@ __global__ __launch_bounds__(256, (TERMS == 2 && QT == 1) ? 2 : 1) void attn_spl
 #pragma unroll
     for (int t = 0; t < QT; ++t) s[t] = (f32x16){0};
     const bf16_raw* krow = stage_base + koff;
+    sb16x8 ka[NCH][2];                                           // every K term's fragments once; each feeds the products of all the Q terms it is paired with
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-      const sb16x8 ka = *reinterpret_cast<const sb16x8*>(krow + j * 32);
-      const sb16x8 kb2 = *reinterpret_cast<const sb16x8*>(krow + j * 32 + 8);
+      ka[j][0] = *reinterpret_cast<const sb16x8*>(krow + j * 32);
+      ka[j][1] = *reinterpret_cast<const sb16x8*>(krow + j * 32 + 8);
+    }
 #pragma unroll
-      for (int t = 0; t < QT; ++t) {
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qreg[t][j][0], s[t], 0, 0, 0);
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2, qreg[t][j][1], s[t], 0, 0, 0);
+    for (int pr = 0; pr < P; ++pr) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[2 * A_TERM(pr) + c][0], qreg[t][2 * B_TERM(pr) + c][0], s[t], 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[2 * A_TERM(pr) + c][1], qreg[t][2 * B_TERM(pr) + c][1], s[t], 0, 0, 0);
+        }
       }
     }
   };
@@ -540,7 +564,7 @@ extern "C" int ucod_patch_im2col_split(const float* img, void* patches, int B, i
 extern "C" size_t ucod_attention_split_operand_bytes(int B, int tok, int heads, int terms) {
   if (B <= 0 || tok <= 0 || heads <= 0 || !terms_ok(terms)) return 0;
   const size_t tok_pad = (size_t)(tok + 31) / 32 * 32, bh = (size_t)B * heads;
-  const size_t qk = bh * tok_pad * products_of(terms) * 64 * 2, v = (size_t)terms * bh * 64 * tok_pad * 2;
+  const size_t qk = bh * tok_pad * terms * 64 * 2, v = (size_t)terms * bh * 64 * tok_pad * 2;
   return 2 * qk + v;
 }
 
@@ -549,7 +573,7 @@ extern "C" int ucod_qkv_split(const float* qkv, void* operands, int B, int tok, 
   if (!qkv || !operands || B <= 0 || tok <= 0 || heads <= 0 || !terms_ok(terms)) return UCOD_EINVAL;
   const int tok_pad = (tok + 31) / 32 * 32, bh = B * heads;
   if (bh > 65535) return UCOD_EINVAL;
-  const size_t qk = (size_t)bh * tok_pad * products_of(terms) * 64;
+  const size_t qk = (size_t)bh * tok_pad * terms * 64;
   bf16_raw* Qc = (bf16_raw*)operands;
   bf16_raw* Kc = Qc + qk;
   bf16_raw* Vt = Kc + qk;
@@ -566,7 +590,7 @@ extern "C" int ucod_attention_split_fwd(const void* operands, void* out_split, i
   if (!operands || !out_split || B <= 0 || tok <= 0 || heads <= 0 || !terms_ok(terms)) return UCOD_EINVAL;
   const int tok_pad = (tok + 31) / 32 * 32, bh = B * heads;
   if (bh > 65535) return UCOD_EINVAL;
-  const size_t qk = (size_t)bh * tok_pad * products_of(terms) * 64;
+  const size_t qk = (size_t)bh * tok_pad * terms * 64;
   const bf16_raw* Qc = (const bf16_raw*)operands;
   const bf16_raw* Kc = Qc + qk;
   const bf16_raw* Vt = Kc + qk;
