@@ -629,7 +629,7 @@ SplitPlan split_plan(const ucod_vit_desc* d, int terms) {
   p.off_qkv = take((size_t)p.M * 3 * d->D * 4);
   p.off_att = take(ucod_attention_split_operand_bytes(d->B, p.tok, d->heads, terms));
   p.off_a = take((size_t)p.M * p.P * d->D * 2);
-  p.off_f1 = take((size_t)p.M * d->F * 4);
+  p.off_f1 = take(terms == 2 ? 0 : (size_t)p.M * d->F * 4);       // (two terms: fc1 + GELU + split in one launch, no f32 copy of the MLP hidden)
   p.off_g = take((size_t)p.M * p.P * d->F * 2);
   p.off_patch = take((size_t)d->B * gh * gw * p.P * d->Kpad * 2);
   p.total = o;
