@@ -257,6 +257,9 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict_
 // LDS rows are padded by 16 bytes (K rows: TERMS 128 + 16 B, V^T rows: 64 + 16 B): the 16 lanes of a ds_read_b128 group then start at 16 different multiples of
 // four banks (strides of 68 / 100 and 20 banks) -- conflict-free by the 64-bank / 16-lane-group rule.  K and Q are held as TERMS segments (a term once), the
 // kernel pairs them: S^T = sum over the P (A term, B term) pairs of K_a Q_b^T -- a third / half fewer K bytes staged and read than the GEMM layout's P segments.
+template <int V>
+struct IntTag { static constexpr int value = V; };
+
 template <int TERMS>
 struct AttnSplitLds {
   static constexpr int P = products_of(TERMS);
@@ -348,15 +351,12 @@ __global__ __launch_bounds__(256, (TERMS == 2 && QT == 1) ? 2 : 1) void attn_spl
   const int voff = L::K_ELEMS + n * L::VROW + 8 * h;             // this lane's V^T row (term 0, channel n) in a stage
   f32x16 o0[QT], o1[QT];
   float m_run[QT], l_run[QT];
-  sb16x8 pb[QT][TERMS][2];                                       // probabilities of the PREVIOUS block as P V operands (zero before the first)
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     o0[t] = (f32x16){0};
     o1[t] = (f32x16){0};
     m_run[t] = -INFINITY;
     l_run[t] = 0.f;
-#pragma unroll
-    for (int tt = 0; tt < TERMS; ++tt) pb[t][tt][0] = pb[t][tt][1] = __builtin_bit_cast(sb16x8, (u32x4){0u, 0u, 0u, 0u});
   }
   auto scores = [&](const bf16_raw* stage_base, f32x16 (&s)[QT]) {
 #pragma unroll
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256, (TERMS == 2 && QT == 1) ? 2 : 1) void attn_spl
       }
     }
   };
-  auto pv = [&](const bf16_raw* stage_base) {                     // o += V^T(block in the stage) P^T(pb)
+  auto pv = [&](const bf16_raw* stage_base, const sb16x8 (&pp)[QT][TERMS][2]) {   // o += V^T(block in the stage) P^T(pp)
     const bf16_raw* vrow = stage_base + voff;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -394,52 +394,61 @@ __global__ __launch_bounds__(256, (TERMS == 2 && QT == 1) ? 2 : 1) void attn_spl
       for (int pr = 0; pr < P; ++pr) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-          o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][0], pb[t][B_TERM(pr)][st], o0[t], 0, 0, 0);
-          o1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][1], pb[t][B_TERM(pr)][st], o1[t], 0, 0, 0);
+          o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][0], pp[t][B_TERM(pr)][st], o0[t], 0, 0, 0);
+          o1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[A_TERM(pr)][1], pp[t][B_TERM(pr)][st], o1[t], 0, 0, 0);
         }
       }
     }
   };
-  f32x16 s_cur[QT];
+  // Two sets of score accumulators and probability operands, swapped by unrolling the block loop by two (a copy per iteration would be 32 vector moves); the key
+  // mask of the last block lives in a separate instantiation of the step (a select per score in every block would be 32 more): profiles/r06_split_attn_pmc.txt
+  // counted 8.8 vector instructions per MFMA before these two changes -- the kernel was bound by them, not by the matrix pipe.
+  f32x16 sA[QT], sB[QT];
+  sb16x8 pA[QT][TERMS][2], pB[QT][TERMS][2];
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int tt = 0; tt < TERMS; ++tt) pA[t][tt][0] = pA[t][tt][1] = pB[t][tt][0] = pB[t][tt][1] = __builtin_bit_cast(sb16x8, (u32x4){0u, 0u, 0u, 0u});
   fetch(0, -1);
   stash(1, false);                                               // K(0) alone, in the K area of stage 1
   fetch(1, -1);
   stash(0, false);                                               // stage 0 = [K(1) | zeros: there is no block -1]
   for (int i = tid; i < L::V_ELEMS / 8; i += 256) *reinterpret_cast<u32x4*>(lds + L::K_ELEMS + i * 8) = (u32x4){0u, 0u, 0u, 0u};
   __syncthreads();
-  if (active) scores(lds + L::STAGE, s_cur);
+  if (active) scores(lds + L::STAGE, sA);
   __syncthreads();                                               // every wave has read K(0) before iteration 0 overwrites stage 1
-  for (int kb = 0; kb < nkb; ++kb) {
+  // one block: scores of block kb + 1 into sn, P V of block kb - 1 with pp, softmax of block kb (scores in sc) into pn
+  auto step = [&](int kb, f32x16 (&sc)[QT], f32x16 (&sn)[QT], const sb16x8 (&pp)[QT][TERMS][2], sb16x8 (&pn)[QT][TERMS][2], auto masked) {
     const bf16_raw* st_base = lds + (kb & 1) * L::STAGE;
     fetch(kb + 2, kb);                                           // for the next iteration's stage [K(kb + 2) | V^T(kb)]; in flight under this block's MFMAs
     if (active) {
-      f32x16 s_next[QT];
-      scores(st_base, s_next);                                   // K(kb + 1) (in the last iteration: a stale block, result unused)
-      pv(st_base);                                               // V^T(kb - 1) with the previous block's probabilities
-      const int lim = tok - kb * 32;                             // keys of this block that exist
+      scores(st_base, sn);                                       // K(kb + 1) (in the last iteration: a stale block, result unused)
+      pv(st_base, pp);                                           // V^T(kb - 1) with the previous block's probabilities
       float alpha[QT];
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
         // register i of lane (n, h) = key kb * 32 + 16 (i / 8) + 8 h + (i % 8)
+        if constexpr (decltype(masked)::value) {
+          const int lim = tok - kb * 32;                         // keys of this block that exist
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s_cur[t][i] = (16 * (i >> 3) + 8 * h + (i & 7) < lim) ? s_cur[t][i] : -INFINITY;
-        float mx = s_cur[t][0];
+          for (int i = 0; i < 16; ++i) sc[t][i] = (16 * (i >> 3) + 8 * h + (i & 7) < lim) ? sc[t][i] : -INFINITY;
+        }
+        float mx = sc[t][0];
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s_cur[t][i]);
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sc[t][i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run[t], mx);
         alpha[t] = __builtin_amdgcn_exp2f(m_run[t] - m_new);
         float p[16], rs = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          p[i] = __builtin_amdgcn_exp2f(s_cur[t][i] - m_new);
+          p[i] = __builtin_amdgcn_exp2f(sc[t][i] - m_new);
           rs += p[i];
         }
         rs += __shfl_xor(rs, 32, 64);
         l_run[t] = l_run[t] * alpha[t] + rs;
         m_run[t] = m_new;
-        // probabilities -> TERMS bf16 operands per PV step (consumed by the NEXT iteration's pv)
-        sb16x8 pn[TERMS][2];
+        // probabilities -> TERMS bf16 operands per PV step (consumed by the NEXT step's pv)
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
           unsigned w[TERMS][4];
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(256, (TERMS == 2 && QT == 1) ? 2 : 1) void attn_spl
             for (int tt = 0; tt < TERMS; ++tt) w[tt][e >> 1] = (unsigned)a[tt] | ((unsigned)c[tt] << 16);
           }
 #pragma unroll
-          for (int tt = 0; tt < TERMS; ++tt) pn[tt][st] = __builtin_bit_cast(sb16x8, (u32x4){w[tt][0], w[tt][1], w[tt][2], w[tt][3]});
+          for (int tt = 0; tt < TERMS; ++tt) pn[t][tt][st] = __builtin_bit_cast(sb16x8, (u32x4){w[tt][0], w[tt][1], w[tt][2], w[tt][3]});
         }
         // hints: one MFMA, then a handful of vector instructions, over the iteration's 8 P MFMAs (LLVM's IGroupLP; groups it cannot fill are skipped)
 #pragma unroll
@@ -460,18 +469,48 @@ __global__ __launch_bounds__(256, (TERMS == 2 && QT == 1) ? 2 : 1) void attn_spl
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
         }
-        // everything above was independent of this iteration's MFMAs; the rescale and the hand-over of the operands are not
+        // everything above was independent of this iteration's MFMAs; the rescale is not
 #pragma unroll
         for (int i = 0; i < 16; ++i) { o0[t][i] *= alpha[t]; o1[t][i] *= alpha[t]; }
-#pragma unroll
-        for (int tt = 0; tt < TERMS; ++tt) { pb[t][tt][0] = pn[tt][0]; pb[t][tt][1] = pn[tt][1]; }
-        s_cur[t] = s_next[t];
       }
     }
     stash((kb + 1) & 1, true);                                   // the other stage = [K(kb + 2) | V^T(kb)]: every wave left it at the previous barrier
     __syncthreads();
+  };
+  using No = IntTag<0>;
+  using Yes = IntTag<1>;
+  if constexpr (TERMS == 2) {
+    int kb = 0;
+    for (; kb + 2 <= nkb - 1; kb += 2) {
+      step(kb, sA, sB, pA, pB, No{});
+      step(kb + 1, sB, sA, pB, pA, No{});
+    }
+    if (kb < nkb - 1) {                                          // one more unmasked block, then the last one
+      step(kb, sA, sB, pA, pB, No{});
+      step(kb + 1, sB, sA, pB, pA, Yes{});
+      if (active) pv(lds + (nkb & 1) * L::STAGE, pA);            // the last block's P V (its V^T was staged by the last step)
+    } else {
+      step(kb, sA, sB, pA, pB, Yes{});
+      if (active) pv(lds + (nkb & 1) * L::STAGE, pB);
+    }
+  } else {
+    // three terms: two live sets of accumulators AND operands do not fit beside the 96-register Q operand (measured: 482 registers, 1 629 us against 1 346): one
+    // loop body, the sets handed over by copies
+    auto hand_over = [&]() {
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        sA[t] = sB[t];
+#pragma unroll
+        for (int tt = 0; tt < TERMS; ++tt) { pA[t][tt][0] = pB[t][tt][0]; pA[t][tt][1] = pB[t][tt][1]; }
+      }
+    };
+    for (int kb = 0; kb < nkb - 1; ++kb) {
+      step(kb, sA, sB, pA, pB, No{});
+      hand_over();
+    }
+    step(nkb - 1, sA, sB, pA, pB, Yes{});
+    if (active) pv(lds + (nkb & 1) * L::STAGE, pB);
   }
-  if (active) pv(lds + (nkb & 1) * L::STAGE);                    // the last block's P V (its V^T was staged by the last iteration)
   if (!active) return;
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
