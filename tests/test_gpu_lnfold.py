@@ -246,7 +246,7 @@ def test_gemm_lnfold_from_row_partials_with_a_common_mode_offset(M, Nn, K, varia
     summed over K in f32 at magnitude |mean| |colsum| before they cancel -- 2^-24 sqrt(K) of that, times rstd: 0.2 fp16 ulp of the outputs at 100 sigma, ~2 ulps at
     1000 sigma; (3) that range is GUARDED: both statistics paths count every row with |mean| > 256 sigma into the fp16 stream's device counter (the engine raises),
     and count nothing at 10 / 100 sigma."""
-    assert fold_guard_count() == 0
+    fold_guard_count()                                            # (clear whatever an earlier test of this process left in the per-device word)
     g = torch.Generator().manual_seed(int(offset) + M)
     Mp = max(M, 2048)
     x0 = (torch.randn(Mp, K, generator=g) + offset * (1 + 0.1 * torch.rand(Mp, 1, generator=g))).to(torch.float16)
