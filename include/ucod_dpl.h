@@ -365,6 +365,9 @@ int ucod_attention_split_fwd(const void* operands, void* out_split_bf16, int B, 
  *   +9 fc1_w [F, P D]  +11 fc2_w [D, P F]  (B side),  +14 the K rows of qkv_w as an A-side operand [D, P D] (key hook; needed for the last layer of the pass),
  *   the f32 vectors (+0 +1 +3 +5 +6 +7 +8 +10 +12 +13) as in ucod_vit_forward. */
 size_t ucod_vit_split_workspace_bytes(const ucod_vit_desc* d, int terms);
+/* byte offset of the f32 residual stream x [B tok, D] inside that workspace: after the pass it holds the input of the pass's last layer (whose CLS rows the pseudo-label
+ * generator's attention row is computed from, generate_pseudo_label.py:78-89); (size_t)-1 for a descriptor the pass does not take */
+size_t ucod_vit_split_stream_offset(const ucod_vit_desc* d, int terms);
 int ucod_vit_forward_split(const ucod_vit_desc* d, int terms, const void* const* table_host, const float* img, float* key_out, void* workspace,
                            size_t workspace_bytes, void* stream);
 

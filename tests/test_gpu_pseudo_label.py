@@ -45,6 +45,35 @@ def test_cls_attention_row_and_whole_generator():
     assert agree > 0.9, agree                                    # the bf16 key map moves a few near-threshold patches
 
 
+def test_cls_attention_row_and_generator_at_the_reference_precision():
+    """Round 6: the reference's generate_pseudo_label.py runs the backbone in plain fp32 (no autocast), and its output is a thresholded map.  The split-operand
+    engine's CLS attention row against the HF model's own (G14: 2e-2 relative L2 for the 16-bit engine above, f32 rounding here); a ``backbone`` wrapper handed to
+    ``PseudoLabelGenerator`` is asked for its f32-equivalent sibling by default, and the raw masks then equal the reference's away from the threshold."""
+    from ucod_dpl_amd.vit_engine import SplitViTEngine
+    from ucod_dpl_amd.data.utils.feature_extractor import backbone
+    g = load_golden("g14_pseudo_label")
+    sd = sub(g, "sd.")
+    eng = SplitViTEngine(sd, heads=2, device="cuda", terms=3)
+    key, att = eng.forward_with_cls_attention(g["x"].cuda())
+    ref_att = g["attn_cls"][:, :, 1:]
+    assert ((att.cpu() - ref_att).norm() / ref_att.norm()).item() < 2e-5
+    kref = g["key"][:, 1:, :]                                     # the hook's raw tensor [B, N, C] minus CLS
+    assert ((key.cpu().flatten(2).transpose(1, 2) - kref).norm() / kref.norm()).item() < 5e-6
+    assert maxdiff(att.sum(-1).cpu() + g["attn_cls"][:, :, 0], torch.ones(3, 2)) < 1e-5
+    bb = backbone.from_state_dict(sd, heads=2, device="cuda")
+    gen = PseudoLabelGenerator(bb, th_bkg=0.6)
+    assert isinstance(gen.engine, SplitViTEngine) and gen.engine.terms == 3
+    assert isinstance(PseudoLabelGenerator(bb, precision=None).engine, ViTEngine)
+    raw = gen.raw_masks(g["x"]).cpu()                             # 1 - bkg_mask, [B, h, w]
+    _, _, row = OPL.bkg_seg(g["attn_cls"], g["key"], (8, 8), 0.6, dim=64, apply_weights=True)
+    safe = ((row - 0.6).abs() > 1e-5).reshape(raw.shape)
+    assert torch.equal(raw[safe], (1 - g["mask.th6_w1"]).reshape(raw.shape)[safe]) and int(safe.sum()) > 0.95 * safe.numel()
+    masks = gen.generate_masks(g["x"])
+    ref = [OPL.refine_post_process((1 - g["mask.th6_w1"][i]).unsqueeze(0)) for i in range(3)]
+    agree = sum(float((a == b).float().mean()) for a, b in zip(masks, ref)) / 3
+    assert agree > 0.995, agree                                  # (the 16-bit engine: > 0.9 -- its key map moves a few near-threshold patches)
+
+
 def test_refine_post_process_matches_reference():
     g = load_golden("g14_pseudo_label")
     for key, a in (("pp_out", 4), ("pp_out_a9", 9)):

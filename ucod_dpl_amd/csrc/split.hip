@@ -688,6 +688,9 @@ bool split_valid(const ucod_vit_desc* d, int terms) {
   } while (0)
 
 extern "C" size_t ucod_vit_split_workspace_bytes(const ucod_vit_desc* d, int terms) { return split_valid(d, terms) ? split_plan(d, terms).total : 0; }
+// byte offset, inside the workspace, of the f32 residual stream x [B tok, D]: after a key-minimal pass it holds the INPUT of the pass's last layer (the last layer
+// only runs LayerNorm 1 and the key hook), which is what the CLS-attention row of the pseudo-label generator is computed from
+extern "C" size_t ucod_vit_split_stream_offset(const ucod_vit_desc* d, int terms) { return split_valid(d, terms) ? split_plan(d, terms).off_x : (size_t)-1; }
 
 extern "C" int ucod_vit_forward_split(const ucod_vit_desc* d, int terms, const void* const* T, const float* img, float* key_out, void* workspace, size_t workspace_bytes,
                                       void* stream) {

@@ -34,7 +34,12 @@ def refine_post_process(mask, area_threshold=4):
 
 
 class PseudoLabelGenerator:
-    def __init__(self, feature_extractor, th_bkg=0.6, area_threshold=4):
+    def __init__(self, feature_extractor, th_bkg=0.6, area_threshold=4, precision="f32eq"):
+        """``precision``: the reference's script runs the backbone in plain fp32 under ``torch.no_grad()`` (generate_pseudo_label.py:71-89: no autocast), and its
+        output is a THRESHOLDED map -- so a ``backbone`` wrapper is asked for its f32-equivalent sibling by default (``with_precision("f32eq")``: the
+        split-operand engine); ``precision=None`` keeps the extractor as given (a bare engine is always used as it is)."""
+        if precision is not None and hasattr(feature_extractor, "with_precision"):
+            feature_extractor = feature_extractor.with_precision(precision)
         self.engine = getattr(feature_extractor, "engine", feature_extractor)
         self.th_bkg, self.area_threshold = th_bkg, area_threshold
 

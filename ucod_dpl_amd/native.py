@@ -73,6 +73,7 @@ SIGNATURES = {
     "ucod_qkv_split": (ci, [vp, vp, ci, ci, ci, ci, cf, vp]),
     "ucod_attention_split_fwd": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "ucod_vit_split_workspace_bytes": (sz, [C.POINTER(VitDesc), ci]),
+    "ucod_vit_split_stream_offset": (sz, [C.POINTER(VitDesc), ci]),
     "ucod_vit_forward_split": (ci, [C.POINTER(VitDesc), ci, C.POINTER(vp), vp, vp, vp, sz, vp]),
     "ucod_gemm_bf16": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
     "ucod_gemm_lnfold": (ci, [ci, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, cf, vp, ci, vp]),

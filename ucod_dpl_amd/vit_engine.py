@@ -449,6 +449,9 @@ class SplitViTEngine:
                                 f32(l["ls1"]) if l["ls1"] is not None else ones, f32(l["ln2_g"]), f32(l["ln2_b"]), sw(l["fc1_w"]),
                                 f32(l["fc1_b"]), sw(l["fc2_w"]), f32(l["fc2_b"]), f32(l["ls2"]) if l["ls2"] is not None else ones,
                                 sw(l["qkv_w"][D:2 * D], role=0), None])      # +14: the K rows as the A side of the key hook's GEMM
+        last = c["layers"][-1]                                   # f32 copies for forward_with_cls_attention: the CLS query / key of the LAST layer
+        self._last = dict(ln_g=f32(last["ln1_g"]), ln_b=f32(last["ln1_b"]), wq=f32(last["qkv_w"][:D]), bq=f32(last["qkv_b"][:D]),
+                          wk=f32(last["qkv_w"][D:2 * D]), bk=f32(last["qkv_b"][D:2 * D]))
         self._ws = None
         self._side = self._side_ws = None
 
@@ -511,6 +514,26 @@ class SplitViTEngine:
 
     def forward_async(self, img, out=None):
         return self.forward(img, out=out, _async=True)
+
+    def forward_with_cls_attention(self, img):
+        """(key [B,D,h,w], att [B,heads,h*w]) like ``ViTEngine.forward_with_cls_attention``: the key map plus ``outputs.attentions[-1][:, :, 0, 1:]`` of the HF model
+        (data/utils/found_bkg_mask.py:23; generate_pseudo_label.py:78-89 -- a plain fp32 pass under torch.no_grad() in the reference, which is why the
+        pseudo-label generator asks for this engine).  The CLS rows of the last layer's input are taken from the f32 residual stream the pass leaves in its
+        workspace, normalised by the f32 LayerNorm kernel, projected to the CLS query / key on split operands, and fed to the f32 attention-row kernel."""
+        key = self.forward(img)
+        B, _, H, W = img.shape
+        d = self._desc(B, H, W)
+        d.resid16 = d.ln_fold = d.full_last_layer = d.attn_variant = 0
+        off = self.lib.ucod_vit_split_stream_offset(C.byref(d), self.terms)
+        tok = key.shape[-2] * key.shape[-1] + 1
+        x = self._ws[0][off:off + B * tok * self.D * 4].view(torch.float32).view(B, tok, self.D)
+        L_ = self._last
+        h_cls = ops.layernorm(x[:, 0].contiguous(), L_["ln_g"], L_["ln_b"], self.eps, out_f32=True)
+        q = ops.linear_split(h_cls, L_["wq"], L_["bq"], self.terms)
+        k = ops.linear_split(h_cls, L_["wk"], L_["bk"], self.terms)
+        att = torch.empty(B, self.heads, tok - 1, dtype=torch.float32, device=self.device)
+        N.check(self.lib.ucod_cls_attention(N.ptr(q), N.ptr(k), N.ptr(key), N.ptr(att), B, self.heads, tok - 1, 0.125, N.stream()), "ucod_cls_attention")
+        return key, att
 
     __call__ = forward
 
