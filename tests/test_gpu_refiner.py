@@ -190,8 +190,14 @@ def test_coral_loop_run_and_window_features():
     from oracle import look_twice as OLT
     crop = wf.crop_center(img)
     big = OLT.crop_resize_normalize(crop, [0, 0, crop.shape[1], crop.shape[0]], (168, 168))
-    _, ref_key = bb(big[:, 56:112, 112:168].unsqueeze(0).cuda())                   # window (row 1, col 2) = index 5
-    assert torch.equal(hin[0, 5], ref_key[0])
+    from ucod_dpl_amd.vit_engine import SplitViTEngine
+    assert isinstance(wf.fe.engine, SplitViTEngine)                                # (round 6: the reference computes these features in plain fp32, lr_dataset.py:97-157)
+    _, ref_key = wf.fe(big[:, 56:112, 112:168].unsqueeze(0).cuda())               # window (row 1, col 2) = index 5
+    assert torch.equal(hin[0, 5], ref_key[0]) or float((hin[0, 5] - ref_key[0]).norm() / ref_key[0].norm()) < 1e-6
+    wf16 = WindowFeatures(bb, lt, window_size=3, grid=(56, 56), extractor_size=(84, 84), image_size=(56, 56), precision=None)
+    _, h16, _ = wf16.get_features(img, require_m_patches=False, crop_center=True)
+    assert torch.equal(h16[0, 5], bb(big[:, 56:112, 112:168].unsqueeze(0).cuda())[1][0])      # the extractor as given: the 16-bit engine, bit for bit
+    assert float((h16 - hin).norm() / hin.norm()) < 5e-3
 
 
 def test_local_refine_runner_from_the_coral_config(tmp_path):

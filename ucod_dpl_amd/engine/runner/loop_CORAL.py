@@ -21,7 +21,11 @@ from ..utils.metrics import statistics
 class WindowFeatures:
     """lr_dataset.py::get_features (:82-166) for an in-memory uint8 RGB image."""
 
-    def __init__(self, feature_extractor, look_twice_loop, window_size=3, grid=(518, 518), extractor_size=(756, 756), image_size=(518, 518)):
+    def __init__(self, feature_extractor, look_twice_loop, window_size=3, grid=(518, 518), extractor_size=(756, 756), image_size=(518, 518), precision="f32eq"):
+        # the reference computes these features inside its dataset (lr_dataset.py:97-157: a backbone of its own, outside accelerate's autocast) -- plain fp32: a
+        # `backbone` wrapper is asked for its f32-equivalent sibling by default (precision=None keeps the extractor as given)
+        if precision is not None and hasattr(feature_extractor, "with_precision"):
+            feature_extractor = feature_extractor.with_precision(precision)
         self.fe = feature_extractor
         self.lt = look_twice_loop                      # owns the Pillow-exact crop / resize / normalise kernel
         self.window_size, self.grid = window_size, grid
