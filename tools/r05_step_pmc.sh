@@ -8,7 +8,7 @@ for half in f16 bf16; do
   i=0
   for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS"; do
     i=$((i+1))
-    timeout 900 rocprofv3 --pmc $set --output-format csv -d $O/step_pmc_${half}_$i -- python3 $R/bench.py --half $half --steps 2 --warmup 1 --no-cpu-baseline --lora-steps -1 --no-pipeline --streams 1 > /dev/null 2> $O/step_pmc_${half}_$i.err
+    timeout 900 rocprofv3 --pmc $set --output-format csv -d $O/step_pmc_${half}_$i -- python3 $R/bench.py --half $half --steps 2 --warmup 1 --no-cpu-baseline --lora-steps -1 --no-pipeline --streams 1 --sustain-s 0 > /dev/null 2> $O/step_pmc_${half}_$i.err
   done
 done
 cd $R; python3 - <<'PY' > gpurun_out/r05_step_pmc.txt
